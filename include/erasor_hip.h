@@ -1,0 +1,193 @@
+/*
+ * erasor_hip.h — C ABI of the MI355X-native ERASOR hot path (liberasor_hip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, POD
+ * structs, no C++/torch types, never throws.  Every entry point names the
+ * reference interface it replaces (paths relative to the reference checkout):
+ *
+ *   erasor.h   = include/erasor/erasor.h
+ *   erasor.cpp = src/offline_map_updater/src/erasor.cpp
+ *   OMU.cpp    = src/offline_map_updater/src/OfflineMapUpdater.cpp
+ *   utils.cpp  = src/offline_map_updater/src/erasor_utils.cpp
+ *
+ * Point layout everywhere: rows of 4 floats {x, y, z, intensity}; intensity carries
+ * the SemanticKITTI label as a *numeric* float (utils.cpp:64).  4x4 transforms are
+ * 16 floats, row-major.
+ *
+ * Threading: one handle = one GPU + one HIP stream; a handle is not thread-safe,
+ * distinct handles are independent (reference: single-threaded ros::spin()).
+ */
+#ifndef ERASOR_HIP_H
+#define ERASOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+#define ERASOR_OK               0
+#define ERASOR_E_INVALID       -1  /* bad argument (reference: std::invalid_argument, OMU.cpp:125,274,312) */
+#define ERASOR_E_NO_DEVICE     -2  /* no usable HIP device / HIP runtime error */
+#define ERASOR_E_CAPACITY      -3  /* caller buffer too small */
+#define ERASOR_E_STATE         -4  /* call order (e.g. step before set_map) */
+#define ERASOR_E_UNSUPPORTED   -5  /* e.g. version not in {2,3} (OMU.cpp:273-275) */
+#define ERASOR_E_INTERNAL      -6
+
+/* ---- bin status codes (erasor.h:12-18), reported as the reference's doubles */
+#define ERASOR_ST_LITTLE_NUM      0.0   /* == NOT_ASSIGNED */
+#define ERASOR_ST_MERGE_BINS      0.25
+#define ERASOR_ST_MAP_IS_HIGHER   0.5
+#define ERASOR_ST_BLOCKED         0.8
+#define ERASOR_ST_CURR_IS_HIGHER  1.0
+
+/* ---- parameters: the rosparam names of erasor.h:47-61 and OMU.cpp:66-83 --- */
+typedef struct erasor_params {
+    /* /erasor/... (erasor.h:47-61) */
+    double  max_range;             /* max_r            default 10.0 (erasor.h:47) */
+    int32_t num_rings;             /*                  default 20   */
+    int32_t num_sectors;           /*                  default 60   */
+    double  max_h;                 /*                  default 3.0  */
+    double  min_h;                 /*                  default 0.0  */
+    double  th_bin_max_h;          /* v2 only          default 0.39 */
+    double  scan_ratio_threshold;  /*                  default 0.22 */
+    int32_t num_lowest_pts;        /*                  default 5    */
+    int32_t minimum_num_pts;       /*                  default 4    */
+    double  rejection_ratio;       /* unused upstream  default 0.33 */
+    double  gf_dist_thr;           /* th_dist_         default 0.05 */
+    int32_t gf_iter;               /*                  default 3    */
+    int32_t gf_num_lpr;            /*                  default 10   */
+    double  gf_th_seeds_height;    /*                  default 0.5  */
+    double  map_voxel_size;        /* /erasor/map_voxel_size, v3 per-bin voxelise, default 0.2 */
+    int32_t version;               /* /erasor/version  2 or 3, default 3 (OMU.cpp:81) */
+    /* /MapUpdater/... (OMU.cpp:66-73) */
+    double  query_voxel_size;      /* default 0.05 */
+    int32_t removal_interval;      /* default 2; gating is done by the caller-side shim (OMU.cpp:206-209) */
+    /* VoI radius used by fetch_VoI: /erasor/max_range read a second time with a
+     * different default (60.0, OMU.cpp:78).  <=0 means "same as max_range". */
+    double  voi_max_range;
+    int32_t reserved_[7];
+} erasor_params;
+
+/* Per-step result: the sizes the reference prints (OMU.cpp:431-433,452-464) plus
+ * the parity/edge counters this implementation defines. */
+typedef struct erasor_step_result {
+    uint64_t n_map_in;          /* |map_arranged_| before the step */
+    uint64_t n_voi;             /* |map_voi_|                       (OMU.cpp:431) */
+    uint64_t n_outskirts;       /* |map_outskirts_|                 */
+    uint64_t n_query;           /* |query_voi_| after voxelise       (OMU.cpp:238-241) */
+    uint64_t n_static_estimate; /* |map_static_estimate_|  incl. duplicated ground (erasor.cpp:616) */
+    uint64_t n_complement;      /* |map_egocentric_complement_| */
+    uint64_t n_map_rejected;    /* |map_rejected_| = the dynamic-point mask */
+    uint64_t n_curr_rejected;   /* |query_rejected_| (v2 only)      */
+    uint64_t n_ground;          /* |ground_viz|                      */
+    uint64_t n_map_out;         /* |map_arranged_| after the step    */
+    uint64_t n_static;          /* parse_dynamic_obj static count    (utils.cpp:57-78) */
+    uint64_t n_dynamic;         /* parse_dynamic_obj dynamic count   */
+    uint32_t n_reverted_bins;   /* bins where R-GPF ran (erasor.cpp:511-533 / 383-394) */
+    uint32_t n_neg_sector;      /* y==-0.0f,x<0 hazard: reference throws (erasor.cpp:112), here clamped to sector 0 */
+    uint32_t n_ambiguous;       /* points whose theta/sector_size is within 1e-11 of an integer (device atan2 vs libm) */
+    uint32_t n_degenerate_plane;/* estimate_plane_ on an empty ground set (uninitialised in reference, erasor.cpp:184-186) */
+    uint32_t n_voxel_overflow;  /* VoxelGrid dx*dy*dz > INT_MAX passthroughs */
+    uint32_t n_sort_fallback;   /* introsort depth-limit (heapsort) fallbacks taken */
+    uint32_t reserved_[6];
+} erasor_step_result;
+
+/* cloud selectors for erasor_hip_get_cloud */
+#define ERASOR_CLOUD_QUERY_VOI        0  /* query_voi_ (body frame)            OMU.cpp:241      */
+#define ERASOR_CLOUD_MAP_VOI          1  /* map_voi_ (egocentric)              OMU.cpp:435-437  */
+#define ERASOR_CLOUD_STATIC_ESTIMATE  2  /* map_static_estimate_ (egocentric)  erasor.cpp:612-616 */
+#define ERASOR_CLOUD_COMPLEMENT       3  /* map_egocentric_complement_         erasor.cpp:622   */
+#define ERASOR_CLOUD_MAP_REJECTED     4  /* map_rejected_ in map frame         OMU.cpp:284,287  */
+#define ERASOR_CLOUD_CURR_REJECTED    5  /* query_rejected_ in map frame       OMU.cpp:284,288  */
+#define ERASOR_CLOUD_GROUND_VIZ       6  /* ERASOR::ground_viz (egocentric)    erasor.h:127     */
+#define ERASOR_CLOUD_MAP              7  /* map_arranged_ (same as get_map)    OMU.cpp:290      */
+
+typedef struct erasor_hip_handle erasor_hip_handle;
+
+/* library identity; safe without a GPU */
+const char *erasor_hip_version(void);
+
+/* fills the reference's compiled-in defaults (erasor.h:47-61, OMU.cpp:66-83) */
+int erasor_hip_params_default(erasor_params *p);
+
+/* replaces: OfflineMapUpdater ctor + `new ERASOR(&nh)` (OMU.cpp:5-32, erasor.h:46-103) */
+int  erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **out);
+void erasor_hip_destroy(erasor_hip_handle *h);
+const char *erasor_hip_last_error(const erasor_hip_handle *h);
+
+/* replaces: load_global_map's `*map_arranged_ = *map_init_` (OMU.cpp:107-167).
+ * The map becomes device-resident.  _device: xyzi is a device pointer (same GPU). */
+int erasor_hip_set_map(erasor_hip_handle *h, const float *xyzi, size_t n);
+int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n);
+
+/* replaces: the body of callback_node between OMU.cpp:237 and OMU.cpp:294:
+ *   voxelize_preserving_labels(query) + transformPointCloud(tf_lidar2body_)   (OMU.cpp:238-241)
+ *   fetch_VoI                                                                  (OMU.cpp:254, 381-438)
+ *   ERASOR::set_inputs                                                         (OMU.cpp:266, erasor.cpp:57-85)
+ *   compare_vois_and_revert_ground[_w_block]                                   (OMU.cpp:268/271)
+ *   get_static_estimate / get_outliers / body2origin / map re-assembly         (OMU.cpp:272-290)
+ *   parse_dynamic_obj counters                                                 (OMU.cpp:294)
+ * T_origin2body is tf_body2origin_.inverse() (OMU.cpp:436), computed once by the
+ * caller so host and device use the same 16 floats. */
+int erasor_hip_step(erasor_hip_handle *h, const float *scan_xyzi, size_t n_scan,
+                    const float T_lidar2body[16], const float T_body2origin[16],
+                    const float T_origin2body[16], erasor_step_result *res);
+int erasor_hip_step_device(erasor_hip_handle *h, const void *d_scan_xyzi, size_t n_scan,
+                           const float T_lidar2body[16], const float T_body2origin[16],
+                           const float T_origin2body[16], erasor_step_result *res);
+
+/* map_arranged_ read-back (OMU.cpp:183: what save_static_map starts from) */
+int erasor_hip_map_size(erasor_hip_handle *h, size_t *n);
+int erasor_hip_get_map(erasor_hip_handle *h, float *dst_xyzi, size_t cap_points, size_t *n);
+
+/* replaces: ERASOR::get_static_estimate / get_outliers outputs and the public
+ * members of erasor.h:127,139-141 — clouds of the *last* step. */
+int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst_xyzi, size_t cap_points, size_t *n);
+
+/* index of every map_rejected_ point in the map *before* the step (the dynamic-point mask
+ * of BASELINE.json:north_star, as indices into the pre-step map_arranged_ order) */
+int erasor_hip_get_rejected_indices(erasor_hip_handle *h, uint64_t *dst, size_t cap, size_t *n);
+
+/* replaces: r_pod_map / r_pod_curr descriptors (erasor.h:143-144; Bin erasor.h:24-33).
+ * which: 0 = map, 1 = curr.  Arrays of num_rings*num_sectors, index = ring*num_sectors + sector.
+ * Empty bins report count 0, min_h = +1e13, max_h = -1e13 (erasor.h:3, erasor.cpp:45-46). */
+int erasor_hip_get_bins(erasor_hip_handle *h, int which, uint32_t *count, double *min_h, double *max_h);
+
+/* r_pod_selected[r][theta].status after the step (erasor.cpp:503-560), index = ring*num_sectors + sector */
+int erasor_hip_get_status(erasor_hip_handle *h, double *status);
+
+/* R-GPF plane per reverted bin, in the (theta, ring) order the reference visits them
+ * (erasor.cpp:493-494): for reverted bin k and iteration it < gf_iter:
+ *   normal[(k*gf_iter+it)*3 .. +3], d[k*gf_iter+it]  (erasor.cpp:183-198);
+ * bin_index[k] = ring*num_sectors + sector. */
+int erasor_hip_get_planes(erasor_hip_handle *h, uint32_t *bin_index, float *normal, double *d,
+                          size_t cap_bins, size_t *n_bins);
+
+/* replaces: erasor_utils::voxelize_preserving_labels (utils.cpp:80-114), standalone */
+int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src_xyzi, size_t n,
+                                          double leaf_size, float *dst_xyzi, size_t cap_points,
+                                          size_t *n_out);
+
+/* replaces: erasor_utils::parse_dynamic_obj as counters (utils.cpp:57-78) over the current map */
+int erasor_hip_count_static_dynamic(erasor_hip_handle *h, uint64_t *n_static, uint64_t *n_dynamic);
+
+/* ---- measurement hooks (no reference counterpart) ------------------------ */
+/* When enabled, every kernel launch of a step is bracketed by HIP events on the
+ * handle's stream; totals are accumulated per kernel name. */
+int erasor_hip_profiling(erasor_hip_handle *h, int enable);
+int erasor_hip_profile_reset(erasor_hip_handle *h);
+/* returns number of distinct kernels; fills up to cap entries */
+int erasor_hip_profile_get(erasor_hip_handle *h, const char **names, double *total_ms,
+                           uint64_t *launches, size_t cap, size_t *n);
+/* HBM bytes the voi_split kernel must read per launch for the current map: 16 * physical entries */
+int erasor_hip_voi_split_bytes(erasor_hip_handle *h, uint64_t *algorithmic_bytes, uint64_t *physical_entries);
+/* the hipStream_t the handle launches on (as void*) */
+void *erasor_hip_stream(erasor_hip_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ERASOR_HIP_H */

@@ -1,0 +1,1176 @@
+// erasor_oracle.cpp — CPU restatement of ERASOR's per-scan hot path.
+//
+// *** TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED. ***
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file.
+// The product (erasor_amd/csrc, liberasor_hip.so) never links, imports or calls it.
+//
+// "Parity unpinned": the reference (LimHyungTae/ERASOR) ships no tests, golden vectors or
+// fixtures for this path, and its C++ cannot be compiled here (needs ROS, PCL, Eigen, tf,
+// Boost — none installed, no network).  This file therefore *restates* the algorithm,
+// single-threaded, operation for operation, including the float/double mix, and restates
+// from their published algorithms the third-party pieces the reference calls:
+//   PCL 1.8.1  (transformPointCloud, computeMeanAndCovarianceMatrix, VoxelGrid, KdTreeFLANN 1-NN)
+//   Eigen 3.3.4 (JacobiSVD 3x3, dense products), tf (Quaternion -> Matrix3x3), libstdc++ std::sort.
+// (versions = Ubuntu 18.04 / ROS Melodic, the reference's stated environment, README.md:41-43;
+//  CMakeLists.txt:36 only asks for PCL >= 1.7, no lockfile.)
+//
+// Reference citations use these short names (paths under /root/reference):
+//   erasor.h   = include/erasor/erasor.h
+//   erasor.cpp = src/offline_map_updater/src/erasor.cpp
+//   OMU.cpp    = src/offline_map_updater/src/OfflineMapUpdater.cpp
+//   utils.cpp  = src/offline_map_updater/src/erasor_utils.cpp
+//
+// Build: g++ -O2 -std=c++17 -ffp-contract=off (no -march: the reference has none, CMakeLists.txt:4,
+// so no FMA contraction anywhere).
+//
+// Defined behaviour where the reference is undefined / throws (documented in DESIGN.md):
+//   * y == -0.0f, x < 0  -> negative sector index -> vector::at throws (erasor.cpp:112,136):
+//       here sector is clamped to 0 and n_neg_sector is incremented.
+//   * estimate_plane_ on an empty cloud leaves cov / mean uninitialised (erasor.cpp:184-186):
+//       here cov = 0, mean = 0 and n_degenerate_plane is incremented.
+//   * exact ties of the 1-NN label search (FLANN traversal order): lowest input index wins.
+//   * tf_body2origin_.inverse() (OMU.cpp:436, Eigen SSE path using rcpss) is not restated:
+//       the caller passes T_origin2body; orc_invert4 offers a double-precision cofactor inverse.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../include/erasor_hip.h"
+
+namespace orc {
+
+// erasor.h:3-4
+static const double INF_H = 10000000000000.0;
+static const double PI_REF = 3.1415926535;
+
+struct Pt {
+    float x, y, z, i;
+};
+typedef std::vector<Pt> Cloud;
+
+// ---------------------------------------------------------------------------------------------
+// tf::Matrix3x3(tf::Quaternion) + geoPose2eigen (utils.cpp:35-55).  pose7 = x y z qx qy qz qw.
+// ---------------------------------------------------------------------------------------------
+static void geoPose2eigen(const double pose[7], float T[16]) {
+    const double x = pose[3], y = pose[4], z = pose[5], w = pose[6];
+    const double d = x * x + y * y + z * z + w * w;  // tf: q.length2()
+    const double s = 2.0 / d;
+    const double xs = x * s, ys = y * s, zs = z * s;
+    const double wx = w * xs, wy = w * ys, wz = w * zs;
+    const double xx = x * xs, xy = x * ys, xz = x * zs;
+    const double yy = y * ys, yz = y * zs, zz = z * zs;
+    const double m[9] = {1.0 - (yy + zz), xy - wz,         xz + wy,
+                         xy + wz,         1.0 - (xx + zz), yz - wx,
+                         xz - wy,         yz + wx,         1.0 - (xx + yy)};
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) T[r * 4 + c] = (float)m[r * 3 + c];
+    T[3] = (float)pose[0];
+    T[7] = (float)pose[1];
+    T[11] = (float)pose[2];
+    T[12] = T[13] = T[14] = 0.f;
+    T[15] = 1.f;
+}
+
+// general 4x4 inverse in double (cofactors), narrowed to float.  NOT a restatement of Eigen's SSE
+// inverse (OMU.cpp:436): both oracle and device receive the same 16 floats from the caller.
+static int invert4(const float Tf[16], float out[16]) {
+    double m[16], inv[16];
+    for (int k = 0; k < 16; ++k) m[k] = Tf[k];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0.0) return -1;
+    det = 1.0 / det;
+    for (int k = 0; k < 16; ++k) out[k] = (float)(inv[k] * det);
+    return 0;
+}
+
+// pcl::transformPointCloud (PCL <= 1.9, dense cloud), float32, left-associated, no FMA:
+//   x' = ((T00*x + T01*y) + T02*z) + T03   (OMU.cpp:240,436,447)
+static inline Pt transform_pt(const Pt &p, const float T[16]) {
+    Pt o;
+    o.x = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
+    o.y = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
+    o.z = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
+    o.i = p.i;
+    return o;
+}
+static void transform_cloud(const Cloud &in, Cloud &out, const float T[16]) {
+    Cloud tmp(in.size());
+    for (size_t k = 0; k < in.size(); ++k) tmp[k] = transform_pt(in[k], T);
+    out.swap(tmp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// label decode (utils.cpp:3,57-78,116-138): numeric cast, & 0xFFFF, classes 252..259
+// ---------------------------------------------------------------------------------------------
+static inline bool is_dynamic_label(float intensity) {
+    uint32_t u = static_cast<uint32_t>(intensity);
+    uint32_t sem = u & 0xFFFF;
+    return sem >= 252 && sem <= 259;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PCL 1.8 VoxelGrid<PointXYZI> (downsample_all_data, min_points_per_voxel 0) — utils.cpp:88-91
+// ---------------------------------------------------------------------------------------------
+struct IdxPair {  // pcl::cloud_point_index_idx
+    unsigned int idx;
+    unsigned int pi;
+    bool operator<(const IdxPair &o) const { return idx < o.idx; }
+};
+
+struct VoxelGridOut {
+    bool overflow = false;          // dx*dy*dz > INT_MAX: output = input
+    int min_b[3] = {0, 0, 0};
+    int div_b[3] = {0, 0, 0};
+    float inv_leaf = 0.f;
+    std::vector<IdxPair> sorted;    // after std::sort
+    std::vector<uint32_t> run_begin;  // per output voxel: [run_begin[v], run_begin[v+1]) into sorted
+    Cloud centroids;                // intensity = averaged (before label reassignment)
+};
+
+static void voxel_grid(const Cloud &in, double leaf_d, VoxelGridOut &vo) {
+    vo = VoxelGridOut();
+    const size_t n = in.size();
+    if (n == 0) {
+        vo.run_begin.push_back(0);
+        return;
+    }
+    const float leaf = (float)leaf_d;      // setLeafSize(float,float,float)
+    const float inv = 1.0f / leaf;         // inverse_leaf_size_ = Array4f::Ones() / leaf_size_
+    vo.inv_leaf = inv;
+    float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+    float mx[3] = {-mn[0], -mn[1], -mn[2]};
+    for (size_t k = 0; k < n; ++k) {  // getMinMax3D, dense
+        const float c[3] = {in[k].x, in[k].y, in[k].z};
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = (c[a] < mn[a]) ? c[a] : mn[a];
+            mx[a] = (c[a] > mx[a]) ? c[a] : mx[a];
+        }
+    }
+    int64_t d[3];
+    for (int a = 0; a < 3; ++a) d[a] = static_cast<int64_t>((mx[a] - mn[a]) * inv) + 1;
+    if ((d[0] * d[1] * d[2]) > static_cast<int64_t>(std::numeric_limits<int32_t>::max())) {
+        vo.overflow = true;  // "Leaf size is too small ... Integer indices would overflow." -> output = *input_
+        return;
+    }
+    int max_b[3];
+    for (int a = 0; a < 3; ++a) {
+        vo.min_b[a] = static_cast<int>(std::floor(mn[a] * inv));
+        max_b[a] = static_cast<int>(std::floor(mx[a] * inv));
+        vo.div_b[a] = max_b[a] - vo.min_b[a] + 1;
+    }
+    const int mul[3] = {1, vo.div_b[0], vo.div_b[0] * vo.div_b[1]};
+    vo.sorted.resize(n);
+    for (size_t k = 0; k < n; ++k) {
+        const int ijk0 = static_cast<int>(std::floor(in[k].x * inv) - static_cast<float>(vo.min_b[0]));
+        const int ijk1 = static_cast<int>(std::floor(in[k].y * inv) - static_cast<float>(vo.min_b[1]));
+        const int ijk2 = static_cast<int>(std::floor(in[k].z * inv) - static_cast<float>(vo.min_b[2]));
+        const int idx = ijk0 * mul[0] + ijk1 * mul[1] + ijk2 * mul[2];
+        vo.sorted[k].idx = static_cast<unsigned int>(idx);
+        vo.sorted[k].pi = static_cast<unsigned int>(k);
+    }
+    std::sort(vo.sorted.begin(), vo.sorted.end(), std::less<IdxPair>());  // unstable; tie order = libstdc++ introsort
+    size_t index = 0;
+    while (index < n) {
+        size_t i = index + 1;
+        while (i < n && vo.sorted[i].idx == vo.sorted[index].idx) ++i;
+        vo.run_begin.push_back((uint32_t)index);
+        // CentroidPoint<PointXYZI>: float running sums in sorted order, each divided by (float)n
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        for (size_t li = index; li < i; ++li) {
+            const Pt &p = in[vo.sorted[li].pi];
+            sx += p.x;
+            sy += p.y;
+            sz += p.z;
+            si += p.i;
+        }
+        const float cnt = static_cast<float>(i - index);
+        Pt c;
+        c.x = sx / cnt;
+        c.y = sy / cnt;
+        c.z = sz / cnt;
+        c.i = si / cnt;
+        vo.centroids.push_back(c);
+        index = i;
+    }
+    vo.run_begin.push_back((uint32_t)n);
+}
+
+// exact 1-NN (float32 squared L2 as FLANN L2_Simple: ((0+dx*dx)+dy*dy)+dz*dz; lowest index on ties)
+// over `in`, accelerated by the voxel runs of `vo` (cells of one leaf).  The result does not
+// depend on the acceleration structure (every point inside the final search ball is examined).
+static inline float l2_simple(const Pt &a, const Pt &b) {
+    float r = 0.f;
+    float d0 = a.x - b.x;
+    r += d0 * d0;
+    float d1 = a.y - b.y;
+    r += d1 * d1;
+    float d2 = a.z - b.z;
+    r += d2 * d2;
+    return r;
+}
+
+static uint32_t nn_index_grid(const Cloud &in, const VoxelGridOut &vo, const std::vector<uint32_t> &ukeys,
+                              size_t v /*voxel whose centroid is queried*/) {
+    const Pt &c = vo.centroids[v];
+    const uint32_t key = ukeys[v];
+    const int dx = vo.div_b[0], dy = vo.div_b[1], dz = vo.div_b[2];
+    const int ci = (int)(key % (uint32_t)dx), cj = (int)((key / (uint32_t)dx) % (uint32_t)dy), ck = (int)(key / ((uint32_t)dx * (uint32_t)dy));
+    const double L = 1.0 / (double)vo.inv_leaf;
+    float best = std::numeric_limits<float>::infinity();
+    uint32_t best_i = 0xFFFFFFFFu;
+    const int maxrho = std::max(dx, std::max(dy, dz));
+    for (int rho = 1;; ++rho) {
+        // visit the shell of cells at Chebyshev distance exactly rho-? : simply (re)visit the whole
+        // (2rho+1)^3 block minus the (2rho-1)^3 block already visited (rho==1: whole block).
+        for (int kk = ck - rho; kk <= ck + rho; ++kk) {
+            if (kk < 0 || kk >= dz) continue;
+            for (int jj = cj - rho; jj <= cj + rho; ++jj) {
+                if (jj < 0 || jj >= dy) continue;
+                for (int ii = ci - rho; ii <= ci + rho; ++ii) {
+                    if (ii < 0 || ii >= dx) continue;
+                    if (rho > 1 && std::abs(ii - ci) < rho && std::abs(jj - cj) < rho && std::abs(kk - ck) < rho) continue;
+                    const uint32_t q = (uint32_t)ii + (uint32_t)jj * (uint32_t)dx + (uint32_t)kk * (uint32_t)dx * (uint32_t)dy;
+                    auto it = std::lower_bound(ukeys.begin(), ukeys.end(), q);
+                    if (it == ukeys.end() || *it != q) continue;
+                    const size_t u = (size_t)(it - ukeys.begin());
+                    for (uint32_t li = vo.run_begin[u]; li < vo.run_begin[u + 1]; ++li) {
+                        const uint32_t pi = vo.sorted[li].pi;
+                        const float dd = l2_simple(c, in[pi]);
+                        if (dd < best || (dd == best && pi < best_i)) {
+                            best = dd;
+                            best_i = pi;
+                        }
+                    }
+                }
+            }
+        }
+        if (rho >= maxrho) break;
+        // conservative distance from c to the outside of the visited block
+        const double cc[3] = {c.x, c.y, c.z};
+        const int cidx[3] = {ci, cj, ck};
+        double g = std::numeric_limits<double>::infinity();
+        for (int a = 0; a < 3; ++a) {
+            const double lo = (double)(vo.min_b[a] + cidx[a] - rho) * L;
+            const double hi = (double)(vo.min_b[a] + cidx[a] + rho + 1) * L;
+            const double margin = 1e-3 * L + 1e-6 * std::fabs(cc[a]);
+            g = std::min(g, std::min(cc[a] - lo, hi - cc[a]) - margin);
+        }
+        if (best_i != 0xFFFFFFFFu && g > 0.0 && (double)best <= g * g) break;
+    }
+    return best_i;
+}
+
+// erasor_utils::voxelize_preserving_labels (utils.cpp:80-114)
+static void voxelize_preserving_labels(const Cloud &src, Cloud &dst, double leaf, uint32_t *n_overflow = nullptr) {
+    VoxelGridOut vo;
+    voxel_grid(src, leaf, vo);
+    Cloud vox;
+    if (vo.overflow) {
+        if (n_overflow) ++*n_overflow;
+        vox = src;  // VoxelGrid returned the input unchanged
+        // every "voxel" is an input point: its nearest input point is itself or an exact duplicate
+        // with a lower index (distance 0) -> brute force would be O(n^2); use a sort to find the
+        // lowest-index exact duplicate.
+        std::vector<uint32_t> order(src.size());
+        for (uint32_t k = 0; k < src.size(); ++k) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            if (src[a].x != src[b].x) return src[a].x < src[b].x;
+            if (src[a].y != src[b].y) return src[a].y < src[b].y;
+            return src[a].z < src[b].z;
+        });
+        Cloud out(src.size());
+        size_t k = 0;
+        while (k < order.size()) {
+            size_t e = k + 1;
+            while (e < order.size() && src[order[e]].x == src[order[k]].x && src[order[e]].y == src[order[k]].y && src[order[e]].z == src[order[k]].z) ++e;
+            for (size_t t = k; t < e; ++t) {
+                out[order[t]] = src[order[t]];
+                out[order[t]].i = src[order[k]].i;  // order[k] is the lowest index of the duplicate group
+            }
+            k = e;
+        }
+        dst.swap(out);
+        return;
+    }
+    const size_t nv = vo.centroids.size();
+    std::vector<uint32_t> ukeys(nv);
+    for (size_t v = 0; v < nv; ++v) ukeys[v] = vo.sorted[vo.run_begin[v]].idx;
+    Cloud out(nv);
+    for (size_t v = 0; v < nv; ++v) {
+        const uint32_t nn = nn_index_grid(src, vo, ukeys, v);
+        out[v] = vo.centroids[v];
+        out[v].i = src[nn].i;  // utils.cpp:109
+    }
+    dst.swap(out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pcl::computeMeanAndCovarianceMatrix (PCL 1.7-1.9, float) — erasor.cpp:186
+// ---------------------------------------------------------------------------------------------
+static unsigned mean_and_cov(const Cloud &c, float cov[9], float mean[4], bool *degenerate) {
+    float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t n = c.size();
+    for (size_t k = 0; k < n; ++k) {
+        const Pt &p = c[k];
+        a[0] += p.x * p.x;
+        a[1] += p.x * p.y;
+        a[2] += p.x * p.z;
+        a[3] += p.y * p.y;
+        a[4] += p.y * p.z;
+        a[5] += p.z * p.z;
+        a[6] += p.x;
+        a[7] += p.y;
+        a[8] += p.z;
+    }
+    if (n == 0) {  // reference: outputs untouched (uninitialised).  Defined here as zeros.
+        for (int k = 0; k < 9; ++k) cov[k] = 0.f;
+        mean[0] = mean[1] = mean[2] = 0.f;
+        mean[3] = 1.f;
+        if (degenerate) *degenerate = true;
+        return 0;
+    }
+    const float fn = static_cast<float>(n);
+    for (int k = 0; k < 9; ++k) a[k] /= fn;
+    mean[0] = a[6];
+    mean[1] = a[7];
+    mean[2] = a[8];
+    mean[3] = 1.f;
+    cov[0] = a[0] - a[6] * a[6];
+    cov[1] = a[1] - a[6] * a[7];
+    cov[2] = a[2] - a[6] * a[8];
+    cov[4] = a[3] - a[7] * a[7];
+    cov[5] = a[4] - a[7] * a[8];
+    cov[8] = a[5] - a[8] * a[8];
+    cov[3] = cov[1];
+    cov[6] = cov[2];
+    cov[7] = cov[5];
+    return (unsigned)n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Eigen 3.3 JacobiSVD<MatrixXf>(3x3, ComputeFullU) — erasor.cpp:188-190.  W row-major 3x3.
+// ---------------------------------------------------------------------------------------------
+struct Rot {
+    float c, s;
+};
+static inline Rot make_jacobi(float x, float y, float z) {  // JacobiRotation::makeJacobi(x,y,z)
+    Rot r;
+    const float deno = 2.0f * std::fabs(y);
+    if (deno < std::numeric_limits<float>::min()) {
+        r.c = 1.f;
+        r.s = 0.f;
+    } else {
+        const float tau = (x - z) / deno;
+        const float w = std::sqrt(tau * tau + 1.0f);
+        float t;
+        if (tau > 0.f)
+            t = 1.0f / (tau + w);
+        else
+            t = 1.0f / (tau - w);
+        const float sign_t = t > 0.f ? 1.0f : -1.0f;
+        const float n = 1.0f / std::sqrt(t * t + 1.0f);
+        r.s = -sign_t * (y / std::fabs(y)) * std::fabs(t) * n;
+        r.c = n;
+    }
+    return r;
+}
+// apply_rotation_in_the_plane(x, y, j): x' = c*x + s*y ; y' = -s*x + c*y
+static inline void rot_apply(float &x, float &y, float c, float s) {
+    const float xi = x, yi = y;
+    x = c * xi + s * yi;
+    y = -s * xi + c * yi;
+}
+static void jacobi_svd3(const float cov[9], float U[9], float sv[3]) {
+    const float precision = 2.0f * std::numeric_limits<float>::epsilon();
+    const float considerAsZero = std::numeric_limits<float>::min();
+    float scale = 0.f;
+    for (int k = 0; k < 9; ++k) scale = std::max(scale, std::fabs(cov[k]));  // cwiseAbs().maxCoeff()
+    if (scale == 0.f) scale = 1.f;
+    float W[9];
+    for (int k = 0; k < 9; ++k) W[k] = cov[k] / scale;
+    for (int k = 0; k < 9; ++k) U[k] = (k % 4 == 0) ? 1.f : 0.f;
+    float maxDiag = std::max(std::fabs(W[0]), std::max(std::fabs(W[4]), std::fabs(W[8])));
+    bool finished = false;
+    int guard = 0;
+    while (!finished && guard++ < 1000) {
+        finished = true;
+        for (int p = 1; p < 3; ++p) {
+            for (int q = 0; q < p; ++q) {
+                const float threshold = std::max(considerAsZero, precision * maxDiag);
+                if (std::fabs(W[p * 3 + q]) > threshold || std::fabs(W[q * 3 + p]) > threshold) {
+                    finished = false;
+                    // real_2x2_jacobi_svd(W, p, q, &j_left, &j_right)
+                    float m00 = W[p * 3 + p], m01 = W[p * 3 + q], m10 = W[q * 3 + p], m11 = W[q * 3 + q];
+                    Rot rot1;
+                    const float t = m00 + m11;
+                    const float d = m10 - m01;
+                    if (std::fabs(d) < std::numeric_limits<float>::min()) {
+                        rot1.s = 0.f;
+                        rot1.c = 1.f;
+                    } else {
+                        const float u = t / d;
+                        const float tmp = std::sqrt(1.0f + u * u);
+                        rot1.s = 1.0f / tmp;
+                        rot1.c = u / tmp;
+                    }
+                    // m.applyOnTheLeft(0,1,rot1): rows 0,1 of m
+                    if (!(rot1.c == 1.f && rot1.s == 0.f)) {
+                        rot_apply(m00, m10, rot1.c, rot1.s);
+                        rot_apply(m01, m11, rot1.c, rot1.s);
+                    }
+                    const Rot jr = make_jacobi(m00, m01, m11);
+                    // j_left = rot1 * j_right.transpose();  transpose = (c, -s)
+                    const float oc = jr.c, os = -jr.s;
+                    Rot jl;
+                    jl.c = rot1.c * oc - rot1.s * os;
+                    jl.s = rot1.c * os + rot1.s * oc;
+                    // W.applyOnTheLeft(p,q,j_left): rows p,q
+                    if (!(jl.c == 1.f && jl.s == 0.f)) {
+                        for (int col = 0; col < 3; ++col) rot_apply(W[p * 3 + col], W[q * 3 + col], jl.c, jl.s);
+                        // U.applyOnTheRight(p,q,j_left.transpose()) -> rotation_in_the_plane(col p, col q, j_left)
+                        for (int row = 0; row < 3; ++row) rot_apply(U[row * 3 + p], U[row * 3 + q], jl.c, jl.s);
+                    }
+                    // W.applyOnTheRight(p,q,j_right) -> rotation_in_the_plane(col p, col q, j_right.transpose() = (c,-s))
+                    if (!(jr.c == 1.f && -jr.s == 0.f)) {
+                        for (int row = 0; row < 3; ++row) rot_apply(W[row * 3 + p], W[row * 3 + q], jr.c, -jr.s);
+                    }
+                    maxDiag = std::max(maxDiag, std::max(std::fabs(W[p * 3 + p]), std::fabs(W[q * 3 + q])));
+                }
+            }
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        const float a = W[i * 3 + i];
+        sv[i] = std::fabs(a);
+        if (a < 0.f)
+            for (int row = 0; row < 3; ++row) U[row * 3 + i] = -U[row * 3 + i];
+    }
+    for (int i = 0; i < 3; ++i) sv[i] *= scale;
+    for (int i = 0; i < 3; ++i) {  // selection sort, descending; maxCoeff = first maximum
+        int pos = 0;
+        float mx = sv[i];
+        for (int k = i + 1; k < 3; ++k)
+            if (sv[k] > mx) {
+                mx = sv[k];
+                pos = k - i;
+            }
+        if (mx == 0.f) break;
+        if (pos) {
+            pos += i;
+            std::swap(sv[i], sv[pos]);
+            for (int row = 0; row < 3; ++row) std::swap(U[row * 3 + i], U[row * 3 + pos]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ERASOR (erasor.h:43-228, erasor.cpp)
+// ---------------------------------------------------------------------------------------------
+struct Bin {  // erasor.h:24-33
+    double max_h, min_h, x, y, status;
+    bool is_occupied;
+    Cloud points;
+    std::vector<uint64_t> src;  // (oracle extra) index of each point in the pre-step map, ~0 for scan/centroid points
+};
+
+struct PlaneRec {
+    uint32_t bin;       // ring*num_sectors + sector
+    std::vector<float> normal;  // gf_iter*3
+    std::vector<double> d;      // gf_iter
+    std::vector<uint32_t> n_ground;  // per iteration
+};
+
+struct Erasor {
+    erasor_params P;
+    double ring_size, sector_size;
+    std::vector<Bin> map, curr, sel;  // index ring*S + sector
+    Cloud debug_curr_rejected, debug_map_rejected, map_complement, ground_viz;
+    std::vector<uint64_t> map_rejected_src, complement_src;
+    std::vector<PlaneRec> planes;
+    std::vector<int32_t> map_code;  // per map_voi point: bin index or -1 (complement)
+    uint32_t n_neg_sector = 0, n_degenerate_plane = 0, n_voxel_overflow = 0, n_ambiguous = 0;
+    // R-GPF state (erasor.h:191-193)
+    float normal_[3];
+    double th_dist_d_, d_;
+
+    void init(const erasor_params &p) {
+        P = p;
+        ring_size = P.max_range / P.num_rings;        // erasor.h:63
+        sector_size = 2 * PI_REF / P.num_sectors;     // erasor.h:64
+        const size_t B = (size_t)P.num_rings * P.num_sectors;
+        map.assign(B, Bin());
+        curr.assign(B, Bin());
+        sel.assign(B, Bin());
+        for (size_t b = 0; b < B; ++b) {
+            clear_bin(map[b]);
+            clear_bin(curr[b]);
+            clear_bin(sel[b]);
+        }
+    }
+    static void clear_bin(Bin &b) {  // erasor.cpp:44-52
+        b.max_h = -INF_H;
+        b.min_h = INF_H;
+        b.x = 0;
+        b.y = 0;
+        b.is_occupied = false;
+        b.status = ERASOR_ST_LITTLE_NUM;
+        b.points.clear();
+        b.src.clear();
+    }
+    inline size_t bi(int r, int theta) const { return (size_t)r * P.num_sectors + theta; }
+
+    static double xy2theta(double x, double y) {  // erasor.cpp:11-17
+        if (y >= 0) return atan2(y, x);
+        return 2 * PI_REF + atan2(y, x);
+    }
+    static double xy2radius(double x, double y) { return sqrt(x * x + y * y); }  // erasor.cpp:19-21 (pow(.,2) == exact square)
+
+    // returns bin index, -1 if the point fails a gate (erasor.cpp:104-110)
+    int bin_of(const Pt &pt) {
+        if (pt.z < P.max_h && pt.z > P.min_h) {
+            const double r = xy2radius(pt.x, pt.y);
+            if (r <= P.max_range) {
+                const double theta = xy2theta(pt.x, pt.y);
+                const double q = theta / sector_size;
+                if (q != 0.0 && std::fabs(q - std::nearbyint(q)) < 1e-11) ++n_ambiguous;  // q == 0: atan2(+-0, x>0) is exact everywhere
+                int sector_idx = std::min(static_cast<int>(q), P.num_sectors - 1);
+                const int ring_idx = std::min(static_cast<int>(r / ring_size), P.num_rings - 1);
+                if (sector_idx < 0) {  // reference: vector::at throws std::out_of_range
+                    sector_idx = 0;
+                    ++n_neg_sector;
+                }
+                return ring_idx * P.num_sectors + sector_idx;
+            }
+        }
+        return -1;
+    }
+    static void pt2r_pod(const Pt &pt, uint64_t src, Bin &bin) {  // erasor.cpp:87-98
+        bin.is_occupied = true;
+        bin.points.push_back(pt);
+        bin.src.push_back(src);
+        if (pt.z >= bin.max_h) {
+            bin.max_h = pt.z;
+            bin.x = pt.x;
+            bin.y = pt.y;
+        }
+        if (pt.z <= bin.min_h) bin.min_h = pt.z;
+    }
+
+    // erasor.cpp:57-85
+    void set_inputs(const Cloud &map_voi, const std::vector<uint64_t> &map_src, const Cloud &query_voi) {
+        debug_curr_rejected.clear();
+        debug_map_rejected.clear();
+        map_rejected_src.clear();
+        map_complement.clear();
+        complement_src.clear();
+        planes.clear();
+        for (size_t b = 0; b < map.size(); ++b) {
+            clear_bin(map[b]);
+            clear_bin(curr[b]);
+            clear_bin(sel[b]);
+        }
+        for (const Pt &pt : query_voi) {  // erasor.cpp:100-115 (failing points are dropped)
+            const int b = bin_of(pt);
+            if (b >= 0) pt2r_pod(pt, ~0ull, curr[b]);
+        }
+        map_code.assign(map_voi.size(), -1);
+        for (size_t k = 0; k < map_voi.size(); ++k) {  // erasor.cpp:124-139
+            const Pt &pt = map_voi[k];
+            const int b = bin_of(pt);
+            map_code[k] = b;
+            if (b >= 0)
+                pt2r_pod(pt, map_src[k], map[b]);
+            else {
+                map_complement.push_back(pt);
+                complement_src.push_back(map_src[k]);
+            }
+        }
+    }
+
+    // erasor.cpp:183-198
+    void estimate_plane_(const Cloud &ground) {
+        float cov[9], mean[4], U[9], sv[3];
+        bool degenerate = false;
+        mean_and_cov(ground, cov, mean, &degenerate);
+        if (degenerate) ++n_degenerate_plane;
+        jacobi_svd3(cov, U, sv);
+        normal_[0] = U[0 * 3 + 2];
+        normal_[1] = U[1 * 3 + 2];
+        normal_[2] = U[2 * 3 + 2];
+        const float dot = (normal_[0] * mean[0] + normal_[1] * mean[1]) + normal_[2] * mean[2];  // float 1x3 * 3x1
+        d_ = -dot;
+        th_dist_d_ = P.gf_dist_thr - d_;
+    }
+
+    // erasor.cpp:204-231
+    void extract_initial_seeds_(const Cloud &p_sorted, Cloud &init_seeds) {
+        init_seeds.clear();
+        double sum = 0;
+        int cnt = 0;
+        // reference: `int i = num_lowest_pts; i < size()` compares as unsigned -> a negative start never enters the loop
+        if (P.num_lowest_pts >= 0)
+            for (size_t i = (size_t)P.num_lowest_pts; i < p_sorted.size() && cnt < P.gf_num_lpr; i++) {
+                sum += p_sorted[i].z;
+                cnt++;
+            }
+        const double lpr_height = cnt != 0 ? sum / cnt : 0;
+        for (size_t i = 0; i < p_sorted.size(); i++)
+            if (p_sorted[i].z < lpr_height + P.gf_th_seeds_height) init_seeds.push_back(p_sorted[i]);
+    }
+
+    // erasor.cpp:233-294.  ground_idx/nonground_idx: positions in src.
+    void extract_ground(const Cloud &src, std::vector<uint32_t> &ground_idx, std::vector<uint32_t> &nonground_idx, PlaneRec &rec) {
+        ground_idx.clear();
+        nonground_idx.clear();
+        Cloud src_copy = src;
+        std::sort(src_copy.begin(), src_copy.end(), [](Pt a, Pt b) { return a.z < b.z; });  // erasor.cpp:200-202,240
+        size_t drop = 0;  // erasor.cpp:242-251
+        for (size_t i = 0; i < src_copy.size(); i++) {
+            if (src_copy[i].z < P.min_h)
+                drop++;
+            else
+                break;
+        }
+        src_copy.erase(src_copy.begin(), src_copy.begin() + drop);
+        Cloud ground_pc;
+        extract_initial_seeds_(src_copy, ground_pc);
+        for (int i = 0; i < P.gf_iter; i++) {
+            estimate_plane_(ground_pc);
+            rec.normal.push_back(normal_[0]);
+            rec.normal.push_back(normal_[1]);
+            rec.normal.push_back(normal_[2]);
+            rec.d.push_back(d_);
+            ground_pc.clear();
+            ground_idx.clear();
+            for (size_t r = 0; r < src.size(); r++) {
+                // Eigen (N x 3) * (3 x 1), float32: (x*n0 + y*n1) + z*n2
+                const float result = (src[r].x * normal_[0] + src[r].y * normal_[1]) + src[r].z * normal_[2];
+                if (result < th_dist_d_) {
+                    ground_pc.push_back(src[r]);
+                    ground_idx.push_back((uint32_t)r);
+                } else if (i == P.gf_iter - 1) {
+                    nonground_idx.push_back((uint32_t)r);
+                }
+            }
+            rec.n_ground.push_back((uint32_t)ground_pc.size());
+        }
+    }
+
+    void revert_common(size_t b, bool voxelize) {
+        // selected = bin_curr (copy incl. is_occupied, min/max) — erasor.cpp:384 / 512
+        const Bin &bin_map = map[b];
+        sel[b] = curr[b];
+        sel[b].status = ERASOR_ST_MAP_IS_HIGHER;
+        std::vector<uint32_t> gi, ngi;
+        PlaneRec rec;
+        rec.bin = (uint32_t)b;
+        extract_ground(bin_map.points, gi, ngi, rec);
+        planes.push_back(rec);
+        for (uint32_t k : gi) {  // selected.points += piecewise_ground_
+            sel[b].points.push_back(bin_map.points[k]);
+            sel[b].src.push_back(bin_map.src[k]);
+        }
+        if (voxelize) {  // erasor.cpp:526-528
+            Cloud tmp = sel[b].points;
+            voxelize_preserving_labels(tmp, sel[b].points, P.map_voxel_size, &n_voxel_overflow);
+            sel[b].src.assign(sel[b].points.size(), ~0ull);
+        }
+        for (uint32_t k : gi) ground_viz.push_back(bin_map.points[k]);
+        for (uint32_t k : ngi) {
+            debug_map_rejected.push_back(bin_map.points[k]);
+            map_rejected_src.push_back(bin_map.src[k]);
+        }
+    }
+
+    // Version 2 — erasor.cpp:332-434
+    void compare_vois_and_revert_ground() {
+        ground_viz.clear();
+        for (int theta = 0; theta < P.num_sectors; theta++) {
+            for (int r = 0; r < P.num_rings; r++) {
+                const size_t b = bi(r, theta);
+                Bin &bin_curr = curr[b];
+                Bin &bin_map = map[b];
+                if ((int64_t)bin_curr.points.size() < (int64_t)P.minimum_num_pts) {
+                    sel[b] = bin_map;
+                    continue;
+                }
+                if (bin_curr.is_occupied && bin_map.is_occupied) {
+                    const double map_h_diff = bin_map.max_h - bin_map.min_h;
+                    const double curr_h_diff = bin_curr.max_h - bin_curr.min_h;
+                    const double scan_ratio = std::min(map_h_diff / curr_h_diff, curr_h_diff / map_h_diff);
+                    if (scan_ratio < P.scan_ratio_threshold) {
+                        if (map_h_diff >= curr_h_diff) {
+                            if (bin_map.max_h > P.th_bin_max_h) {
+                                revert_common(b, false);
+                            } else {
+                                sel[b] = bin_map;
+                            }
+                            sel[b].status = ERASOR_ST_MAP_IS_HIGHER;
+                        } else if (map_h_diff <= curr_h_diff) {
+                            sel[b] = bin_map;
+                            sel[b].status = ERASOR_ST_CURR_IS_HIGHER;
+                            if (bin_curr.max_h > P.th_bin_max_h)
+                                for (const Pt &p : bin_curr.points) debug_curr_rejected.push_back(p);
+                        }
+                    } else {
+                        Bin merged;  // merge_bins(bin_curr, bin_map, merged) — erasor.cpp:296-307
+                        clear_bin(merged);
+                        merged.max_h = std::max(bin_curr.max_h, bin_map.max_h);
+                        merged.min_h = std::min(bin_curr.min_h, bin_map.min_h);
+                        merged.is_occupied = true;
+                        merged.points = bin_curr.points;
+                        merged.src = bin_curr.src;
+                        merged.points.insert(merged.points.end(), bin_map.points.begin(), bin_map.points.end());
+                        merged.src.insert(merged.src.end(), bin_map.src.begin(), bin_map.src.end());
+                        sel[b] = merged;
+                        sel[b].status = ERASOR_ST_MERGE_BINS;
+                    }
+                } else if (bin_curr.is_occupied) {
+                    sel[b] = bin_curr;
+                } else if (bin_map.is_occupied) {
+                    sel[b] = bin_map;
+                }
+            }
+        }
+    }
+
+    // erasor.cpp:573-595 (theta wrap uses num_rings — reference quirk, kept)
+    bool is_dynamic_obj_close(int r_target, int theta_target, int r_range, int theta_range) {
+        std::vector<int> theta_candidates;
+        for (int j = theta_target - theta_range; j <= theta_target + theta_range; j++) {
+            if (j < 0)
+                theta_candidates.push_back(j + P.num_rings);
+            else if (j >= P.num_sectors)
+                theta_candidates.push_back(j - P.num_rings);
+            else
+                theta_candidates.push_back(j);
+        }
+        for (int r = std::max(0, r_target - r_range); r <= std::min(r_target + r_range, P.num_rings - 1); r++) {
+            for (int theta : theta_candidates) {
+                if ((r == r_target) && (theta == theta_target)) continue;
+                if (theta < 0 || theta >= P.num_sectors) continue;  // reference: out-of-bounds operator[] (UB) when num_rings > num_sectors
+                if (sel[bi(r, theta)].status == ERASOR_ST_CURR_IS_HIGHER) return true;
+            }
+        }
+        return false;
+    }
+
+    // Version 3 — erasor.cpp:438-571
+    void compare_vois_and_revert_ground_w_block() {
+        ground_viz.clear();
+        for (int theta = 0; theta < P.num_sectors; theta++) {  // 1. status (erasor.cpp:448-486)
+            for (int r = 0; r < P.num_rings; r++) {
+                const size_t b = bi(r, theta);
+                Bin &bin_curr = curr[b];
+                Bin &bin_map = map[b];
+                if (bin_map.points.empty()) {
+                    sel[b].status = ERASOR_ST_LITTLE_NUM;
+                    continue;
+                }
+                if ((int64_t)bin_curr.points.size() < (int64_t)P.minimum_num_pts) {
+                    sel[b].status = ERASOR_ST_LITTLE_NUM;
+                } else {
+                    const double map_h_diff = bin_map.max_h - bin_map.min_h;
+                    const double curr_h_diff = bin_curr.max_h - bin_curr.min_h;
+                    const double scan_ratio = std::min(map_h_diff / curr_h_diff, curr_h_diff / map_h_diff);
+                    if (bin_curr.is_occupied && bin_map.is_occupied) {
+                        if (scan_ratio < P.scan_ratio_threshold) {
+                            if (map_h_diff >= curr_h_diff)
+                                sel[b].status = ERASOR_ST_MAP_IS_HIGHER;
+                            else if (map_h_diff <= curr_h_diff)
+                                sel[b].status = ERASOR_ST_CURR_IS_HIGHER;
+                        } else {
+                            sel[b].status = ERASOR_ST_MERGE_BINS;
+                        }
+                    } else if (bin_map.is_occupied) {
+                        sel[b].status = ERASOR_ST_LITTLE_NUM;
+                    }
+                }
+            }
+        }
+        for (int theta = 0; theta < P.num_sectors; theta++) {  // 2. set bins (erasor.cpp:493-563)
+            for (int r = 0; r < P.num_rings; r++) {
+                const size_t b = bi(r, theta);
+                Bin &bin_map = map[b];
+                const double st = sel[b].status;
+                if (st == ERASOR_ST_LITTLE_NUM) {
+                    sel[b] = bin_map;
+                    sel[b].status = ERASOR_ST_LITTLE_NUM;
+                } else if (st == ERASOR_ST_MAP_IS_HIGHER) {
+                    if ((bin_map.max_h - bin_map.min_h) > 0.5) {
+                        revert_common(b, true);
+                    } else {
+                        sel[b] = bin_map;
+                        sel[b].status = ERASOR_ST_LITTLE_NUM;  // NOT_ASSIGNED
+                    }
+                } else if (st == ERASOR_ST_CURR_IS_HIGHER) {
+                    sel[b] = bin_map;
+                    sel[b].status = ERASOR_ST_CURR_IS_HIGHER;
+                } else if (st == ERASOR_ST_MERGE_BINS) {
+                    const bool blocked = is_dynamic_obj_close(r, theta, 1, 1);
+                    sel[b] = bin_map;
+                    sel[b].status = blocked ? ERASOR_ST_BLOCKED : ERASOR_ST_MERGE_BINS;
+                }
+            }
+        }
+    }
+
+    // erasor.cpp:309-320, 612-626
+    void get_static_estimate(Cloud &arranged, std::vector<uint64_t> &arranged_src) {
+        arranged.clear();
+        arranged_src.clear();
+        for (int theta = 0; theta < P.num_sectors; theta++)
+            for (int r = 0; r < P.num_rings; r++) {
+                const Bin &b = sel[bi(r, theta)];
+                if (b.is_occupied) {
+                    arranged.insert(arranged.end(), b.points.begin(), b.points.end());
+                    arranged_src.insert(arranged_src.end(), b.src.begin(), b.src.end());
+                }
+            }
+        arranged.insert(arranged.end(), ground_viz.begin(), ground_viz.end());
+        arranged_src.insert(arranged_src.end(), ground_viz.size(), ~0ull);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// OfflineMapUpdater hot path (OMU.cpp:237-294), non-large-scale mode
+// ---------------------------------------------------------------------------------------------
+struct Updater {
+    erasor_params P;
+    Erasor er;
+    Cloud map_arranged;
+    // last-step products
+    Cloud query_voi, map_voi, map_outskirts, static_estimate, complement, map_rejected, curr_rejected, ground_viz;
+    std::vector<uint64_t> voi_src, rejected_src;
+    erasor_step_result res;
+    double t_voi = 0, t_erasor = 0, t_step = 0;
+    std::string err;
+
+    void step(const Cloud &scan, const float T_l2b[16], const float T_b2o[16], const float T_o2b[16]) {
+        memset(&res, 0, sizeof(res));
+        er.n_neg_sector = er.n_degenerate_plane = er.n_voxel_overflow = er.n_ambiguous = 0;
+        res.n_map_in = map_arranged.size();
+        // 1. query (OMU.cpp:237-241)
+        Cloud q_vox;
+        voxelize_preserving_labels(scan, q_vox, P.query_voxel_size, &er.n_voxel_overflow);
+        transform_cloud(q_vox, query_voi, T_l2b);
+        // 2. fetch_VoI (OMU.cpp:246-254, 381-438)
+        const double x_c = T_b2o[3], y_c = T_b2o[7];
+        const double R = (P.voi_max_range > 0 ? P.voi_max_range : P.max_range);
+        const double max_dist_square = R * R;  // pow(max_range_ + margin, 2), margin = 0
+        Cloud voi_wrt_origin;
+        voi_src.clear();
+        map_outskirts.clear();
+        for (size_t k = 0; k < map_arranged.size(); ++k) {
+            const Pt &pt = map_arranged[k];
+            const double dxx = pt.x - x_c, dyy = pt.y - y_c;
+            const double dist_square = dxx * dxx + dyy * dyy;
+            if (dist_square < max_dist_square) {
+                voi_wrt_origin.push_back(pt);
+                voi_src.push_back(k);
+            } else {
+                map_outskirts.push_back(pt);
+            }
+        }
+        transform_cloud(voi_wrt_origin, map_voi, T_o2b);
+        // 3. ERASOR (OMU.cpp:266-272)
+        er.set_inputs(map_voi, voi_src, query_voi);
+        if (P.version == 2)
+            er.compare_vois_and_revert_ground();
+        else
+            er.compare_vois_and_revert_ground_w_block();
+        std::vector<uint64_t> arranged_src;
+        er.get_static_estimate(static_estimate, arranged_src);
+        complement = er.map_complement;
+        ground_viz = er.ground_viz;
+        // 4. write-back (OMU.cpp:281-290)
+        Cloud map_filtered = static_estimate;
+        map_filtered.insert(map_filtered.end(), complement.begin(), complement.end());
+        transform_cloud(map_filtered, map_filtered, T_b2o);
+        transform_cloud(er.debug_map_rejected, map_rejected, T_b2o);
+        transform_cloud(er.debug_curr_rejected, curr_rejected, T_b2o);
+        rejected_src = er.map_rejected_src;
+        map_arranged = map_filtered;
+        map_arranged.insert(map_arranged.end(), map_outskirts.begin(), map_outskirts.end());
+        // 5. parse_dynamic_obj counters (OMU.cpp:294)
+        uint64_t ns = 0, nd = 0;
+        for (const Pt &p : map_arranged) (is_dynamic_label(p.i) ? nd : ns)++;
+        res.n_voi = map_voi.size();
+        res.n_outskirts = map_outskirts.size();
+        res.n_query = query_voi.size();
+        res.n_static_estimate = static_estimate.size();
+        res.n_complement = complement.size();
+        res.n_map_rejected = map_rejected.size();
+        res.n_curr_rejected = curr_rejected.size();
+        res.n_ground = ground_viz.size();
+        res.n_map_out = map_arranged.size();
+        res.n_static = ns;
+        res.n_dynamic = nd;
+        res.n_reverted_bins = (uint32_t)er.planes.size();
+        res.n_neg_sector = er.n_neg_sector;
+        res.n_ambiguous = er.n_ambiguous;
+        res.n_degenerate_plane = er.n_degenerate_plane;
+        res.n_voxel_overflow = er.n_voxel_overflow;
+    }
+};
+
+}  // namespace orc
+
+// =================================================================================================
+// C API for ctypes (tests / bench cpu_baseline)
+// =================================================================================================
+using namespace orc;
+
+static void to_cloud(const float *xyzi, size_t n, Cloud &c) {
+    c.resize(n);
+    if (n) memcpy(c.data(), xyzi, n * sizeof(Pt));
+}
+static int from_cloud(const Cloud &c, float *dst, size_t cap, size_t *n) {
+    if (n) *n = c.size();
+    if (!dst) return 0;
+    if (c.size() > cap) return ERASOR_E_CAPACITY;
+    if (!c.empty()) memcpy(dst, c.data(), c.size() * sizeof(Pt));
+    return 0;
+}
+
+extern "C" {
+
+void orc_params_default(erasor_params *p) {
+    memset(p, 0, sizeof(*p));
+    p->max_range = 10.0;
+    p->num_rings = 20;
+    p->num_sectors = 60;
+    p->max_h = 3.0;
+    p->min_h = 0.0;
+    p->th_bin_max_h = 0.39;
+    p->scan_ratio_threshold = 0.22;
+    p->num_lowest_pts = 5;
+    p->minimum_num_pts = 4;
+    p->rejection_ratio = 0.33;
+    p->gf_dist_thr = 0.05;
+    p->gf_iter = 3;
+    p->gf_num_lpr = 10;
+    p->gf_th_seeds_height = 0.5;
+    p->map_voxel_size = 0.2;
+    p->version = 3;
+    p->query_voxel_size = 0.05;
+    p->removal_interval = 2;
+    p->voi_max_range = 0.0;
+}
+
+void orc_geopose2eigen(const double pose7[7], float T[16]) { geoPose2eigen(pose7, T); }
+int orc_invert4(const float T[16], float Ti[16]) { return invert4(T, Ti); }
+
+void orc_transform(const float *src, size_t n, const float T[16], float *dst) {
+    for (size_t k = 0; k < n; ++k) {
+        Pt p;
+        memcpy(&p, src + 4 * k, sizeof(Pt));
+        Pt o = transform_pt(p, T);
+        memcpy(dst + 4 * k, &o, sizeof(Pt));
+    }
+}
+
+int orc_voxelize_preserving_labels(const float *src, size_t n, double leaf, float *dst, size_t cap, size_t *n_out) {
+    Cloud in, out;
+    to_cloud(src, n, in);
+    voxelize_preserving_labels(in, out, leaf);
+    return from_cloud(out, dst, cap, n_out);
+}
+
+// raw VoxelGrid (centroids with averaged intensity) + the std::sort permutation
+int orc_voxel_grid(const float *src, size_t n, double leaf, float *dst, size_t cap, size_t *n_out, uint32_t *sorted_pi /*n or null*/,
+                   uint32_t *sorted_idx /*n or null*/) {
+    Cloud in;
+    to_cloud(src, n, in);
+    VoxelGridOut vo;
+    voxel_grid(in, leaf, vo);
+    if (vo.overflow) {
+        if (n_out) *n_out = n;
+        return 1;
+    }
+    for (size_t k = 0; k < vo.sorted.size(); ++k) {
+        if (sorted_pi) sorted_pi[k] = vo.sorted[k].pi;
+        if (sorted_idx) sorted_idx[k] = vo.sorted[k].idx;
+    }
+    return from_cloud(vo.centroids, dst, cap, n_out);
+}
+
+// std::sort permutation of (key,payload) pairs compared on key only — pins the device introsort emulation
+void orc_std_sort_u32(uint32_t *keys, uint32_t *vals, size_t n) {
+    std::vector<IdxPair> v(n);
+    for (size_t k = 0; k < n; ++k) {
+        v[k].idx = keys[k];
+        v[k].pi = vals[k];
+    }
+    std::sort(v.begin(), v.end(), std::less<IdxPair>());
+    for (size_t k = 0; k < n; ++k) {
+        keys[k] = v[k].idx;
+        vals[k] = v[k].pi;
+    }
+}
+// std::sort of points by z (erasor.cpp:240); returns the permutation (payload = original index)
+void orc_std_sort_z(const float *xyzi, size_t n, uint32_t *perm) {
+    struct PZ {
+        Pt p;
+        uint32_t i;
+    };
+    std::vector<PZ> v(n);
+    for (size_t k = 0; k < n; ++k) {
+        memcpy(&v[k].p, xyzi + 4 * k, sizeof(Pt));
+        v[k].i = (uint32_t)k;
+    }
+    std::sort(v.begin(), v.end(), [](PZ a, PZ b) { return a.p.z < b.p.z; });
+    for (size_t k = 0; k < n; ++k) perm[k] = v[k].i;
+}
+
+void orc_mean_and_cov(const float *xyzi, size_t n, float cov[9], float mean[4]) {
+    Cloud c;
+    to_cloud(xyzi, n, c);
+    mean_and_cov(c, cov, mean, nullptr);
+}
+void orc_jacobi_svd3(const float cov[9], float U[9], float sv[3]) { jacobi_svd3(cov, U, sv); }
+
+// bin index of one point (ring*S+sector, or -1)
+int orc_bin_of(const erasor_params *p, float x, float y, float z) {
+    Erasor e;
+    e.init(*p);
+    Pt pt = {x, y, z, 0.f};
+    return e.bin_of(pt);
+}
+double orc_xy2theta(double x, double y) { return Erasor::xy2theta(x, y); }
+
+// R-GPF on one bin's points (erasor.cpp:233-294).  ground_mask[n]: 1 = ground after the last iteration.
+int orc_extract_ground(const erasor_params *p, const float *xyzi, size_t n, uint8_t *ground_mask, float *normals /*gf_iter*3*/,
+                       double *ds /*gf_iter*/, uint32_t *n_degenerate) {
+    Erasor e;
+    e.init(*p);
+    Cloud c;
+    to_cloud(xyzi, n, c);
+    std::vector<uint32_t> gi, ngi;
+    PlaneRec rec;
+    e.extract_ground(c, gi, ngi, rec);
+    memset(ground_mask, 0, n);
+    for (uint32_t k : gi) ground_mask[k] = 1;
+    for (size_t k = 0; k < rec.normal.size(); ++k) normals[k] = rec.normal[k];
+    for (size_t k = 0; k < rec.d.size(); ++k) ds[k] = rec.d[k];
+    if (n_degenerate) *n_degenerate = e.n_degenerate_plane;
+    return 0;
+}
+
+// ---- full updater ----
+void *orc_create(const erasor_params *p) {
+    if (!p || p->num_rings <= 0 || p->num_sectors <= 0) return nullptr;
+    Updater *u = new Updater();
+    u->P = *p;
+    u->er.init(*p);
+    memset(&u->res, 0, sizeof(u->res));
+    return u;
+}
+void orc_destroy(void *h) { delete (Updater *)h; }
+int orc_set_map(void *h, const float *xyzi, size_t n) {
+    to_cloud(xyzi, n, ((Updater *)h)->map_arranged);
+    return 0;
+}
+int orc_step(void *h, const float *scan, size_t n, const float T_l2b[16], const float T_b2o[16], const float T_o2b[16], erasor_step_result *res) {
+    Updater *u = (Updater *)h;
+    if (u->P.version != 2 && u->P.version != 3) return ERASOR_E_UNSUPPORTED;  // OMU.cpp:273-275
+    Cloud s;
+    to_cloud(scan, n, s);
+    u->step(s, T_l2b, T_b2o, T_o2b);
+    if (res) *res = u->res;
+    return 0;
+}
+int orc_map_size(void *h, size_t *n) {
+    *n = ((Updater *)h)->map_arranged.size();
+    return 0;
+}
+int orc_get_map(void *h, float *dst, size_t cap, size_t *n) { return from_cloud(((Updater *)h)->map_arranged, dst, cap, n); }
+int orc_get_cloud(void *h, int which, float *dst, size_t cap, size_t *n) {
+    Updater *u = (Updater *)h;
+    switch (which) {
+        case ERASOR_CLOUD_QUERY_VOI: return from_cloud(u->query_voi, dst, cap, n);
+        case ERASOR_CLOUD_MAP_VOI: return from_cloud(u->map_voi, dst, cap, n);
+        case ERASOR_CLOUD_STATIC_ESTIMATE: return from_cloud(u->static_estimate, dst, cap, n);
+        case ERASOR_CLOUD_COMPLEMENT: return from_cloud(u->complement, dst, cap, n);
+        case ERASOR_CLOUD_MAP_REJECTED: return from_cloud(u->map_rejected, dst, cap, n);
+        case ERASOR_CLOUD_CURR_REJECTED: return from_cloud(u->curr_rejected, dst, cap, n);
+        case ERASOR_CLOUD_GROUND_VIZ: return from_cloud(u->ground_viz, dst, cap, n);
+        case ERASOR_CLOUD_MAP: return from_cloud(u->map_arranged, dst, cap, n);
+    }
+    return ERASOR_E_INVALID;
+}
+int orc_get_rejected_indices(void *h, uint64_t *dst, size_t cap, size_t *n) {
+    Updater *u = (Updater *)h;
+    if (n) *n = u->rejected_src.size();
+    if (!dst) return 0;
+    if (u->rejected_src.size() > cap) return ERASOR_E_CAPACITY;
+    for (size_t k = 0; k < u->rejected_src.size(); ++k) dst[k] = u->rejected_src[k];
+    return 0;
+}
+int orc_get_bins(void *h, int which, uint32_t *count, double *min_h, double *max_h) {
+    Updater *u = (Updater *)h;
+    const std::vector<Bin> &v = which == 0 ? u->er.map : u->er.curr;
+    for (size_t b = 0; b < v.size(); ++b) {
+        count[b] = (uint32_t)v[b].points.size();
+        min_h[b] = v[b].min_h;
+        max_h[b] = v[b].max_h;
+    }
+    return 0;
+}
+int orc_get_status(void *h, double *status) {
+    Updater *u = (Updater *)h;
+    for (size_t b = 0; b < u->er.sel.size(); ++b) status[b] = u->er.sel[b].status;
+    return 0;
+}
+int orc_get_planes(void *h, uint32_t *bin_index, float *normal, double *d, size_t cap_bins, size_t *n_bins) {
+    Updater *u = (Updater *)h;
+    const size_t nb = u->er.planes.size();
+    if (n_bins) *n_bins = nb;
+    if (!bin_index) return 0;
+    if (nb > cap_bins) return ERASOR_E_CAPACITY;
+    const int it = u->P.gf_iter;
+    for (size_t k = 0; k < nb; ++k) {
+        bin_index[k] = u->er.planes[k].bin;
+        for (int i = 0; i < it; ++i) {
+            for (int a = 0; a < 3; ++a) normal[(k * it + i) * 3 + a] = u->er.planes[k].normal[i * 3 + a];
+            d[k * it + i] = u->er.planes[k].d[i];
+        }
+    }
+    return 0;
+}
+// per map_voi point bin code (ring*S+sector, -1 = complement) and pre-step index
+int orc_get_voi_codes(void *h, int32_t *code, uint64_t *src, size_t cap, size_t *n) {
+    Updater *u = (Updater *)h;
+    if (n) *n = u->er.map_code.size();
+    if (!code) return 0;
+    if (u->er.map_code.size() > cap) return ERASOR_E_CAPACITY;
+    for (size_t k = 0; k < u->er.map_code.size(); ++k) {
+        code[k] = u->er.map_code[k];
+        if (src) src[k] = u->voi_src[k];
+    }
+    return 0;
+}
+
+}  // extern "C"
