@@ -1,0 +1,258 @@
+"""erasor_amd — MI355X-native ERASOR hot path.
+
+The product is `liberasor_hip.so` (hand-written HIP for gfx950, C ABI in include/erasor_hip.h) plus the
+C++ shim in erasor_amd/csrc/shim (reference-compatible ERASOR / OfflineMapUpdater / erasor_utils
+surface).  This Python package is plumbing only: a ctypes binding used by tests, bench.py and
+__graft_entry__.py.  There is no CPU fallback: if the HIP library or a GPU is missing, calls fail loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liberasor_hip.so")
+_SRC_DIR = os.path.join(_HERE, "csrc")
+
+
+class Params(C.Structure):
+    """erasor_params (include/erasor_hip.h) — the reference's rosparam names (erasor.h:47-61, OMU.cpp:66-83)."""
+    _fields_ = [
+        ("max_range", C.c_double), ("num_rings", C.c_int32), ("num_sectors", C.c_int32),
+        ("max_h", C.c_double), ("min_h", C.c_double), ("th_bin_max_h", C.c_double),
+        ("scan_ratio_threshold", C.c_double), ("num_lowest_pts", C.c_int32),
+        ("minimum_num_pts", C.c_int32), ("rejection_ratio", C.c_double),
+        ("gf_dist_thr", C.c_double), ("gf_iter", C.c_int32), ("gf_num_lpr", C.c_int32),
+        ("gf_th_seeds_height", C.c_double), ("map_voxel_size", C.c_double),
+        ("version", C.c_int32), ("query_voxel_size", C.c_double),
+        ("removal_interval", C.c_int32), ("voi_max_range", C.c_double),
+        ("reserved_", C.c_int32 * 7),
+    ]
+
+
+class StepResult(C.Structure):
+    """erasor_step_result (include/erasor_hip.h)"""
+    _fields_ = [(k, C.c_uint64) for k in (
+        "n_map_in", "n_voi", "n_outskirts", "n_query", "n_static_estimate", "n_complement",
+        "n_map_rejected", "n_curr_rejected", "n_ground", "n_map_out", "n_static", "n_dynamic")] + [
+        (k, C.c_uint32) for k in (
+            "n_reverted_bins", "n_neg_sector", "n_ambiguous", "n_degenerate_plane",
+            "n_voxel_overflow", "n_sort_fallback")] + [("reserved_", C.c_uint32 * 6)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved_"}
+
+
+CLOUD_QUERY_VOI, CLOUD_MAP_VOI, CLOUD_STATIC_ESTIMATE, CLOUD_COMPLEMENT = 0, 1, 2, 3
+CLOUD_MAP_REJECTED, CLOUD_CURR_REJECTED, CLOUD_GROUND_VIZ, CLOUD_MAP = 4, 5, 6, 7
+
+E_NO_DEVICE = -2
+
+
+class ErasorError(RuntimeError):
+    def __init__(self, rc, msg):
+        super().__init__("erasor_hip rc=%d: %s" % (rc, msg))
+        self.rc = rc
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 … -shared -> erasor_amd/liberasor_hip.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_SRC_DIR, f) for f in ("erasor_hip.hip", "kernels.hip.h", "exact_sort.hip.h", "exact_sort_core.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "erasor_hip.h"))
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-C", _SRC_DIR, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load liberasor_hip.so.  Raises if it has not been built — there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ErasorError(E_NO_DEVICE, "liberasor_hip.so missing: run erasor_amd.build() (hipcc) first; no CPU fallback exists")
+        l = C.CDLL(LIB_PATH)
+        l.erasor_hip_version.restype = C.c_char_p
+        l.erasor_hip_last_error.restype = C.c_char_p
+        l.erasor_hip_last_error.argtypes = [C.c_void_p]
+        l.erasor_hip_stream.restype = C.c_void_p
+        l.erasor_hip_stream.argtypes = [C.c_void_p]
+        l.erasor_hip_destroy.argtypes = [C.c_void_p]
+        l.erasor_hip_destroy.restype = None
+        _lib = l
+    return _lib
+
+
+def params_default():
+    p = Params()
+    rc = lib().erasor_hip_params_default(C.byref(p))
+    assert rc == 0
+    return p
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def invert_rigid(T):
+    """T_origin2body from T_body2origin: general 4x4 inverse in float64, narrowed to float32 (the caller owns this
+    choice — the reference's Eigen SSE inverse (OMU.cpp:436) is not bit-reproducible across CPUs)."""
+    T = np.asarray(T, np.float32).reshape(4, 4).astype(np.float64)
+    return np.linalg.inv(T).astype(np.float32).reshape(16)
+
+
+class Erasor:
+    """Handle of the HIP hot path (one GPU, one stream)."""
+
+    def __init__(self, params, device=0):
+        self.params = params
+        self.B = params.num_rings * params.num_sectors
+        self._h = C.c_void_p()
+        rc = lib().erasor_hip_create(C.byref(params), C.c_int(device), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise ErasorError(rc, "erasor_hip_create failed (no GPU / invalid parameters)")
+
+    # -- lifetime --
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().erasor_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ErasorError(rc, (lib().erasor_hip_last_error(self._h) or b"").decode())
+
+    # -- map --
+    def set_map(self, cloud):
+        cloud = _f32(cloud).reshape(-1, 4)
+        self._check(lib().erasor_hip_set_map(self._h, _p(cloud), C.c_size_t(len(cloud))))
+
+    def set_map_device(self, dptr, n):
+        self._check(lib().erasor_hip_set_map_device(self._h, C.c_void_p(dptr), C.c_size_t(n)))
+
+    def map_size(self):
+        n = C.c_size_t(0)
+        self._check(lib().erasor_hip_map_size(self._h, C.byref(n)))
+        return n.value
+
+    def get_map(self):
+        return self.get_cloud(CLOUD_MAP)
+
+    # -- step --
+    def step(self, scan, T_l2b, T_b2o, T_o2b):
+        scan = _f32(scan).reshape(-1, 4)
+        res = StepResult()
+        self._check(lib().erasor_hip_step(self._h, _p(scan), C.c_size_t(len(scan)), _p(_f32(T_l2b).reshape(16)),
+                                          _p(_f32(T_b2o).reshape(16)), _p(_f32(T_o2b).reshape(16)), C.byref(res)))
+        return res
+
+    def step_device(self, dptr, n, T_l2b, T_b2o, T_o2b):
+        res = StepResult()
+        self._check(lib().erasor_hip_step_device(self._h, C.c_void_p(dptr), C.c_size_t(n), _p(_f32(T_l2b).reshape(16)),
+                                                 _p(_f32(T_b2o).reshape(16)), _p(_f32(T_o2b).reshape(16)), C.byref(res)))
+        return res
+
+    # -- read-back --
+    def get_cloud(self, which):
+        n = C.c_size_t(0)
+        self._check(lib().erasor_hip_get_cloud(self._h, which, None, C.c_size_t(0), C.byref(n)))
+        out = np.empty((n.value, 4), np.float32)
+        self._check(lib().erasor_hip_get_cloud(self._h, which, _p(out), C.c_size_t(n.value), C.byref(n)))
+        return out
+
+    def get_rejected_indices(self):
+        n = C.c_size_t(0)
+        self._check(lib().erasor_hip_get_rejected_indices(self._h, None, C.c_size_t(0), C.byref(n)))
+        out = np.empty(n.value, np.uint64)
+        self._check(lib().erasor_hip_get_rejected_indices(self._h, _p(out), C.c_size_t(n.value), C.byref(n)))
+        return out
+
+    def get_bins(self, which):
+        cnt = np.zeros(self.B, np.uint32)
+        mn = np.zeros(self.B, np.float64)
+        mx = np.zeros(self.B, np.float64)
+        self._check(lib().erasor_hip_get_bins(self._h, which, _p(cnt), _p(mn), _p(mx)))
+        return cnt, mn, mx
+
+    def get_status(self):
+        st = np.zeros(self.B, np.float64)
+        self._check(lib().erasor_hip_get_status(self._h, _p(st)))
+        return st
+
+    def get_planes(self):
+        n = C.c_size_t(0)
+        self._check(lib().erasor_hip_get_planes(self._h, None, None, None, C.c_size_t(0), C.byref(n)))
+        nb, it = n.value, self.params.gf_iter
+        bins = np.zeros(nb, np.uint32)
+        normal = np.zeros((nb, it, 3), np.float32)
+        d = np.zeros((nb, it), np.float64)
+        if nb:
+            self._check(lib().erasor_hip_get_planes(self._h, _p(bins), _p(normal), _p(d), C.c_size_t(nb), C.byref(n)))
+        return bins, normal, d
+
+    def voxelize_preserving_labels(self, cloud, leaf):
+        cloud = _f32(cloud).reshape(-1, 4)
+        out = np.empty((max(len(cloud), 1), 4), np.float32)
+        n = C.c_size_t(0)
+        self._check(lib().erasor_hip_voxelize_preserving_labels(self._h, _p(cloud), C.c_size_t(len(cloud)), C.c_double(leaf), _p(out),
+                                                                C.c_size_t(len(out)), C.byref(n)))
+        return out[: n.value].copy()
+
+    def count_static_dynamic(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(lib().erasor_hip_count_static_dynamic(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # -- measurement --
+    def profiling(self, on):
+        self._check(lib().erasor_hip_profiling(self._h, C.c_int(1 if on else 0)))
+
+    def profile_reset(self):
+        self._check(lib().erasor_hip_profile_reset(self._h))
+
+    def profile_get(self):
+        n = C.c_size_t(0)
+        self._check(lib().erasor_hip_profile_get(self._h, None, None, None, C.c_size_t(0), C.byref(n)))
+        k = n.value
+        names = (C.c_char_p * max(k, 1))()
+        ms = (C.c_double * max(k, 1))()
+        cnt = (C.c_uint64 * max(k, 1))()
+        self._check(lib().erasor_hip_profile_get(self._h, names, ms, cnt, C.c_size_t(k), C.byref(n)))
+        return {names[i].decode(): (ms[i], int(cnt[i])) for i in range(k)}
+
+    def voi_split_bytes(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(lib().erasor_hip_voi_split_bytes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def stream(self):
+        return lib().erasor_hip_stream(self._h)
+
+    # -- test hooks --
+    def probe_math(self, x, y):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.ascontiguousarray(y, np.float64)
+        o = [np.zeros_like(x) for _ in range(3)]
+        self._check(lib().erasor_hip_probe_math(self._h, _p(x), _p(y), C.c_size_t(len(x)), _p(o[0]), _p(o[1]), _p(o[2])))
+        return o
+
+    def exact_sort_u32(self, keys, vals):
+        keys = np.ascontiguousarray(keys, np.uint32).copy()
+        vals = np.ascontiguousarray(vals, np.uint32).copy()
+        nf = C.c_uint32(0)
+        self._check(lib().erasor_hip_exact_sort_u32(self._h, _p(keys), _p(vals), C.c_size_t(len(keys)), C.byref(nf)))
+        return keys, vals, int(nf.value)

@@ -1,0 +1,1008 @@
+// erasor_hip.hip — host side of liberasor_hip.so: handle, HBM map store, step orchestration.
+// C ABI declared in include/erasor_hip.h.  All arithmetic happens in kernels.hip.h; this file only
+// sizes buffers, launches kernels on the handle's stream and copies small result structs back.
+//
+// There is NO CPU fallback: without a usable HIP device every entry point that needs the GPU
+// returns ERASOR_E_NO_DEVICE.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/erasor_hip.h"
+#include "kernels.hip.h"
+
+using namespace ek;
+
+namespace {
+
+struct ProfEntry {
+    double ms = 0;
+    uint64_t launches = 0;
+};
+
+struct PendingEvt {
+    int name_id;
+    hipEvent_t a, b;
+};
+
+template <class T>
+struct DBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct erasor_hip_handle {
+    erasor_params P;
+    DP dp;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool have_map = false, have_step = false;
+
+    // ---- map store ----
+    uint32_t capMap = 0, capF = 0, capO = 0, capV = 0, capS = 0, capG = 0;
+    uint32_t B = 0;
+    DBuf<float4> F[2];
+    int curF = 0;
+    DBuf<float2> Oxy, Ozi;
+    uint32_t nF = 0, o_begin = 0;  // host mirrors
+    uint64_t o_valid = 0;          // live outskirts entries
+    // ---- VoI split ----
+    DBuf<unsigned long long> vmask, hmask;
+    DBuf<uint32_t> cinfo, pvl, phl, topv, toph;
+    // ---- VoI-order arrays ----
+    DBuf<float4> voi_ego, spts, rejected;
+    DBuf<uint32_t> voi_key, voi_src, ssrc, rejected_src, grank, glist;
+    DBuf<uint8_t> gflag;
+    // ---- radix ----
+    DBuf<uint32_t> rk_a, rk_b, rv_a, rv_b, hist, hist_l, hist_t, dn;
+    // ---- bins ----
+    DBuf<uint32_t> moff, mcnt, qoff, ccnt, rev_idx, rev_list, vox_off, nvox, ng, out_off, ground_off, rej_off, crej_off;
+    DBuf<float> mmin, mmax, cmin, cmax, plane_n;
+    DBuf<double> plane_d;
+    DBuf<uint8_t> st1, status, action;
+    // ---- query ----
+    DBuf<float4> scan, cent, query, sq, curr_rejected;
+    DBuf<uint32_t> bb, qk_a, qk_b, qv_a, qv_b, qposL, qposR, qflag, qpl, qtops, run_begin, ukeys, qkey;
+    DBuf<uint8_t> qhead;
+    DBuf<esort::Seg> esq0, esq1, essmall;
+    DBuf<EsQueues> esqs;
+    DBuf<VoxGrid> qgrid;
+    // ---- per-bin scratch (R-GPF / bin voxelise global paths) ----
+    DBuf<uint32_t> gsK, gsV, gsL, gsR, gsK2, gsV2;
+    DBuf<uint8_t> gsH;
+    DBuf<float4> gsC, vox_out;
+    // ---- state ----
+    DBuf<DevState> d_st;
+    DBuf<Counters> d_ctr;
+    DevState st;
+    Counters ctr;
+    Xf Tl2b, Tb2o, To2b;
+    uint32_t last_n_voi = 0, last_nq = 0, last_n_scan = 0;
+    const uint32_t *last_skeys = nullptr;  // sorted VoI keys of the last step
+    erasor_step_result last_res;
+    // ---- profiling ----
+    bool prof = false;
+    std::vector<std::string> prof_names;
+    std::map<std::string, int> prof_ids;
+    std::vector<ProfEntry> prof_tab;
+    std::vector<PendingEvt> pending;
+    std::vector<hipEvent_t> evt_pool;
+};
+
+namespace {
+
+#define HIPC(h, call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            return ERASOR_E_NO_DEVICE;                                                        \
+        }                                                                                     \
+    } while (0)
+
+template <class T>
+int ensure(erasor_hip_handle *h, DBuf<T> &b, size_t n, bool keep = false) {
+    if (n <= b.cap) return 0;
+    T *np = nullptr;
+    size_t ncap = n + n / 8 + 64;
+    HIPC(h, hipMalloc((void **)&np, ncap * sizeof(T)));
+    if (keep && b.p) HIPC(h, hipMemcpyAsync(np, b.p, b.cap * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    if (b.p) {
+        HIPC(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(b.p);
+    }
+    b.p = np;
+    b.cap = ncap;
+    return 0;
+}
+template <class T>
+void release(DBuf<T> &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+hipEvent_t get_evt(erasor_hip_handle *h) {
+    if (!h->evt_pool.empty()) {
+        hipEvent_t e = h->evt_pool.back();
+        h->evt_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+int prof_id(erasor_hip_handle *h, const char *name) {
+    auto it = h->prof_ids.find(name);
+    if (it != h->prof_ids.end()) return it->second;
+    const int id = (int)h->prof_names.size();
+    h->prof_names.push_back(name);
+    h->prof_tab.push_back(ProfEntry());
+    h->prof_ids[name] = id;
+    return id;
+}
+void prof_collect(erasor_hip_handle *h) {
+    for (auto &p : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            h->prof_tab[p.name_id].ms += ms;
+            h->prof_tab[p.name_id].launches += 1;
+        }
+        h->evt_pool.push_back(p.a);
+        h->evt_pool.push_back(p.b);
+    }
+    h->pending.clear();
+}
+
+// kernel launch with optional event bracketing on the handle's stream
+#define LAUNCH(h, name, kern, grid, block, ...)                                   \
+    do {                                                                          \
+        PendingEvt pe_;                                                           \
+        if ((h)->prof) {                                                          \
+            pe_.name_id = prof_id((h), name);                                     \
+            pe_.a = get_evt(h);                                                   \
+            pe_.b = get_evt(h);                                                   \
+            (void)hipEventRecord(pe_.a, (h)->stream);                             \
+        }                                                                         \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (h)->stream, __VA_ARGS__); \
+        if ((h)->prof) {                                                          \
+            (void)hipEventRecord(pe_.b, (h)->stream);                             \
+            (h)->pending.push_back(pe_);                                          \
+        }                                                                         \
+    } while (0)
+
+inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+inline uint32_t rup(uint64_t a, uint64_t b) { return (uint32_t)(((a + b - 1) / b) * b); }
+
+Xf to_xf(const float T[16]) {
+    Xf x;
+    for (int k = 0; k < 12; ++k) x.m[k] = T[k];
+    return x;
+}
+
+void fill_dp(erasor_hip_handle *h) {
+    const erasor_params &p = h->P;
+    DP &d = h->dp;
+    d.max_r = p.max_range;
+    d.R = p.num_rings;
+    d.S = p.num_sectors;
+    d.B = p.num_rings * p.num_sectors;
+    d.ring_size = p.max_range / p.num_rings;    // erasor.h:63
+    d.sector_size = 2 * PI_REF / p.num_sectors;  // erasor.h:64
+    d.max_h = p.max_h;
+    d.min_h = p.min_h;
+    d.th_bin_max_h = p.th_bin_max_h;
+    d.srt_thr = p.scan_ratio_threshold;
+    d.gf_dist = p.gf_dist_thr;
+    d.gf_seeds_h = p.gf_th_seeds_height;
+    const double R = p.voi_max_range > 0 ? p.voi_max_range : p.max_range;
+    d.voi_r2 = R * R;  // pow(max_range_ + margin, 2), margin = 0 (OMU.cpp:385,391)
+    d.num_lowest = p.num_lowest_pts;
+    d.min_pts = p.minimum_num_pts;
+    d.gf_iter = p.gf_iter;
+    d.gf_lpr = p.gf_num_lpr;
+    d.version = p.version;
+    d.leaf_map = (float)p.map_voxel_size;     // setLeafSize(float...) narrowing
+    d.leaf_query = (float)p.query_voxel_size;
+}
+
+// two-level exclusive scan helper (n on host or device)
+int scan_u32(erasor_hip_handle *h, const uint32_t *in, uint32_t *out_local, uint32_t *tops, uint32_t n_host_max, uint32_t n_host,
+             const uint32_t *n_dev, uint32_t *total_out, const char *tag) {
+    const uint32_t nb = std::max(1u, cdiv(n_host_max, 1024));
+    LAUNCH(h, tag, k_scan_local, nb, 256, in, out_local, tops, n_host, n_dev);
+    LAUNCH(h, tag, k_scan_top, 1, 1024, tops, n_host, n_dev, total_out);
+    return 0;
+}
+
+// stable LSD radix sort of keys[0..n) (n known on the host); returns pointers to the sorted keys / permutation
+int radix_sort(erasor_hip_handle *h, const uint32_t *keys_in, uint32_t n, int bits, uint32_t *ka, uint32_t *kb, uint32_t *va,
+               uint32_t *vb, const uint32_t **skeys, const uint32_t **sperm, const char *tag) {
+    const uint32_t nblk = std::max(1u, cdiv(n, RTILE));
+    const uint32_t nhist = 256u * nblk;
+    if (ensure(h, h->hist, nhist) || ensure(h, h->hist_l, nhist) || ensure(h, h->hist_t, cdiv(nhist, 1024) + 2)) return ERASOR_E_NO_DEVICE;
+    const uint32_t *kin = keys_in;
+    const uint32_t *vin = nullptr;
+    uint32_t *kout = ka, *vout = va;
+    for (int shift = 0; shift < bits; shift += 8) {
+        LAUNCH(h, tag, k_radix_hist, nblk, 256, kin, n, (const uint32_t *)nullptr, shift, h->hist.p);
+        scan_u32(h, h->hist.p, h->hist_l.p, h->hist_t.p, nhist, nhist, nullptr, nullptr, tag);
+        LAUNCH(h, tag, k_radix_scatter, nblk, 256, kin, vin, n, (const uint32_t *)nullptr, shift, (const uint32_t *)h->hist_l.p,
+               (const uint32_t *)h->hist_t.p, kout, vout);
+        kin = kout;
+        vin = vout;
+        kout = (kout == ka) ? kb : ka;
+        vout = (vout == va) ? vb : va;
+    }
+    *skeys = kin;
+    *sperm = vin;
+    return 0;
+}
+
+int key_bits(uint32_t nbuckets) {
+    int b = 1;
+    while ((1u << b) < nbuckets) ++b;
+    return b;
+}
+
+int alloc_bins(erasor_hip_handle *h) {
+    const size_t B = h->B;
+    int rc = 0;
+    rc |= ensure(h, h->moff, B + 2) | ensure(h, h->qoff, B + 2) | ensure(h, h->mcnt, B) | ensure(h, h->ccnt, B);
+    rc |= ensure(h, h->mmin, B) | ensure(h, h->mmax, B) | ensure(h, h->cmin, B) | ensure(h, h->cmax, B);
+    rc |= ensure(h, h->st1, B) | ensure(h, h->status, B) | ensure(h, h->action, B) | ensure(h, h->rev_idx, B) | ensure(h, h->rev_list, B);
+    rc |= ensure(h, h->vox_off, B) | ensure(h, h->nvox, B) | ensure(h, h->ng, B) | ensure(h, h->out_off, B) | ensure(h, h->ground_off, B);
+    rc |= ensure(h, h->rej_off, B) | ensure(h, h->crej_off, B);
+    rc |= ensure(h, h->plane_n, B * (size_t)std::max(h->P.gf_iter, 1) * 3) | ensure(h, h->plane_d, B * (size_t)std::max(h->P.gf_iter, 1));
+    rc |= ensure(h, h->d_st, 1) | ensure(h, h->d_ctr, 1) | ensure(h, h->dn, 16) | ensure(h, h->bb, 8) | ensure(h, h->qgrid, 1) | ensure(h, h->esqs, 1);
+    return rc ? ERASOR_E_NO_DEVICE : 0;
+}
+
+// capacity-sized buffers that depend on the map size
+int alloc_map(erasor_hip_handle *h, uint32_t n) {
+    const uint64_t slack = std::max<uint64_t>(n / 4, 1u << 20);
+    const uint64_t capMap = (uint64_t)n + slack;
+    if (2 * capMap + (1u << 22) >= 0xFFFFFFF0ull) {
+        h->err = "map too large for 32-bit indexing";
+        return ERASOR_E_INVALID;
+    }
+    h->capMap = (uint32_t)capMap;
+    h->capV = h->capMap;
+    h->capO = rup(capMap + std::max<uint64_t>(capMap / 2, 1u << 20), CHUNK);
+    int rc = 0;
+    rc |= ensure(h, h->Oxy, h->capO) | ensure(h, h->Ozi, h->capO);
+    const uint32_t V = h->capV;
+    rc |= ensure(h, h->voi_ego, V) | ensure(h, h->spts, V) | ensure(h, h->voi_key, V) | ensure(h, h->voi_src, V) | ensure(h, h->ssrc, V);
+    rc |= ensure(h, h->rejected, V) | ensure(h, h->rejected_src, V) | ensure(h, h->grank, V) | ensure(h, h->glist, V) | ensure(h, h->gflag, V);
+    rc |= ensure(h, h->rk_a, V) | ensure(h, h->rk_b, V) | ensure(h, h->rv_a, V) | ensure(h, h->rv_b, V);
+    return rc ? ERASOR_E_NO_DEVICE : 0;
+}
+
+int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
+    if (ns <= h->capS && h->capS) return 0;
+    const uint32_t S = ns + ns / 4 + 1024;
+    h->capS = S;
+    int rc = 0;
+    rc |= ensure(h, h->scan, S) | ensure(h, h->cent, S) | ensure(h, h->query, S) | ensure(h, h->sq, S) | ensure(h, h->curr_rejected, S);
+    rc |= ensure(h, h->qk_a, S) | ensure(h, h->qk_b, S) | ensure(h, h->qv_a, S) | ensure(h, h->qv_b, S) | ensure(h, h->qposL, S) | ensure(h, h->qposR, S);
+    rc |= ensure(h, h->qflag, S) | ensure(h, h->qpl, S) | ensure(h, h->qtops, S / 1024 + 4) | ensure(h, h->run_begin, S + 1) | ensure(h, h->ukeys, S);
+    rc |= ensure(h, h->qkey, S) | ensure(h, h->qhead, S + 4);
+    rc |= ensure(h, h->esq0, 65536) | ensure(h, h->esq1, 65536) | ensure(h, h->essmall, 65536);
+    return rc ? ERASOR_E_NO_DEVICE : 0;
+}
+
+// per-step scratch whose size depends on (VoI size + query size)
+int alloc_step(erasor_hip_handle *h, uint32_t n_voi, uint32_t nq) {
+    const size_t G = (size_t)n_voi + nq + 8;
+    int rc = 0;
+    rc |= ensure(h, h->gsK, G) | ensure(h, h->gsV, G) | ensure(h, h->gsL, G) | ensure(h, h->gsR, G) | ensure(h, h->gsK2, G) | ensure(h, h->gsV2, G);
+    rc |= ensure(h, h->gsH, G) | ensure(h, h->gsC, G) | ensure(h, h->vox_out, G);
+    const size_t needF = 2 * (size_t)n_voi + nq + 64;
+    rc |= ensure(h, h->F[h->curF ^ 1], needF);
+    return rc ? ERASOR_E_NO_DEVICE : 0;
+}
+
+// rebuild the outskirts region without tombstones at the end of the buffer (stable)
+int rebuild_outskirts(erasor_hip_handle *h, uint32_t min_front_room) {
+    const uint32_t span = h->capO - h->o_begin;
+    DBuf<uint32_t> flag, pl, tops;
+    DBuf<float4> tmp;
+    if (ensure(h, flag, span + 1) || ensure(h, pl, span + 1) || ensure(h, tops, span / 1024 + 4)) return ERASOR_E_NO_DEVICE;
+    uint32_t nvalid = 0;
+    if (span) {
+        LAUNCH(h, "o_rebuild", k_o_valid, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, h->o_begin, h->capO, flag.p);
+        scan_u32(h, flag.p, pl.p, tops.p, span, span, nullptr, h->dn.p, "o_rebuild");
+        HIPC(h, hipMemcpyAsync(&nvalid, h->dn.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+    }
+    if (ensure(h, tmp, (size_t)nvalid + 1)) return ERASOR_E_NO_DEVICE;
+    if (span) LAUNCH(h, "o_rebuild", k_o_compact, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, (const float2 *)h->Ozi.p, h->o_begin,
+                     h->capO, (const uint32_t *)flag.p, (const uint32_t *)pl.p, (const uint32_t *)tops.p, tmp.p);
+    uint32_t need = rup((uint64_t)nvalid + min_front_room + CHUNK, CHUNK);
+    if (need > h->capO) {
+        const uint32_t ncap = rup((uint64_t)need + need / 2, CHUNK);
+        HIPC(h, hipStreamSynchronize(h->stream));
+        release(h->Oxy);
+        release(h->Ozi);
+        if (ensure(h, h->Oxy, ncap) || ensure(h, h->Ozi, ncap)) return ERASOR_E_NO_DEVICE;
+        h->capO = ncap;
+    }
+    h->o_begin = h->capO - nvalid;
+    if (nvalid) LAUNCH(h, "o_rebuild", k_store_outskirts, cdiv(nvalid, 256), 256, (const float4 *)tmp.p, nvalid, h->Oxy.p, h->Ozi.p, h->o_begin);
+    HIPC(h, hipStreamSynchronize(h->stream));
+    h->o_valid = nvalid;
+    release(flag);
+    release(pl);
+    release(tops);
+    release(tmp);
+    return 0;
+}
+
+int push_state(erasor_hip_handle *h) {
+    h->st.nF = h->nF;
+    h->st.o_begin = h->o_begin;
+    HIPC(h, hipMemcpyAsync(h->d_st.p, &h->st, sizeof(DevState), hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char *erasor_hip_version(void) { return "erasor_hip 0.1 (gfx950, hand-written HIP; no CPU fallback)"; }
+
+int erasor_hip_params_default(erasor_params *p) {
+    if (!p) return ERASOR_E_INVALID;
+    memset(p, 0, sizeof(*p));
+    p->max_range = 10.0;   // erasor.h:47
+    p->num_rings = 20;     // :48
+    p->num_sectors = 60;   // :49
+    p->max_h = 3.0;        // :50
+    p->min_h = 0.0;        // :51
+    p->th_bin_max_h = 0.39;
+    p->scan_ratio_threshold = 0.22;
+    p->num_lowest_pts = 5;
+    p->minimum_num_pts = 4;
+    p->rejection_ratio = 0.33;
+    p->gf_dist_thr = 0.05;
+    p->gf_iter = 3;
+    p->gf_num_lpr = 10;
+    p->gf_th_seeds_height = 0.5;
+    p->map_voxel_size = 0.2;   // erasor.h:61
+    p->version = 3;            // OMU.cpp:81
+    p->query_voxel_size = 0.05;  // OMU.cpp:66
+    p->removal_interval = 2;     // OMU.cpp:69
+    p->voi_max_range = 0.0;
+    return ERASOR_OK;
+}
+
+int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **out) {
+    if (!p || !out) return ERASOR_E_INVALID;
+    *out = nullptr;
+    if (p->num_rings <= 0 || p->num_sectors <= 0 || (int64_t)p->num_rings * p->num_sectors > 65000) return ERASOR_E_INVALID;
+    if (p->gf_iter < 1 || p->gf_iter > 64) return ERASOR_E_INVALID;
+    if (p->version != 2 && p->version != 3) return ERASOR_E_UNSUPPORTED;  // OMU.cpp:273-275 "Other version is not implemented!"
+    if (!(p->max_range > 0) || !(p->map_voxel_size > 0) || !(p->query_voxel_size > 0)) return ERASOR_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return ERASOR_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return ERASOR_E_NO_DEVICE;
+    erasor_hip_handle *h = new erasor_hip_handle();
+    h->P = *p;
+    h->device = device;
+    h->B = (uint32_t)(p->num_rings * p->num_sectors);
+    fill_dp(h);
+    memset(&h->st, 0, sizeof(h->st));
+    memset(&h->ctr, 0, sizeof(h->ctr));
+    memset(&h->last_res, 0, sizeof(h->last_res));
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return ERASOR_E_NO_DEVICE;
+    }
+    if (alloc_bins(h)) {
+        erasor_hip_destroy(h);
+        return ERASOR_E_NO_DEVICE;
+    }
+    *out = h;
+    return ERASOR_OK;
+}
+
+void erasor_hip_destroy(erasor_hip_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    prof_collect(h);
+    for (auto e : h->evt_pool) (void)hipEventDestroy(e);
+    release(h->F[0]); release(h->F[1]); release(h->Oxy); release(h->Ozi);
+    release(h->vmask); release(h->hmask); release(h->cinfo); release(h->pvl); release(h->phl); release(h->topv); release(h->toph);
+    release(h->voi_ego); release(h->spts); release(h->rejected); release(h->voi_key); release(h->voi_src); release(h->ssrc);
+    release(h->rejected_src); release(h->grank); release(h->glist); release(h->gflag);
+    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->dn);
+    release(h->moff); release(h->mcnt); release(h->qoff); release(h->ccnt); release(h->rev_idx); release(h->rev_list); release(h->vox_off);
+    release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
+    release(h->mmin); release(h->mmax); release(h->cmin); release(h->cmax); release(h->plane_n); release(h->plane_d);
+    release(h->st1); release(h->status); release(h->action);
+    release(h->scan); release(h->cent); release(h->query); release(h->sq); release(h->curr_rejected);
+    release(h->bb); release(h->qk_a); release(h->qk_b); release(h->qv_a); release(h->qv_b); release(h->qposL); release(h->qposR);
+    release(h->qflag); release(h->qpl); release(h->qtops); release(h->run_begin); release(h->ukeys); release(h->qkey); release(h->qhead);
+    release(h->esq0); release(h->esq1); release(h->essmall); release(h->esqs); release(h->qgrid);
+    release(h->gsK); release(h->gsV); release(h->gsL); release(h->gsR); release(h->gsK2); release(h->gsV2); release(h->gsH); release(h->gsC);
+    release(h->vox_out); release(h->d_st); release(h->d_ctr);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char *erasor_hip_last_error(const erasor_hip_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+static int set_map_common(erasor_hip_handle *h, const void *src, size_t n, bool src_is_device) {
+    if (!h) return ERASOR_E_INVALID;
+    if (!src && n) return ERASOR_E_INVALID;
+    HIPC(h, hipSetDevice(h->device));
+    if (n > 0x7FFFFFF0ull) return ERASOR_E_INVALID;
+    int rc = alloc_map(h, (uint32_t)n);
+    if (rc) return rc;
+    // stage the AoS cloud in voi_ego (capV >= n), then split into the outskirts layout at the END of the O buffer
+    if (n) {
+        HIPC(h, hipMemcpyAsync(h->voi_ego.p, src, n * sizeof(float4), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    }
+    h->nF = 0;
+    h->curF = 0;
+    h->o_begin = h->capO - (uint32_t)n;
+    h->o_valid = n;
+    if (n) LAUNCH(h, "set_map", k_store_outskirts, cdiv(n, 256), 256, (const float4 *)h->voi_ego.p, (uint32_t)n, h->Oxy.p, h->Ozi.p, h->o_begin);
+    memset(&h->st, 0, sizeof(h->st));
+    rc = push_state(h);
+    if (rc) return rc;
+    // initial label counters of the outskirts (parse_dynamic_obj, utils.cpp:57-78)
+    if (n) {
+        DevState *ds = h->d_st.p;
+        LAUNCH(h, "set_map", k_count_labels4, std::min<uint32_t>(cdiv(n, 256), 2048), 256, (const float4 *)h->voi_ego.p, (uint32_t)n,
+               (const uint32_t *)nullptr, &ds->O_static, &ds->O_dynamic);
+    }
+    HIPC(h, hipMemcpyAsync(&h->st, h->d_st.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    h->have_map = true;
+    h->have_step = false;
+    return ERASOR_OK;
+}
+int erasor_hip_set_map(erasor_hip_handle *h, const float *xyzi, size_t n) { return set_map_common(h, xyzi, n, false); }
+int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n) { return set_map_common(h, d_xyzi, n, true); }
+
+// ---- exact voxelisation of the cloud in h->scan[0..n): fills run_begin / cent / ukeys, d_st->q_nvox -------------------
+static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf) {
+    DevState *ds = h->d_st.p;
+    Counters *dc = h->d_ctr.p;
+    LAUNCH(h, "q_bbox", k_bbox_init, 1, 64, h->bb.p);
+    if (n) LAUNCH(h, "q_bbox", k_bbox, std::min<uint32_t>(cdiv(n, 256), 1024), 256, (const float4 *)h->scan.p, n, h->bb.p);
+    LAUNCH(h, "q_keys", k_voxel_keys, std::max(1u, cdiv(n, 256)), 256, (const float4 *)h->scan.p, n, (const uint32_t *)h->bb.p, leaf, h->qk_a.p,
+           h->qv_a.p, h->qgrid.p, dc);
+    // exact std::sort: a few global levels (one workgroup per big segment), then per-segment completion in LDS
+    LAUNCH(h, "q_esort", k_esort_init, 1, 1, h->esq0.p, h->essmall.p, h->esqs.p, n);
+    int cur = 0;
+    if (n > ES_LMAX) {
+        const int levels = 2 * esort::lg2_floor(n);  // == the introsort depth budget: no big segment can survive it
+        const int nlev = std::min(levels, 14);
+        for (int l = 0; l < nlev; ++l) {
+            LAUNCH(h, "q_esort", k_esort_level, 64, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, cur ? h->esq1.p : h->esq0.p,
+                   cur ? h->esq0.p : h->esq1.p, h->essmall.p, h->esqs.p, cur, 65536u, dc);
+            LAUNCH(h, "q_esort", k_esort_level_reset, 1, 1, h->esqs.p, cur);
+            cur ^= 1;
+        }
+    }
+    LAUNCH(h, "q_esort", k_esort_final, 256, 256, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->qhead.p, h->qk_b.p, h->qv_b.p,
+           (const esort::Seg *)h->essmall.p, (const esort::Seg *)(cur ? h->esq1.p : h->esq0.p), h->esqs.p, cur, dc);
+    // runs
+    if (n) LAUNCH(h, "q_runs", k_run_heads, cdiv(n, 256), 256, (const uint32_t *)h->qk_b.p, n, h->qflag.p);
+    scan_u32(h, h->qflag.p, h->qpl.p, h->qtops.p, n, n, nullptr, nullptr, "q_runs");
+    LAUNCH(h, "q_runs", k_run_begin, cdiv((uint64_t)n + 1, 256), 256, (const uint32_t *)h->qflag.p, (const uint32_t *)h->qpl.p,
+           (const uint32_t *)h->qtops.p, n, h->run_begin.p, &ds->q_nvox);
+    return 0;
+}
+
+static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan, bool src_is_device, const float T_l2b[16],
+                       const float T_b2o[16], const float T_o2b[16], erasor_step_result *res) {
+    if (!h) return ERASOR_E_INVALID;
+    if (!h->have_map) {
+        h->err = "erasor_hip_step before erasor_hip_set_map";
+        return ERASOR_E_STATE;
+    }
+    if (!T_l2b || !T_b2o || !T_o2b || (!scan_src && n_scan) || n_scan > 0x3FFFFFFFull) return ERASOR_E_INVALID;
+    HIPC(h, hipSetDevice(h->device));
+    prof_collect(h);
+    const uint32_t ns = (uint32_t)n_scan;
+    int rc = alloc_scan(h, std::max(ns, 1u));
+    if (rc) return rc;
+    h->Tl2b = to_xf(T_l2b);
+    h->Tb2o = to_xf(T_b2o);
+    h->To2b = to_xf(T_o2b);
+    const double xc = (double)T_b2o[3], yc = (double)T_b2o[7];  // OMU.cpp:246-247
+    DevState *ds = h->d_st.p;
+    Counters *dc = h->d_ctr.p;
+    const DP &P = h->dp;
+    const uint32_t B = h->B;
+
+    // room for the points that may leave the VoI-resident region (upper bound nF)
+    if ((uint64_t)h->o_begin < (uint64_t)h->nF + CHUNK || (uint64_t)(h->capO - h->o_begin) > 2 * h->o_valid + (1u << 20)) {
+        rc = rebuild_outskirts(h, h->nF + CHUNK);
+        if (rc) return rc;
+    }
+    const uint64_t n_map_in = (uint64_t)h->nF + h->o_valid;
+    if (n_map_in + ns + 64 > h->capV) {
+        h->err = "map grew beyond the capacity reserved at set_map";
+        return ERASOR_E_CAPACITY;
+    }
+    rc = push_state(h);
+    if (rc) return rc;
+    LAUNCH(h, "step_begin", k_step_begin, 1, 1, ds, dc);
+    if (ns) HIPC(h, hipMemcpyAsync(h->scan.p, scan_src, (size_t)ns * sizeof(float4), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+
+    // ---- query voxelisation, part 1 (OMU.cpp:238) ----
+    voxelize_query_part1(h, ns, P.leaf_query);
+
+    // ---- VoI split (OMU.cpp:254 fetch_VoI membership) ----
+    const uint32_t nFchunks = cdiv(h->nF, CHUNK);
+    const uint32_t o_chunk0 = h->o_begin / CHUNK;
+    const uint32_t nOchunks = h->capO / CHUNK - o_chunk0;
+    const uint32_t nchunks = nFchunks + nOchunks;
+    if (ensure(h, h->vmask, (size_t)nchunks * CHUNK_TILES + 8) || ensure(h, h->hmask, (size_t)nchunks * CHUNK_TILES + 8) ||
+        ensure(h, h->cinfo, nchunks + 8) || ensure(h, h->pvl, nchunks + 8) || ensure(h, h->phl, nchunks + 8) ||
+        ensure(h, h->topv, nchunks / 1024 + 8) || ensure(h, h->toph, nchunks / 1024 + 8))
+        return ERASOR_E_NO_DEVICE;
+    {
+        const uint32_t waves_needed = nchunks;
+        const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(waves_needed, 4), 256 * 8));
+        LAUNCH(h, "voi_split", k_voi_split, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, (const float2 *)h->Oxy.p, h->o_begin,
+               o_chunk0, nOchunks, xc, yc, P.voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p);
+        const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));
+        LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p);
+        LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
+               nchunks, nFchunks, ds);
+    }
+    // ---- mid-step read-back: VoI size and query voxel count size the remaining launches ----
+    HIPC(h, hipMemcpyAsync(&h->st, ds, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    const uint32_t n_voi = h->st.voi_total, nq = h->st.q_nvox;
+    {
+        VoxGrid g;
+        HIPC(h, hipMemcpy(&g, h->qgrid.p, sizeof(g), hipMemcpyDeviceToHost));
+        if (ns && g.overflow) {
+            h->err = "VoxelGrid index overflow on the query scan (reference returns the input unvoxelised): not supported on device";
+            return ERASOR_E_UNSUPPORTED;
+        }
+    }
+    rc = alloc_step(h, n_voi, nq);
+    if (rc) return rc;
+
+    // ---- query voxelisation, part 2: centroids, label NN, lidar->body, R-POD key ----
+    const uint32_t *sq_keys = nullptr, *sq_perm = nullptr;
+    if (nq) {
+        LAUNCH(h, "q_centroids", k_centroids, cdiv(nq, 256), 256, (const float4 *)h->scan.p, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
+               (const uint32_t *)h->run_begin.p, (const uint32_t *)&ds->q_nvox, h->cent.p, h->ukeys.p);
+        LAUNCH(h, "q_nn", k_query_nn, cdiv(nq, 256), 256, (const float4 *)h->scan.p, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
+               (const uint32_t *)h->ukeys.p, (const float4 *)h->cent.p, (const uint32_t *)&ds->q_nvox, (const VoxGrid *)h->qgrid.p, h->Tl2b, P, dc,
+               h->query.p, h->qkey.p);
+    }
+    const int bits = key_bits(B + 1);
+    // the radix ping-pong buffers are shared by the query and the map side (capV >= capS is not guaranteed -> use q buffers)
+    radix_sort(h, h->qkey.p, nq, bits, h->qk_a.p, h->qposL.p, h->qv_a.p, h->qposR.p, &sq_keys, &sq_perm, "q_bucket");
+    if (nq) LAUNCH(h, "q_bucket", k_gather, cdiv(nq, 256), 256, (const float4 *)h->query.p, (const uint32_t *)nullptr, sq_perm, nq,
+                   (const uint32_t *)nullptr, h->sq.p, (uint32_t *)nullptr);
+    LAUNCH(h, "q_bucket", k_bin_offsets, cdiv((uint64_t)std::max(nq, B + 2) + 1, 256), 256, sq_keys, nq, (const uint32_t *)nullptr, B + 1, h->qoff.p);
+    LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->sq.p, (const uint32_t *)h->qoff.p, B, h->ccnt.p,
+           h->cmin.p, h->cmax.p);
+
+    // ---- VoI gather + egocentric transform + R-POD key (OMU.cpp:435-437; erasor.cpp:124-139) ----
+    {
+        const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nchunks, 4), 256 * 8));
+        LAUNCH(h, "voi_gather", k_voi_gather, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, h->Oxy.p, h->Ozi.p, o_chunk0, nOchunks,
+               (const unsigned long long *)h->vmask.p, (const unsigned long long *)h->hmask.p, (const uint32_t *)h->cinfo.p,
+               (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p, (const uint32_t *)h->topv.p, (const uint32_t *)h->toph.p, h->To2b, P, ds, dc,
+               h->voi_ego.p, h->voi_key.p, h->voi_src.p);
+    }
+    const uint32_t *sm_keys = nullptr, *sm_perm = nullptr;
+    radix_sort(h, h->voi_key.p, n_voi, bits, h->rk_a.p, h->rk_b.p, h->rv_a.p, h->rv_b.p, &sm_keys, &sm_perm, "voi_bucket");
+    if (n_voi) LAUNCH(h, "voi_bucket", k_gather, cdiv(n_voi, 256), 256, (const float4 *)h->voi_ego.p, (const uint32_t *)h->voi_src.p, sm_perm, n_voi,
+                      (const uint32_t *)nullptr, h->spts.p, h->ssrc.p);
+    LAUNCH(h, "voi_bucket", k_bin_offsets, cdiv((uint64_t)std::max(n_voi, B + 2) + 1, 256), 256, sm_keys, n_voi, (const uint32_t *)nullptr, B + 1,
+           h->moff.p);
+    LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->spts.p, (const uint32_t *)h->moff.p, B, h->mcnt.p,
+           h->mmin.p, h->mmax.p);
+
+    // ---- Scan Ratio Test, R-GPF, per-bin voxelisation (erasor.cpp:332-571) ----
+    LAUNCH(h, "srt", k_srt, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)h->ccnt.p,
+           (const float *)h->cmin.p, (const float *)h->cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
+    LAUNCH(h, "rgpf", k_rgpf, B, 256, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->moff.p,
+           (const float4 *)h->spts.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p, h->gflag.p, h->grank.p, h->glist.p,
+           h->ng.p, h->plane_n.p, h->plane_d.p, dc);
+    if (P.version == 3)
+        LAUNCH(h, "bin_voxelize", k_binvox, B, 256, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->moff.p,
+               (const float4 *)h->spts.p, (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->glist.p,
+               (const uint32_t *)h->ng.p, (const uint32_t *)h->vox_off.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p,
+               h->gsC.p, h->vox_out.p, h->nvox.p, dc);
+    LAUNCH(h, "layout", k_layout, 1, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->mcnt.p,
+           (const uint32_t *)h->ccnt.p, (const uint32_t *)h->moff.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->ng.p, h->out_off.p,
+           h->ground_off.p, h->rej_off.p, h->crej_off.p, ds);
+
+    // ---- map write-back (OMU.cpp:281-290) ----
+    float4 *Fnew = h->F[h->curF ^ 1].p;
+    if (n_voi)
+        LAUNCH(h, "assemble", k_assemble_map<true>, cdiv(n_voi, 256), 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
+               sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p, (const uint32_t *)h->ccnt.p,
+               (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p,
+               (const uint32_t *)h->rej_off.p, (const DevState *)ds, n_voi, Fnew, h->rejected.p, h->rejected_src.p);
+    LAUNCH(h, "assemble", k_assemble_bins<true>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
+           (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
+           (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, Fnew, h->curr_rejected.p);
+    LAUNCH(h, "count_labels", k_count_labels4, std::max(1u, std::min<uint32_t>(cdiv(2 * (uint64_t)n_voi + nq, 256), 1024)), 256,
+           (const float4 *)Fnew, 0u, (const uint32_t *)&ds->nF_new, &ds->F_static, &ds->F_dynamic);
+    LAUNCH(h, "step_end", k_step_end, 1, 1, ds);
+    HIPC(h, hipMemcpyAsync(&h->st, ds, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipMemcpyAsync(&h->ctr, dc, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+        h->err = std::string("kernel launch: ") + hipGetErrorString(le);
+        return ERASOR_E_NO_DEVICE;
+    }
+    if (h->ctr.err || h->ctr.sort_qoverflow) {
+        h->err = h->ctr.sort_qoverflow ? "exact-sort segment queue overflow" : "per-bin VoxelGrid index overflow (unsupported on device)";
+        return ERASOR_E_INTERNAL;
+    }
+    // commit
+    h->curF ^= 1;
+    h->nF = h->st.nF;
+    h->o_begin = h->st.o_begin;
+    const uint64_t n_out = (uint64_t)(h->o_valid) - (n_voi - h->st.voiF) + h->st.n_leaving;
+    h->o_valid = n_out;
+    h->last_n_voi = n_voi;
+    h->last_nq = nq;
+    h->last_n_scan = ns;
+    h->last_skeys = sm_keys;
+    h->have_step = true;
+    erasor_step_result r;
+    memset(&r, 0, sizeof(r));
+    r.n_map_in = n_map_in;
+    r.n_voi = n_voi;
+    r.n_outskirts = n_out;
+    r.n_query = nq;
+    r.n_static_estimate = h->st.n_static_est;
+    r.n_complement = h->st.n_compl;
+    r.n_map_rejected = h->st.n_rejected;
+    r.n_curr_rejected = h->st.n_curr_rejected;
+    r.n_ground = h->st.n_ground;
+    r.n_map_out = (uint64_t)h->nF + n_out;
+    r.n_static = h->st.F_static + h->st.O_static;
+    r.n_dynamic = h->st.F_dynamic + h->st.O_dynamic;
+    r.n_reverted_bins = h->st.n_rev;
+    r.n_neg_sector = h->ctr.n_neg_sector;
+    r.n_ambiguous = h->ctr.n_ambiguous;
+    r.n_degenerate_plane = h->ctr.n_degenerate;
+    r.n_voxel_overflow = h->ctr.n_voxel_overflow;
+    r.n_sort_fallback = h->ctr.n_sort_fallback;
+    h->last_res = r;
+    if (res) *res = r;
+    return ERASOR_OK;
+}
+
+int erasor_hip_step(erasor_hip_handle *h, const float *scan_xyzi, size_t n_scan, const float T_lidar2body[16], const float T_body2origin[16],
+                    const float T_origin2body[16], erasor_step_result *res) {
+    return step_common(h, scan_xyzi, n_scan, false, T_lidar2body, T_body2origin, T_origin2body, res);
+}
+int erasor_hip_step_device(erasor_hip_handle *h, const void *d_scan_xyzi, size_t n_scan, const float T_lidar2body[16],
+                           const float T_body2origin[16], const float T_origin2body[16], erasor_step_result *res) {
+    return step_common(h, d_scan_xyzi, n_scan, true, T_lidar2body, T_body2origin, T_origin2body, res);
+}
+
+int erasor_hip_map_size(erasor_hip_handle *h, size_t *n) {
+    if (!h || !n) return ERASOR_E_INVALID;
+    if (!h->have_map) return ERASOR_E_STATE;
+    *n = (size_t)h->nF + (size_t)h->o_valid;
+    return ERASOR_OK;
+}
+
+// copies a device float4 range to a caller buffer with the (cap, *n) convention
+static int out_cloud(erasor_hip_handle *h, const float4 *d, size_t cnt, float *dst, size_t cap, size_t *n) {
+    if (n) *n = cnt;
+    if (!dst) return ERASOR_OK;
+    if (cnt > cap) return ERASOR_E_CAPACITY;
+    if (cnt) HIPC(h, hipMemcpy(dst, d, cnt * sizeof(float4), hipMemcpyDeviceToHost));
+    return ERASOR_OK;
+}
+
+int erasor_hip_get_map(erasor_hip_handle *h, float *dst, size_t cap, size_t *n) {
+    if (!h) return ERASOR_E_INVALID;
+    if (!h->have_map) return ERASOR_E_STATE;
+    HIPC(h, hipSetDevice(h->device));
+    const size_t total = (size_t)h->nF + (size_t)h->o_valid;
+    if (n) *n = total;
+    if (!dst) return ERASOR_OK;
+    if (total > cap) return ERASOR_E_CAPACITY;
+    if (h->nF) HIPC(h, hipMemcpy(dst, h->F[h->curF].p, (size_t)h->nF * sizeof(float4), hipMemcpyDeviceToHost));
+    const uint32_t span = h->capO - h->o_begin;
+    if (span && h->o_valid) {
+        DBuf<uint32_t> flag, pl, tops;
+        DBuf<float4> tmp;
+        if (ensure(h, flag, span + 1) || ensure(h, pl, span + 1) || ensure(h, tops, span / 1024 + 4) || ensure(h, tmp, h->o_valid + 1))
+            return ERASOR_E_NO_DEVICE;
+        LAUNCH(h, "get_map", k_o_valid, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, h->o_begin, h->capO, flag.p);
+        scan_u32(h, flag.p, pl.p, tops.p, span, span, nullptr, nullptr, "get_map");
+        LAUNCH(h, "get_map", k_o_compact, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, (const float2 *)h->Ozi.p, h->o_begin, h->capO,
+               (const uint32_t *)flag.p, (const uint32_t *)pl.p, (const uint32_t *)tops.p, tmp.p);
+        HIPC(h, hipStreamSynchronize(h->stream));
+        HIPC(h, hipMemcpy(dst + (size_t)h->nF * 4, tmp.p, (size_t)h->o_valid * sizeof(float4), hipMemcpyDeviceToHost));
+        release(flag);
+        release(pl);
+        release(tops);
+        release(tmp);
+    }
+    return ERASOR_OK;
+}
+
+int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap, size_t *n) {
+    if (!h) return ERASOR_E_INVALID;
+    if (which == ERASOR_CLOUD_MAP) return erasor_hip_get_map(h, dst, cap, n);
+    if (!h->have_step) return ERASOR_E_STATE;
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    const DevState &s = h->st;
+    switch (which) {
+        case ERASOR_CLOUD_QUERY_VOI: return out_cloud(h, h->query.p, h->last_nq, dst, cap, n);
+        case ERASOR_CLOUD_MAP_VOI: return out_cloud(h, h->voi_ego.p, h->last_n_voi, dst, cap, n);
+        case ERASOR_CLOUD_MAP_REJECTED: return out_cloud(h, h->rejected.p, s.n_rejected, dst, cap, n);
+        case ERASOR_CLOUD_CURR_REJECTED: return out_cloud(h, h->curr_rejected.p, s.n_curr_rejected, dst, cap, n);
+        case ERASOR_CLOUD_STATIC_ESTIMATE:
+        case ERASOR_CLOUD_COMPLEMENT:
+        case ERASOR_CLOUD_GROUND_VIZ: {
+            // re-run the assembly without tf_body2origin_ into the retired F buffer (free until the next step)
+            size_t cnt = which == ERASOR_CLOUD_STATIC_ESTIMATE ? s.n_static_est : (which == ERASOR_CLOUD_COMPLEMENT ? s.n_compl : s.n_ground);
+            if (n) *n = cnt;
+            if (!dst) return ERASOR_OK;
+            if (cnt > cap) return ERASOR_E_CAPACITY;
+            if (ensure(h, h->F[h->curF ^ 1], (size_t)s.nF_new + 8)) return ERASOR_E_NO_DEVICE;
+            float4 *tmp = h->F[h->curF ^ 1].p;
+            const DP &P = h->dp;
+            const uint32_t B = h->B, n_voi = h->last_n_voi;
+            if (n_voi)
+                LAUNCH(h, "get_cloud", k_assemble_map<false>, cdiv(n_voi, 256), 256, P, h->Tb2o, (const uint8_t *)h->action.p,
+                       (const uint32_t *)h->rev_idx.p, h->last_skeys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p,
+                       (const uint32_t *)h->moff.p, (const uint32_t *)h->ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p,
+                       (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p, (const uint32_t *)h->rej_off.p,
+                       (const DevState *)h->d_st.p, n_voi, tmp, (float4 *)nullptr, (uint32_t *)nullptr);
+            LAUNCH(h, "get_cloud", k_assemble_bins<false>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
+                   (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
+                   (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, tmp, (float4 *)nullptr);
+            HIPC(h, hipStreamSynchronize(h->stream));
+            const size_t off = which == ERASOR_CLOUD_STATIC_ESTIMATE ? 0 : (which == ERASOR_CLOUD_COMPLEMENT ? s.n_static_est : s.total_bins);
+            if (cnt) HIPC(h, hipMemcpy(dst, tmp + off, cnt * sizeof(float4), hipMemcpyDeviceToHost));
+            return ERASOR_OK;
+        }
+    }
+    return ERASOR_E_INVALID;
+}
+
+int erasor_hip_get_rejected_indices(erasor_hip_handle *h, uint64_t *dst, size_t cap, size_t *n) {
+    if (!h) return ERASOR_E_INVALID;
+    if (!h->have_step) return ERASOR_E_STATE;
+    HIPC(h, hipSetDevice(h->device));
+    const size_t cnt = h->st.n_rejected;
+    if (n) *n = cnt;
+    if (!dst) return ERASOR_OK;
+    if (cnt > cap) return ERASOR_E_CAPACITY;
+    std::vector<uint32_t> tmp(cnt);
+    if (cnt) HIPC(h, hipMemcpy(tmp.data(), h->rejected_src.p, cnt * 4, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < cnt; ++k) dst[k] = tmp[k];
+    return ERASOR_OK;
+}
+
+int erasor_hip_get_bins(erasor_hip_handle *h, int which, uint32_t *count, double *min_h, double *max_h) {
+    if (!h || !count || !min_h || !max_h || (which != 0 && which != 1)) return ERASOR_E_INVALID;
+    if (!h->have_step) return ERASOR_E_STATE;
+    HIPC(h, hipSetDevice(h->device));
+    const uint32_t B = h->B, R = h->P.num_rings, S = h->P.num_sectors;
+    std::vector<uint32_t> c(B);
+    std::vector<float> mn(B), mx(B);
+    HIPC(h, hipMemcpy(c.data(), which ? h->ccnt.p : h->mcnt.p, B * 4, hipMemcpyDeviceToHost));
+    HIPC(h, hipMemcpy(mn.data(), which ? h->cmin.p : h->mmin.p, B * 4, hipMemcpyDeviceToHost));
+    HIPC(h, hipMemcpy(mx.data(), which ? h->cmax.p : h->mmax.p, B * 4, hipMemcpyDeviceToHost));
+    for (uint32_t key = 0; key < B; ++key) {  // device key = sector*R + ring -> API index = ring*S + sector
+        const uint32_t ring = key % R, sector = key / R;
+        const uint32_t o = ring * S + sector;
+        count[o] = c[key];
+        min_h[o] = c[key] ? (double)mn[key] : INF_H;
+        max_h[o] = c[key] ? (double)mx[key] : -INF_H;
+    }
+    return ERASOR_OK;
+}
+
+int erasor_hip_get_status(erasor_hip_handle *h, double *status) {
+    if (!h || !status) return ERASOR_E_INVALID;
+    if (!h->have_step) return ERASOR_E_STATE;
+    HIPC(h, hipSetDevice(h->device));
+    const uint32_t B = h->B, R = h->P.num_rings, S = h->P.num_sectors;
+    std::vector<uint8_t> s(B);
+    HIPC(h, hipMemcpy(s.data(), h->status.p, B, hipMemcpyDeviceToHost));
+    static const double tab[6] = {ERASOR_ST_LITTLE_NUM, ERASOR_ST_MERGE_BINS, ERASOR_ST_MAP_IS_HIGHER, ERASOR_ST_BLOCKED, ERASOR_ST_CURR_IS_HIGHER,
+                                  ERASOR_ST_LITTLE_NUM};
+    for (uint32_t key = 0; key < B; ++key) status[(key % R) * S + key / R] = tab[s[key] < 6 ? s[key] : 0];
+    return ERASOR_OK;
+}
+
+int erasor_hip_get_planes(erasor_hip_handle *h, uint32_t *bin_index, float *normal, double *d, size_t cap_bins, size_t *n_bins) {
+    if (!h) return ERASOR_E_INVALID;
+    if (!h->have_step) return ERASOR_E_STATE;
+    HIPC(h, hipSetDevice(h->device));
+    const size_t nb = h->st.n_rev;
+    if (n_bins) *n_bins = nb;
+    if (!bin_index || !normal || !d) return ERASOR_OK;
+    if (nb > cap_bins) return ERASOR_E_CAPACITY;
+    const uint32_t R = h->P.num_rings, S = h->P.num_sectors;
+    const size_t it = h->P.gf_iter;
+    std::vector<uint32_t> keys(nb);
+    if (nb) {
+        HIPC(h, hipMemcpy(keys.data(), h->rev_list.p, nb * 4, hipMemcpyDeviceToHost));
+        HIPC(h, hipMemcpy(normal, h->plane_n.p, nb * it * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        HIPC(h, hipMemcpy(d, h->plane_d.p, nb * it * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    for (size_t k = 0; k < nb; ++k) bin_index[k] = (keys[k] % R) * S + keys[k] / R;
+    return ERASOR_OK;
+}
+
+int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src, size_t n, double leaf_size, float *dst, size_t cap,
+                                          size_t *n_out) {
+    if (!h || (!src && n) || !(leaf_size > 0) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
+    HIPC(h, hipSetDevice(h->device));
+    prof_collect(h);
+    const uint32_t ns = (uint32_t)n;
+    int rc = alloc_scan(h, std::max(ns, 1u));
+    if (rc) return rc;
+    if (ns) HIPC(h, hipMemcpyAsync(h->scan.p, src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    LAUNCH(h, "step_begin", k_step_begin, 1, 1, h->d_st.p, h->d_ctr.p);
+    voxelize_query_part1(h, ns, (float)leaf_size);
+    DevState st;
+    VoxGrid g;
+    HIPC(h, hipMemcpyAsync(&st, h->d_st.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipMemcpyAsync(&g, h->qgrid.p, sizeof(g), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if (ns && g.overflow) {
+        h->err = "VoxelGrid index overflow (reference returns the input unvoxelised): not supported on device";
+        return ERASOR_E_UNSUPPORTED;
+    }
+    const uint32_t nq = st.q_nvox;
+    if (n_out) *n_out = nq;
+    if (nq) {
+        // identity lidar->body; the R-POD key output is ignored
+        const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        // x*1 + y*0 + z*0 + 0 reproduces x exactly (0*finite = 0, x+0 = x; -0.0 would become +0.0, irrelevant for a centroid)
+        LAUNCH(h, "q_centroids", k_centroids, cdiv(nq, 256), 256, (const float4 *)h->scan.p, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
+               (const uint32_t *)h->run_begin.p, (const uint32_t *)&h->d_st.p->q_nvox, h->cent.p, h->ukeys.p);
+        LAUNCH(h, "q_nn", k_query_nn, cdiv(nq, 256), 256, (const float4 *)h->scan.p, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
+               (const uint32_t *)h->ukeys.p, (const float4 *)h->cent.p, (const uint32_t *)&h->d_st.p->q_nvox, (const VoxGrid *)h->qgrid.p, to_xf(I),
+               h->dp, h->d_ctr.p, h->query.p, h->qkey.p);
+        HIPC(h, hipStreamSynchronize(h->stream));
+    }
+    Counters c;
+    HIPC(h, hipMemcpy(&c, h->d_ctr.p, sizeof(c), hipMemcpyDeviceToHost));
+    if (c.sort_qoverflow) {
+        h->err = "exact-sort segment queue overflow";
+        return ERASOR_E_INTERNAL;
+    }
+    if (!dst) return ERASOR_OK;
+    if (nq > cap) return ERASOR_E_CAPACITY;
+    if (nq) HIPC(h, hipMemcpy(dst, h->query.p, (size_t)nq * sizeof(float4), hipMemcpyDeviceToHost));
+    return ERASOR_OK;
+}
+
+int erasor_hip_count_static_dynamic(erasor_hip_handle *h, uint64_t *n_static, uint64_t *n_dynamic) {
+    if (!h || !n_static || !n_dynamic) return ERASOR_E_INVALID;
+    if (!h->have_map) return ERASOR_E_STATE;
+    *n_static = h->st.F_static + h->st.O_static;
+    *n_dynamic = h->st.F_dynamic + h->st.O_dynamic;
+    return ERASOR_OK;
+}
+
+int erasor_hip_profiling(erasor_hip_handle *h, int enable) {
+    if (!h) return ERASOR_E_INVALID;
+    h->prof = enable != 0;
+    return ERASOR_OK;
+}
+int erasor_hip_profile_reset(erasor_hip_handle *h) {
+    if (!h) return ERASOR_E_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    prof_collect(h);
+    for (auto &e : h->prof_tab) e = ProfEntry();
+    return ERASOR_OK;
+}
+int erasor_hip_profile_get(erasor_hip_handle *h, const char **names, double *total_ms, uint64_t *launches, size_t cap, size_t *n) {
+    if (!h) return ERASOR_E_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    prof_collect(h);
+    const size_t cnt = h->prof_names.size();
+    if (n) *n = cnt;
+    for (size_t k = 0; k < cnt && k < cap; ++k) {
+        if (names) names[k] = h->prof_names[k].c_str();
+        if (total_ms) total_ms[k] = h->prof_tab[k].ms;
+        if (launches) launches[k] = h->prof_tab[k].launches;
+    }
+    return ERASOR_OK;
+}
+int erasor_hip_voi_split_bytes(erasor_hip_handle *h, uint64_t *algorithmic_bytes, uint64_t *physical_entries) {
+    if (!h) return ERASOR_E_INVALID;
+    if (!h->have_map) return ERASOR_E_STATE;
+    const uint64_t oe = (uint64_t)h->capO - h->o_begin;
+    if (physical_entries) *physical_entries = (uint64_t)h->nF + oe;
+    // F region streams 16 B/entry (float4), the outskirts region 8 B/entry ({x,y} only); + 16 B of masks per 64 entries
+    if (algorithmic_bytes) *algorithmic_bytes = 16ull * h->nF + 8ull * oe + ((uint64_t)h->nF + oe) / 4;
+    return ERASOR_OK;
+}
+void *erasor_hip_stream(erasor_hip_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+// test hook: device libm probe (sqrt / div / atan2 in double)
+int erasor_hip_probe_math(erasor_hip_handle *h, const double *x, const double *y, size_t n, double *o_sqrt, double *o_div, double *o_atan2) {
+    if (!h || !x || !y || !o_sqrt || !o_div || !o_atan2) return ERASOR_E_INVALID;
+    HIPC(h, hipSetDevice(h->device));
+    double *d = nullptr;
+    HIPC(h, hipMalloc((void **)&d, 5 * n * sizeof(double)));
+    HIPC(h, hipMemcpy(d, x, n * 8, hipMemcpyHostToDevice));
+    HIPC(h, hipMemcpy(d + n, y, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_math, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, (const double *)d, (const double *)(d + n), (uint32_t)n, d + 2 * n,
+                       d + 3 * n, d + 4 * n);
+    HIPC(h, hipStreamSynchronize(h->stream));
+    HIPC(h, hipMemcpy(o_sqrt, d + 2 * n, n * 8, hipMemcpyDeviceToHost));
+    HIPC(h, hipMemcpy(o_div, d + 3 * n, n * 8, hipMemcpyDeviceToHost));
+    HIPC(h, hipMemcpy(o_atan2, d + 4 * n, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return ERASOR_OK;
+}
+
+// test hook: exact std::sort emulation of (key,payload) pairs on the device
+int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *vals, size_t n, uint32_t *n_fallback) {
+    if (!h || (!keys && n) || (!vals && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
+    HIPC(h, hipSetDevice(h->device));
+    const uint32_t ns = (uint32_t)n;
+    int rc = alloc_scan(h, std::max(ns, 1u));
+    if (rc) return rc;
+    LAUNCH(h, "step_begin", k_step_begin, 1, 1, h->d_st.p, h->d_ctr.p);
+    if (ns) {
+        HIPC(h, hipMemcpyAsync(h->qk_a.p, keys, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
+        HIPC(h, hipMemcpyAsync(h->qv_a.p, vals, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    Counters *dc = h->d_ctr.p;
+    LAUNCH(h, "q_esort", k_esort_init, 1, 1, h->esq0.p, h->essmall.p, h->esqs.p, ns);
+    int cur = 0;
+    if (ns > ES_LMAX) {
+        const int nlev = std::min(2 * esort::lg2_floor(ns), 14);
+        for (int l = 0; l < nlev; ++l) {
+            LAUNCH(h, "q_esort", k_esort_level, 64, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, cur ? h->esq1.p : h->esq0.p,
+                   cur ? h->esq0.p : h->esq1.p, h->essmall.p, h->esqs.p, cur, 65536u, dc);
+            LAUNCH(h, "q_esort", k_esort_level_reset, 1, 1, h->esqs.p, cur);
+            cur ^= 1;
+        }
+    }
+    LAUNCH(h, "q_esort", k_esort_final, 256, 256, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->qhead.p, h->qk_b.p, h->qv_b.p,
+           (const esort::Seg *)h->essmall.p, (const esort::Seg *)(cur ? h->esq1.p : h->esq0.p), h->esqs.p, cur, dc);
+    HIPC(h, hipStreamSynchronize(h->stream));
+    Counters c;
+    HIPC(h, hipMemcpy(&c, dc, sizeof(c), hipMemcpyDeviceToHost));
+    if (c.sort_qoverflow) {
+        h->err = "exact-sort segment queue overflow";
+        return ERASOR_E_INTERNAL;
+    }
+    if (n_fallback) *n_fallback = c.n_sort_fallback;
+    if (ns) {
+        HIPC(h, hipMemcpy(keys, h->qk_b.p, (size_t)ns * 4, hipMemcpyDeviceToHost));
+        HIPC(h, hipMemcpy(vals, h->qv_b.p, (size_t)ns * 4, hipMemcpyDeviceToHost));
+    }
+    return ERASOR_OK;
+}
+
+}  // extern "C"

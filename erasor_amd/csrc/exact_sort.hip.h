@@ -1,0 +1,228 @@
+// exact_sort.hip.h — wavefront / workgroup drivers of exact_sort_core.h (gfx950, wave64).
+//
+//   block_esort()      : one workgroup sorts K[0..n) / V[0..n) (LDS or global pointers) exactly as
+//                        std::sort would: level-synchronous segment queue, ONE WAVEFRONT PER SEGMENT
+//                        (ballot-ranked stop lists), leaf finalisation by stable ranking.
+//   block_partition()  : one workgroup performs a single partition of a large global-memory segment
+//                        (used for the top levels of the query-scan voxel sort).
+#ifndef ERASOR_EXACT_SORT_HIP_H
+#define ERASOR_EXACT_SORT_HIP_H
+
+#include <hip/hip_runtime.h>
+
+#include "exact_sort_core.h"
+
+namespace esort {
+
+struct Seg {
+    uint32_t first, last;
+    int32_t depth;
+};
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    const uint32_t lane = threadIdx.x & 63u;
+    return lane == 0 ? 0ull : (~0ull >> (64u - lane));
+}
+
+// intra-wave visibility of LDS/global writes made by other lanes of the same wave
+__device__ __forceinline__ void wave_sync() { __threadfence_block(); }
+
+// One wavefront partitions [first,last) (size > kThreshold).  posL/posR: scratch, same index space
+// as K (entries [first+1,last) are used).  Returns the cut (wave-uniform).
+template <class KP, class VP, class PP>
+__device__ uint32_t wave_partition(KP K, VP V, PP posL, PP posR, uint32_t first, uint32_t last) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lt = lanemask_lt();
+    if (lane == 0) move_median_to_first(K, V, first, last);
+    wave_sync();
+    const uint32_t p = K[first];
+    const uint32_t lo = first + 1, hi = last;
+    uint32_t nL = 0, nR = 0;
+    for (uint32_t base = lo; base < hi; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < hi;
+        const uint32_t k = valid ? (uint32_t)K[i] : 0u;
+        const bool isL = valid && !(k < p);
+        const bool isR = valid && !(p < k);
+        const uint64_t mL = __ballot(isL), mR = __ballot(isR);
+        if (isL) posL[lo + nL + __popcll(mL & lt)] = i;
+        if (isR) posR[lo + nR + __popcll(mR & lt)] = i;
+        nL += __popcll(mL);
+        nR += __popcll(mR);
+    }
+    wave_sync();
+    const uint32_t lim = nL < nR ? nL : nR;
+    uint32_t m = 0;
+    for (uint32_t base = 0; base < lim; base += 64) {
+        const uint32_t k = base + lane;
+        const bool ok = (k < lim) && ((uint32_t)posL[lo + k] < (uint32_t)posR[lo + nR - 1 - k]);
+        const uint32_t c = __popcll(__ballot(ok));
+        m += c;
+        if (c < 64) break;  // monotone predicate
+    }
+    uint32_t cut = 0xFFFFFFFFu;
+    if (m < nL) cut = posL[lo + m];
+    if (m > 0) {
+        const uint32_t r = posR[lo + nR - m];
+        if (r < cut) cut = r;
+    }
+    for (uint32_t k = lane; k < m; k += 64) swap_kv(K, V, (uint32_t)posL[lo + k], (uint32_t)posR[lo + nR - 1 - k]);
+    wave_sync();
+    return cut;
+}
+
+// Whole-subtree sort of K[base..base+n) by one workgroup.  All pointers index the same space
+// (element e lives at K[e]); the segment handled is [seg_first, seg_last) with introsort depth
+// budget `depth`.  qa/qb: LDS queues of capacity qcap; qcnt: 2 LDS counters; head: byte flags for
+// [seg_first, seg_last] (indexable with the same element indices).  On return K2/V2[seg range] hold
+// the final order.  K2/V2 may alias posL/posR (they are dead by then) but not K/V.
+template <class KP, class VP, class PP, class HP, class K2P, class V2P>
+__device__ void block_esort(KP K, VP V, PP posL, PP posR, HP head, K2P K2, V2P V2, uint32_t seg_first, uint32_t seg_last,
+                            int32_t depth, Seg *qa, Seg *qb, uint32_t *qcnt, uint32_t qcap, uint32_t *n_fallback,
+                            uint32_t *overflow_flag) {
+    const uint32_t tid = threadIdx.x, bs = blockDim.x;
+    const uint32_t wave = tid >> 6, nwaves = bs >> 6, lane = tid & 63u;
+    const uint32_t n = seg_last - seg_first;
+    for (uint32_t i = seg_first + tid; i <= seg_last; i += bs) head[i] = (i == seg_first || i == seg_last) ? 1 : 0;
+    if (tid == 0) {
+        qcnt[0] = 0;
+        qcnt[1] = 0;
+        if (n > (uint32_t)kThreshold) {
+            qa[0].first = seg_first;
+            qa[0].last = seg_last;
+            qa[0].depth = depth;
+            qcnt[0] = 1;
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (;;) {
+        const uint32_t nseg = qcnt[cur];
+        if (nseg == 0) break;
+        Seg *q = cur ? qb : qa;
+        Seg *qn = cur ? qa : qb;
+        for (uint32_t s = wave; s < nseg; s += nwaves) {
+            const Seg sg = q[s];
+            if (sg.depth == 0) {
+                if (lane == 0) {
+                    heapsort_exact(K, V, sg.first, sg.last);
+                    // a heapsorted segment is fully sorted: make every element its own leaf
+                    for (uint32_t i = sg.first; i < sg.last; ++i) head[i] = 1;
+                    atomicAdd(n_fallback, 1u);
+                }
+                continue;
+            }
+            const uint32_t cut = wave_partition(K, V, posL, posR, sg.first, sg.last);
+            if (lane == 0) {
+                head[cut] = 1;
+                if (cut - sg.first > (uint32_t)kThreshold) {
+                    const uint32_t at = atomicAdd(&qcnt[cur ^ 1], 1u);
+                    if (at < qcap) {
+                        qn[at].first = sg.first;
+                        qn[at].last = cut;
+                        qn[at].depth = sg.depth - 1;
+                    } else
+                        *overflow_flag = 1;
+                }
+                if (sg.last - cut > (uint32_t)kThreshold) {
+                    const uint32_t at = atomicAdd(&qcnt[cur ^ 1], 1u);
+                    if (at < qcap) {
+                        qn[at].first = cut;
+                        qn[at].last = sg.last;
+                        qn[at].depth = sg.depth - 1;
+                    } else
+                        *overflow_flag = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (qcnt[cur ^ 1] > qcap) qcnt[cur ^ 1] = qcap;
+            qcnt[cur] = 0;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    __syncthreads();
+    // leaves -> stable ranks.  Results go to registers first because K2/V2 may alias posL/posR only,
+    // never K/V, so a direct write is safe.
+    for (uint32_t i = seg_first + tid; i < seg_last; i += bs) {
+        uint32_t a = i;
+        while (!head[a]) --a;
+        uint32_t b = i + 1;
+        while (!head[b]) ++b;
+        const uint32_t r = leaf_rank(K, a, b, i);
+        K2[a + r] = K[i];
+        V2[a + r] = V[i];
+    }
+    __syncthreads();
+}
+
+// One workgroup performs ONE partition of the global-memory segment [first,last).  sm: >= 2*nwaves+4 uint32.
+template <class KP, class VP, class PP>
+__device__ uint32_t block_partition(KP K, VP V, PP posL, PP posR, uint32_t first, uint32_t last, uint32_t *sm) {
+    const uint32_t tid = threadIdx.x, bs = blockDim.x;
+    const uint32_t wave = tid >> 6, nwaves = bs >> 6, lane = tid & 63u;
+    const uint64_t lt = lanemask_lt();
+    if (tid == 0) move_median_to_first(K, V, first, last);
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t p = K[first];
+    const uint32_t lo = first + 1, hi = last;
+    uint32_t carryL = 0, carryR = 0;  // uniform across the block (recomputed identically by all threads)
+    for (uint32_t base = lo; base < hi; base += bs) {
+        const uint32_t i = base + tid;
+        const bool valid = i < hi;
+        const uint32_t k = valid ? (uint32_t)K[i] : 0u;
+        const bool isL = valid && !(k < p);
+        const bool isR = valid && !(p < k);
+        const uint64_t mL = __ballot(isL), mR = __ballot(isR);
+        if (lane == 0) {
+            sm[wave] = __popcll(mL);
+            sm[nwaves + wave] = __popcll(mR);
+        }
+        __syncthreads();
+        uint32_t preL = 0, preR = 0, totL = 0, totR = 0;
+        for (uint32_t w = 0; w < nwaves; ++w) {
+            const uint32_t a = sm[w], b = sm[nwaves + w];
+            if (w < wave) {
+                preL += a;
+                preR += b;
+            }
+            totL += a;
+            totR += b;
+        }
+        if (isL) posL[lo + carryL + preL + __popcll(mL & lt)] = i;
+        if (isR) posR[lo + carryR + preR + __popcll(mR & lt)] = i;
+        carryL += totL;
+        carryR += totR;
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t nL = carryL, nR = carryR;
+    const uint32_t lim = nL < nR ? nL : nR;
+    // m = number of k < lim with posL[k] < R[k]; monotone -> count in parallel
+    uint32_t cnt = 0;
+    for (uint32_t k = tid; k < lim; k += bs) cnt += ((uint32_t)posL[lo + k] < (uint32_t)posR[lo + nR - 1 - k]) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if (lane == 0) sm[wave] = cnt;
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) m += sm[w];
+    __syncthreads();
+    uint32_t cut = 0xFFFFFFFFu;
+    if (m < nL) cut = posL[lo + m];
+    if (m > 0) {
+        const uint32_t r = posR[lo + nR - m];
+        if (r < cut) cut = r;
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < m; k += bs) swap_kv(K, V, (uint32_t)posL[lo + k], (uint32_t)posR[lo + nR - 1 - k]);
+    __threadfence_block();
+    __syncthreads();
+    return cut;
+}
+
+}  // namespace esort
+#endif

@@ -1,0 +1,1661 @@
+// kernels.hip.h — hand-written gfx950 kernels of the ERASOR hot path.
+//
+// Reference citations (paths under the reference checkout):
+//   erasor.cpp = src/offline_map_updater/src/erasor.cpp, erasor.h = include/erasor/erasor.h,
+//   OMU.cpp = src/offline_map_updater/src/OfflineMapUpdater.cpp, utils.cpp = .../erasor_utils.cpp
+//
+// Arithmetic contract (compiled with -ffp-contract=off, no fast-math): every float/double operation
+// below is a separate IEEE operation in the reference's order, so results are bit-identical to the
+// reference's x86-64 SSE2 build.  The only libm call whose last bit may differ is atan2 (OCML vs
+// glibc); points where that could change a sector index are counted in Counters::n_ambiguous.
+#ifndef ERASOR_KERNELS_HIP_H
+#define ERASOR_KERNELS_HIP_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "exact_sort.hip.h"
+
+namespace ek {
+
+static constexpr uint32_t HOLE_BITS = 0xFFC0DEADu;  // x of a tombstoned outskirts slot (a quiet NaN payload)
+static constexpr int TILE = 64;
+static constexpr int CHUNK_TILES = 8;
+static constexpr int CHUNK = TILE * CHUNK_TILES;  // 512 points handled by one wavefront iteration
+static constexpr double INF_H = 10000000000000.0;  // erasor.h:3
+static constexpr double PI_REF = 3.1415926535;     // erasor.h:4
+
+// status codes on device
+enum : uint8_t { ST_LITTLE = 0, ST_MERGE = 1, ST_MAP = 2, ST_BLOCKED = 3, ST_CURR = 4, ST_NOT_ASSIGNED = 5 };
+
+struct Xf {
+    float m[12];
+};
+
+struct DP {  // device copy of the parameters
+    double max_r, ring_size, sector_size, max_h, min_h, th_bin_max_h, srt_thr, gf_dist, gf_seeds_h, voi_r2;
+    int32_t R, S, B, num_lowest, min_pts, gf_iter, gf_lpr, version;
+    float leaf_map, leaf_query;
+};
+
+struct Counters {
+    uint32_t n_neg_sector, n_ambiguous, n_degenerate, n_voxel_overflow, n_sort_fallback, sort_qoverflow, err, pad;
+};
+
+// device-resident step state (copied to the host twice per step)
+struct DevState {
+    // map store
+    uint32_t nF, o_begin;
+    // VoI split products
+    uint32_t voi_total, voiF, valid_total, validF, n_leaving, o_new_begin;
+    // query
+    uint32_t q_nvox, q_overflow, q_nbinned, pad0;
+    int32_t q_min_b[3], q_div_b[3];
+    // SRT / R-GPF
+    uint32_t n_rev, vox_scratch_total;
+    // assembly
+    uint32_t total_bins, n_static_est, n_ground, n_compl, n_rejected, nF_new, n_curr_rejected, pad1;
+    // label counters
+    unsigned long long F_static, F_dynamic, O_static, O_dynamic;
+};
+
+__device__ __forceinline__ uint64_t lanemask_lt() { return esort::lanemask_lt(); }
+
+// pcl::transformPointCloud, PCL <= 1.9 scalar formula (OMU.cpp:240,436,447): ((a*x + b*y) + c*z) + d
+__device__ __forceinline__ float4 xform(const Xf &T, float4 p) {
+    float4 o;
+    o.x = ((T.m[0] * p.x + T.m[1] * p.y) + T.m[2] * p.z) + T.m[3];
+    o.y = ((T.m[4] * p.x + T.m[5] * p.y) + T.m[6] * p.z) + T.m[7];
+    o.z = ((T.m[8] * p.x + T.m[9] * p.y) + T.m[10] * p.z) + T.m[11];
+    o.w = p.w;
+    return o;
+}
+
+// label decode (utils.cpp:64-65): numeric cast, & 0xFFFF, dynamic = 252..259
+__device__ __forceinline__ bool is_dynamic_label(float intensity) {
+    // static_cast<uint32_t>(float): x86 cvttss2si semantics for in-range values; labels are < 2^24
+    const uint32_t u = (uint32_t)intensity;
+    const uint32_t sem = u & 0xFFFFu;
+    return sem >= 252u && sem <= 259u;
+}
+
+// R-POD bin of an egocentric point (erasor.cpp:104-110, 11-21).  Returns theta-major key
+// sector*R + ring, or B if the point fails a gate.
+__device__ __forceinline__ uint32_t bin_key(const DP &P, float x, float y, float z, Counters *ctr) {
+    if ((double)z < P.max_h && (double)z > P.min_h) {
+        const double dx = (double)x, dy = (double)y;
+        const double r = sqrt(dx * dx + dy * dy);
+        if (r <= P.max_r) {
+            double theta;
+            if (dy >= 0)
+                theta = atan2(dy, dx);
+            else
+                theta = 2 * PI_REF + atan2(dy, dx);
+            const double q = theta / P.sector_size;
+            if (q != 0.0 && fabs(q - rint(q)) < 1e-11) atomicAdd(&ctr->n_ambiguous, 1u);
+            int sidx = (int)q;
+            if (sidx > P.S - 1) sidx = P.S - 1;
+            int ridx = (int)(r / P.ring_size);
+            if (ridx > P.R - 1) ridx = P.R - 1;
+            if (sidx < 0) {  // y == -0.0f, x < 0: the reference throws (vector::at); defined clamp
+                sidx = 0;
+                atomicAdd(&ctr->n_neg_sector, 1u);
+            }
+            return (uint32_t)(sidx * P.R + ridx);
+        }
+    }
+    return (uint32_t)P.B;
+}
+
+// ---- small block-level helpers -------------------------------------------------------------------
+// exclusive scan of one value per thread; sm >= 34 uint32; returns prefix, writes block total
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *sm, uint32_t &total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    uint32_t inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if ((int)lane >= off) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) sm[wave] = inc;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+    for (uint32_t w = 0; w < nw; ++w) {
+        const uint32_t t = sm[w];
+        if (w < wave) pre += t;
+        tot += t;
+    }
+    total = tot;
+    return pre + inc - v;
+}
+
+// ================================================================================================
+// (1) voi_split — THE HBM-bound kernel.  fetch_VoI's membership test (OMU.cpp:391-395) over every
+// physical entry of the map store.  One wavefront per 512-point chunk, 8 loads in flight per lane.
+//   F region: dense float4 (the previous step's VoI-resident part of the map, nF entries)
+//   O region: outskirts, split SoA-of-pairs layout {x,y} | {z,intensity}; only {x,y} is streamed.
+// Outputs: per 64-point tile an in-VoI mask and a valid mask, per chunk (voi | valid<<16).
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F, uint32_t nF, uint32_t nFchunks,
+                                                    const float2 *__restrict__ Oxy, uint32_t o_begin, uint32_t o_chunk0,
+                                                    uint32_t nOchunks, double xc, double yc, double r2,
+                                                    unsigned long long *__restrict__ vmask,
+                                                    unsigned long long *__restrict__ hmask, uint32_t *__restrict__ cinfo) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nchunks = nFchunks + nOchunks;
+    for (uint32_t c = wid; c < nchunks; c += nwaves) {
+        float px[CHUNK_TILES], py[CHUNK_TILES];
+        bool valid[CHUNK_TILES];
+        if (c < nFchunks) {
+            const uint32_t base = c * CHUNK + lane;
+#pragma unroll
+            for (int t = 0; t < CHUNK_TILES; ++t) {
+                const uint32_t idx = base + t * TILE;
+                valid[t] = idx < nF;
+                const float4 p = valid[t] ? F[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                px[t] = p.x;
+                py[t] = p.y;
+            }
+        } else {
+            const uint32_t base = (c - nFchunks + o_chunk0) * CHUNK + lane;
+#pragma unroll
+            for (int t = 0; t < CHUNK_TILES; ++t) {
+                const uint32_t idx = base + t * TILE;
+                const bool inr = idx >= o_begin;
+                const float2 p = inr ? Oxy[idx] : make_float2(0.f, 0.f);
+                valid[t] = inr && (__float_as_uint(p.x) != HOLE_BITS);
+                px[t] = p.x;
+                py[t] = p.y;
+            }
+        }
+        unsigned long long myv = 0, myh = 0;
+        uint32_t cv = 0, ch = 0;
+#pragma unroll
+        for (int t = 0; t < CHUNK_TILES; ++t) {
+            // double dist_square = pow(pt.x - x_criterion, 2) + pow(pt.y - y_criterion, 2)  (OMU.cpp:394)
+            const double dx = (double)px[t] - xc, dy = (double)py[t] - yc;
+            const double d2 = dx * dx + dy * dy;
+            const bool in = valid[t] && (d2 < r2);
+            const unsigned long long vm = __ballot(in), hm = __ballot(valid[t]);
+            if ((int)lane == t) {
+                myv = vm;
+                myh = hm;
+            }
+            cv += __popcll(vm);
+            ch += __popcll(hm);
+        }
+        if (lane < CHUNK_TILES) {
+            vmask[(size_t)c * CHUNK_TILES + lane] = myv;
+            hmask[(size_t)c * CHUNK_TILES + lane] = myh;
+        }
+        if (lane == 0) cinfo[c] = cv | (ch << 16);
+    }
+}
+
+// ---- chunk prefix sums (two-level) --------------------------------------------------------------
+// level 1: 1024 chunks per block; local exclusive prefixes of the voi and valid counts + block totals
+__global__ __launch_bounds__(256) void k_chunk_scan_local(const uint32_t *__restrict__ cinfo, uint32_t nchunks,
+                                                           uint32_t *__restrict__ pvl, uint32_t *__restrict__ phl,
+                                                           uint32_t *__restrict__ topv, uint32_t *__restrict__ toph) {
+    __shared__ uint32_t sm[40];
+    const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t v[4], h[4];
+    uint32_t sv = 0, sh = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t ci = (base + j < nchunks) ? cinfo[base + j] : 0u;
+        v[j] = ci & 0xFFFFu;
+        h[j] = ci >> 16;
+        sv += v[j];
+        sh += h[j];
+    }
+    uint32_t tv, th;
+    uint32_t pv = block_excl_scan(sv, sm, tv);
+    uint32_t ph = block_excl_scan(sh, sm, th);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (base + j < nchunks) {
+            pvl[base + j] = pv;
+            phl[base + j] = ph;
+        }
+        pv += v[j];
+        ph += h[j];
+    }
+    if (threadIdx.x == 0) {
+        topv[blockIdx.x] = tv;
+        toph[blockIdx.x] = th;
+    }
+}
+
+// level 2 (single block): exclusive scan of the block totals in place; derive the step's VoI sizes.
+__global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ topv, uint32_t *__restrict__ toph, uint32_t ntop,
+                                                          const uint32_t *__restrict__ pvl, const uint32_t *__restrict__ phl,
+                                                          uint32_t nchunks, uint32_t nFchunks, DevState *st) {
+    __shared__ uint32_t sm[40];
+    __shared__ uint32_t carry[2];
+    if (threadIdx.x == 0) carry[0] = carry[1] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < ntop; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < ntop ? topv[i] : 0u, h = i < ntop ? toph[i] : 0u;
+        uint32_t tv, th;
+        const uint32_t pv = block_excl_scan(v, sm, tv);
+        const uint32_t ph = block_excl_scan(h, sm, th);
+        const uint32_t c0 = carry[0], c1 = carry[1];
+        if (i < ntop) {
+            topv[i] = c0 + pv;
+            toph[i] = c1 + ph;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            carry[0] = c0 + tv;
+            carry[1] = c1 + th;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t voi_total = carry[0], valid_total = carry[1];
+        uint32_t voiF = voi_total, validF = valid_total;
+        if (nFchunks < nchunks) {
+            voiF = pvl[nFchunks] + topv[nFchunks >> 10];
+            validF = phl[nFchunks] + toph[nFchunks >> 10];
+        }
+        st->voi_total = voi_total;
+        st->valid_total = valid_total;
+        st->voiF = voiF;
+        st->validF = validF;
+        st->n_leaving = validF - voiF;
+        st->o_new_begin = st->o_begin - (validF - voiF);
+    }
+}
+
+// ================================================================================================
+// (2) voi_gather — for every set VoI bit: fetch the point, egocentric transform (OMU.cpp:435-437),
+// R-POD key (erasor.cpp:124-139), write into VoI order; tombstone outskirts sources; move the
+// points that left the VoI from the F region to the front of the outskirts region.
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F, uint32_t nF, uint32_t nFchunks,
+                                                     float2 *__restrict__ Oxy, float2 *__restrict__ Ozi, uint32_t o_chunk0,
+                                                     uint32_t nOchunks, const unsigned long long *__restrict__ vmask,
+                                                     const unsigned long long *__restrict__ hmask,
+                                                     const uint32_t *__restrict__ cinfo, const uint32_t *__restrict__ pvl,
+                                                     const uint32_t *__restrict__ phl, const uint32_t *__restrict__ topv,
+                                                     const uint32_t *__restrict__ toph, Xf To2b, DP P, DevState *st,
+                                                     Counters *ctr, float4 *__restrict__ voi_ego, uint32_t *__restrict__ voi_key,
+                                                     uint32_t *__restrict__ voi_src) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nchunks = nFchunks + nOchunks;
+    const uint64_t lt = lanemask_lt();
+    const uint32_t validF = st->validF, voiF = st->voiF, o_new_begin = st->o_new_begin;
+    uint32_t dyn_leave = 0, stat_leave = 0, dyn_enter = 0, stat_enter = 0;
+    for (uint32_t c = wid; c < nchunks; c += nwaves) {
+        const uint32_t ci = cinfo[c];
+        const uint32_t cv = ci & 0xFFFFu, ch = ci >> 16;
+        const bool isF = c < nFchunks;
+        if (cv == 0 && !(isF && ch > cv)) continue;
+        uint32_t pv = pvl[c] + topv[c >> 10];
+        uint32_t ph = phl[c] + toph[c >> 10];
+        const unsigned long long mv = lane < CHUNK_TILES ? vmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
+        const unsigned long long mh = lane < CHUNK_TILES ? hmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
+        for (int t = 0; t < CHUNK_TILES; ++t) {
+            const unsigned long long vm = __shfl(mv, t, 64), hm = __shfl(mh, t, 64);
+            if (isF) {
+                const unsigned long long lm = hm & ~vm;
+                if (hm != 0ull) {
+                    const uint32_t idx = c * CHUNK + t * TILE + lane;
+                    const bool in = (vm >> lane) & 1ull, lv = (lm >> lane) & 1ull;
+                    if (in || lv) {
+                        const float4 p = F[idx];
+                        if (in) {
+                            const uint32_t rank = pv + __popcll(vm & lt);
+                            const float4 e = xform(To2b, p);
+                            voi_ego[rank] = e;
+                            voi_key[rank] = bin_key(P, e.x, e.y, e.z, ctr);
+                            voi_src[rank] = idx;
+                        } else {
+                            // leaving: logical order of the new outskirts = [leaving (F order) | old outskirts]
+                            const uint32_t lr = (ph - pv) + __popcll(lm & lt);
+                            const uint32_t dst = o_new_begin + lr;
+                            Oxy[dst] = make_float2(p.x, p.y);
+                            Ozi[dst] = make_float2(p.z, p.w);
+                            if (is_dynamic_label(p.w)) ++dyn_leave; else ++stat_leave;
+                        }
+                    }
+                }
+            } else if (vm != 0ull) {
+                const uint32_t idx = (c - nFchunks + o_chunk0) * CHUNK + t * TILE + lane;
+                if ((vm >> lane) & 1ull) {
+                    const float2 a = Oxy[idx], b = Ozi[idx];
+                    const uint32_t rank = pv + __popcll(vm & lt);
+                    const float4 e = xform(To2b, make_float4(a.x, a.y, b.x, b.y));
+                    voi_ego[rank] = e;
+                    voi_key[rank] = bin_key(P, e.x, e.y, e.z, ctr);
+                    voi_src[rank] = nF + (ph - validF) + __popcll(hm & lt);
+                    reinterpret_cast<uint32_t *>(Oxy)[(size_t)idx * 2] = HOLE_BITS;  // tombstone
+                    if (is_dynamic_label(b.y)) ++dyn_enter; else ++stat_enter;
+                }
+            }
+            pv += __popcll(vm);
+            ph += __popcll(hm);
+        }
+    }
+    (void)voiF;
+    // outskirts label counters (parse_dynamic_obj is maintained incrementally, OMU.cpp:294)
+    for (int off = 32; off > 0; off >>= 1) {
+        dyn_leave += __shfl_down(dyn_leave, off, 64);
+        stat_leave += __shfl_down(stat_leave, off, 64);
+        dyn_enter += __shfl_down(dyn_enter, off, 64);
+        stat_enter += __shfl_down(stat_enter, off, 64);
+    }
+    if (lane == 0) {
+        if (dyn_leave | dyn_enter) atomicAdd(&st->O_dynamic, (unsigned long long)dyn_leave - (unsigned long long)dyn_enter);
+        if (stat_leave | stat_enter) atomicAdd(&st->O_static, (unsigned long long)stat_leave - (unsigned long long)stat_enter);
+    }
+}
+
+// ================================================================================================
+// generic two-level exclusive scan of uint32 (n read from device memory when n_dev != nullptr)
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_scan_local(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                     uint32_t *__restrict__ tops, uint32_t n_host, const uint32_t *n_dev) {
+    __shared__ uint32_t sm[40];
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
+    if (blockIdx.x * 1024 >= n && blockIdx.x != 0) return;
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = (base + j < n) ? in[base + j] : 0u;
+        s += v[j];
+    }
+    uint32_t tot;
+    uint32_t p = block_excl_scan(s, sm, tot);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (base + j < n) out[base + j] = p;
+        p += v[j];
+    }
+    if (threadIdx.x == 0) tops[blockIdx.x] = tot;
+}
+// single block; tops[ntop] receives the grand total
+__global__ __launch_bounds__(1024) void k_scan_top(uint32_t *__restrict__ tops, uint32_t n_host, const uint32_t *n_dev,
+                                                    uint32_t *total_out) {
+    __shared__ uint32_t sm[40];
+    __shared__ uint32_t carry;
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t ntop = (n + 1023) / 1024;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < ntop; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < ntop ? tops[i] : 0u;
+        uint32_t t;
+        const uint32_t p = block_excl_scan(v, sm, t);
+        const uint32_t c0 = carry;
+        if (i < ntop) tops[i] = c0 + p;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c0 + t;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tops[ntop] = carry;
+        if (total_out) *total_out = carry;
+    }
+}
+
+// ================================================================================================
+// stable LSD radix sort (8-bit digits) of uint32 keys with implicit/explicit uint32 payload.
+// Tile = 2048 keys per 256-thread block; each wavefront owns a contiguous 512-key strip so that
+// (block, wave, round, lane) order == index order (stability).
+// ================================================================================================
+static constexpr int RTILE = 2048;
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t m = __ballot(valid && bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t *__restrict__ keys, uint32_t n_host, const uint32_t *n_dev,
+                                                     int shift, uint32_t *__restrict__ hist /* [256][nblk] */) {
+    __shared__ uint32_t wcnt[4][256];
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t nblk = (n + RTILE - 1) / RTILE;
+    if (blockIdx.x >= nblk) return;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint64_t lt = lanemask_lt();
+    for (uint32_t i = tid; i < 4 * 256; i += 256) (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t strip = blockIdx.x * RTILE + wave * 512;
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t i = strip + r * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t d = valid ? ((keys[i] >> shift) & 0xFFu) : 0u;
+        const uint64_t peers = match_digit(d, valid);
+        if (valid && (peers & lt) == 0) wcnt[wave][d] += __popcll(peers);
+        esort::wave_sync();
+    }
+    __syncthreads();
+    const uint32_t tot = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+    hist[(size_t)tid * nblk + blockIdx.x] = tot;
+}
+
+// writes *cnt_out = 256 * nblk (the number of histogram entries to scan)
+__global__ void k_radix_count(uint32_t n_host, const uint32_t *n_dev, uint32_t *cnt_out) {
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    *cnt_out = 256u * ((n + RTILE - 1) / RTILE);
+}
+
+__global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                        uint32_t n_host, const uint32_t *n_dev, int shift,
+                                                        const uint32_t *__restrict__ hist_local, const uint32_t *__restrict__ hist_tops,
+                                                        uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+    __shared__ uint32_t wcnt[4][256];
+    __shared__ uint32_t wbase[4][256];
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t nblk = (n + RTILE - 1) / RTILE;
+    if (blockIdx.x >= nblk) return;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint64_t lt = lanemask_lt();
+    for (uint32_t i = tid; i < 4 * 256; i += 256) (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t strip = blockIdx.x * RTILE + wave * 512;
+    uint32_t k[8], v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t i = strip + r * 64 + lane;
+        const bool valid = i < n;
+        k[r] = valid ? keys[i] : 0u;
+        v[r] = valid ? (vals ? vals[i] : i) : 0u;
+        const uint32_t d = (k[r] >> shift) & 0xFFu;
+        const uint64_t peers = match_digit(d, valid);
+        if (valid && (peers & lt) == 0) wcnt[wave][d] += __popcll(peers);
+        esort::wave_sync();
+    }
+    __syncthreads();
+    {
+        const size_t e = (size_t)tid * nblk + blockIdx.x;  // digit = tid
+        uint32_t b = hist_local[e] + hist_tops[e >> 10];
+        for (int w = 0; w < 4; ++w) {
+            wbase[w][tid] = b;
+            b += wcnt[w][tid];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t i = strip + r * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t d = (k[r] >> shift) & 0xFFu;
+        const uint64_t peers = match_digit(d, valid);
+        if (valid) {
+            const uint32_t pos = wbase[wave][d] + __popcll(peers & lt);
+            keys_out[pos] = k[r];
+            vals_out[pos] = v[r];
+        }
+        esort::wave_sync();
+        if (valid && (peers & lt) == 0) wbase[wave][d] += __popcll(peers);
+        esort::wave_sync();
+    }
+}
+
+// gather points (and optionally a uint32 side array) into sorted order
+__global__ __launch_bounds__(256) void k_gather(const float4 *__restrict__ src, const uint32_t *__restrict__ src_aux,
+                                                 const uint32_t *__restrict__ perm, uint32_t n_host, const uint32_t *n_dev,
+                                                 float4 *__restrict__ dst, uint32_t *__restrict__ dst_aux) {
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = perm[i];
+    dst[i] = src[p];
+    if (src_aux) dst_aux[i] = src_aux[p];
+}
+
+// off[k] = first sorted position with key >= k, for k in [0, nkeys]; off[nkeys] = n  (nkeys = B+1 buckets -> B+2 entries)
+__global__ __launch_bounds__(256) void k_bin_offsets(const uint32_t *__restrict__ skeys, uint32_t n_host, const uint32_t *n_dev,
+                                                      uint32_t nbuckets, uint32_t *__restrict__ off) {
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) {
+        if (i <= nbuckets) off[i] = 0;
+        return;
+    }
+    if (i > n) return;
+    if (i == n) {
+        for (uint32_t b = skeys[n - 1] + 1; b <= nbuckets; ++b) off[b] = n;
+        return;
+    }
+    const uint32_t kcur = skeys[i];
+    const uint32_t kprev = i == 0 ? 0xFFFFFFFFu : skeys[i - 1];
+    if (i == 0) {
+        for (uint32_t b = 0; b <= kcur; ++b) off[b] = 0;
+    } else if (kcur != kprev) {
+        for (uint32_t b = kprev + 1; b <= kcur; ++b) off[b] = i;
+    }
+}
+
+// per-bin pseudo-occupancy descriptor (erasor.cpp:87-98): count, min z, max z.  One wavefront per bin.
+__global__ __launch_bounds__(256) void k_bin_stats(const float4 *__restrict__ spts, const uint32_t *__restrict__ off, uint32_t B,
+                                                    uint32_t *__restrict__ cnt, float *__restrict__ minz, float *__restrict__ maxz) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= B) return;
+    const uint32_t s = off[b], e = off[b + 1];
+    float mn = __int_as_float(0x7F800000), mx = __int_as_float(0xFF800000);
+    for (uint32_t i = s + lane; i < e; i += 64) {
+        const float z = spts[i].z;
+        mn = z < mn ? z : mn;
+        mx = z > mx ? z : mx;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float a = __shfl_down(mn, o, 64), c = __shfl_down(mx, o, 64);
+        mn = a < mn ? a : mn;
+        mx = c > mx ? c : mx;
+    }
+    if (lane == 0) {
+        cnt[b] = e - s;
+        minz[b] = mn;
+        maxz[b] = mx;
+    }
+}
+
+// ================================================================================================
+// query-scan voxelisation: PCL 1.8 VoxelGrid + label-preserving 1-NN (utils.cpp:80-114; OMU.cpp:238)
+// ================================================================================================
+__device__ __forceinline__ uint32_t fkey_ord(float f) {  // total-order key for float min/max atomics
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+    const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(b);
+}
+
+__global__ void k_bbox_init(uint32_t *bb) {
+    if (threadIdx.x < 3) bb[threadIdx.x] = 0xFFFFFFFFu;
+    if (threadIdx.x >= 3 && threadIdx.x < 6) bb[threadIdx.x] = 0u;
+}
+// getMinMax3D (dense): plain min/max; -0.0/+0.0 order is irrelevant downstream (only products/floors of it)
+__global__ __launch_bounds__(256) void k_bbox(const float4 *__restrict__ pts, uint32_t n, uint32_t *bb) {
+    __shared__ uint32_t sm[6];
+    if (threadIdx.x < 3) sm[threadIdx.x] = 0xFFFFFFFFu;
+    if (threadIdx.x >= 3 && threadIdx.x < 6) sm[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = pts[i];
+        const uint32_t k[3] = {fkey_ord(p.x), fkey_ord(p.y), fkey_ord(p.z)};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = k[a] < mn[a] ? k[a] : mn[a];
+            mx[a] = k[a] > mx[a] ? k[a] : mx[a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t0 = __shfl_down(mn[a], o, 64), t1 = __shfl_down(mx[a], o, 64);
+            mn[a] = t0 < mn[a] ? t0 : mn[a];
+            mx[a] = t1 > mx[a] ? t1 : mx[a];
+        }
+        if ((threadIdx.x & 63u) == 0) {
+            atomicMin(&sm[a], mn[a]);
+            atomicMax(&sm[3 + a], mx[a]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&bb[threadIdx.x], sm[threadIdx.x]);
+    if (threadIdx.x >= 3 && threadIdx.x < 6) atomicMax(&bb[threadIdx.x], sm[threadIdx.x]);
+}
+
+struct VoxGrid {  // PCL VoxelGrid geometry of one cloud
+    int32_t min_b[3], div_b[3];
+    float inv_leaf;
+    int32_t overflow;
+};
+__device__ __forceinline__ VoxGrid vox_grid_from_bbox(const float mn[3], const float mx[3], float leaf) {
+    VoxGrid g;
+    const float inv = 1.0f / leaf;
+    g.inv_leaf = inv;
+    long long d[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) d[a] = (long long)((mx[a] - mn[a]) * inv) + 1;
+    g.overflow = (d[0] * d[1] * d[2]) > 2147483647LL ? 1 : 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        g.min_b[a] = (int)floorf(mn[a] * inv);
+        const int maxb = (int)floorf(mx[a] * inv);
+        g.div_b[a] = maxb - g.min_b[a] + 1;
+    }
+    return g;
+}
+__device__ __forceinline__ uint32_t vox_index(const VoxGrid &g, float x, float y, float z) {
+    const int i0 = (int)(floorf(x * g.inv_leaf) - (float)g.min_b[0]);
+    const int i1 = (int)(floorf(y * g.inv_leaf) - (float)g.min_b[1]);
+    const int i2 = (int)(floorf(z * g.inv_leaf) - (float)g.min_b[2]);
+    return (uint32_t)(i0 + i1 * g.div_b[0] + i2 * (g.div_b[0] * g.div_b[1]));
+}
+
+__global__ __launch_bounds__(256) void k_voxel_keys(const float4 *__restrict__ pts, uint32_t n, const uint32_t *__restrict__ bb,
+                                                     float leaf, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                     VoxGrid *gout, Counters *ctr) {
+    const float mn[3] = {fkey_inv(bb[0]), fkey_inv(bb[1]), fkey_inv(bb[2])};
+    const float mx[3] = {fkey_inv(bb[3]), fkey_inv(bb[4]), fkey_inv(bb[5])};
+    const VoxGrid g = vox_grid_from_bbox(mn, mx, leaf);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        *gout = g;
+        if (g.overflow) atomicAdd(&ctr->n_voxel_overflow, 1u);
+    }
+    if (i >= n) return;
+    const float4 p = pts[i];
+    keys[i] = g.overflow ? 0u : vox_index(g, p.x, p.y, p.z);
+    vals[i] = i;
+}
+
+// ---- exact std::sort of the (idx, point) pairs, global memory -----------------------------------
+static constexpr uint32_t ES_LMAX = 4096;   // segments up to this size are finished inside LDS
+struct EsQueues {
+    uint32_t cnt[2];      // level queues
+    uint32_t small_cnt;   // segments handed to the final kernel
+    uint32_t pad;
+};
+__global__ void k_esort_init(esort::Seg *q0, esort::Seg *smallq, EsQueues *qs, uint32_t n) {
+    qs->cnt[0] = qs->cnt[1] = 0;
+    qs->small_cnt = 0;
+    if (n == 0) return;
+    esort::Seg s;
+    s.first = 0;
+    s.last = n;
+    s.depth = 2 * esort::lg2_floor(n);
+    if (n > ES_LMAX) {
+        q0[0] = s;
+        qs->cnt[0] = 1;
+    } else {
+        smallq[0] = s;
+        qs->small_cnt = 1;
+    }
+}
+// one level: each workgroup takes big segments of queue[cur] and performs one partition
+__global__ __launch_bounds__(1024) void k_esort_level(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, esort::Seg *qcur,
+                                                       esort::Seg *qnext, esort::Seg *smallq, EsQueues *qs, int cur, uint32_t qcap,
+                                                       Counters *ctr) {
+    __shared__ uint32_t sm[40];
+    const uint32_t nseg = qs->cnt[cur];
+    for (uint32_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const esort::Seg sg = qcur[s];
+        if (sg.depth == 0) {  // hand over: the final kernel runs the exact heapsort
+            if (threadIdx.x == 0) {
+                const uint32_t at = atomicAdd(&qs->small_cnt, 1u);
+                if (at < qcap) smallq[at] = sg; else ctr->sort_qoverflow = 1;
+            }
+            continue;
+        }
+        const uint32_t cut = esort::block_partition(K, V, posL, posR, sg.first, sg.last, sm);
+        if (threadIdx.x == 0) {
+            esort::Seg a, b;
+            a.first = sg.first; a.last = cut; a.depth = sg.depth - 1;
+            b.first = cut; b.last = sg.last; b.depth = sg.depth - 1;
+            const esort::Seg ch[2] = {a, b};
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t len = ch[t].last - ch[t].first;
+                if (len == 0) continue;
+                if (len > ES_LMAX) {
+                    const uint32_t at = atomicAdd(&qs->cnt[cur ^ 1], 1u);
+                    if (at < qcap) qnext[at] = ch[t]; else ctr->sort_qoverflow = 1;
+                } else {
+                    const uint32_t at = atomicAdd(&qs->small_cnt, 1u);
+                    if (at < qcap) smallq[at] = ch[t]; else ctr->sort_qoverflow = 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+__global__ void k_esort_level_reset(EsQueues *qs, int cur) { qs->cnt[cur] = 0; }
+
+// final: every remaining segment (any size) is sorted to completion by one workgroup.
+// Segments <= ES_LMAX run in LDS; larger ones (only if the level budget ran out) run in place in global memory.
+__global__ __launch_bounds__(256) void k_esort_final(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, uint8_t *head,
+                                                      uint32_t *K2, uint32_t *V2, const esort::Seg *smallq, const esort::Seg *bigq,
+                                                      EsQueues *qs, int bigcur, Counters *ctr) {
+    __shared__ uint32_t sK[ES_LMAX], sV[ES_LMAX], sL[ES_LMAX], sR[ES_LMAX];
+    __shared__ uint8_t sH[ES_LMAX + 4];
+    __shared__ esort::Seg qa[ES_LMAX / 16 + 2], qb[ES_LMAX / 16 + 2];
+    __shared__ uint32_t qcnt[2];
+    const uint32_t nsmall = qs->small_cnt, nbig = qs->cnt[bigcur];
+    for (uint32_t s = blockIdx.x; s < nsmall + nbig; s += gridDim.x) {
+        const esort::Seg sg = s < nsmall ? smallq[s] : bigq[s - nsmall];
+        const uint32_t len = sg.last - sg.first;
+        if (len <= ES_LMAX) {
+            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+                sK[i] = K[sg.first + i];
+                sV[i] = V[sg.first + i];
+            }
+            __syncthreads();
+            esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, len, sg.depth, qa, qb, qcnt, (uint32_t)(ES_LMAX / 16 + 2),
+                               &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+                K2[sg.first + i] = sL[i];
+                V2[sg.first + i] = sR[i];
+            }
+            __syncthreads();
+        } else {
+            // in-place global path.  Queue capacity is the LDS queue; a segment this large after the level
+            // budget means pathological input; correctness is kept as long as the queue does not overflow.
+            esort::block_esort(K, V, posL, posR, head, K2, V2, sg.first, sg.last, sg.depth, qa, qb, qcnt,
+                               (uint32_t)(ES_LMAX / 16 + 2), &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+        }
+    }
+}
+
+// run heads of the sorted voxel keys
+__global__ __launch_bounds__(256) void k_run_heads(const uint32_t *__restrict__ skeys, uint32_t n, uint32_t *__restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || skeys[i] != skeys[i - 1]) ? 1u : 0u;
+}
+// run_begin[vid] = i for heads; run_begin[nv] = n
+__global__ __launch_bounds__(256) void k_run_begin(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pl,
+                                                    const uint32_t *__restrict__ tops, uint32_t n, uint32_t *__restrict__ run_begin,
+                                                    uint32_t *nv_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) {
+        const uint32_t nv = n ? tops[(n + 1023) / 1024] : 0u;
+        run_begin[nv] = n;
+        *nv_out = nv;
+        return;
+    }
+    if (flag[i]) run_begin[pl[i] + tops[i >> 10]] = i;
+}
+
+// CentroidPoint<PointXYZI>: float32 running sums in sorted order, each / (float)count
+__global__ __launch_bounds__(256) void k_centroids(const float4 *__restrict__ pts, const uint32_t *__restrict__ skeys,
+                                                    const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ run_begin,
+                                                    const uint32_t *nv_dev, float4 *__restrict__ cent, uint32_t *__restrict__ ukeys) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= *nv_dev) return;
+    const uint32_t s = run_begin[v], e = run_begin[v + 1];
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    for (uint32_t li = s; li < e; ++li) {
+        const float4 p = pts[sperm[li]];
+        sx += p.x;
+        sy += p.y;
+        sz += p.z;
+        si += p.w;
+    }
+    const float c = (float)(e - s);
+    cent[v] = make_float4(sx / c, sy / c, sz / c, si / c);
+    ukeys[v] = skeys[s];
+}
+
+// FLANN L2_Simple: ((0 + dx*dx) + dy*dy) + dz*dz in float32
+__device__ __forceinline__ float l2_simple(float ax, float ay, float az, float bx, float by, float bz) {
+    float r = 0.f;
+    const float d0 = ax - bx;
+    r += d0 * d0;
+    const float d1 = ay - by;
+    r += d1 * d1;
+    const float d2 = az - bz;
+    r += d2 * d2;
+    return r;
+}
+
+// exact 1-NN of every centroid among the input points (lowest index on float ties), searched through
+// the sorted voxel runs; then tf_lidar2body and the query's R-POD key (OMU.cpp:240; erasor.cpp:100-115).
+__global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts, const uint32_t *__restrict__ sperm,
+                                                   const uint32_t *__restrict__ run_begin, const uint32_t *__restrict__ ukeys,
+                                                   const float4 *__restrict__ cent, const uint32_t *nv_dev, const VoxGrid *gp, Xf Tl2b,
+                                                   DP P, Counters *ctr, float4 *__restrict__ query, uint32_t *__restrict__ qkey) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nv = *nv_dev;
+    if (v >= nv) return;
+    const VoxGrid g = *gp;
+    const float4 c = cent[v];
+    const uint32_t key = ukeys[v];
+    const int dx = g.div_b[0], dy = g.div_b[1], dz = g.div_b[2];
+    const int ci = (int)(key % (uint32_t)dx), cj = (int)((key / (uint32_t)dx) % (uint32_t)dy), ck = (int)(key / ((uint32_t)dx * (uint32_t)dy));
+    const double L = 1.0 / (double)g.inv_leaf;
+    float best = __int_as_float(0x7F800000);
+    uint32_t best_i = 0xFFFFFFFFu;
+    const int maxrho = max(dx, max(dy, dz));
+    for (int rho = 1;; ++rho) {
+        for (int kk = ck - rho; kk <= ck + rho; ++kk) {
+            if (kk < 0 || kk >= dz) continue;
+            for (int jj = cj - rho; jj <= cj + rho; ++jj) {
+                if (jj < 0 || jj >= dy) continue;
+                const bool shell_jk = (abs(jj - cj) == rho) || (abs(kk - ck) == rho);
+                for (int ii = ci - rho; ii <= ci + rho; ++ii) {
+                    if (ii < 0 || ii >= dx) continue;
+                    if (rho > 1 && !shell_jk && abs(ii - ci) < rho) continue;
+                    const uint32_t q = (uint32_t)ii + (uint32_t)jj * (uint32_t)dx + (uint32_t)kk * (uint32_t)dx * (uint32_t)dy;
+                    uint32_t lo = 0, hi = nv;  // lower_bound
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (ukeys[mid] < q) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo >= nv || ukeys[lo] != q) continue;
+                    for (uint32_t li = run_begin[lo]; li < run_begin[lo + 1]; ++li) {
+                        const uint32_t pi = sperm[li];
+                        const float4 p = pts[pi];
+                        const float dd = l2_simple(c.x, c.y, c.z, p.x, p.y, p.z);
+                        if (dd < best || (dd == best && pi < best_i)) {
+                            best = dd;
+                            best_i = pi;
+                        }
+                    }
+                }
+            }
+        }
+        if (rho >= maxrho) break;
+        const double cc[3] = {(double)c.x, (double)c.y, (double)c.z};
+        const int cidx[3] = {ci, cj, ck};
+        double gmin = 1e300;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double lo = (double)(g.min_b[a] + cidx[a] - rho) * L;
+            const double hi = (double)(g.min_b[a] + cidx[a] + rho + 1) * L;
+            const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
+            const double t = fmin(cc[a] - lo, hi - cc[a]) - margin;
+            gmin = fmin(gmin, t);
+        }
+        if (best_i != 0xFFFFFFFFu && gmin > 0.0 && (double)best <= gmin * gmin) break;
+    }
+    float4 o = c;
+    o.w = pts[best_i].w;  // utils.cpp:109
+    const float4 b = xform(Tl2b, o);
+    query[v] = b;
+    qkey[v] = bin_key(P, b.x, b.y, b.z, ctr);
+}
+
+// ================================================================================================
+// Scan Ratio Test + bin selection (v3: erasor.cpp:438-563; v2: erasor.cpp:332-427).  Single block.
+// Keys are theta-major (key = sector*R + ring), so key order == the reference's loop order.
+// ================================================================================================
+__device__ __forceinline__ double std_min_d(double a, double b) { return (b < a) ? b : a; }
+
+__global__ __launch_bounds__(1024) void k_srt(DP P, const uint32_t *__restrict__ mcnt, const float *__restrict__ mmin,
+                                               const float *__restrict__ mmax, const uint32_t *__restrict__ ccnt,
+                                               const float *__restrict__ cmin, const float *__restrict__ cmax, uint8_t *__restrict__ st1,
+                                               uint8_t *__restrict__ status, uint8_t *__restrict__ action, uint32_t *__restrict__ rev_idx,
+                                               uint32_t *__restrict__ rev_list, uint32_t *__restrict__ vox_off, DevState *st) {
+    // action: 0 keep map bin, 1 revert (curr + ground(map)), 2 v2 merge (curr then map), 3 v2 curr only
+    __shared__ uint32_t sm[40];
+    __shared__ uint32_t carry[2];
+    const int B = P.B;
+    for (int key = threadIdx.x; key < B; key += blockDim.x) {
+        const uint32_t mc = mcnt[key], cc = ccnt[key];
+        const double mmaxh = mc ? (double)mmax[key] : -INF_H, mminh = mc ? (double)mmin[key] : INF_H;
+        const double cmaxh = cc ? (double)cmax[key] : -INF_H, cminh = cc ? (double)cmin[key] : INF_H;
+        uint8_t s = ST_LITTLE;
+        if (P.version == 3) {
+            if (mc == 0) {
+                s = ST_LITTLE;
+            } else if ((long long)cc < (long long)P.min_pts) {
+                s = ST_LITTLE;
+            } else {
+                const double md = mmaxh - mminh, cd = cmaxh - cminh;
+                const double ratio = std_min_d(md / cd, cd / md);
+                if (cc > 0 && mc > 0) {
+                    if (ratio < P.srt_thr) {
+                        if (md >= cd) s = ST_MAP;
+                        else if (md <= cd) s = ST_CURR;
+                    } else {
+                        s = ST_MERGE;
+                    }
+                }
+            }
+        }
+        st1[key] = s;
+    }
+    __syncthreads();
+    for (int key = threadIdx.x; key < B; key += blockDim.x) {
+        const uint32_t mc = mcnt[key], cc = ccnt[key];
+        const double mmaxh = mc ? (double)mmax[key] : -INF_H, mminh = mc ? (double)mmin[key] : INF_H;
+        const double cmaxh = cc ? (double)cmax[key] : -INF_H, cminh = cc ? (double)cmin[key] : INF_H;
+        uint8_t fs = ST_LITTLE, act = 0;
+        if (P.version == 3) {
+            const uint8_t s = st1[key];
+            if (s == ST_MAP) {
+                if ((mmaxh - mminh) > 0.5) {  // erasor.cpp:511
+                    fs = ST_MAP;
+                    act = 1;
+                } else {
+                    fs = ST_NOT_ASSIGNED;
+                }
+            } else if (s == ST_CURR) {
+                fs = ST_CURR;
+            } else if (s == ST_MERGE) {
+                // is_dynamic_obj_close(r, theta, 1, 1): erasor.cpp:573-595 (theta wrap uses num_rings)
+                const int r_t = key % P.R, th_t = key / P.R;
+                bool close = false;
+                for (int j = th_t - 1; j <= th_t + 1; ++j) {
+                    int th = j;
+                    if (j < 0) th = j + P.R;
+                    else if (j >= P.S) th = j - P.R;
+                    if (th < 0 || th >= P.S) continue;  // reference: out-of-bounds read when num_rings > num_sectors
+                    for (int r = max(0, r_t - 1); r <= min(r_t + 1, P.R - 1); ++r) {
+                        if (r == r_t && th == th_t) continue;
+                        if (st1[th * P.R + r] == ST_CURR) close = true;
+                    }
+                }
+                fs = close ? ST_BLOCKED : ST_MERGE;
+            }
+        } else {  // version 2
+            if ((long long)cc < (long long)P.min_pts) {
+                act = 0;
+            } else if (cc > 0 && mc > 0) {
+                const double md = mmaxh - mminh, cd = cmaxh - cminh;
+                const double ratio = std_min_d(md / cd, cd / md);
+                if (ratio < P.srt_thr) {
+                    if (md >= cd) {
+                        fs = ST_MAP;
+                        act = (mmaxh > P.th_bin_max_h) ? 1 : 0;
+                    } else if (md <= cd) {
+                        fs = ST_CURR;
+                        act = (cmaxh > P.th_bin_max_h) ? 4 : 0;  // 4: keep map bin, curr points -> curr_rejected
+                    }
+                } else {
+                    fs = ST_MERGE;
+                    act = 2;
+                }
+            } else if (cc > 0) {
+                act = 3;
+            }
+        }
+        status[key] = fs;
+        action[key] = act;
+    }
+    __syncthreads();
+    // reverted list in key order + voxel scratch offsets
+    if (threadIdx.x == 0) carry[0] = carry[1] = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += blockDim.x) {
+        const int key = base + threadIdx.x;
+        const bool rv = key < B && action[key] == 1;
+        const uint32_t cap = rv ? (mcnt[key] + ccnt[key]) : 0u;
+        uint32_t t0, t1;
+        const uint32_t p0 = block_excl_scan(rv ? 1u : 0u, sm, t0);
+        const uint32_t p1 = block_excl_scan(cap, sm, t1);
+        const uint32_t c0 = carry[0], c1 = carry[1];
+        if (key < B) rev_idx[key] = rv ? (c0 + p0) : 0xFFFFFFFFu;
+        if (rv) {
+            rev_list[c0 + p0] = (uint32_t)key;
+            vox_off[c0 + p0] = c1 + p1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            carry[0] = c0 + t0;
+            carry[1] = c1 + t1;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st->n_rev = carry[0];
+        st->vox_scratch_total = carry[1];
+    }
+}
+
+// ================================================================================================
+// R-GPF (extract_ground, erasor.cpp:233-294; estimate_plane_ :183-198; seeds :204-231).
+// One workgroup per reverted bin.
+// ================================================================================================
+struct Rot {
+    float c, s;
+};
+__device__ __forceinline__ Rot make_jacobi(float x, float y, float z) {  // Eigen 3.3 JacobiRotation::makeJacobi
+    Rot r;
+    const float deno = 2.0f * fabsf(y);
+    if (deno < 1.17549435e-38f) {
+        r.c = 1.f;
+        r.s = 0.f;
+    } else {
+        const float tau = (x - z) / deno;
+        const float w = sqrtf(tau * tau + 1.0f);
+        float t;
+        if (tau > 0.f) t = 1.0f / (tau + w);
+        else t = 1.0f / (tau - w);
+        const float sign_t = t > 0.f ? 1.0f : -1.0f;
+        const float n = 1.0f / sqrtf(t * t + 1.0f);
+        r.s = -sign_t * (y / fabsf(y)) * fabsf(t) * n;
+        r.c = n;
+    }
+    return r;
+}
+__device__ __forceinline__ void rot_apply(float &x, float &y, float c, float s) {
+    const float xi = x, yi = y;
+    x = c * xi + s * yi;
+    y = -s * xi + c * yi;
+}
+// Eigen 3.3 JacobiSVD<MatrixXf>(3x3, ComputeFullU): U (row-major) and singular values
+__device__ void jacobi_svd3(const float cov[9], float U[9], float sv[3]) {
+    const float precision = 2.0f * 1.1920929e-07f;
+    const float considerAsZero = 1.17549435e-38f;
+    float scale = 0.f;
+    for (int k = 0; k < 9; ++k) scale = fmaxf(scale, fabsf(cov[k]));
+    if (scale == 0.f) scale = 1.f;
+    float W[9];
+    for (int k = 0; k < 9; ++k) W[k] = cov[k] / scale;
+    for (int k = 0; k < 9; ++k) U[k] = (k % 4 == 0) ? 1.f : 0.f;
+    float maxDiag = fmaxf(fabsf(W[0]), fmaxf(fabsf(W[4]), fabsf(W[8])));
+    bool finished = false;
+    int guard = 0;
+    while (!finished && guard++ < 1000) {
+        finished = true;
+        for (int p = 1; p < 3; ++p) {
+            for (int q = 0; q < p; ++q) {
+                const float threshold = fmaxf(considerAsZero, precision * maxDiag);
+                if (fabsf(W[p * 3 + q]) > threshold || fabsf(W[q * 3 + p]) > threshold) {
+                    finished = false;
+                    float m00 = W[p * 3 + p], m01 = W[p * 3 + q], m10 = W[q * 3 + p], m11 = W[q * 3 + q];
+                    Rot rot1;
+                    const float t = m00 + m11;
+                    const float d = m10 - m01;
+                    if (fabsf(d) < 1.17549435e-38f) {
+                        rot1.s = 0.f;
+                        rot1.c = 1.f;
+                    } else {
+                        const float u = t / d;
+                        const float tmp = sqrtf(1.0f + u * u);
+                        rot1.s = 1.0f / tmp;
+                        rot1.c = u / tmp;
+                    }
+                    if (!(rot1.c == 1.f && rot1.s == 0.f)) {
+                        rot_apply(m00, m10, rot1.c, rot1.s);
+                        rot_apply(m01, m11, rot1.c, rot1.s);
+                    }
+                    const Rot jr = make_jacobi(m00, m01, m11);
+                    const float oc = jr.c, os = -jr.s;
+                    Rot jl;
+                    jl.c = rot1.c * oc - rot1.s * os;
+                    jl.s = rot1.c * os + rot1.s * oc;
+                    if (!(jl.c == 1.f && jl.s == 0.f)) {
+                        for (int col = 0; col < 3; ++col) rot_apply(W[p * 3 + col], W[q * 3 + col], jl.c, jl.s);
+                        for (int row = 0; row < 3; ++row) rot_apply(U[row * 3 + p], U[row * 3 + q], jl.c, jl.s);
+                    }
+                    if (!(jr.c == 1.f && -jr.s == 0.f)) {
+                        for (int row = 0; row < 3; ++row) rot_apply(W[row * 3 + p], W[row * 3 + q], jr.c, -jr.s);
+                    }
+                    maxDiag = fmaxf(maxDiag, fmaxf(fabsf(W[p * 3 + p]), fabsf(W[q * 3 + q])));
+                }
+            }
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        const float a = W[i * 3 + i];
+        sv[i] = fabsf(a);
+        if (a < 0.f)
+            for (int row = 0; row < 3; ++row) U[row * 3 + i] = -U[row * 3 + i];
+    }
+    for (int i = 0; i < 3; ++i) sv[i] *= scale;
+    for (int i = 0; i < 3; ++i) {
+        int pos = 0;
+        float mx = sv[i];
+        for (int k = i + 1; k < 3; ++k)
+            if (sv[k] > mx) {
+                mx = sv[k];
+                pos = k - i;
+            }
+        if (mx == 0.f) break;
+        if (pos) {
+            pos += i;
+            const float ts = sv[i];
+            sv[i] = sv[pos];
+            sv[pos] = ts;
+            for (int row = 0; row < 3; ++row) {
+                const float tu = U[row * 3 + i];
+                U[row * 3 + i] = U[row * 3 + pos];
+                U[row * 3 + pos] = tu;
+            }
+        }
+    }
+}
+
+static constexpr uint32_t RG_LMAX = 4096;
+
+// gsK..gsH: global scratch arrays (capV [+1]) used when a bin has more than RG_LMAX points.
+__global__ __launch_bounds__(256) void k_rgpf(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
+                                               const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *gsK,
+                                               uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint8_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
+                                               uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
+                                               uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
+                                               Counters *ctr) {
+    __shared__ uint32_t sK[RG_LMAX], sV[RG_LMAX], sL[RG_LMAX], sR[RG_LMAX];
+    __shared__ uint8_t sH[RG_LMAX + 4];
+    __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
+    __shared__ uint32_t qcnt[2];
+    __shared__ uint32_t sm[40];
+    __shared__ float s_n[3];
+    __shared__ double s_th;
+    __shared__ uint32_t s_ng, s_carry;
+    const int key = blockIdx.x;
+    if (action[key] != 1) return;
+    const uint32_t rk = rev_idx[key];
+    const uint32_t o0 = moff[key], M = moff[key + 1] - o0;
+    const float4 *pts = spts + o0;
+    const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6;
+    const bool local = M <= RG_LMAX;
+    // --- std::sort(src_copy, point_cmp) : erasor.cpp:239-240 ---
+    uint32_t *sortedV;  // sorted order (bin-local indices)
+    uint32_t *glist;    // current ground list (bin-local indices); reuses the key array
+    if (local) {
+        for (uint32_t i = tid; i < M; i += bs) {
+            sK[i] = esort::float_key(__float_as_uint(pts[i].z));
+            sV[i] = i;
+        }
+        __syncthreads();
+        esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
+                           &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+        sortedV = sR;
+        glist = sK;
+    } else {
+        uint32_t *K = gsK + o0, *V = gsV + o0;
+        for (uint32_t i = tid; i < M; i += bs) {
+            K[i] = esort::float_key(__float_as_uint(pts[i].z));
+            V[i] = i;
+        }
+        __threadfence_block();
+        __syncthreads();
+        esort::block_esort(K, V, gsL + o0, gsR + o0, gsH + o0, gsK2 + o0, gsV2 + o0, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt,
+                           (uint32_t)(RG_LMAX / 16 + 2), &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+        __threadfence_block();
+        __syncthreads();
+        sortedV = gsV2 + o0;
+        glist = K;
+    }
+    // --- drop leading z < min_h (erasor.cpp:242-251); monotone in sorted order ---
+    uint32_t cnt = 0;
+    for (uint32_t k = tid; k < M; k += bs) cnt += ((double)pts[sortedV[k]].z < P.min_h) ? 1u : 0u;
+    {
+        uint32_t tot;
+        block_excl_scan(cnt, sm, tot);
+        cnt = tot;
+    }
+    const uint32_t drop = cnt, Ms = M - drop;
+    // --- extract_initial_seeds_ (erasor.cpp:204-231) ---
+    __shared__ double s_lpr;
+    if (tid == 0) {
+        double sum = 0;
+        int c = 0;
+        if (P.num_lowest >= 0)
+            for (uint32_t i = (uint32_t)P.num_lowest; i < Ms && c < P.gf_lpr; i++) {
+                sum += (double)pts[sortedV[drop + i]].z;
+                c++;
+            }
+        s_lpr = c != 0 ? sum / c : 0;
+    }
+    __syncthreads();
+    const double seed_thr = s_lpr + P.gf_seeds_h;
+    cnt = 0;
+    for (uint32_t k = tid; k < Ms; k += bs) cnt += ((double)pts[sortedV[drop + k]].z < seed_thr) ? 1u : 0u;
+    {
+        uint32_t tot;
+        block_excl_scan(cnt, sm, tot);
+        cnt = tot;
+    }
+    uint32_t ng = cnt;  // seeds = the first ng of the sorted points (predicate is monotone in z)
+    __syncthreads();
+    for (uint32_t k = tid; k < ng; k += bs) glist[k] = sortedV[drop + k];
+    __threadfence_block();
+    __syncthreads();
+    for (int it = 0; it < P.gf_iter; ++it) {
+        // --- estimate_plane_: pcl::computeMeanAndCovarianceMatrix, nine float32 accumulators in list order ---
+        if (wave == 0) {
+            float acc = 0.f;
+            const int ia = lane < 3 ? 0 : (lane < 5 ? 1 : (lane == 5 ? 2 : (int)lane - 6));
+            const int ib = lane < 3 ? (int)lane : (lane < 5 ? (int)lane - 2 : (lane == 5 ? 2 : 3));
+            for (uint32_t base = 0; base < ng; base += 64) {
+                const uint32_t k = base + lane;
+                float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < ng) mine = pts[glist[k]];
+                const uint32_t lim = min(64u, ng - base);
+                for (uint32_t j = 0; j < lim; ++j) {
+                    const float x = __shfl(mine.x, (int)j, 64), y = __shfl(mine.y, (int)j, 64), z = __shfl(mine.z, (int)j, 64);
+                    // lane L owns accumulator L of PCL's accu[9]: xx xy xz yy yz zz x y z  (x*1.0f == x exactly)
+                    const float A = ia == 0 ? x : (ia == 1 ? y : z);
+                    const float Bv = ib == 0 ? x : (ib == 1 ? y : (ib == 2 ? z : 1.0f));
+                    const float term = A * Bv;
+                    acc += term;
+                }
+            }
+            float a[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a[k] = __shfl(acc, k, 64);
+            if (lane == 0) {
+                float cov[9], mean[3], U[9], sv[3];
+                if (ng == 0) {
+                    for (int k = 0; k < 9; ++k) cov[k] = 0.f;
+                    mean[0] = mean[1] = mean[2] = 0.f;
+                    atomicAdd(&ctr->n_degenerate, 1u);
+                } else {
+                    const float fn = (float)ng;
+                    for (int k = 0; k < 9; ++k) a[k] /= fn;
+                    mean[0] = a[6];
+                    mean[1] = a[7];
+                    mean[2] = a[8];
+                    cov[0] = a[0] - a[6] * a[6];
+                    cov[1] = a[1] - a[6] * a[7];
+                    cov[2] = a[2] - a[6] * a[8];
+                    cov[4] = a[3] - a[7] * a[7];
+                    cov[5] = a[4] - a[7] * a[8];
+                    cov[8] = a[5] - a[8] * a[8];
+                    cov[3] = cov[1];
+                    cov[6] = cov[2];
+                    cov[7] = cov[5];
+                }
+                jacobi_svd3(cov, U, sv);
+                const float n0 = U[2], n1 = U[5], n2 = U[8];
+                const float dot = (n0 * mean[0] + n1 * mean[1]) + n2 * mean[2];
+                const double d = -dot;
+                s_n[0] = n0;
+                s_n[1] = n1;
+                s_n[2] = n2;
+                s_th = P.gf_dist - d;
+                plane_n[((size_t)rk * P.gf_iter + it) * 3 + 0] = n0;
+                plane_n[((size_t)rk * P.gf_iter + it) * 3 + 1] = n1;
+                plane_n[((size_t)rk * P.gf_iter + it) * 3 + 2] = n2;
+                plane_d[(size_t)rk * P.gf_iter + it] = d;
+            }
+        }
+        __syncthreads();
+        // --- points * normal_ < th_dist_d_ in source order (erasor.cpp:265-281) ---
+        const float n0 = s_n[0], n1 = s_n[1], n2 = s_n[2];
+        const double th = s_th;
+        const bool last = it == P.gf_iter - 1;
+        if (tid == 0) s_carry = 0;
+        __syncthreads();
+        for (uint32_t base = 0; base < M; base += bs) {
+            const uint32_t i = base + tid;
+            bool g = false;
+            if (i < M) {
+                const float4 p = pts[i];
+                const float res = (p.x * n0 + p.y * n1) + p.z * n2;
+                g = (double)res < th;
+            }
+            uint32_t tot;
+            const uint32_t pre = block_excl_scan(g ? 1u : 0u, sm, tot);
+            const uint32_t c0 = s_carry;
+            if (i < M) {
+                if (g) glist[c0 + pre] = i;
+                if (last) {
+                    gflag[o0 + i] = g ? 1 : 0;
+                    grank[o0 + i] = g ? (c0 + pre) : (i - (c0 + pre));  // rank among ground / among rejected
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_carry = c0 + tot;
+            __syncthreads();
+        }
+        ng = s_carry;
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (uint32_t k = tid; k < ng; k += bs) glist_out[o0 + k] = glist[k];
+    if (tid == 0) ng_out[rk] = ng;
+}
+
+// ================================================================================================
+// per-bin voxelize_preserving_labels(curr points + reverted ground, /erasor/map_voxel_size) —
+// erasor.cpp:523-528.  One workgroup per reverted bin.
+// ================================================================================================
+static constexpr uint32_t BV_LMAX = 2048;
+
+__global__ __launch_bounds__(256) void k_binvox(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
+                                                 const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
+                                                 const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq,
+                                                 const uint32_t *__restrict__ glist, const uint32_t *__restrict__ ng_arr,
+                                                 const uint32_t *__restrict__ vox_off, uint32_t *gsK, uint32_t *gsV, uint32_t *gsL,
+                                                 uint32_t *gsR, uint8_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
+                                                 float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr) {
+    __shared__ uint32_t sK[BV_LMAX], sV[BV_LMAX], sL[BV_LMAX], sR[BV_LMAX];
+    __shared__ uint8_t sH[BV_LMAX + 4];
+    __shared__ float4 sC[BV_LMAX];
+    __shared__ esort::Seg qa[BV_LMAX / 16 + 2], qb[BV_LMAX / 16 + 2];
+    __shared__ uint32_t qcnt[2];
+    __shared__ uint32_t sm[40];
+    __shared__ uint32_t sbb[6];
+    __shared__ uint32_t s_carry;
+    const int key = blockIdx.x;
+    if (action[key] != 1) return;
+    const uint32_t rk = rev_idx[key];
+    const uint32_t tid = threadIdx.x, bs = blockDim.x;
+    const uint32_t mo = moff[key], qo = qoff[key];
+    const uint32_t nc = qoff[key + 1] - qo, ngr = ng_arr[rk];
+    const uint32_t m = nc + ngr;
+    if (nc == 0) {  // selected = bin_curr with is_occupied == false: r_pod2pc skips the bin
+        if (tid == 0) nvox_out[rk] = 0;
+        return;
+    }
+    const uint32_t vo = vox_off[rk];
+    const bool local = m <= BV_LMAX;
+    // input cloud of this call: curr bin points (scan order) then the reverted ground (source order)
+    float4 *C = local ? sC : (gsC + vo);
+    for (uint32_t j = tid; j < m; j += bs) C[j] = j < nc ? sq[qo + j] : spts[mo + glist[mo + (j - nc)]];
+    if (tid < 3) sbb[tid] = 0xFFFFFFFFu;
+    if (tid >= 3 && tid < 6) sbb[tid] = 0u;
+    __threadfence_block();
+    __syncthreads();
+    {
+        uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+        for (uint32_t j = tid; j < m; j += bs) {
+            const float4 p = C[j];
+            const uint32_t k3[3] = {fkey_ord(p.x), fkey_ord(p.y), fkey_ord(p.z)};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = k3[a] < mn[a] ? k3[a] : mn[a];
+                mx[a] = k3[a] > mx[a] ? k3[a] : mx[a];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&sbb[a], mn[a]);
+            atomicMax(&sbb[3 + a], mx[a]);
+        }
+    }
+    __syncthreads();
+    const float mn[3] = {fkey_inv(sbb[0]), fkey_inv(sbb[1]), fkey_inv(sbb[2])};
+    const float mx[3] = {fkey_inv(sbb[3]), fkey_inv(sbb[4]), fkey_inv(sbb[5])};
+    const VoxGrid g = vox_grid_from_bbox(mn, mx, P.leaf_map);
+    if (g.overflow) {  // VoxelGrid returns the input unchanged; not supported on device -> flagged, host fails the step
+        if (tid == 0) {
+            atomicAdd(&ctr->n_voxel_overflow, 1u);
+            ctr->err = 1;
+            nvox_out[rk] = 0;
+        }
+        return;
+    }
+    uint32_t *K = local ? sK : (gsK + vo), *V = local ? sV : (gsV + vo);
+    uint32_t *K2 = local ? sL : (gsK2 + vo), *V2 = local ? sR : (gsV2 + vo);
+    for (uint32_t j = tid; j < m; j += bs) {
+        const float4 p = C[j];
+        K[j] = vox_index(g, p.x, p.y, p.z);
+        V[j] = j;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (local)
+        esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, m, 2 * esort::lg2_floor(m), qa, qb, qcnt, (uint32_t)(BV_LMAX / 16 + 2),
+                           &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+    else
+        esort::block_esort(K, V, gsL + vo, gsR + vo, gsH + vo, K2, V2, 0u, m, 2 * esort::lg2_floor(m), qa, qb, qcnt,
+                           (uint32_t)(BV_LMAX / 16 + 2), &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+    __threadfence_block();
+    __syncthreads();
+    // phase A: runs -> centroids (CentroidPoint float sums in sorted order).  K / V are dead: reuse as cx / cy, head bytes
+    // are dead too but too small, so cz goes to the position array slot of the voxel (written after its last read).
+    float *CX = reinterpret_cast<float *>(K), *CY = reinterpret_cast<float *>(V);
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < m; base += bs) {
+        const uint32_t i = base + tid;
+        const bool head = i < m && (i == 0 || K2[i] != K2[i - 1]);
+        uint32_t tot;
+        const uint32_t pre = block_excl_scan(head ? 1u : 0u, sm, tot);
+        const uint32_t c0 = s_carry;
+        if (head) {
+            float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+            uint32_t e = i;
+            const uint32_t kk = K2[i];
+            while (e < m && K2[e] == kk) {
+                const float4 p = C[V2[e]];
+                sx += p.x;
+                sy += p.y;
+                sz += p.z;
+                si += p.w;
+                ++e;
+            }
+            const float c = (float)(e - i);
+            const uint32_t v = c0 + pre;  // v <= i: slots of K/V below the current tile's heads are free
+            CX[v] = sx / c;
+            CY[v] = sy / c;
+            vox_out[vo + v].z = sz / c;
+            (void)si;  // the averaged intensity is overwritten by the nearest input point's label (utils.cpp:109)
+        }
+        __syncthreads();
+        if (tid == 0) s_carry = c0 + tot;
+        __syncthreads();
+    }
+    const uint32_t nv = s_carry;
+    __threadfence_block();
+    __syncthreads();
+    // phase B: exact 1-NN of every centroid over all inputs of this call (lowest index on float ties)
+    for (uint32_t v = tid; v < nv; v += bs) {
+        const float cx = CX[v], cy = CY[v], cz = vox_out[vo + v].z;
+        float best = __int_as_float(0x7F800000);
+        uint32_t best_j = 0;
+        for (uint32_t j = 0; j < m; ++j) {
+            const float4 p = C[j];
+            const float dd = l2_simple(cx, cy, cz, p.x, p.y, p.z);
+            if (dd < best) {
+                best = dd;
+                best_j = j;
+            }
+        }
+        vox_out[vo + v] = make_float4(cx, cy, cz, C[best_j].w);
+    }
+    if (tid == 0) nvox_out[rk] = nv;
+}
+
+// ================================================================================================
+// output layout of the new F region (get_static_estimate erasor.cpp:612-626; OMU.cpp:281-290):
+//   [selected bins, theta-major | ground_viz (reverted bins' ground, again) | complement]
+// ================================================================================================
+__global__ __launch_bounds__(1024) void k_layout(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
+                                                  const uint32_t *__restrict__ mcnt, const uint32_t *__restrict__ ccnt,
+                                                  const uint32_t *__restrict__ moff, const uint32_t *__restrict__ nvox,
+                                                  const uint32_t *__restrict__ ng_arr, uint32_t *__restrict__ out_off,
+                                                  uint32_t *__restrict__ ground_off, uint32_t *__restrict__ rej_off,
+                                                  uint32_t *__restrict__ crej_off, DevState *st) {
+    __shared__ uint32_t sm[40];
+    __shared__ uint32_t carry[4];
+    const int B = P.B;
+    if (threadIdx.x == 0) carry[0] = carry[1] = carry[2] = carry[3] = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += blockDim.x) {
+        const int key = base + threadIdx.x;
+        uint32_t sz = 0, g = 0, rj = 0, cr = 0;
+        if (key < B) {
+            const uint8_t act = action[key];
+            const uint32_t mc = mcnt[key], cc = ccnt[key];
+            if (act == 1) {
+                const uint32_t rk = rev_idx[key];
+                g = ng_arr[rk];
+                rj = mc - g;
+                if (P.version == 3) sz = cc > 0 ? nvox[rk] : 0u;
+                else sz = cc > 0 ? (cc + g) : 0u;  // v2: curr points then ground, no voxelisation (erasor.cpp:384-392)
+            } else if (act == 2) {
+                sz = cc + mc;  // merge_bins: curr then map (erasor.cpp:296-307)
+            } else if (act == 3) {
+                sz = cc;
+            } else {
+                sz = mc;
+                if (act == 4) cr = cc;
+            }
+        }
+        uint32_t t0, t1, t2, t3;
+        const uint32_t p0 = block_excl_scan(sz, sm, t0);
+        const uint32_t p1 = block_excl_scan(g, sm, t1);
+        const uint32_t p2 = block_excl_scan(rj, sm, t2);
+        const uint32_t p3 = block_excl_scan(cr, sm, t3);
+        const uint32_t c0 = carry[0], c1 = carry[1], c2 = carry[2], c3 = carry[3];
+        if (key < B) {
+            out_off[key] = c0 + p0;
+            crej_off[key] = c3 + p3;
+            if (action[key] == 1) {
+                const uint32_t rk = rev_idx[key];
+                ground_off[rk] = c1 + p1;  // relative to total_bins
+                rej_off[rk] = c2 + p2;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            carry[0] = c0 + t0;
+            carry[1] = c1 + t1;
+            carry[2] = c2 + t2;
+            carry[3] = c3 + t3;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t ncompl = moff[B + 1] - moff[B];
+        st->total_bins = carry[0];
+        st->n_ground = carry[1];
+        st->n_rejected = carry[2];
+        st->n_curr_rejected = carry[3];
+        st->n_static_est = carry[0] + carry[1];
+        st->n_compl = ncompl;
+        st->nF_new = carry[0] + carry[1] + ncompl;
+    }
+}
+
+// one thread per sorted VoI point.  XFORM: apply tf_body2origin_ (map write-back) or keep egocentric
+// coordinates (the clouds get_static_estimate / get_outliers hand out).
+template <bool XFORM>
+__global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8_t *__restrict__ action,
+                                                       const uint32_t *__restrict__ rev_idx, const uint32_t *__restrict__ skeys,
+                                                       const float4 *__restrict__ spts, const uint32_t *__restrict__ ssrc,
+                                                       const uint32_t *__restrict__ moff, const uint32_t *__restrict__ ccnt,
+                                                       const uint8_t *__restrict__ gflag, const uint32_t *__restrict__ grank,
+                                                       const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ ground_off,
+                                                       const uint32_t *__restrict__ rej_off, const DevState *st, uint32_t n_voi,
+                                                       float4 *__restrict__ Fnew, float4 *__restrict__ rejected,
+                                                       uint32_t *__restrict__ rejected_src) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_voi) return;
+    const uint32_t key = skeys[i];
+    const float4 p = spts[i];
+    const float4 w = XFORM ? xform(Tb2o, p) : p;
+    if (key == (uint32_t)P.B) {
+        Fnew[st->n_static_est + (i - moff[P.B])] = w;
+        return;
+    }
+    const uint8_t act = action[key];
+    const uint32_t r = i - moff[key];
+    if (act == 1) {
+        const uint32_t rk = rev_idx[key];
+        const uint32_t gr = grank[i];
+        if (gflag[i]) {
+            Fnew[st->total_bins + ground_off[rk] + gr] = w;                              // ground_viz copy
+            if (P.version == 2 && ccnt[key] > 0) Fnew[out_off[key] + ccnt[key] + gr] = w;  // v2: inside the bin too
+        } else if (rejected) {
+            rejected[rej_off[rk] + gr] = xform(Tb2o, p);  // map_rejected_ is handed out in the map frame (OMU.cpp:287)
+            rejected_src[rej_off[rk] + gr] = ssrc[i];
+        }
+    } else if (act == 2) {
+        Fnew[out_off[key] + ccnt[key] + r] = w;  // merged bin: curr points first
+    } else if (act == 3) {
+        // map bin empty by construction
+    } else {
+        Fnew[out_off[key] + r] = w;
+    }
+}
+
+// scan-side contributions: v3 voxelised reverted bins; v2 curr points of reverted / merged / curr-only bins
+template <bool XFORM>
+__global__ __launch_bounds__(256) void k_assemble_bins(DP P, Xf Tb2o, const uint8_t *__restrict__ action,
+                                                        const uint32_t *__restrict__ rev_idx, const uint32_t *__restrict__ qoff,
+                                                        const float4 *__restrict__ sq, const uint32_t *__restrict__ nvox,
+                                                        const uint32_t *__restrict__ vox_off, const float4 *__restrict__ vox_out,
+                                                        const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ crej_off,
+                                                        float4 *__restrict__ Fnew, float4 *__restrict__ curr_rejected) {
+    const int key = blockIdx.x;
+    const uint8_t act = action[key];
+    if (act == 0) return;
+    const uint32_t qo = qoff[key], cc = qoff[key + 1] - qo;
+    if (act == 1 && P.version == 3) {
+        if (cc == 0) return;
+        const uint32_t rk = rev_idx[key];
+        const uint32_t nv = nvox[rk], vo = vox_off[rk], oo = out_off[key];
+        for (uint32_t v = threadIdx.x; v < nv; v += blockDim.x) {
+            const float4 p = vox_out[vo + v];
+            Fnew[oo + v] = XFORM ? xform(Tb2o, p) : p;
+        }
+    } else if (act == 4) {
+        if (curr_rejected)
+            for (uint32_t j = threadIdx.x; j < cc; j += blockDim.x) curr_rejected[crej_off[key] + j] = xform(Tb2o, sq[qo + j]);
+    } else {  // v2: act 1 (with curr occupied), 2, 3: curr points lead the bin
+        const uint32_t oo = out_off[key];
+        for (uint32_t j = threadIdx.x; j < cc; j += blockDim.x) {
+            const float4 p = sq[qo + j];
+            Fnew[oo + j] = XFORM ? xform(Tb2o, p) : p;
+        }
+    }
+}
+
+// label counters over a float4 cloud (parse_dynamic_obj as counters, utils.cpp:57-78)
+__global__ __launch_bounds__(256) void k_count_labels4(const float4 *__restrict__ pts, uint32_t n_host, const uint32_t *n_dev,
+                                                        unsigned long long *n_static, unsigned long long *n_dynamic) {
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    uint32_t d = 0, s = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (is_dynamic_label(pts[i].w)) ++d; else ++s;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        d += __shfl_down(d, o, 64);
+        s += __shfl_down(s, o, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (d) atomicAdd(n_dynamic, (unsigned long long)d);
+        if (s) atomicAdd(n_static, (unsigned long long)s);
+    }
+}
+
+__global__ void k_step_begin(DevState *st, Counters *ctr) {
+    ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
+    ctr->sort_qoverflow = ctr->err = 0;
+    st->F_static = st->F_dynamic = 0;
+    st->n_rev = 0;
+}
+__global__ void k_step_end(DevState *st) {
+    st->nF = st->nF_new;
+    st->o_begin = st->o_new_begin;
+}
+
+// ---- map store maintenance ---------------------------------------------------------------------
+// split an AoS float4 cloud into the outskirts layout at O[dst0 ...]
+__global__ __launch_bounds__(256) void k_store_outskirts(const float4 *__restrict__ src, uint32_t n, float2 *__restrict__ Oxy,
+                                                          float2 *__restrict__ Ozi, uint32_t dst0) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = src[i];
+    Oxy[dst0 + i] = make_float2(p.x, p.y);
+    Ozi[dst0 + i] = make_float2(p.z, p.w);
+}
+// valid flags of the outskirts region (for compaction / read-back)
+__global__ __launch_bounds__(256) void k_o_valid(const float2 *__restrict__ Oxy, uint32_t o_begin, uint32_t o_cap,
+                                                  uint32_t *__restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= o_cap - o_begin) return;
+    flag[i] = (__float_as_uint(Oxy[o_begin + i].x) != HOLE_BITS) ? 1u : 0u;
+}
+// stable compaction of the valid outskirts entries into an AoS float4 buffer
+__global__ __launch_bounds__(256) void k_o_compact(const float2 *__restrict__ Oxy, const float2 *__restrict__ Ozi, uint32_t o_begin,
+                                                    uint32_t o_cap, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pl,
+                                                    const uint32_t *__restrict__ tops, float4 *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= o_cap - o_begin) return;
+    if (!flag[i]) return;
+    const float2 a = Oxy[o_begin + i], b = Ozi[o_begin + i];
+    dst[pl[i] + tops[i >> 10]] = make_float4(a.x, a.y, b.x, b.y);
+}
+
+// device libm probe: sqrt / div / atan2 in double, as the binning uses them (tests pin these vs host libm)
+__global__ void k_probe_math(const double *x, const double *y, uint32_t n, double *o_sqrt, double *o_div, double *o_atan2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    o_sqrt[i] = sqrt(x[i] * x[i] + y[i] * y[i]);
+    o_div[i] = x[i] / y[i];
+    o_atan2[i] = atan2(y[i], x[i]);
+}
+
+}  // namespace ek
+#endif
