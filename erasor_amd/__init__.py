@@ -256,3 +256,10 @@ class Erasor:
         nf = C.c_uint32(0)
         self._check(lib().erasor_hip_exact_sort_u32(self._h, _p(keys), _p(vals), C.c_size_t(len(keys)), C.byref(nf)))
         return keys, vals, int(nf.value)
+
+    def radix_sort_u32(self, keys, bits):
+        keys = np.ascontiguousarray(keys, np.uint32)
+        ko = np.zeros_like(keys)
+        po = np.zeros_like(keys)
+        self._check(lib().erasor_hip_radix_sort_u32(self._h, _p(keys), C.c_size_t(len(keys)), C.c_int(bits), _p(ko), _p(po)))
+        return ko, po

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -101,6 +102,8 @@ struct erasor_hip_handle {
 
 namespace {
 
+const bool g_debug_sync = getenv("ERASOR_HIP_DEBUG_SYNC") != nullptr;  // bring-up aid: sync + log every launch
+
 #define HIPC(h, call)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \
@@ -174,7 +177,12 @@ void prof_collect(erasor_hip_handle *h) {
             pe_.b = get_evt(h);                                                   \
             (void)hipEventRecord(pe_.a, (h)->stream);                             \
         }                                                                         \
+        if (g_debug_sync) fprintf(stderr, "[erasor_hip] launch %s grid=%u\n", name, (unsigned)(grid)); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (h)->stream, __VA_ARGS__); \
+        if (g_debug_sync) {                                                       \
+            hipError_t e2_ = hipStreamSynchronize((h)->stream);                   \
+            if (e2_ != hipSuccess) fprintf(stderr, "[erasor_hip]   -> %s\n", hipGetErrorString(e2_)); \
+        }                                                                         \
         if ((h)->prof) {                                                          \
             (void)hipEventRecord(pe_.b, (h)->stream);                             \
             (h)->pending.push_back(pe_);                                          \
@@ -595,6 +603,26 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     const int bits = key_bits(B + 1);
     // the radix ping-pong buffers are shared by the query and the map side (capV >= capS is not guaranteed -> use q buffers)
     radix_sort(h, h->qkey.p, nq, bits, h->qk_a.p, h->qposL.p, h->qv_a.p, h->qposR.p, &sq_keys, &sq_perm, "q_bucket");
+    if (g_debug_sync && nq) {
+        std::vector<uint32_t> tk(nq), tq(nq);
+        (void)hipMemcpy(tk.data(), sq_keys, (size_t)nq * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(tq.data(), h->qkey.p, (size_t)nq * 4, hipMemcpyDeviceToHost);
+        uint32_t mx = 0, mxq = 0, unsorted = 0;
+        for (uint32_t i = 0; i < nq; ++i) {
+            mx = std::max(mx, tk[i]);
+            mxq = std::max(mxq, tq[i]);
+            if (i && tk[i] < tk[i - 1]) ++unsorted;
+        }
+        fprintf(stderr, "[erasor_hip] debug: nq=%u bits=%d B=%u max sorted key=%u max raw key=%u unsorted=%u\n", nq, bits, B, mx, mxq, unsorted);
+        std::vector<float> qp((size_t)nq * 4);
+        (void)hipMemcpy(qp.data(), h->query.p, (size_t)nq * 16, hipMemcpyDeviceToHost);
+        int shown = 0;
+        for (uint32_t i = 0; i < nq && shown < 12; ++i)
+            if (tq[i] > B) {
+                fprintf(stderr, "   bad key[%u]=%u (0x%08x) pt=(%.9g %.9g %.9g %.9g)\n", i, tq[i], tq[i], qp[4 * i], qp[4 * i + 1], qp[4 * i + 2], qp[4 * i + 3]);
+                ++shown;
+            }
+    }
     if (nq) LAUNCH(h, "q_bucket", k_gather, cdiv(nq, 256), 256, (const float4 *)h->query.p, (const uint32_t *)nullptr, sq_perm, nq,
                    (const uint32_t *)nullptr, h->sq.p, (uint32_t *)nullptr);
     LAUNCH(h, "q_bucket", k_bin_offsets, cdiv((uint64_t)std::max(nq, B + 2) + 1, 256), 256, sq_keys, nq, (const uint32_t *)nullptr, B + 1, h->qoff.p);
@@ -1001,6 +1029,25 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
     if (ns) {
         HIPC(h, hipMemcpy(keys, h->qk_b.p, (size_t)ns * 4, hipMemcpyDeviceToHost));
         HIPC(h, hipMemcpy(vals, h->qv_b.p, (size_t)ns * 4, hipMemcpyDeviceToHost));
+    }
+    return ERASOR_OK;
+}
+
+// test hook: the stable LSD radix sort used for R-POD bucketing
+int erasor_hip_radix_sort_u32(erasor_hip_handle *h, const uint32_t *keys, size_t n, int bits, uint32_t *keys_out, uint32_t *perm_out) {
+    if (!h || (!keys && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
+    HIPC(h, hipSetDevice(h->device));
+    const uint32_t ns = (uint32_t)n;
+    int rc = alloc_scan(h, std::max(ns, 1u));
+    if (rc) return rc;
+    if (ns) HIPC(h, hipMemcpyAsync(h->qkey.p, keys, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
+    const uint32_t *sk = nullptr, *sp = nullptr;
+    rc = radix_sort(h, h->qkey.p, ns, bits, h->qk_a.p, h->qposL.p, h->qv_a.p, h->qposR.p, &sk, &sp, "radix_test");
+    if (rc) return rc;
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if (ns) {
+        HIPC(h, hipMemcpy(keys_out, sk, (size_t)ns * 4, hipMemcpyDeviceToHost));
+        HIPC(h, hipMemcpy(perm_out, sp, (size_t)ns * 4, hipMemcpyDeviceToHost));
     }
     return ERASOR_OK;
 }

@@ -82,29 +82,26 @@ __device__ __forceinline__ bool is_dynamic_label(float intensity) {
 // R-POD bin of an egocentric point (erasor.cpp:104-110, 11-21).  Returns theta-major key
 // sector*R + ring, or B if the point fails a gate.
 __device__ __forceinline__ uint32_t bin_key(const DP &P, float x, float y, float z, Counters *ctr) {
-    if ((double)z < P.max_h && (double)z > P.min_h) {
-        const double dx = (double)x, dy = (double)y;
-        const double r = sqrt(dx * dx + dy * dy);
-        if (r <= P.max_r) {
-            double theta;
-            if (dy >= 0)
-                theta = atan2(dy, dx);
-            else
-                theta = 2 * PI_REF + atan2(dy, dx);
-            const double q = theta / P.sector_size;
-            if (q != 0.0 && fabs(q - rint(q)) < 1e-11) atomicAdd(&ctr->n_ambiguous, 1u);
-            int sidx = (int)q;
-            if (sidx > P.S - 1) sidx = P.S - 1;
-            int ridx = (int)(r / P.ring_size);
-            if (ridx > P.R - 1) ridx = P.R - 1;
-            if (sidx < 0) {  // y == -0.0f, x < 0: the reference throws (vector::at); defined clamp
-                sidx = 0;
-                atomicAdd(&ctr->n_neg_sector, 1u);
-            }
-            return (uint32_t)(sidx * P.R + ridx);
-        }
+    uint32_t key = (uint32_t)P.B;
+    const double dx = (double)x, dy = (double)y;
+    const double r = sqrt(dx * dx + dy * dy);
+    const bool gate = ((double)z < P.max_h) && ((double)z > P.min_h) && (r <= P.max_r);
+    if (gate) {
+        const double at = atan2(dy, dx);
+        const double theta = (dy >= 0) ? at : (2 * PI_REF + at);
+        const double q = theta / P.sector_size;
+        const bool amb = (q != 0.0) && (fabs(q - rint(q)) < 1e-11);
+        int sidx = (int)q;
+        if (sidx > P.S - 1) sidx = P.S - 1;
+        int ridx = (int)(r / P.ring_size);
+        if (ridx > P.R - 1) ridx = P.R - 1;
+        const bool neg = sidx < 0;  // y == -0.0f, x < 0: the reference throws (vector::at); defined clamp
+        if (neg) sidx = 0;
+        key = (uint32_t)(sidx * P.R + ridx);
+        if (amb) atomicAdd(&ctr->n_ambiguous, 1u);
+        if (neg) atomicAdd(&ctr->n_neg_sector, 1u);
     }
-    return (uint32_t)P.B;
+    return key;
 }
 
 // ---- small block-level helpers -------------------------------------------------------------------

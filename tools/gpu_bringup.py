@@ -73,6 +73,13 @@ def main():
         ok, ov = orc.std_sort_u32(k, v)
         r = cmp("esort n=%d r=%d" % (n, rngk), np.stack([gk, gv]), np.stack([ok, ov]))
         print("        (%.1f ms wall, %d heapsort fallbacks)" % (dt * 1e3, nf))
+    print("== stable radix bucketing")
+    for n, B in ((0, 900), (5, 900), (3000, 900), (12453, 900), (100000, 2160), (300001, 2160)):
+        k = rng.integers(0, B + 1, n).astype(np.uint32)
+        bits = max(1, int(np.ceil(np.log2(B + 1))))
+        ko, po = g.radix_sort_u32(k, bits)
+        order = np.argsort(k, kind="stable").astype(np.uint32)
+        cmp("radix n=%d B=%d" % (n, B), np.stack([ko, po]), np.stack([k[order], order]))
     print("== voxelize_preserving_labels (standalone)")
     for leaf in (0.2, 0.5):
         vg = g.voxelize_preserving_labels(sc["scans"][0], leaf)
