@@ -101,6 +101,23 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def geopose2eigen(pose7):
+    """erasor_utils::geoPose2eigen (erasor_utils.cpp:35-55): tf::Matrix3x3(tf::Quaternion) evaluated in double with
+    tf's association, each entry narrowed to float32.  pose7 = x y z qx qy qz qw.  Returns 16 floats, row-major."""
+    px, py, pz, x, y, z, w = [float(v) for v in pose7]
+    d = x * x + y * y + z * z + w * w
+    s = 2.0 / d
+    xs, ys, zs = x * s, y * s, z * s
+    wx, wy, wz = w * xs, w * ys, w * zs
+    xx, xy, xz = x * xs, x * ys, x * zs
+    yy, yz, zz = y * ys, y * zs, z * zs
+    T = np.array([1.0 - (yy + zz), xy - wz, xz + wy, px,
+                  xy + wz, 1.0 - (xx + zz), yz - wx, py,
+                  xz - wy, yz + wx, 1.0 - (xx + yy), pz,
+                  0.0, 0.0, 0.0, 1.0], np.float64)
+    return T.astype(np.float32)
+
+
 def invert_rigid(T):
     """T_origin2body from T_body2origin: general 4x4 inverse in float64, narrowed to float32 (the caller owns this
     choice — the reference's Eigen SSE inverse (OMU.cpp:436) is not bit-reproducible across CPUs)."""
@@ -219,7 +236,7 @@ class Erasor:
 
     # -- measurement --
     def profiling(self, on):
-        self._check(lib().erasor_hip_profiling(self._h, C.c_int(1 if on else 0)))
+        self._check(lib().erasor_hip_profiling(self._h, C.c_int(int(on))))
 
     def profile_reset(self):
         self._check(lib().erasor_hip_profile_reset(self._h))

@@ -92,7 +92,7 @@ struct erasor_hip_handle {
     const uint32_t *last_skeys = nullptr;  // sorted VoI keys of the last step
     erasor_step_result last_res;
     // ---- profiling ----
-    bool prof = false;
+    int prof = 0;  // 0 off, 1 every kernel, 2 only the roofline kernel (voi_split)
     std::vector<std::string> prof_names;
     std::map<std::string, int> prof_ids;
     std::vector<ProfEntry> prof_tab;
@@ -171,7 +171,8 @@ void prof_collect(erasor_hip_handle *h) {
 #define LAUNCH(h, name, kern, grid, block, ...)                                   \
     do {                                                                          \
         PendingEvt pe_;                                                           \
-        if ((h)->prof) {                                                          \
+        const bool prof_ = (h)->prof == 1 || ((h)->prof == 2 && strcmp(name, "voi_split") == 0); \
+        if (prof_) {                                                              \
             pe_.name_id = prof_id((h), name);                                     \
             pe_.a = get_evt(h);                                                   \
             pe_.b = get_evt(h);                                                   \
@@ -183,7 +184,7 @@ void prof_collect(erasor_hip_handle *h) {
             hipError_t e2_ = hipStreamSynchronize((h)->stream);                   \
             if (e2_ != hipSuccess) fprintf(stderr, "[erasor_hip]   -> %s\n", hipGetErrorString(e2_)); \
         }                                                                         \
-        if ((h)->prof) {                                                          \
+        if (prof_) {                                                              \
             (void)hipEventRecord(pe_.b, (h)->stream);                             \
             (h)->pending.push_back(pe_);                                          \
         }                                                                         \
@@ -940,7 +941,7 @@ int erasor_hip_count_static_dynamic(erasor_hip_handle *h, uint64_t *n_static, ui
 
 int erasor_hip_profiling(erasor_hip_handle *h, int enable) {
     if (!h) return ERASOR_E_INVALID;
-    h->prof = enable != 0;
+    h->prof = enable;
     return ERASOR_OK;
 }
 int erasor_hip_profile_reset(erasor_hip_handle *h) {

@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_rgpf(DP P, const uint8_t *__restrict__ 
     __shared__ uint32_t sm[40];
     __shared__ float s_n[3];
     __shared__ double s_th;
-    __shared__ uint32_t s_ng, s_carry;
+    __shared__ uint32_t s_carry;
     const int key = blockIdx.x;
     if (action[key] != 1) return;
     const uint32_t rk = rev_idx[key];

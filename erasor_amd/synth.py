@@ -165,7 +165,26 @@ class World:
         ok = down & (t > 0)
         best_t = np.where(ok, t, best_t)
         best_l = np.where(ok, self.ground_label(o[1] + np.where(ok, t, 0) * D[:, 1]), best_l)
-        # boxes (static + moving), z offset by local ground at the box centre
+        # boxes (static + moving) and poles: only the azimuth columns a primitive can occupy are tested
+        nb_, na_ = lidar.beams, lidar.az_steps
+        yaw = np.arctan2(Tb[1, 0], Tb[0, 0])
+        az0, daz = -np.pi, 2 * np.pi / na_
+
+        def az_columns(px, py):
+            """indices of the azimuth columns covering the xy points (world), in the sensor's frame"""
+            ang = np.arctan2(py - o[1], px - o[0]) - yaw
+            ang = np.mod(ang + np.pi, 2 * np.pi) - np.pi
+            lo_, hi_ = ang.min(), ang.max()
+            if hi_ - lo_ > np.pi:  # wraps through +-pi
+                pos, neg = ang[ang >= 0], ang[ang < 0]
+                i0 = int(np.floor((pos.min() - az0) / daz)) - 1
+                i1 = int(np.ceil((neg.max() - az0) / daz)) + 1
+                return np.concatenate([np.arange(max(i0, 0), na_), np.arange(0, min(i1 + 1, na_))])
+            i0 = int(np.floor((lo_ - az0) / daz)) - 1
+            i1 = int(np.ceil((hi_ - az0) / daz)) + 1
+            return np.arange(max(i0, 0), min(i1 + 1, na_))
+
+        rows = np.arange(nb_)[:, None] * na_
         mb, ml = self.moving_boxes(frame * 0.1)
         boxes = np.concatenate([self.boxes, mb], 0)
         labels = np.concatenate([self.box_labels, ml], 0)
@@ -174,41 +193,42 @@ class World:
             near = (np.abs(c[:, 0] - o[0]) < cull) & (np.abs(c[:, 1] - o[1]) < cull)
             boxes, labels, c = boxes[near], labels[near], c[near]
             gz = self.ground_h(c[:, 0], c[:, 1])
-            lo = boxes[:, :3].copy()
-            hi = boxes[:, 3:].copy()
-            lo[:, 2] += gz
-            hi[:, 2] += gz
             inv = 1.0 / np.where(np.abs(D) < 1e-12, 1e-12, D)
-            CH = 16
-            for s in range(0, len(boxes), CH):
-                l_, h_, lab = lo[s:s + CH], hi[s:s + CH], labels[s:s + CH]
-                t0 = (l_[None, :, :] - o[None, None, :]) * inv[:, None, :]
-                t1 = (h_[None, :, :] - o[None, None, :]) * inv[:, None, :]
+            for bi in range(len(boxes)):
+                bx0, by0, bz0, bx1, by1, bz1 = boxes[bi]
+                if bx0 <= o[0] <= bx1 and by0 <= o[1] <= by1:
+                    continue
+                cols = az_columns(np.array([bx0, bx0, bx1, bx1]), np.array([by0, by1, by0, by1]))
+                ridx = (rows + cols[None, :]).ravel()
+                lo = np.array([bx0, by0, bz0 + gz[bi]])
+                hi = np.array([bx1, by1, bz1 + gz[bi]])
+                t0 = (lo[None, :] - o[None, :]) * inv[ridx]
+                t1 = (hi[None, :] - o[None, :]) * inv[ridx]
                 tn = np.minimum(t0, t1).max(-1)
                 tf = np.maximum(t0, t1).min(-1)
-                hit = (tn <= tf) & (tn > 0)
-                tn = np.where(hit, tn, np.inf)
-                j = np.argmin(tn, 1)
-                tb = tn[np.arange(n), j]
-                upd = tb < best_t
-                best_t = np.where(upd, tb, best_t)
-                best_l = np.where(upd, lab[j], best_l)
-        # poles
+                hit = (tn <= tf) & (tn > 0) & (tn < best_t[ridx])
+                hidx = ridx[hit]
+                best_t[hidx] = tn[hit]
+                best_l[hidx] = labels[bi]
         if len(self.poles):
             P = self.poles[(np.abs(self.poles[:, 0] - o[0]) < 80.0) & (np.abs(self.poles[:, 1] - o[1]) < 80.0)]
-            a = D[:, 0] ** 2 + D[:, 1] ** 2
             for px, py, pr, ph in P:
+                cols = az_columns(np.array([px - pr, px - pr, px + pr, px + pr]), np.array([py - pr, py + pr, py - pr, py + pr]))
+                ridx = (rows + cols[None, :]).ravel()
+                Dr = D[ridx]
+                a = Dr[:, 0] ** 2 + Dr[:, 1] ** 2
                 ox, oy = o[0] - px, o[1] - py
-                b = ox * D[:, 0] + oy * D[:, 1]
+                b = ox * Dr[:, 0] + oy * Dr[:, 1]
                 cc = ox * ox + oy * oy - pr * pr
                 disc = b * b - a * cc
                 okc = (disc > 0) & (a > 1e-9)
                 tt = np.where(okc, (-b - np.sqrt(np.where(okc, disc, 0))) / np.where(a > 1e-9, a, 1), np.inf)
-                zz = o[2] + tt * D[:, 2]
+                zz = o[2] + tt * Dr[:, 2]
                 g = self.ground_h(px, py)
-                okc &= (tt > 0) & (zz > g) & (zz < g + ph) & (tt < best_t)
-                best_t = np.where(okc, tt, best_t)
-                best_l = np.where(okc, LABEL_POLE, best_l)
+                okc &= (tt > 0) & (zz > g) & (zz < g + ph) & (tt < best_t[ridx])
+                hidx = ridx[okc]
+                best_t[hidx] = tt[okc]
+                best_l[hidx] = LABEL_POLE
         keep = np.isfinite(best_t) & (best_t < lidar.max_range) & (best_t > lidar.min_range)
         tk = best_t[keep] + rng.normal(0, lidar.noise, size=int(keep.sum()))
         pts = lidar.dirs[keep] * tk[:, None]  # lidar frame (rotation of the body, origin at the sensor)
