@@ -280,3 +280,6 @@ class Erasor:
         po = np.zeros_like(keys)
         self._check(lib().erasor_hip_radix_sort_u32(self._h, _p(keys), C.c_size_t(len(keys)), C.c_int(bits), _p(ko), _p(po)))
         return ko, po
+
+    def debug_rebuild_outskirts(self):
+        self._check(lib().erasor_hip_debug_rebuild_outskirts(self._h))

@@ -1034,6 +1034,14 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
     return ERASOR_OK;
 }
 
+// test hook: force the tombstone-free rebuild of the outskirts region (normally triggered by hole / room heuristics)
+int erasor_hip_debug_rebuild_outskirts(erasor_hip_handle *h) {
+    if (!h) return ERASOR_E_INVALID;
+    if (!h->have_map) return ERASOR_E_STATE;
+    HIPC(h, hipSetDevice(h->device));
+    return rebuild_outskirts(h, h->nF + CHUNK);
+}
+
 // test hook: the stable LSD radix sort used for R-POD bucketing
 int erasor_hip_radix_sort_u32(erasor_hip_handle *h, const uint32_t *keys, size_t n, int bits, uint32_t *keys_out, uint32_t *perm_out) {
     if (!h || (!keys && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;

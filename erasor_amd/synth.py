@@ -25,7 +25,7 @@ def yaw_pose(x, y, z, yaw):
 
 
 def pose_to_matrix(pose7):
-    """float64 4x4 of a pose (tf formula); tests use oracle.geopose2eigen for the float32 one."""
+    """float64 4x4 of a pose (tf formula); erasor_amd.geopose2eigen gives the float32 one the step consumes."""
     x, y, z, w = pose7[3:]
     s = 2.0 / (x * x + y * y + z * z + w * w)
     R = np.array([
@@ -378,7 +378,7 @@ SEQ_PARAMS = {
 
 
 def apply_params(p, name, **over):
-    """fill a Params ctypes struct (oracle.orc.Params or erasor_amd.Params) from SEQ_PARAMS[name]"""
+    """fill a Params ctypes struct from SEQ_PARAMS[name]"""
     d = dict(SEQ_PARAMS[name])
     d.update(over)
     for k, v in d.items():

@@ -1,0 +1,296 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for every point, index, count and status; plane coefficients within the 1e-5 that
+BASELINE.json:north_star states (asserted) — and in fact bit-identical (also asserted).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import scenarios
+from erasor_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+I4 = np.eye(4, dtype=np.float32).reshape(16)
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32 if a.dtype == np.float32 else (np.uint64 if a.dtype == np.float64 else a.dtype))
+
+
+def same(a, b, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    eq = bits(a) == bits(b)
+    assert eq.all(), "%s: %d of %d elements differ (first at %s)" % (what, (~eq).sum(), eq.size, np.argwhere(~eq)[:3].tolist())
+
+
+@pytest.fixture(scope="module")
+def gpu_mod():
+    import erasor_amd
+    erasor_amd.build()
+    return erasor_amd
+
+
+def make_pair(gpu_mod, p_oracle):
+    from oracle import orc
+    return gpu_mod.Erasor(scenarios.to_product_params(p_oracle)), orc.Oracle(p_oracle)
+
+
+def compare_step(g, o, rg, ro, full=True):
+    do, dg = ro.as_dict(), rg.as_dict()
+    for k in do:
+        if k in ("n_ambiguous", "n_sort_fallback"):
+            continue
+        assert do[k] == dg[k], (k, dg[k], do[k])
+    assert dg["n_ambiguous"] == 0, "a point sits within 1e-11 of a sector boundary: device atan2 could decide differently"
+    same(g.get_rejected_indices(), o.get_rejected_indices(), "dynamic-point mask (indices)")
+    same(g.get_cloud(4), o.get_cloud(4), "map_rejected")
+    bg, ng, dg_ = g.get_planes()
+    bo, no, do_ = o.get_planes()
+    same(bg, bo, "plane bins")
+    assert np.allclose(ng, no, atol=1e-5, rtol=0) and np.allclose(dg_, do_, atol=1e-5, rtol=0)  # north_star tolerance
+    same(ng, no, "plane normals (bit-exact)")
+    same(dg_, do_, "plane d (bit-exact)")
+    same(g.get_status(), o.get_status(), "status")
+    if full:
+        same(g.get_cloud(0), o.get_cloud(0), "query_voi")
+        same(g.get_cloud(1), o.get_cloud(1), "map_voi")
+        for w in (0, 1):
+            for a, b, nm in zip(g.get_bins(w), o.get_bins(w), ("count", "min_h", "max_h")):
+                same(a, b, "bins[%d].%s" % (w, nm))
+        same(g.get_cloud(6), o.get_cloud(6), "ground_viz")
+        same(g.get_cloud(2), o.get_cloud(2), "static_estimate")
+        same(g.get_cloud(3), o.get_cloud(3), "complement")
+        same(g.get_cloud(5), o.get_cloud(5), "curr_rejected")
+    same(g.get_map(), o.get_map(), "map_arranged_")
+    assert g.count_static_dynamic() == (ro.n_static, ro.n_dynamic)
+
+
+# ---------------------------------------------------------------------------------------------
+# building blocks
+# ---------------------------------------------------------------------------------------------
+def test_device_libm_as_used_by_the_binning(gpu_mod):
+    g = gpu_mod.Erasor(gpu_mod.params_default())
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-80, 80, 300000).astype(np.float32).astype(np.float64)
+    y = rng.uniform(-80, 80, 300000).astype(np.float32).astype(np.float64)
+    s, d, a = g.probe_math(x, y)
+    same(s, np.sqrt(x * x + y * y), "sqrt f64 (correctly rounded)")
+    same(d, x / y, "div f64 (correctly rounded)")
+    at = np.arctan2(y, x)
+    ulp = np.abs(a - at) / np.spacing(np.abs(at))
+    assert ulp.max() <= 4.0   # OCML vs glibc differ by <= 2 ulp: the reason for the n_ambiguous guard band (1e-11 >> 1e-15)
+
+
+@pytest.mark.parametrize("n,key_range", [(0, 5), (1, 5), (16, 3), (17, 3), (100, 7), (5000, 50), (5000, 1 << 30), (70000, 300),
+                                         (200000, 40000), (300000, 5)])
+def test_exact_std_sort_emulation(gpu_mod, n, key_range):
+    from oracle import orc
+    g = gpu_mod.Erasor(gpu_mod.params_default())
+    rng = np.random.default_rng(n + key_range)
+    k = rng.integers(0, key_range, n).astype(np.uint32)
+    v = np.arange(n, dtype=np.uint32)
+    gk, gv, _ = g.exact_sort_u32(k, v)
+    ok, ov = orc.std_sort_u32(k, v)
+    same(gk, ok, "keys")
+    same(gv, ov, "tie order (libstdc++ introsort permutation)")
+
+
+def test_exact_sort_heapsort_fallback_on_median_of_3_killer(gpu_mod):
+    from oracle import orc
+    g = gpu_mod.Erasor(gpu_mod.params_default())
+    for n in (1000, 4096, 30000):
+        a = np.zeros(n, np.uint32)
+        k = n // 2
+        for i in range(1, k + 1):
+            if i & 1:
+                a[i - 1] = i
+                a[i] = k + i
+            a[k + i - 1] = 2 * i
+        gk, gv, nf = g.exact_sort_u32(a, np.arange(n, dtype=np.uint32))
+        ok, ov = orc.std_sort_u32(a, np.arange(n, dtype=np.uint32))
+        same(gk, ok)
+        same(gv, ov)
+        assert nf > 0, "depth limit was never hit: the fallback is not exercised"
+
+
+@pytest.mark.parametrize("n,B", [(0, 900), (5, 900), (12453, 900), (100000, 2160), (300001, 2160)])
+def test_stable_radix_bucketing(gpu_mod, n, B):
+    g = gpu_mod.Erasor(gpu_mod.params_default())
+    k = np.random.default_rng(n).integers(0, B + 1, n).astype(np.uint32)
+    ko, po = g.radix_sort_u32(k, max(1, int(np.ceil(np.log2(B + 1)))))
+    order = np.argsort(k, kind="stable").astype(np.uint32)
+    same(ko, k[order])
+    same(po, order)
+
+
+@pytest.mark.parametrize("leaf", [0.2, 0.5, 1.0])
+def test_voxelize_preserving_labels_standalone(gpu_mod, leaf):
+    from oracle import orc
+    sc = scenarios.small()
+    g = gpu_mod.Erasor(gpu_mod.params_default())
+    for f in (0, 3):
+        same(g.voxelize_preserving_labels(sc["scans"][f], leaf), orc.voxelize_preserving_labels(sc["scans"][f], leaf), "voxelised scan")
+    rng = np.random.default_rng(2)
+    dup = np.repeat(rng.uniform(-3, 3, (50, 4)).astype(np.float32), 9, axis=0)  # exact duplicates: ties everywhere
+    same(g.voxelize_preserving_labels(dup, leaf), orc.voxelize_preserving_labels(dup, leaf), "duplicates")
+    one = np.array([[1.0, 2.0, 3.0, 40.0]], np.float32)
+    same(g.voxelize_preserving_labels(one, leaf), one)
+    assert len(g.voxelize_preserving_labels(np.zeros((0, 4), np.float32), leaf)) == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# full steps
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seq,version,steps", [("05", 3, 10), ("00", 3, 4), ("07", 3, 4), ("01", 3, 3), ("05", 2, 4), ("ouster", 3, 3)])
+def test_step_parity_on_synthetic_sequences(gpu_mod, seq, version, steps):
+    sc = scenarios.small(seq=seq, version=version)
+    g, o = make_pair(gpu_mod, sc["params"])
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    same(g.get_map(), o.get_map(), "map after set_map")
+    for f in range(steps):
+        ro = o.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        rg = g.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        compare_step(g, o, rg, ro)
+
+
+def test_outskirts_rebuild_is_invisible(gpu_mod):
+    """tombstones + front growth are an HBM layout detail: forcing the compaction must not change anything"""
+    sc = scenarios.small()
+    g, o = make_pair(gpu_mod, sc["params"])
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    for f in range(6):
+        ro = o.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        rg = g.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        if f % 2 == 1:
+            g.debug_rebuild_outskirts()
+            same(g.get_map(), o.get_map(), "map after forced rebuild")
+        compare_step(g, o, rg, ro, full=False)
+
+
+def test_revisiting_the_same_pose_and_moving_back(gpu_mod):
+    """points leave the VoI and come back: F <-> outskirts traffic in both directions, duplicates of reverted ground included"""
+    sc = scenarios.small()
+    g, o = make_pair(gpu_mod, sc["params"])
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    for f in (0, 5, 11, 5, 0, 0, 11):
+        ro = o.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        rg = g.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        compare_step(g, o, rg, ro, full=False)
+
+
+def test_edge_cases(gpu_mod):
+    from oracle import orc
+    sc = scenarios.small()
+    # empty scan: nothing can be reverted, the VoI still round-trips map -> body -> map in float32
+    g, o = make_pair(gpu_mod, sc["params"])
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    e = np.zeros((0, 4), np.float32)
+    compare_step(g, o, g.step(e, sc["T_l2b"], sc["T_b2o"][0], sc["T_o2b"][0]), o.step(e, sc["T_l2b"], sc["T_b2o"][0], sc["T_o2b"][0]))
+    # empty map
+    g, o = make_pair(gpu_mod, sc["params"])
+    g.set_map(e)
+    o.set_map(e)
+    compare_step(g, o, g.step(sc["scans"][0], sc["T_l2b"], sc["T_b2o"][0], sc["T_o2b"][0]),
+                 o.step(sc["scans"][0], sc["T_l2b"], sc["T_b2o"][0], sc["T_o2b"][0]))
+    assert g.map_size() == 0
+    # whole map inside the VoI (no outskirts), pose far away (VoI empty), ragged tiny inputs
+    p = orc.params_default()
+    synth.apply_params(p, "05", max_range=500.0, num_rings=15, num_sectors=60)
+    g, o = make_pair(gpu_mod, p)
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    rg = g.step(sc["scans"][1], sc["T_l2b"], sc["T_b2o"][1], sc["T_o2b"][1])
+    ro = o.step(sc["scans"][1], sc["T_l2b"], sc["T_b2o"][1], sc["T_o2b"][1])
+    assert ro.n_outskirts == 0
+    compare_step(g, o, rg, ro)
+    from erasor_amd import geopose2eigen, invert_rigid
+    far = geopose2eigen([5000.0, 5000.0, 0, 0, 0, 0, 1])
+    rg = g.step(sc["scans"][2], sc["T_l2b"], far, invert_rigid(far))
+    ro = o.step(sc["scans"][2], sc["T_l2b"], far, invert_rigid(far))
+    assert ro.n_voi == 0
+    compare_step(g, o, rg, ro)
+    for n in (1, 63, 64, 65, 511, 513):
+        g, o = make_pair(gpu_mod, sc["params"])
+        g.set_map(sc["map"][:n])
+        o.set_map(sc["map"][:n])
+        compare_step(g, o, g.step(sc["scans"][0][:n], sc["T_l2b"], sc["T_b2o"][0], sc["T_o2b"][0]),
+                     o.step(sc["scans"][0][:n], sc["T_l2b"], sc["T_b2o"][0], sc["T_o2b"][0]))
+
+
+def test_one_bin_known_answers_on_the_gpu(gpu_mod):
+    """the hand-derived SRT / gate cases of test_oracle_known_answers, through the HIP path"""
+    import test_oracle_known_answers as ka
+    cases = [
+        (ka.one_bin_params(), ka.column(5, 0.0, 1.0), ka.column(5, 0.0, 1.0, dy=0.6)),            # merge
+        (ka.one_bin_params(), ka.column(6, 0.0, 1.0), ka.column(4, 0.0, 0.0, dy=0.6)),            # zero-height scan -> revert
+        (ka.one_bin_params(), ka.column(4, 0.25, 0.25), ka.column(4, 0.5, 0.5, dy=0.6)),          # NaN ratio -> merge
+        (ka.one_bin_params(minimum_num_pts=4), ka.column(6, 0.0, 1.0), ka.column(3, 0.0, 0.0, dy=0.6)),
+        (ka.one_bin_params(), ka.column(6, 0.0, 0.5), ka.column(4, 0.0, 0.0, dy=0.6)),            # gate == 0.5: not reverted
+        (ka.one_bin_params(), ka.column(6, 0.0, float(np.nextafter(np.float32(0.5), np.float32(1)))), ka.column(4, 0.0, 0.0, dy=0.6)),
+        (ka.one_bin_params(version=2, th_bin_max_h=0.75), ka.column(6, 0.0, 0.8), ka.column(4, 0.0, 0.0, dy=0.6)),
+        (ka.one_bin_params(version=2, th_bin_max_h=0.75), ka.column(5, 0.0, 1.0), ka.column(5, 0.0, 1.0, dy=0.6)),   # v2 merge: curr then map
+        (ka.one_bin_params(version=2, th_bin_max_h=0.05), ka.column(5, 0.0, 0.1), ka.column(5, 0.0, 2.0, dy=0.6)),  # v2 curr rejected
+        (ka.one_bin_params(num_lowest_pts=5, gf_num_lpr=10), ka.column(3, 1.0, 2.0), ka.column(4, 0.0, 0.0, dy=0.6)),  # degenerate plane
+    ]
+    for p, m, s in cases:
+        g, o = make_pair(gpu_mod, p)
+        g.set_map(m)
+        o.set_map(m)
+        compare_step(g, o, g.step(s, I4, I4, I4), o.step(s, I4, I4, I4))
+
+
+def test_api_error_behaviour(gpu_mod):
+    p = gpu_mod.params_default()
+    g = gpu_mod.Erasor(p)
+    with pytest.raises(gpu_mod.ErasorError) as e:   # step before set_map
+        g.step(np.zeros((1, 4), np.float32), I4, I4, I4)
+    assert e.value.rc == -4
+    p.version = 4                                    # OMU.cpp:273-275
+    with pytest.raises(gpu_mod.ErasorError) as e:
+        gpu_mod.Erasor(p)
+    assert e.value.rc == -5
+    p.version = 3
+    p.num_rings = 0
+    with pytest.raises(gpu_mod.ErasorError):
+        gpu_mod.Erasor(p)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json sizes: ~10 M-pt map, 120 k-pt scans, 20 x 108 bins
+# ---------------------------------------------------------------------------------------------
+def test_full_size_parity_and_properties(gpu_mod):
+    from oracle import orc
+    w = synth.World(seed=20210305 + 5, length=1000.0, n_streets=5, street_gap=50.0, n_moving=10, n_peds=6)
+    lid = synth.Lidar.hdl64(2000)
+    m = w.sample_map(spacing=0.2, frames=range(0, 320, 2))
+    assert len(m) > 9_000_000
+    p = orc.params_default()
+    synth.apply_params(p, "05", max_range=80.0, num_rings=20, num_sectors=108)
+    g, o = make_pair(gpu_mod, p)
+    g.set_map(m)
+    o.set_map(m)
+    jr = np.random.default_rng(7)
+    Tl = gpu_mod.geopose2eigen([0, 0, synth.LIDAR_HEIGHT, 0, 0, 0, 1])
+    n_prev = len(m)
+    for k in range(3):
+        p7 = w.pose(k * 3, 1.0, x0=300.0, jitter_rng=jr)
+        s = w.cast(p7, lid, k * 3)
+        Tb = gpu_mod.geopose2eigen(p7)
+        To = gpu_mod.invert_rigid(Tb)
+        rg = g.step(s, Tl, Tb, To)
+        # size-independent properties (OMU.cpp:431-433, 452-458)
+        assert rg.n_map_in == n_prev == rg.n_voi + rg.n_outskirts
+        assert rg.n_map_out == rg.n_static_estimate + rg.n_complement + rg.n_outskirts
+        assert rg.n_static + rg.n_dynamic == rg.n_map_out
+        n_prev = rg.n_map_out
+        ro = o.step(s, Tl, Tb, To)
+        compare_step(g, o, rg, ro, full=(k == 0))
