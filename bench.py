@@ -57,16 +57,10 @@ def main():
     import erasor_amd
     from erasor_amd import synth
 
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world_size > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world_size)
+    from erasor_amd import dist as ed
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    dist, world_size, rank, local_rank = ed.init("nccl")  # "nccl" is RCCL on ROCm
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -78,33 +72,21 @@ def main():
 
     # ---- the global map: rank 0 samples it, RCCL broadcast over xGMI to every replica ----
     t0 = time.time()
-    if rank == 0:
-        m = world.sample_map(spacing=0.2, frames=range(0, 320, 2), step=1.0)
-        n_map = torch.tensor([m.shape[0]], dtype=torch.int64, device=dev)
-    else:
-        m = None
-        n_map = torch.zeros(1, dtype=torch.int64, device=dev)
+    m = world.sample_map(spacing=0.2, frames=range(0, 320, 2), step=1.0) if rank == 0 else None
     if dist is not None:
-        dist.broadcast(n_map, src=0)
-    N_map = int(n_map.item())
-    d_map = torch.empty((N_map, 4), dtype=torch.float32, device=dev)
-    if rank == 0:
-        d_map.copy_(torch.from_numpy(m))
-    t_bcast = None
-    if dist is not None:
-        torch.cuda.synchronize()
         dist.barrier()
-        tb = time.time()
-        dist.broadcast(d_map, src=0)
-        torch.cuda.synchronize()
-        t_bcast = time.time() - tb
+    tb = time.time()
+    d_map = ed.broadcast_map(dist, rank, dev, m)
+    torch.cuda.synchronize()
+    t_bcast = (time.time() - tb) if dist is not None else None
+    N_map = int(d_map.shape[0])
     t_map = time.time() - t0
 
     # ---- this rank's scans (its shard of the scan stream) and poses; uploaded before the timed region ----
     jr = np.random.default_rng(1234 + rank)
-    x0 = 300.0 + 37.0 * rank
+    x0, frame_ids = ed.shard_frames(rank, world_size, n_frames)
     scans, Tb, To = [], [], []
-    for k in range(n_frames):
+    for k in frame_ids:
         p7 = world.pose(k, 1.0, x0=x0, jitter_rng=jr)
         scans.append(world.cast(p7, lidar, k))
         tb_ = erasor_amd.geopose2eigen(p7)
@@ -140,10 +122,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     prof = g.profile_get()
     g.profiling(0)
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    elapsed = ed.max_over_ranks(dist, elapsed, dev)
 
     if rank != 0:
         if dist is not None:
