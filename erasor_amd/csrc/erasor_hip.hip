@@ -518,8 +518,10 @@ static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf) {
     return 0;
 }
 
+enum { STEP_QUERY_PREVOXELIZED = 1, STEP_VOI_EVERYTHING = 2 };
+
 static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan, bool src_is_device, const float T_l2b[16],
-                       const float T_b2o[16], const float T_o2b[16], erasor_step_result *res) {
+                       const float T_b2o[16], const float T_o2b[16], erasor_step_result *res, int flags = 0) {
     if (!h) return ERASOR_E_INVALID;
     if (!h->have_map) {
         h->err = "erasor_hip_step before erasor_hip_set_map";
@@ -556,7 +558,9 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     if (ns) HIPC(h, hipMemcpyAsync(h->scan.p, scan_src, (size_t)ns * sizeof(float4), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
 
     // ---- query voxelisation, part 1 (OMU.cpp:238) ----
-    voxelize_query_part1(h, ns, P.leaf_query);
+    const bool prevox = (flags & STEP_QUERY_PREVOXELIZED) != 0;
+    if (!prevox) voxelize_query_part1(h, ns, P.leaf_query);
+    const double voi_r2 = (flags & STEP_VOI_EVERYTHING) ? HUGE_VAL : P.voi_r2;
 
     // ---- VoI split (OMU.cpp:254 fetch_VoI membership) ----
     const uint32_t nFchunks = cdiv(h->nF, CHUNK);
@@ -571,7 +575,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         const uint32_t waves_needed = nchunks;
         const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(waves_needed, 4), 256 * 8));
         LAUNCH(h, "voi_split", k_voi_split, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, (const float2 *)h->Oxy.p, h->o_begin,
-               o_chunk0, nOchunks, xc, yc, P.voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p);
+               o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p);
         const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));
         LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p);
         LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
@@ -580,8 +584,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     // ---- mid-step read-back: VoI size and query voxel count size the remaining launches ----
     HIPC(h, hipMemcpyAsync(&h->st, ds, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
-    const uint32_t n_voi = h->st.voi_total, nq = h->st.q_nvox;
-    {
+    const uint32_t n_voi = h->st.voi_total, nq = prevox ? ns : h->st.q_nvox;
+    if (!prevox) {
         VoxGrid g;
         HIPC(h, hipMemcpy(&g, h->qgrid.p, sizeof(g), hipMemcpyDeviceToHost));
         if (ns && g.overflow) {
@@ -594,7 +598,9 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
 
     // ---- query voxelisation, part 2: centroids, label NN, lidar->body, R-POD key ----
     const uint32_t *sq_keys = nullptr, *sq_perm = nullptr;
-    if (nq) {
+    if (prevox) {
+        if (nq) LAUNCH(h, "q_direct", k_query_direct, cdiv(nq, 256), 256, (const float4 *)h->scan.p, nq, P, dc, h->query.p, h->qkey.p);
+    } else if (nq) {
         LAUNCH(h, "q_centroids", k_centroids, cdiv(nq, 256), 256, (const float4 *)h->scan.p, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
                (const uint32_t *)h->run_begin.p, (const uint32_t *)&ds->q_nvox, h->cent.p, h->ukeys.p);
         LAUNCH(h, "q_nn", k_query_nn, cdiv(nq, 256), 256, (const float4 *)h->scan.p, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
@@ -1032,6 +1038,14 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
         HIPC(h, hipMemcpy(vals, h->qv_b.p, (size_t)ns * 4, hipMemcpyDeviceToHost));
     }
     return ERASOR_OK;
+}
+
+int erasor_hip_erasor_run(erasor_hip_handle *h, const float *map_voi_xyzi, size_t n_map, const float *query_voi_xyzi, size_t n_query,
+                          erasor_step_result *res) {
+    int rc = set_map_common(h, map_voi_xyzi, n_map, false);
+    if (rc) return rc;
+    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    return step_common(h, query_voi_xyzi, n_query, false, I, I, I, res, STEP_QUERY_PREVOXELIZED | STEP_VOI_EVERYTHING);
 }
 
 // test hook: force the tombstone-free rebuild of the outskirts region (normally triggered by hole / room heuristics)

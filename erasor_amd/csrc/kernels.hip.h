@@ -874,6 +874,16 @@ __global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts
     qkey[v] = bin_key(P, b.x, b.y, b.z, ctr);
 }
 
+// query handed over already voxelised and in the body frame (ERASOR::set_inputs used directly, erasor.cpp:57-73)
+__global__ __launch_bounds__(256) void k_query_direct(const float4 *__restrict__ src, uint32_t n, DP P, Counters *ctr,
+                                                       float4 *__restrict__ query, uint32_t *__restrict__ qkey) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = src[i];
+    query[i] = p;
+    qkey[i] = bin_key(P, p.x, p.y, p.z, ctr);
+}
+
 // ================================================================================================
 // Scan Ratio Test + bin selection (v3: erasor.cpp:438-563; v2: erasor.cpp:332-427).  Single block.
 // Keys are theta-major (key = sector*R + ring), so key order == the reference's loop order.

@@ -1,0 +1,116 @@
+// erasor_offline_demo — ROS-free driver shaped like src/offline_map_updater/main_in_your_env.cpp:61-127:
+//   <dir>/map.pcd, <dir>/pcds/%06d.pcd, <dir>/poses.csv (header line; idx,?,x,y,z,qx,qy,qz,qw per line, cols 2..8)
+// processes every node through erasor::OfflineMapUpdater and writes <dir>/<data_name>_result.pcd and map_final.pcd.
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+
+#include "erasor_shim.h"
+
+static bool read_bin(const std::string &path, pcl::PointCloud<pcl::PointXYZI> &c) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) return false;
+    const size_t n = (size_t)f.tellg() / 16;
+    f.seekg(0);
+    std::vector<float> v(n * 4);
+    f.read(reinterpret_cast<char *>(v.data()), (std::streamsize)(n * 16));
+    c.points.resize(n);
+    for (size_t i = 0; i < n; ++i) { c.points[i].x = v[4 * i]; c.points[i].y = v[4 * i + 1]; c.points[i].z = v[4 * i + 2]; c.points[i].intensity = v[4 * i + 3]; }
+    return true;
+}
+static void write_bin(const std::string &path, const pcl::PointCloud<pcl::PointXYZI> &c) {
+    std::ofstream f(path, std::ios::binary);
+    for (const auto &p : c.points) {
+        const float v[4] = {p.x, p.y, p.z, p.intensity};
+        f.write(reinterpret_cast<const char *>(v), 16);
+    }
+}
+
+// --erasor-class <map_voi.bin> <query_voi.bin> <out_prefix> <version>: the ERASOR class used the way
+// OfflineMapUpdater.cpp:266-284 uses it (set_inputs -> compare_* -> get_static_estimate -> get_outliers)
+static int erasor_class_mode(int argc, char **argv) {
+    if (argc < 6) return 2;
+    erasor_params p;
+    erasor_hip_params_default(&p);
+    p.max_range = 60.0; p.num_rings = 15; p.num_sectors = 60; p.min_h = -1.3; p.max_h = 3.2; p.th_bin_max_h = 0.05;
+    p.scan_ratio_threshold = 0.3; p.minimum_num_pts = 10; p.gf_dist_thr = 0.15; p.gf_iter = 3; p.gf_num_lpr = 10; p.gf_th_seeds_height = 0.5;
+    pcl::PointCloud<pcl::PointXYZI> map_voi, query_voi, arranged, complement, map_rejected, curr_rejected;
+    if (!read_bin(argv[2], map_voi) || !read_bin(argv[3], query_voi)) return 3;
+    const std::string out = argv[4];
+    const int version = atoi(argv[5]);
+    ERASOR erasor(p);
+    erasor.set_inputs(map_voi, query_voi);
+    if (version == 2) erasor.compare_vois_and_revert_ground(0);
+    else if (version == 3) erasor.compare_vois_and_revert_ground_w_block(0);
+    else throw std::invalid_argument("Other version is not implemented!");
+    erasor.get_static_estimate(arranged, complement);
+    erasor.get_outliers(map_rejected, curr_rejected);
+    write_bin(out + "_arranged.bin", arranged);
+    write_bin(out + "_complement.bin", complement);
+    write_bin(out + "_map_rejected.bin", map_rejected);
+    write_bin(out + "_ground_viz.bin", erasor.ground_viz);
+    printf("ERASOR class: arranged %zu complement %zu rejected %zu max_range %.1f\n", arranged.size(), complement.size(), map_rejected.size(),
+           erasor.get_max_range());
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 2 && std::string(argv[1]) == "--erasor-class") {
+        try {
+            return erasor_class_mode(argc, argv);
+        } catch (const std::exception &e) {
+            fprintf(stderr, "error: %s\n", e.what());
+            return 1;
+        }
+    }
+    if (argc < 3) {
+        fprintf(stderr, "usage: %s <data_dir> <n_frames> [version] [removal_interval]\n", argv[0]);
+        return 2;
+    }
+    const std::string dir = argv[1];
+    const int n = atoi(argv[2]);
+    erasor::OfflineMapUpdater::Config cfg;
+    erasor_hip_params_default(&cfg.params);
+    // config/seq_05.yaml
+    cfg.params.max_range = 60.0; cfg.params.num_rings = 15; cfg.params.num_sectors = 60; cfg.params.min_h = -1.3; cfg.params.max_h = 3.2;
+    cfg.params.th_bin_max_h = 0.05; cfg.params.scan_ratio_threshold = 0.3; cfg.params.minimum_num_pts = 10; cfg.params.gf_dist_thr = 0.15;
+    cfg.params.gf_iter = 3; cfg.params.gf_num_lpr = 10; cfg.params.gf_th_seeds_height = 0.5; cfg.params.query_voxel_size = 0.2;
+    cfg.params.version = argc > 3 ? atoi(argv[3]) : 3;
+    cfg.params.removal_interval = argc > 4 ? atoi(argv[4]) : 1;
+    cfg.lidar2body[2] = 1.73;
+    cfg.initial_map_path = dir + "/map.pcd";
+    cfg.save_path = dir;
+    cfg.data_name = "05";
+    try {
+        erasor::OfflineMapUpdater updater(cfg);
+        std::ifstream in(dir + "/poses.csv");
+        std::string line;
+        std::getline(in, line);  // header
+        for (int i = 0; i < n; ++i) {
+            if (!std::getline(in, line)) break;
+            std::vector<double> v;
+            std::stringstream ss(line);
+            std::string t;
+            while (std::getline(ss, t, ',')) v.push_back(atof(t.c_str()));
+            geometry_msgs::Pose odom;
+            odom.position.x = v[2]; odom.position.y = v[3]; odom.position.z = v[4];
+            odom.orientation.x = v[5]; odom.orientation.y = v[6]; odom.orientation.z = v[7]; odom.orientation.w = v[8];
+            char name[64];
+            snprintf(name, sizeof(name), "/pcds/%06d.pcd", i);
+            pcl::PointCloud<pcl::PointXYZI> scan;
+            if (erasor_utils::load_pcd(dir + name, scan) == -1) return 3;
+            updater.callback_node(i, odom, scan);
+            printf("frame %d: voi %llu rejected %llu reverted bins %u map %llu\n", i, (unsigned long long)updater.last.n_voi,
+                   (unsigned long long)updater.last.n_map_rejected, updater.last.n_reverted_bins, (unsigned long long)updater.last.n_map_out);
+        }
+        pcl::PointCloud<pcl::PointXYZI> m;
+        updater.get_map(m);
+        erasor_utils::save_pcd_ascii(dir + "/map_final.pcd", m);
+        write_bin(dir + "/map_final.bin", m);
+        updater.save_static_map(0.2f);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

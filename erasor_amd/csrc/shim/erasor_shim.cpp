@@ -1,0 +1,303 @@
+// erasor_shim.cpp — see erasor_shim.h.  Host-side glue only; every cloud operation goes through the C ABI of
+// liberasor_hip.so (HIP kernels).  Errors of the C ABI are re-raised as the exceptions the reference throws.
+#include "erasor_shim.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace {
+typedef pcl::PointCloud<pcl::PointXYZI> Cloud;
+
+std::vector<float> to_xyzi(const Cloud &c) {
+    std::vector<float> v(c.size() * 4);
+    for (size_t i = 0; i < c.size(); ++i) {
+        v[4 * i] = c.points[i].x;
+        v[4 * i + 1] = c.points[i].y;
+        v[4 * i + 2] = c.points[i].z;
+        v[4 * i + 3] = c.points[i].intensity;
+    }
+    return v;
+}
+void from_xyzi(const std::vector<float> &v, size_t n, Cloud &c) {
+    c.points.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        c.points[i].x = v[4 * i];
+        c.points[i].y = v[4 * i + 1];
+        c.points[i].z = v[4 * i + 2];
+        c.points[i].intensity = v[4 * i + 3];
+    }
+    c.width = (unsigned)n;
+    c.height = 1;
+}
+void check(erasor_hip_handle *h, int rc, const char *what) {
+    if (rc == ERASOR_OK) return;
+    std::string msg = std::string(what) + ": " + (h ? erasor_hip_last_error(h) : "") + " (rc=" + std::to_string(rc) + ")";
+    if (rc == ERASOR_E_UNSUPPORTED || rc == ERASOR_E_INVALID) throw std::invalid_argument(msg);  // as OMU.cpp:125,149,274,312
+    throw std::runtime_error(msg);
+}
+void fetch_cloud(erasor_hip_handle *h, int which, Cloud &dst) {
+    size_t n = 0;
+    check(h, erasor_hip_get_cloud(h, which, nullptr, 0, &n), "erasor_hip_get_cloud");
+    std::vector<float> v(n * 4 + 4);
+    check(h, erasor_hip_get_cloud(h, which, v.data(), n, &n), "erasor_hip_get_cloud");
+    from_xyzi(v, n, dst);
+}
+void mat16(const Eigen::Matrix4f &T, float out[16]) {
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) out[r * 4 + c] = T(r, c);
+}
+bool is_dynamic_label(float intensity) {  // utils.cpp:3,64-65
+    const uint32_t sem = static_cast<uint32_t>(intensity) & 0xFFFF;
+    return sem >= 252 && sem <= 259;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+namespace erasor_utils {
+
+Eigen::Matrix4f geoPose2eigen(const geometry_msgs::Pose &g) {
+    const double x = g.orientation.x, y = g.orientation.y, z = g.orientation.z, w = g.orientation.w;
+    const double d = x * x + y * y + z * z + w * w;
+    const double s = 2.0 / d;
+    const double xs = x * s, ys = y * s, zs = z * s;
+    const double wx = w * xs, wy = w * ys, wz = w * zs;
+    const double xx = x * xs, xy = x * ys, xz = x * zs;
+    const double yy = y * ys, yz = y * zs, zz = z * zs;
+    Eigen::Matrix4f T = Eigen::Matrix4f::Identity();
+    T(0, 0) = (float)(1.0 - (yy + zz)); T(0, 1) = (float)(xy - wz); T(0, 2) = (float)(xz + wy);
+    T(1, 0) = (float)(xy + wz); T(1, 1) = (float)(1.0 - (xx + zz)); T(1, 2) = (float)(yz - wx);
+    T(2, 0) = (float)(xz - wy); T(2, 1) = (float)(yz + wx); T(2, 2) = (float)(1.0 - (xx + yy));
+    T(0, 3) = (float)g.position.x; T(1, 3) = (float)g.position.y; T(2, 3) = (float)g.position.z;
+    T(3, 0) = T(3, 1) = T(3, 2) = 0.f; T(3, 3) = 1.f;
+    return T;
+}
+
+Eigen::Matrix4f inverse(const Eigen::Matrix4f &Tf) {
+    double m[16], inv[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) m[r * 4 + c] = Tf(r, c);
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0.0) throw std::invalid_argument("singular transform");
+    det = 1.0 / det;
+    Eigen::Matrix4f R;
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) R(r, c) = (float)(inv[r * 4 + c] * det);
+    return R;
+}
+
+void parse_dynamic_obj(const Cloud &cloudIn, Cloud &dynamicOut, Cloud &staticOut) {
+    dynamicOut.points.clear();
+    staticOut.points.clear();
+    for (const auto &pt : cloudIn.points) (is_dynamic_label(pt.intensity) ? dynamicOut : staticOut).points.push_back(pt);
+}
+void count_stat_dyn(const Cloud &cloudIn, int &num_static, int &num_dynamic) {
+    int s = 0, d = 0;
+    for (const auto &pt : cloudIn.points) (is_dynamic_label(pt.intensity) ? d : s)++;
+    num_static = s;
+    num_dynamic = d;
+}
+
+int load_pcd(const std::string &pcd_name, Cloud &dst) {
+    std::ifstream f(pcd_name, std::ios::binary);
+    if (!f) {
+        fprintf(stderr, "Couldn't read file!!! \n");
+        return -1;
+    }
+    std::string line, mode;
+    std::vector<std::string> fields;
+    size_t npts = 0;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ss(line);
+        std::string key;
+        ss >> key;
+        if (key == "FIELDS") {
+            std::string t;
+            while (ss >> t) fields.push_back(t);
+        } else if (key == "POINTS") {
+            ss >> npts;
+        } else if (key == "DATA") {
+            ss >> mode;
+            break;
+        }
+    }
+    int ix = -1, iy = -1, iz = -1, ii = -1;
+    for (size_t k = 0; k < fields.size(); ++k) {
+        if (fields[k] == "x") ix = (int)k;
+        if (fields[k] == "y") iy = (int)k;
+        if (fields[k] == "z") iz = (int)k;
+        if (fields[k] == "intensity") ii = (int)k;
+    }
+    if (ix < 0 || iy < 0 || iz < 0 || fields.empty()) return -1;
+    dst.points.resize(npts);
+    const size_t nf = fields.size();
+    std::vector<float> row(nf);
+    if (mode == "ascii") {
+        for (size_t i = 0; i < npts; ++i) {
+            for (size_t k = 0; k < nf; ++k)
+                if (!(f >> row[k])) return -1;
+            dst.points[i].x = row[ix]; dst.points[i].y = row[iy]; dst.points[i].z = row[iz];
+            dst.points[i].intensity = ii >= 0 ? row[ii] : 0.f;
+        }
+    } else if (mode == "binary") {  // all-float32 fields only
+        for (size_t i = 0; i < npts; ++i) {
+            if (!f.read(reinterpret_cast<char *>(row.data()), (std::streamsize)(nf * 4))) return -1;
+            dst.points[i].x = row[ix]; dst.points[i].y = row[iy]; dst.points[i].z = row[iz];
+            dst.points[i].intensity = ii >= 0 ? row[ii] : 0.f;
+        }
+    } else {
+        return -1;
+    }
+    dst.width = (unsigned)npts;
+    dst.height = 1;
+    return 0;
+}
+
+int save_pcd_ascii(const std::string &pcd_name, const Cloud &src) {
+    FILE *fp = fopen(pcd_name.c_str(), "w");
+    if (!fp) return -1;
+    fprintf(fp, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n");
+    fprintf(fp, "WIDTH %zu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %zu\nDATA ascii\n", src.size(), src.size());
+    for (const auto &p : src.points) fprintf(fp, "%.8g %.8g %.8g %.8g\n", p.x, p.y, p.z, p.intensity);
+    fclose(fp);
+    return 0;
+}
+}  // namespace erasor_utils
+
+// ------------------------------------------------------------------------------------------------
+ERASOR::ERASOR(const erasor_params &p, int device) : P_(p), device_(device) {}
+ERASOR::~ERASOR() {
+    for (auto *h : h_)
+        if (h) erasor_hip_destroy(h);
+}
+void ERASOR::set_inputs(const Cloud &map_voi, const Cloud &query_voi) {
+    debug_curr_rejected.clear();
+    debug_map_rejected.clear();
+    map_complement.clear();
+    map_voi_ = map_voi;
+    query_voi_ = query_voi;
+}
+void ERASOR::run(int version) {
+    erasor_hip_handle *&h = h_[version == 2 ? 0 : 1];
+    if (!h) {
+        erasor_params p = P_;
+        p.version = version;
+        check(nullptr, erasor_hip_create(&p, device_, &h), "erasor_hip_create");
+    }
+    const std::vector<float> m = to_xyzi(map_voi_), q = to_xyzi(query_voi_);
+    erasor_step_result res;
+    check(h, erasor_hip_erasor_run(h, m.data(), map_voi_.size(), q.data(), query_voi_.size(), &res), "erasor_hip_erasor_run");
+    fetch_cloud(h, ERASOR_CLOUD_GROUND_VIZ, ground_viz);
+    fetch_cloud(h, ERASOR_CLOUD_MAP_REJECTED, debug_map_rejected);   // identity transforms: egocentric, as in the reference
+    fetch_cloud(h, ERASOR_CLOUD_CURR_REJECTED, debug_curr_rejected);
+    fetch_cloud(h, ERASOR_CLOUD_COMPLEMENT, map_complement);
+    fetch_cloud(h, ERASOR_CLOUD_STATIC_ESTIMATE, arranged_);
+    status.assign((size_t)P_.num_rings * P_.num_sectors, 0.0);
+    check(h, erasor_hip_get_status(h, status.data()), "erasor_hip_get_status");
+}
+void ERASOR::compare_vois_and_revert_ground(int) { run(2); }
+void ERASOR::compare_vois_and_revert_ground_w_block(int) { run(3); }
+void ERASOR::get_static_estimate(Cloud &arranged, Cloud &complement) {
+    arranged = arranged_;  // r_pod2pc(selected) + ground_viz (erasor.cpp:615-616)
+    complement = map_complement;
+}
+void ERASOR::get_outliers(Cloud &map_rejected, Cloud &curr_rejected) {
+    map_rejected = debug_map_rejected;
+    curr_rejected = debug_curr_rejected;
+}
+double ERASOR::get_max_range() { return P_.max_range; }
+
+// ------------------------------------------------------------------------------------------------
+namespace erasor {
+
+OfflineMapUpdater::OfflineMapUpdater(const Config &cfg) : cfg_(cfg) {
+    if (cfg_.environment == "indoor") throw std::invalid_argument("This `indoor` mode is not perfect!");  // OMU.cpp:149
+    if (cfg_.is_large_scale) throw std::invalid_argument("large-scale (submap) mode is not implemented in the HIP path yet");
+    geometry_msgs::Pose l2b;
+    l2b.position.x = cfg_.lidar2body[0]; l2b.position.y = cfg_.lidar2body[1]; l2b.position.z = cfg_.lidar2body[2];
+    l2b.orientation.x = cfg_.lidar2body[3]; l2b.orientation.y = cfg_.lidar2body[4]; l2b.orientation.z = cfg_.lidar2body[5];
+    l2b.orientation.w = cfg_.lidar2body[6];
+    tf_lidar2body_ = erasor_utils::geoPose2eigen(l2b);  // OMU.cpp:100
+    // fetch_VoI's radius is /erasor/max_range read with another default (OMU.cpp:78); same value when it comes from the YAML
+    int rc = erasor_hip_create(&cfg_.params, cfg_.device, &h_);
+    if (rc == ERASOR_E_UNSUPPORTED) throw std::invalid_argument("Other version is not implemented!");  // OMU.cpp:274
+    check(h_, rc, "erasor_hip_create");
+    memset(&last, 0, sizeof(last));
+    if (!cfg_.initial_map_path.empty()) {
+        Cloud m;
+        if (erasor_utils::load_pcd(cfg_.initial_map_path, m) == -1) throw std::invalid_argument("Maybe intiial map path is not correct!");  // OMU.cpp:125
+        set_global_map(m);
+    }
+}
+OfflineMapUpdater::~OfflineMapUpdater() {
+    if (h_) erasor_hip_destroy(h_);
+}
+void OfflineMapUpdater::set_global_map(const Cloud &map_init) {
+    const std::vector<float> v = to_xyzi(map_init);
+    check(h_, erasor_hip_set_map(h_, v.data(), map_init.size()), "erasor_hip_set_map");
+}
+void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, const Cloud &lidar) {
+    (void)seq;
+    stack_count_++;
+    if (stack_count_ % cfg_.params.removal_interval != 0) {  // OMU.cpp:206-209,327-329 "PASS!"
+        if (cfg_.verbose) printf(" PASS! \n");
+        return;
+    }
+    if (cfg_.environment != "outdoor") throw std::invalid_argument("Other modes are not supported");  // OMU.cpp:312
+    tf_body2origin_ = erasor_utils::geoPose2eigen(odom);  // OMU.cpp:219
+    const Eigen::Matrix4f tf_origin2body = erasor_utils::inverse(tf_body2origin_);
+    float Tl[16], Tb[16], To[16];
+    mat16(tf_lidar2body_, Tl);
+    mat16(tf_body2origin_, Tb);
+    mat16(tf_origin2body, To);
+    const std::vector<float> s = to_xyzi(lidar);
+    check(h_, erasor_hip_step(h_, s.data(), lidar.size(), Tl, Tb, To, &last), "erasor_hip_step");
+    fetch_cloud(h_, ERASOR_CLOUD_MAP_REJECTED, map_rejected);
+    fetch_cloud(h_, ERASOR_CLOUD_CURR_REJECTED, query_rejected);
+    ++num_processed;
+    if (cfg_.verbose) {  // print_status (OMU.cpp:451-465)
+        printf("ERASOR Input: %llu = %llu + %llu - %llu\n", (unsigned long long)last.n_voi, (unsigned long long)last.n_static_estimate,
+               (unsigned long long)last.n_complement, (unsigned long long)last.n_map_rejected);
+        printf("[Debug] Total: %llu  dynamic %llu  static %llu\n", (unsigned long long)last.n_map_out, (unsigned long long)last.n_dynamic,
+               (unsigned long long)last.n_static);
+    }
+}
+void OfflineMapUpdater::get_map(Cloud &dst) {
+    size_t n = 0;
+    check(h_, erasor_hip_map_size(h_, &n), "erasor_hip_map_size");
+    std::vector<float> v(n * 4 + 4);
+    check(h_, erasor_hip_get_map(h_, v.data(), n, &n), "erasor_hip_get_map");
+    from_xyzi(v, n, dst);
+}
+void OfflineMapUpdater::save_static_map(float voxel_size) {
+    Cloud src;
+    get_map(src);  // *ptr_src = *map_arranged_ (OMU.cpp:183)
+    const std::vector<float> v = to_xyzi(src);
+    std::vector<float> out(v.size() + 4);
+    size_t n = 0;
+    check(h_, erasor_hip_voxelize_preserving_labels(h_, v.data(), src.size(), voxel_size, out.data(), src.size(), &n), "voxelize_preserving_labels");
+    Cloud map_to_be_saved;
+    from_xyzi(out, n, map_to_be_saved);
+    const std::string target = cfg_.save_path + "/" + cfg_.data_name + "_result.pcd";  // OMU.cpp:191-193
+    if (erasor_utils::save_pcd_ascii(target, map_to_be_saved) != 0) throw std::runtime_error("cannot write " + target);
+}
+}  // namespace erasor

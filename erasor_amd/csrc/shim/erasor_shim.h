@@ -1,0 +1,92 @@
+// erasor_shim.h — the reference's C++ surface for the hot path, backed by liberasor_hip.so.
+//
+// Same class / function names, argument meaning and error behaviour as
+//   include/erasor/erasor.h:43-147            (class ERASOR)
+//   include/erasor/OfflineMapUpdater.h:9-151   (class erasor::OfflineMapUpdater)
+//   include/tools/erasor_utils.hpp:50-108      (namespace erasor_utils)
+// minus ROS: parameters arrive in an erasor_params struct instead of the rosparam server, the per-node
+// message is passed as (seq, odom pose, lidar cloud), debug topics become public clouds.
+#ifndef ERASOR_SHIM_H
+#define ERASOR_SHIM_H
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/erasor_hip.h"
+#include "erasor_shim_types.h"
+
+namespace erasor_utils {
+typedef pcl::PointCloud<pcl::PointXYZI> Cloud;
+// utils.cpp:35-55 (tf::Matrix3x3(tf::Quaternion) in double, narrowed to float)
+Eigen::Matrix4f geoPose2eigen(const geometry_msgs::Pose &geoPose);
+// tf_body2origin_.inverse() (OMU.cpp:436): double-precision cofactor inverse, narrowed
+Eigen::Matrix4f inverse(const Eigen::Matrix4f &T);
+// utils.cpp:57-78
+void parse_dynamic_obj(const Cloud &cloudIn, Cloud &dynamicOut, Cloud &staticOut);
+// utils.cpp:116-138
+void count_stat_dyn(const Cloud &cloudIn, int &num_static, int &num_dynamic);
+// utils.hpp:75-93 — ASCII or binary .pcd with fields x y z intensity; returns -1 on failure like the reference
+int load_pcd(const std::string &pcd_name, Cloud &dst);
+// pcl::io::savePCDFileASCII as used at OMU.cpp:193
+int save_pcd_ascii(const std::string &pcd_name, const Cloud &src);
+}  // namespace erasor_utils
+
+// class ERASOR (erasor.h:43-228).  Inputs of set_inputs are egocentric clouds, as in the reference.
+class ERASOR {
+public:
+    explicit ERASOR(const erasor_params &p, int device = 0);
+    ~ERASOR();
+    void set_inputs(const pcl::PointCloud<pcl::PointXYZI> &map_voi, const pcl::PointCloud<pcl::PointXYZI> &query_voi);  // erasor.cpp:57-85
+    void compare_vois_and_revert_ground(int frame);           // v2, erasor.cpp:332-434
+    void compare_vois_and_revert_ground_w_block(int frame);   // v3, erasor.cpp:438-571
+    void get_static_estimate(pcl::PointCloud<pcl::PointXYZI> &arranged, pcl::PointCloud<pcl::PointXYZI> &complement);  // :612-626
+    void get_outliers(pcl::PointCloud<pcl::PointXYZI> &map_rejected, pcl::PointCloud<pcl::PointXYZI> &curr_rejected);   // :322-327
+    double get_max_range();  // :628
+    // public members of the reference (erasor.h:127,139-141)
+    pcl::PointCloud<pcl::PointXYZI> ground_viz, debug_curr_rejected, debug_map_rejected, map_complement;
+    // r_pod_selected[r][theta].status after compare_* (erasor.h:145), index = ring*num_sectors + sector
+    std::vector<double> status;
+
+private:
+    void run(int version);
+    erasor_params P_;
+    int device_;
+    erasor_hip_handle *h_[2] = {nullptr, nullptr};  // one handle per algorithm version
+    pcl::PointCloud<pcl::PointXYZI> map_voi_, query_voi_, arranged_;
+};
+
+namespace erasor {
+// erasor::OfflineMapUpdater (OfflineMapUpdater.h:9-151): owns the (device-resident) map, one callback per node.
+class OfflineMapUpdater {
+public:
+    struct Config {
+        erasor_params params;                                  // /erasor/*, /MapUpdater/* (set_params, OMU.cpp:63-105)
+        double lidar2body[7] = {0, 0, 0, 0, 0, 0, 1};          // /tf/lidar2body: x y z qx qy qz qw (OMU.cpp:89-104)
+        std::string environment = "outdoor";                   // /MapUpdater/env
+        std::string initial_map_path, save_path = ".", data_name = "00";
+        bool is_large_scale = false;                           // /large_scale/is_large_scale (not supported yet: rejected)
+        bool verbose = false;
+        int device = 0;
+    };
+    explicit OfflineMapUpdater(const Config &cfg);            // OMU.cpp:5-32 (+ load_global_map when a path is given)
+    ~OfflineMapUpdater();
+    void set_global_map(const pcl::PointCloud<pcl::PointXYZI> &map_init);  // load_global_map's copy, OMU.cpp:133
+    // one erasor::node message: header.seq, odom, lidar (msg/node.msg:1-4) — OMU.cpp:203-330
+    void callback_node(int seq, const geometry_msgs::Pose &odom, const pcl::PointCloud<pcl::PointXYZI> &lidar);
+    void save_static_map(float voxel_size);                    // OMU.cpp:174-196
+    void get_map(pcl::PointCloud<pcl::PointXYZI> &dst);        // *map_arranged_
+    // last step's products (the clouds the reference publishes, OMU.cpp:316-320)
+    pcl::PointCloud<pcl::PointXYZI> map_rejected, query_rejected;
+    erasor_step_result last;
+    size_t num_processed = 0;
+
+private:
+    Config cfg_;
+    erasor_hip_handle *h_ = nullptr;
+    Eigen::Matrix4f tf_lidar2body_, tf_body2origin_;
+    int stack_count_ = 0;
+};
+}  // namespace erasor
+#endif

@@ -139,6 +139,13 @@ int erasor_hip_step_device(erasor_hip_handle *h, const void *d_scan_xyzi, size_t
                            const float T_lidar2body[16], const float T_body2origin[16],
                            const float T_origin2body[16], erasor_step_result *res);
 
+/* replaces: the ERASOR class used on its own (erasor.h:109-141): set_inputs(map_voi, query_voi) +
+ * compare_vois_and_revert_ground[_w_block] on caller-provided EGOCENTRIC clouds (query already voxelised and
+ * in the body frame).  Results: erasor_hip_get_cloud(STATIC_ESTIMATE / COMPLEMENT / MAP_REJECTED /
+ * CURR_REJECTED / GROUND_VIZ), erasor_hip_get_status, erasor_hip_get_bins.  Replaces the handle's map. */
+int erasor_hip_erasor_run(erasor_hip_handle *h, const float *map_voi_xyzi, size_t n_map,
+                          const float *query_voi_xyzi, size_t n_query, erasor_step_result *res);
+
 /* map_arranged_ read-back (OMU.cpp:183: what save_static_map starts from) */
 int erasor_hip_map_size(erasor_hip_handle *h, size_t *n);
 int erasor_hip_get_map(erasor_hip_handle *h, float *dst_xyzi, size_t cap_points, size_t *n);
