@@ -138,8 +138,14 @@ def main():
     alg_bytes = float(np.mean([b for b, _ in split_bytes]))
     entries = float(np.mean([e for _, e in split_bytes]))
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None  # HBM bytes per launch from the PMC counters: measured in a separate rocprofv3 --pmc pass (profiles/)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            traffic = int(json.load(f)["traffic_bytes_per_launch"])
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": "k_voi_split", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": None, "bytes_per_launch": int(alg_bytes),
+                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "bytes_per_launch": int(alg_bytes),
                 "entries_per_launch": int(entries), "avg_launch_us": round(avg_ms * 1e3, 2), "launches": int(vs_n),
                 "aos16_equiv_GBps": round(16.0 * entries / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0}
 

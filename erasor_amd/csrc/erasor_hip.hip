@@ -75,8 +75,11 @@ struct erasor_hip_handle {
     DBuf<float4> scan, cent, query, sq, curr_rejected;
     DBuf<uint32_t> bb, qk_a, qk_b, qv_a, qv_b, qposL, qposR, qflag, qpl, qtops, run_begin, ukeys, qkey;
     DBuf<uint8_t> qhead;
-    DBuf<esort::Seg> esq0, esq1, essmall;
+    DBuf<esort::Seg> esq0, esq1, esq2, essmall;
     DBuf<EsQueues> esqs;
+    DBuf<WideSeg> wseg0, wseg1;
+    DBuf<WideState> wstate;
+    DBuf<uint32_t> wtileL, wtileR;
     DBuf<VoxGrid> qgrid;
     // ---- per-bin scratch (R-GPF / bin voxelise global paths) ----
     DBuf<uint32_t> gsK, gsV, gsL, gsR, gsK2, gsV2;
@@ -306,7 +309,8 @@ int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
     rc |= ensure(h, h->qk_a, S) | ensure(h, h->qk_b, S) | ensure(h, h->qv_a, S) | ensure(h, h->qv_b, S) | ensure(h, h->qposL, S) | ensure(h, h->qposR, S);
     rc |= ensure(h, h->qflag, S) | ensure(h, h->qpl, S) | ensure(h, h->qtops, S / 1024 + 4) | ensure(h, h->run_begin, S + 1) | ensure(h, h->ukeys, S);
     rc |= ensure(h, h->qkey, S) | ensure(h, h->qhead, S + 4);
-    rc |= ensure(h, h->esq0, 65536) | ensure(h, h->esq1, 65536) | ensure(h, h->essmall, 65536);
+    rc |= ensure(h, h->wseg0, WSEG_MAX) | ensure(h, h->wseg1, WSEG_MAX) | ensure(h, h->wstate, 1) | ensure(h, h->wtileL, WTILES_MAX) | ensure(h, h->wtileR, WTILES_MAX);
+    rc |= ensure(h, h->esq0, 65536) | ensure(h, h->esq1, 65536) | ensure(h, h->esq2, 65536) | ensure(h, h->essmall, 65536);
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
 
@@ -444,7 +448,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->scan); release(h->cent); release(h->query); release(h->sq); release(h->curr_rejected);
     release(h->bb); release(h->qk_a); release(h->qk_b); release(h->qv_a); release(h->qv_b); release(h->qposL); release(h->qposR);
     release(h->qflag); release(h->qpl); release(h->qtops); release(h->run_begin); release(h->ukeys); release(h->qkey); release(h->qhead);
-    release(h->esq0); release(h->esq1); release(h->essmall); release(h->esqs); release(h->qgrid);
+    release(h->wseg0); release(h->wseg1); release(h->wstate); release(h->wtileL); release(h->wtileR); release(h->esq0); release(h->esq1); release(h->esq2); release(h->essmall); release(h->esqs); release(h->qgrid);
     release(h->gsK); release(h->gsV); release(h->gsL); release(h->gsR); release(h->gsK2); release(h->gsV2); release(h->gsH); release(h->gsC);
     release(h->vox_out); release(h->d_st); release(h->d_ctr);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -487,6 +491,40 @@ static int set_map_common(erasor_hip_handle *h, const void *src, size_t n, bool 
 int erasor_hip_set_map(erasor_hip_handle *h, const float *xyzi, size_t n) { return set_map_common(h, xyzi, n, false); }
 int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n) { return set_map_common(h, d_xyzi, n, true); }
 
+// exact std::sort of (qk_a, qv_a)[0..n) -> (qk_b, qv_b): global levels (one workgroup per big segment, one partition per
+// launch), then every remaining segment is completed inside LDS by one workgroup.
+static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
+    Counters *dc = h->d_ctr.p;
+    LAUNCH(h, "q_esort", k_esort_init, 1, 1, h->qk_a.p, h->qv_a.p, h->esq0.p, h->essmall.p, h->esqs.p, h->wseg0.p, h->wstate.p, n);
+    int nlev = 0;
+    if (n >= WIDE_MIN && (n - 1 + WTILE - 1) / WTILE <= WTILES_MAX) {
+        // wide levels: segments >= WIDE_MIN keys, many workgroups each.  A segment halves (roughly) per level, so
+        // lg(n / WIDE_MIN) + slack levels empty the wide list; whatever is left is routed to the level queue.
+        const int wl = std::min(esort::lg2_floor(n / WIDE_MIN) + 4, 16);
+        for (int l = 0; l < wl; ++l) {
+            const int cur = l & 1;
+            LAUNCH(h, "q_esort_wide", k_esort_wide_mark, 256, 256, (const uint32_t *)h->qk_a.p, h->qposL.p, h->qposR.p,
+                   (const WideSeg *)(cur ? h->wseg1.p : h->wseg0.p), (const WideState *)h->wstate.p, cur, h->wtileL.p, h->wtileR.p);
+            LAUNCH(h, "q_esort_wide", k_esort_wide_swap, 128, 256, h->qk_a.p, h->qv_a.p, (const uint32_t *)h->qposL.p, (const uint32_t *)h->qposR.p,
+                   cur ? h->wseg1.p : h->wseg0.p, (const WideState *)h->wstate.p, cur, (const uint32_t *)h->wtileL.p, (const uint32_t *)h->wtileR.p);
+            LAUNCH(h, "q_esort_wide", k_esort_wide_children, 1, 64, h->qk_a.p, h->qv_a.p, (const WideSeg *)(cur ? h->wseg1.p : h->wseg0.p),
+                   cur ? h->wseg0.p : h->wseg1.p, h->wstate.p, cur, h->esq0.p, h->essmall.p, h->esqs.p, 65536u, l == wl - 1 ? 1 : 0, dc);
+        }
+    }
+    if (n > ES_LMAX) {
+        // level queue: one workgroup per segment, one partition per launch.  Segments that are still big after `nlev`
+        // levels are finished (slowly, in global memory) by the final kernel, so any nlev is correct.
+        nlev = std::min(2 * esort::lg2_floor(n), n >= WIDE_MIN ? 6 : 12);
+        for (int l = 0; l < nlev; ++l)
+            LAUNCH(h, "q_esort", k_esort_level, 48, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->esq0.p, h->esq1.p, h->esq2.p,
+                   h->essmall.p, h->esqs.p, l, 65536u, dc);
+    }
+    const int bigcur = nlev % 3;
+    esort::Seg *qs3[3] = {h->esq0.p, h->esq1.p, h->esq2.p};
+    LAUNCH(h, "q_esort_final", k_esort_final, 256, 256, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->qhead.p, h->qk_b.p, h->qv_b.p,
+           (const esort::Seg *)h->essmall.p, (const esort::Seg *)qs3[bigcur], h->esqs.p, bigcur, dc);
+}
+
 // ---- exact voxelisation of the cloud in h->scan[0..n): fills run_begin / cent / ukeys, d_st->q_nvox -------------------
 static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf) {
     DevState *ds = h->d_st.p;
@@ -496,20 +534,7 @@ static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf) {
     LAUNCH(h, "q_keys", k_voxel_keys, std::max(1u, cdiv(n, 256)), 256, (const float4 *)h->scan.p, n, (const uint32_t *)h->bb.p, leaf, h->qk_a.p,
            h->qv_a.p, h->qgrid.p, dc);
     // exact std::sort: a few global levels (one workgroup per big segment), then per-segment completion in LDS
-    LAUNCH(h, "q_esort", k_esort_init, 1, 1, h->esq0.p, h->essmall.p, h->esqs.p, n);
-    int cur = 0;
-    if (n > ES_LMAX) {
-        const int levels = 2 * esort::lg2_floor(n);  // == the introsort depth budget: no big segment can survive it
-        const int nlev = std::min(levels, 14);
-        for (int l = 0; l < nlev; ++l) {
-            LAUNCH(h, "q_esort", k_esort_level, 64, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, cur ? h->esq1.p : h->esq0.p,
-                   cur ? h->esq0.p : h->esq1.p, h->essmall.p, h->esqs.p, cur, 65536u, dc);
-            LAUNCH(h, "q_esort", k_esort_level_reset, 1, 1, h->esqs.p, cur);
-            cur ^= 1;
-        }
-    }
-    LAUNCH(h, "q_esort", k_esort_final, 256, 256, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->qhead.p, h->qk_b.p, h->qv_b.p,
-           (const esort::Seg *)h->essmall.p, (const esort::Seg *)(cur ? h->esq1.p : h->esq0.p), h->esqs.p, cur, dc);
+    run_exact_sort(h, n);
     // runs
     if (n) LAUNCH(h, "q_runs", k_run_heads, cdiv(n, 256), 256, (const uint32_t *)h->qk_b.p, n, h->qflag.p);
     scan_u32(h, h->qflag.p, h->qpl.p, h->qtops.p, n, n, nullptr, nullptr, "q_runs");
@@ -678,7 +703,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     LAUNCH(h, "assemble", k_assemble_bins<true>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
            (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
            (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, Fnew, h->curr_rejected.p);
-    LAUNCH(h, "count_labels", k_count_labels4, std::max(1u, std::min<uint32_t>(cdiv(2 * (uint64_t)n_voi + nq, 256), 1024)), 256,
+    LAUNCH(h, "count_labels", k_count_labels4, std::max(1u, std::min<uint32_t>(cdiv(2 * (uint64_t)n_voi + nq, 1024), 512)), 256,
            (const float4 *)Fnew, 0u, (const uint32_t *)&ds->nF_new, &ds->F_static, &ds->F_dynamic);
     LAUNCH(h, "step_end", k_step_end, 1, 1, ds);
     HIPC(h, hipMemcpyAsync(&h->st, ds, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
@@ -1012,19 +1037,7 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
         HIPC(h, hipMemcpyAsync(h->qv_a.p, vals, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
     }
     Counters *dc = h->d_ctr.p;
-    LAUNCH(h, "q_esort", k_esort_init, 1, 1, h->esq0.p, h->essmall.p, h->esqs.p, ns);
-    int cur = 0;
-    if (ns > ES_LMAX) {
-        const int nlev = std::min(2 * esort::lg2_floor(ns), 14);
-        for (int l = 0; l < nlev; ++l) {
-            LAUNCH(h, "q_esort", k_esort_level, 64, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, cur ? h->esq1.p : h->esq0.p,
-                   cur ? h->esq0.p : h->esq1.p, h->essmall.p, h->esqs.p, cur, 65536u, dc);
-            LAUNCH(h, "q_esort", k_esort_level_reset, 1, 1, h->esqs.p, cur);
-            cur ^= 1;
-        }
-    }
-    LAUNCH(h, "q_esort", k_esort_final, 256, 256, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->qhead.p, h->qk_b.p, h->qv_b.p,
-           (const esort::Seg *)h->essmall.p, (const esort::Seg *)(cur ? h->esq1.p : h->esq0.p), h->esqs.p, cur, dc);
+    run_exact_sort(h, ns);
     HIPC(h, hipStreamSynchronize(h->stream));
     Counters c;
     HIPC(h, hipMemcpy(&c, dc, sizeof(c), hipMemcpyDeviceToHost));

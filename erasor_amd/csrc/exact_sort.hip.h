@@ -30,7 +30,7 @@ __device__ __forceinline__ void wave_sync() { __threadfence_block(); }
 // One wavefront partitions [first,last) (size > kThreshold).  posL/posR: scratch, same index space
 // as K (entries [first+1,last) are used).  Returns the cut (wave-uniform).
 template <class KP, class VP, class PP>
-__device__ uint32_t wave_partition(KP K, VP V, PP posL, PP posR, uint32_t first, uint32_t last) {
+__device__ __forceinline__ uint32_t wave_partition(KP K, VP V, PP posL, PP posR, uint32_t first, uint32_t last) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lt = lanemask_lt();
     if (lane == 0) move_median_to_first(K, V, first, last);
@@ -71,13 +71,19 @@ __device__ uint32_t wave_partition(KP K, VP V, PP posL, PP posR, uint32_t first,
     return cut;
 }
 
+template <int EPT, class KP, class VP, class PP>
+__device__ __forceinline__ uint32_t block_partition(KP K, VP V, PP posL, PP posR, uint32_t first, uint32_t last, uint32_t *sm,
+                                                    bool median_done = false);
+
+static constexpr uint32_t kBlockMin = 768;  // inside block_esort, segments longer than this are partitioned by the whole workgroup
+
 // Whole-subtree sort of K[base..base+n) by one workgroup.  All pointers index the same space
 // (element e lives at K[e]); the segment handled is [seg_first, seg_last) with introsort depth
 // budget `depth`.  qa/qb: LDS queues of capacity qcap; qcnt: 2 LDS counters; head: byte flags for
 // [seg_first, seg_last] (indexable with the same element indices).  On return K2/V2[seg range] hold
 // the final order.  K2/V2 may alias posL/posR (they are dead by then) but not K/V.
 template <class KP, class VP, class PP, class HP, class K2P, class V2P>
-__device__ void block_esort(KP K, VP V, PP posL, PP posR, HP head, K2P K2, V2P V2, uint32_t seg_first, uint32_t seg_last,
+__device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP head, K2P K2, V2P V2, uint32_t seg_first, uint32_t seg_last,
                             int32_t depth, Seg *qa, Seg *qb, uint32_t *qcnt, uint32_t qcap, uint32_t *n_fallback,
                             uint32_t *overflow_flag) {
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
@@ -95,6 +101,52 @@ __device__ void block_esort(KP K, VP V, PP posL, PP posR, HP head, K2P K2, V2P V
         }
     }
     __syncthreads();
+    // phase 1: long segments are partitioned by the WHOLE workgroup, one after the other (a short stack); their
+    // children go back on the stack or, once short enough, to the wavefront-per-segment queue of phase 2.
+    {
+        __shared__ Seg stk[48];
+        __shared__ uint32_t sm_bp[40];
+        __shared__ int sp;
+        __shared__ Seg cur_sg;
+        if (tid == 0) {
+            sp = 0;
+            if (n > kBlockMin && depth > 0) {
+                stk[0].first = seg_first;
+                stk[0].last = seg_last;
+                stk[0].depth = depth;
+                sp = 1;
+                qcnt[0] = 0;
+            }
+        }
+        __syncthreads();
+        for (;;) {
+            if (tid == 0 && sp > 0) cur_sg = stk[sp - 1];
+            __syncthreads();
+            if (sp == 0) break;
+            const Seg sg = cur_sg;
+            __syncthreads();
+            if (tid == 0) --sp;
+            const uint32_t cut = block_partition<4>(K, V, posL, posR, sg.first, sg.last, sm_bp);
+            if (tid == 0) {
+                head[cut] = 1;
+                const Seg ch[2] = {{sg.first, cut, sg.depth - 1}, {cut, sg.last, sg.depth - 1}};
+                for (int t = 0; t < 2; ++t) {
+                    const uint32_t len = ch[t].last - ch[t].first;
+                    if (len > kBlockMin && ch[t].depth > 0 && sp < 48) {
+                        stk[sp++] = ch[t];
+                    } else if (len > (uint32_t)kThreshold) {
+                        const uint32_t at = qcnt[0];
+                        if (at < qcap) {
+                            qa[at] = ch[t];
+                            qcnt[0] = at + 1;
+                        } else
+                            *overflow_flag = 1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
     int cur = 0;
     for (;;) {
         const uint32_t nseg = qcnt[cur];
@@ -159,27 +211,41 @@ __device__ void block_esort(KP K, VP V, PP posL, PP posR, HP head, K2P K2, V2P V
 }
 
 // One workgroup performs ONE partition of the global-memory segment [first,last).  sm: >= 2*nwaves+4 uint32.
-template <class KP, class VP, class PP>
-__device__ uint32_t block_partition(KP K, VP V, PP posL, PP posR, uint32_t first, uint32_t last, uint32_t *sm) {
+// Every thread owns EPT consecutive positions of a tile, so a tile is bs*EPT elements and the stop lists are
+// written in ascending position order with one block scan per tile.
+template <int EPT, class KP, class VP, class PP>
+__device__ __forceinline__ uint32_t block_partition(KP K, VP V, PP posL, PP posR, uint32_t first, uint32_t last, uint32_t *sm,
+                                                    bool median_done) {
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
     const uint32_t wave = tid >> 6, nwaves = bs >> 6, lane = tid & 63u;
-    const uint64_t lt = lanemask_lt();
-    if (tid == 0) move_median_to_first(K, V, first, last);
+    if (tid == 0 && !median_done) move_median_to_first(K, V, first, last);
     __threadfence_block();
     __syncthreads();
     const uint32_t p = K[first];
     const uint32_t lo = first + 1, hi = last;
     uint32_t carryL = 0, carryR = 0;  // uniform across the block (recomputed identically by all threads)
-    for (uint32_t base = lo; base < hi; base += bs) {
-        const uint32_t i = base + tid;
-        const bool valid = i < hi;
-        const uint32_t k = valid ? (uint32_t)K[i] : 0u;
-        const bool isL = valid && !(k < p);
-        const bool isR = valid && !(p < k);
-        const uint64_t mL = __ballot(isL), mR = __ballot(isR);
-        if (lane == 0) {
-            sm[wave] = __popcll(mL);
-            sm[nwaves + wave] = __popcll(mR);
+    for (uint32_t base = lo; base < hi; base += bs * EPT) {
+        const uint32_t i0 = base + tid * EPT;
+        uint32_t k[EPT];
+        uint32_t fl = 0, fr = 0;  // bit j: element i0+j is a left / right stop
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) k[j] = (i0 + j < hi) ? (uint32_t)K[i0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const bool valid = i0 + j < hi;
+            fl |= (valid && !(k[j] < p)) ? (1u << j) : 0u;
+            fr |= (valid && !(p < k[j])) ? (1u << j) : 0u;
+        }
+        const uint32_t cl = __popc(fl), cr = __popc(fr);
+        // wave-inclusive scans of (cl, cr) packed in one 32-bit word (each < 2^16 per wave: 64*EPT)
+        uint32_t inc = cl | (cr << 16);
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off, 64);
+            if ((int)lane >= off) inc += t;
+        }
+        if (lane == 63) {
+            sm[wave] = inc & 0xFFFFu;
+            sm[nwaves + wave] = inc >> 16;
         }
         __syncthreads();
         uint32_t preL = 0, preR = 0, totL = 0, totR = 0;
@@ -192,8 +258,13 @@ __device__ uint32_t block_partition(KP K, VP V, PP posL, PP posR, uint32_t first
             totL += a;
             totR += b;
         }
-        if (isL) posL[lo + carryL + preL + __popcll(mL & lt)] = i;
-        if (isR) posR[lo + carryR + preR + __popcll(mR & lt)] = i;
+        uint32_t oL = lo + carryL + preL + (inc & 0xFFFFu) - cl;
+        uint32_t oR = lo + carryR + preR + (inc >> 16) - cr;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            if (fl & (1u << j)) posL[oL++] = i0 + j;
+            if (fr & (1u << j)) posR[oR++] = i0 + j;
+        }
         carryL += totL;
         carryR += totR;
         __syncthreads();
@@ -204,7 +275,17 @@ __device__ uint32_t block_partition(KP K, VP V, PP posL, PP posR, uint32_t first
     const uint32_t lim = nL < nR ? nL : nR;
     // m = number of k < lim with posL[k] < R[k]; monotone -> count in parallel
     uint32_t cnt = 0;
-    for (uint32_t k = tid; k < lim; k += bs) cnt += ((uint32_t)posL[lo + k] < (uint32_t)posR[lo + nR - 1 - k]) ? 1u : 0u;
+    for (uint32_t k0 = tid; k0 < lim; k0 += 4 * bs) {
+        uint32_t l4[4], r4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t k = k0 + u * bs;
+            l4[u] = k < lim ? (uint32_t)posL[lo + k] : 1u;
+            r4[u] = k < lim ? (uint32_t)posR[lo + nR - 1 - k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cnt += (l4[u] < r4[u]) ? 1u : 0u;
+    }
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
     if (lane == 0) sm[wave] = cnt;
     __syncthreads();
@@ -218,7 +299,33 @@ __device__ uint32_t block_partition(KP K, VP V, PP posL, PP posR, uint32_t first
         if (r < cut) cut = r;
     }
     __syncthreads();
-    for (uint32_t k = tid; k < m; k += bs) swap_kv(K, V, (uint32_t)posL[lo + k], (uint32_t)posR[lo + nR - 1 - k]);
+    // swaps touch pairwise-distinct positions: batch 4 per thread so that 4 x (2 position + 4 key/value) loads are in flight
+    for (uint32_t k0 = tid; k0 < m; k0 += 4 * bs) {
+        uint32_t a[4], b[4], ka[4], kb[4], va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t k = k0 + u * bs;
+            const bool ok = k < m;
+            a[u] = ok ? (uint32_t)posL[lo + k] : first;
+            b[u] = ok ? (uint32_t)posR[lo + nR - 1 - k] : first;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ka[u] = K[a[u]];
+            kb[u] = K[b[u]];
+            va[u] = V[a[u]];
+            vb[u] = V[b[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + u * bs < m) {
+                K[a[u]] = kb[u];
+                K[b[u]] = ka[u];
+                V[a[u]] = vb[u];
+                V[b[u]] = va[u];
+            }
+        }
+    }
     __threadfence_block();
     __syncthreads();
     return cut;

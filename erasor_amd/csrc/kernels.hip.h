@@ -661,19 +661,54 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4 *__restrict__ p
 // ---- exact std::sort of the (idx, point) pairs, global memory -----------------------------------
 static constexpr uint32_t ES_LMAX = 4096;   // segments up to this size are finished inside LDS
 struct EsQueues {
-    uint32_t cnt[2];      // level queues
+    uint32_t cnt[3];      // three rotating level queues: level l reads [l%3], appends to [(l+1)%3], clears [(l+2)%3]
     uint32_t small_cnt;   // segments handed to the final kernel
-    uint32_t pad;
 };
-__global__ void k_esort_init(esort::Seg *q0, esort::Seg *smallq, EsQueues *qs, uint32_t n) {
-    qs->cnt[0] = qs->cnt[1] = 0;
+// ---- "wide" partition: the top levels of a big sort, many workgroups per segment ----------------
+// Per level three launches, no intra-kernel cross-workgroup dependency (coherence comes from kernel boundaries):
+//   mark     : one workgroup per 2048-key tile: tile-local stop lists (in the tile's own index range) + counts
+//   swap     : WPARTS workgroups per segment: tile prefix, m by a block-wide multiway search over the two-level
+//              stop lists, cut, then the m swaps split between the workgroups
+//   children : one workgroup: children -> next wide list (median move done here) / level queue / final queue
+static constexpr uint32_t WIDE_MIN = 16384;  // segments at least this long use the wide path
+static constexpr uint32_t WTILE = 2048;      // 256 threads x 8 keys
+static constexpr uint32_t WSEG_MAX = 64;     // wide segments per level
+static constexpr uint32_t WTILES_MAX = 2048; // tiles per level (all wide segments together) -> n up to ~4 M keys
+static constexpr uint32_t WPARTS = 8;        // workgroups sharing one segment's swaps
+static constexpr int32_t MED_DONE = 0x40000000;  // flag in Seg::depth: median already moved to `first`
+
+struct WideSeg {
+    uint32_t first, last;
+    int32_t depth;
+    uint32_t tile0, ntiles, cut, pad0, pad1;
+};
+struct WideState {
+    uint32_t nseg[2];
+    uint32_t ntiles[2];
+};
+
+__global__ void k_esort_init(uint32_t *K, uint32_t *V, esort::Seg *q0, esort::Seg *smallq, EsQueues *qs, WideSeg *w0, WideState *ws,
+                             uint32_t n) {
+    qs->cnt[0] = qs->cnt[1] = qs->cnt[2] = 0;
     qs->small_cnt = 0;
+    ws->nseg[0] = ws->nseg[1] = 0;
+    ws->ntiles[0] = ws->ntiles[1] = 0;
     if (n == 0) return;
     esort::Seg s;
     s.first = 0;
     s.last = n;
     s.depth = 2 * esort::lg2_floor(n);
-    if (n > ES_LMAX) {
+    const uint32_t nt = (n - 1 + WTILE - 1) / WTILE;
+    if (n >= WIDE_MIN && nt <= WTILES_MAX) {
+        esort::move_median_to_first(K, V, 0u, n);
+        w0[0].first = 0;
+        w0[0].last = n;
+        w0[0].depth = s.depth;
+        w0[0].tile0 = 0;
+        w0[0].ntiles = nt;
+        ws->nseg[0] = 1;
+        ws->ntiles[0] = nt;
+    } else if (n > ES_LMAX) {
         q0[0] = s;
         qs->cnt[0] = 1;
     } else {
@@ -681,11 +716,185 @@ __global__ void k_esort_init(esort::Seg *q0, esort::Seg *smallq, EsQueues *qs, u
         qs->small_cnt = 1;
     }
 }
-// one level: each workgroup takes big segments of queue[cur] and performs one partition
-__global__ __launch_bounds__(1024) void k_esort_level(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, esort::Seg *qcur,
-                                                       esort::Seg *qnext, esort::Seg *smallq, EsQueues *qs, int cur, uint32_t qcap,
-                                                       Counters *ctr) {
+
+__global__ __launch_bounds__(256) void k_esort_wide_mark(const uint32_t *__restrict__ K, uint32_t *__restrict__ posL,
+                                                          uint32_t *__restrict__ posR, const WideSeg *__restrict__ wseg,
+                                                          const WideState *ws, int cur, uint32_t *__restrict__ tileL,
+                                                          uint32_t *__restrict__ tileR) {
     __shared__ uint32_t sm[40];
+    const uint32_t nseg = ws->nseg[cur], ntot = ws->ntiles[cur];
+    for (uint32_t gt = blockIdx.x; gt < ntot; gt += gridDim.x) {
+        uint32_t si = 0;
+        while (si + 1 < nseg && gt >= wseg[si + 1].tile0) ++si;
+        const WideSeg sg = wseg[si];
+        const uint32_t t = gt - sg.tile0;
+        const uint32_t p = K[sg.first];
+        const uint32_t lo = sg.first + 1 + t * WTILE;
+        const uint32_t hi = min(lo + WTILE, sg.last);
+        const uint32_t i0 = lo + threadIdx.x * 8;
+        uint32_t k[8], fl = 0, fr = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k[j] = (i0 + j < hi) ? K[i0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool valid = i0 + j < hi;
+            fl |= (valid && !(k[j] < p)) ? (1u << j) : 0u;
+            fr |= (valid && !(p < k[j])) ? (1u << j) : 0u;
+        }
+        const uint32_t cl = __popc(fl), cr = __popc(fr);
+        uint32_t tl, tr;
+        uint32_t oL = lo + block_excl_scan(cl, sm, tl);
+        uint32_t oR = lo + block_excl_scan(cr, sm, tr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (fl & (1u << j)) posL[oL++] = i0 + j;
+            if (fr & (1u << j)) posR[oR++] = i0 + j;
+        }
+        if (threadIdx.x == 0) {
+            tileL[gt] = tl;
+            tileR[gt] = tr;
+        }
+        __syncthreads();
+    }
+}
+
+// asc-th entry of a two-level stop list (tile prefix `pre` in LDS, tile-local lists in `list`)
+__device__ __forceinline__ uint32_t wide_lookup(const uint32_t *pre, uint32_t ntiles, const uint32_t *list, uint32_t base, uint32_t asc) {
+    uint32_t lo = 0, hi = ntiles;  // largest t with pre[t] <= asc
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pre[mid] <= asc) lo = mid; else hi = mid;
+    }
+    return list[base + lo * WTILE + (asc - pre[lo])];
+}
+
+__global__ __launch_bounds__(256) void k_esort_wide_swap(uint32_t *K, uint32_t *V, const uint32_t *__restrict__ posL,
+                                                          const uint32_t *__restrict__ posR, WideSeg *wseg, const WideState *ws, int cur,
+                                                          const uint32_t *__restrict__ tileL, const uint32_t *__restrict__ tileR) {
+    __shared__ uint32_t preL[WTILES_MAX + 1], preR[WTILES_MAX + 1];
+    __shared__ uint32_t sm[40];
+    __shared__ uint32_t s_lo, s_hi;
+    const uint32_t nseg = ws->nseg[cur];
+    const uint32_t tid = threadIdx.x, bs = blockDim.x;
+    for (uint32_t w = blockIdx.x; w < nseg * WPARTS; w += gridDim.x) {
+        const uint32_t si = w / WPARTS, part = w % WPARTS;
+        const WideSeg sg = wseg[si];
+        const uint32_t nt = sg.ntiles, base = sg.first + 1;
+        // tile prefixes (exclusive), entry nt = total
+        uint32_t carryL = 0, carryR = 0;
+        for (uint32_t t0 = 0; t0 < nt; t0 += bs) {
+            const uint32_t t = t0 + tid;
+            const uint32_t a = t < nt ? tileL[sg.tile0 + t] : 0u, b = t < nt ? tileR[sg.tile0 + t] : 0u;
+            uint32_t ta, tb;
+            const uint32_t pa = block_excl_scan(a, sm, ta);
+            const uint32_t pb = block_excl_scan(b, sm, tb);
+            if (t < nt) {
+                preL[t] = carryL + pa;
+                preR[t] = carryR + pb;
+            }
+            carryL += ta;
+            carryR += tb;
+        }
+        if (tid == 0) {
+            preL[nt] = carryL;
+            preR[nt] = carryR;
+        }
+        __syncthreads();
+        const uint32_t nL = carryL, nR = carryR;
+        const uint32_t lim = nL < nR ? nL : nR;
+        // m = first k with !(L[k] < R[k]); monotone predicate -> block-wide multiway search
+        if (tid == 0) {
+            s_lo = 0;
+            s_hi = lim;
+        }
+        __syncthreads();
+        for (;;) {
+            const uint32_t lo = s_lo, hi = s_hi;
+            if (hi <= lo) break;
+            const uint32_t step = (hi - lo + bs - 1) / bs;
+            const uint32_t k = lo + tid * step;
+            bool tr = false;
+            if (k < hi) tr = wide_lookup(preL, nt, posL, base, k) < wide_lookup(preR, nt, posR, base, nR - 1 - k);
+            uint32_t tot;
+            block_excl_scan(tr ? 1u : 0u, sm, tot);  // monotone: the number of true answers is the index of the first false
+            __syncthreads();
+            if (tid == 0) {
+                if (tot == 0) {
+                    s_hi = lo;
+                } else {
+                    const uint32_t ktrue = lo + (tot - 1) * step;
+                    s_lo = ktrue + 1;
+                    s_hi = min(lo + tot * step, hi);
+                }
+            }
+            __syncthreads();
+        }
+        const uint32_t m = s_lo;
+        if (part == 0 && tid == 0) {
+            uint32_t cut = 0xFFFFFFFFu;
+            if (m < nL) cut = wide_lookup(preL, nt, posL, base, m);
+            if (m > 0) {
+                const uint32_t r = wide_lookup(preR, nt, posR, base, nR - m);
+                if (r < cut) cut = r;
+            }
+            wseg[si].cut = cut;
+        }
+        const uint32_t k_begin = (uint32_t)(((uint64_t)m * part) / WPARTS), k_end = (uint32_t)(((uint64_t)m * (part + 1)) / WPARTS);
+        for (uint32_t k = k_begin + tid; k < k_end; k += bs) {
+            const uint32_t a = wide_lookup(preL, nt, posL, base, k), b = wide_lookup(preR, nt, posR, base, nR - 1 - k);
+            esort::swap_kv(K, V, a, b);
+        }
+        __syncthreads();
+    }
+}
+
+// single workgroup: route the children of every wide segment of this level
+__global__ __launch_bounds__(64) void k_esort_wide_children(uint32_t *K, uint32_t *V, const WideSeg *wcur, WideSeg *wnext, WideState *ws,
+                                                             int cur, esort::Seg *q0, esort::Seg *smallq, EsQueues *qs, uint32_t qcap,
+                                                             int last_level, Counters *ctr) {
+    if (threadIdx.x != 0) return;
+    const uint32_t nseg = ws->nseg[cur];
+    uint32_t nn = 0, nt_tot = 0;
+    for (uint32_t si = 0; si < nseg; ++si) {
+        const WideSeg sg = wcur[si];
+        const esort::Seg ch[2] = {{sg.first, sg.cut, sg.depth - 1}, {sg.cut, sg.last, sg.depth - 1}};
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t len = ch[t].last - ch[t].first;
+            if (len == 0) continue;
+            const uint32_t nt = len > 1 ? (len - 1 + WTILE - 1) / WTILE : 0;
+            if (ch[t].depth > 0 && len >= WIDE_MIN && !last_level && nn < WSEG_MAX && nt_tot + nt <= WTILES_MAX) {
+                esort::move_median_to_first(K, V, ch[t].first, ch[t].last);
+                wnext[nn].first = ch[t].first;
+                wnext[nn].last = ch[t].last;
+                wnext[nn].depth = ch[t].depth;
+                wnext[nn].tile0 = nt_tot;
+                wnext[nn].ntiles = nt;
+                ++nn;
+                nt_tot += nt;
+            } else if (len > ES_LMAX && ch[t].depth > 0) {
+                const uint32_t at = qs->cnt[0]++;
+                if (at < qcap) q0[at] = ch[t]; else ctr->sort_qoverflow = 1;
+            } else {
+                const uint32_t at = qs->small_cnt++;
+                if (at < qcap) smallq[at] = ch[t]; else ctr->sort_qoverflow = 1;
+            }
+        }
+    }
+    ws->nseg[cur ^ 1] = nn;
+    ws->ntiles[cur ^ 1] = nt_tot;
+    ws->nseg[cur] = 0;
+    ws->ntiles[cur] = 0;
+}
+
+// one level: each workgroup takes big segments of queue[cur] and performs one partition
+__global__ __launch_bounds__(1024) void k_esort_level(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, esort::Seg *q0,
+                                                       esort::Seg *q1, esort::Seg *q2, esort::Seg *smallq, EsQueues *qs, int level,
+                                                       uint32_t qcap, Counters *ctr) {
+    __shared__ uint32_t sm[40];
+    const int cur = level % 3, nxt = (level + 1) % 3, clr = (level + 2) % 3;
+    esort::Seg *qcur = cur == 0 ? q0 : (cur == 1 ? q1 : q2);
+    esort::Seg *qnext = nxt == 0 ? q0 : (nxt == 1 ? q1 : q2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) qs->cnt[clr] = 0;  // not read or appended to by this launch
     const uint32_t nseg = qs->cnt[cur];
     for (uint32_t s = blockIdx.x; s < nseg; s += gridDim.x) {
         const esort::Seg sg = qcur[s];
@@ -696,7 +905,7 @@ __global__ __launch_bounds__(1024) void k_esort_level(uint32_t *K, uint32_t *V, 
             }
             continue;
         }
-        const uint32_t cut = esort::block_partition(K, V, posL, posR, sg.first, sg.last, sm);
+        const uint32_t cut = esort::block_partition<8>(K, V, posL, posR, sg.first, sg.last, sm);
         if (threadIdx.x == 0) {
             esort::Seg a, b;
             a.first = sg.first; a.last = cut; a.depth = sg.depth - 1;
@@ -706,7 +915,7 @@ __global__ __launch_bounds__(1024) void k_esort_level(uint32_t *K, uint32_t *V, 
                 const uint32_t len = ch[t].last - ch[t].first;
                 if (len == 0) continue;
                 if (len > ES_LMAX) {
-                    const uint32_t at = atomicAdd(&qs->cnt[cur ^ 1], 1u);
+                    const uint32_t at = atomicAdd(&qs->cnt[nxt], 1u);
                     if (at < qcap) qnext[at] = ch[t]; else ctr->sort_qoverflow = 1;
                 } else {
                     const uint32_t at = atomicAdd(&qs->small_cnt, 1u);
@@ -717,13 +926,12 @@ __global__ __launch_bounds__(1024) void k_esort_level(uint32_t *K, uint32_t *V, 
         __syncthreads();
     }
 }
-__global__ void k_esort_level_reset(EsQueues *qs, int cur) { qs->cnt[cur] = 0; }
 
 // final: every remaining segment (any size) is sorted to completion by one workgroup.
 // Segments <= ES_LMAX run in LDS; larger ones (only if the level budget ran out) run in place in global memory.
 __global__ __launch_bounds__(256) void k_esort_final(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, uint8_t *head,
                                                       uint32_t *K2, uint32_t *V2, const esort::Seg *smallq, const esort::Seg *bigq,
-                                                      EsQueues *qs, int bigcur, Counters *ctr) {
+                                                      EsQueues *qs, int bigcur, Counters *ctr) {  // bigcur: queue index (0..2) still holding big segments
     __shared__ uint32_t sK[ES_LMAX], sV[ES_LMAX], sL[ES_LMAX], sR[ES_LMAX];
     __shared__ uint8_t sH[ES_LMAX + 4];
     __shared__ esort::Seg qa[ES_LMAX / 16 + 2], qb[ES_LMAX / 16 + 2];
@@ -825,7 +1033,34 @@ __global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts
     float best = __int_as_float(0x7F800000);
     uint32_t best_i = 0xFFFFFFFFu;
     const int maxrho = max(dx, max(dy, dz));
-    for (int rho = 1;; ++rho) {
+    // stage 0: the voxel's own points.  If the best of them is closer than the centroid's distance to the walls of its
+    // own cell, no point of any other cell can beat or tie it (single-point voxels end here with distance 0).
+    {
+        for (uint32_t li = run_begin[v]; li < run_begin[v + 1]; ++li) {
+            const uint32_t pi = sperm[li];
+            const float4 p = pts[pi];
+            const float dd = l2_simple(c.x, c.y, c.z, p.x, p.y, p.z);
+            if (dd < best || (dd == best && pi < best_i)) {
+                best = dd;
+                best_i = pi;
+            }
+        }
+    }
+    bool done = false;
+    {
+        const double cc[3] = {(double)c.x, (double)c.y, (double)c.z};
+        const int cidx[3] = {ci, cj, ck};
+        double gmin = 1e300;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double lo = (double)(g.min_b[a] + cidx[a]) * L;
+            const double hi = (double)(g.min_b[a] + cidx[a] + 1) * L;
+            const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
+            gmin = fmin(gmin, fmin(cc[a] - lo, hi - cc[a]) - margin);
+        }
+        done = (gmin > 0.0 && (double)best <= gmin * gmin);
+    }
+    for (int rho = 1; !done; ++rho) {
         for (int kk = ck - rho; kk <= ck + rho; ++kk) {
             if (kk < 0 || kk >= dz) continue;
             for (int jj = cj - rho; jj <= cj + rho; ++jj) {
@@ -833,7 +1068,7 @@ __global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts
                 const bool shell_jk = (abs(jj - cj) == rho) || (abs(kk - ck) == rho);
                 for (int ii = ci - rho; ii <= ci + rho; ++ii) {
                     if (ii < 0 || ii >= dx) continue;
-                    if (rho > 1 && !shell_jk && abs(ii - ci) < rho) continue;
+                    if (!shell_jk && abs(ii - ci) < rho) continue;  // interior cells were visited by earlier stages (rho-1, ..., 0)
                     const uint32_t q = (uint32_t)ii + (uint32_t)jj * (uint32_t)dx + (uint32_t)kk * (uint32_t)dx * (uint32_t)dy;
                     uint32_t lo = 0, hi = nv;  // lower_bound
                     while (lo < hi) {
@@ -1129,56 +1364,18 @@ __device__ void jacobi_svd3(const float cov[9], float U[9], float sv[3]) {
 
 static constexpr uint32_t RG_LMAX = 4096;
 
-// gsK..gsH: global scratch arrays (capV [+1]) used when a bin has more than RG_LMAX points.
-__global__ __launch_bounds__(256) void k_rgpf(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
-                                               const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *gsK,
-                                               uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint8_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
-                                               uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
-                                               uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
-                                               Counters *ctr) {
-    __shared__ uint32_t sK[RG_LMAX], sV[RG_LMAX], sL[RG_LMAX], sR[RG_LMAX];
-    __shared__ uint8_t sH[RG_LMAX + 4];
-    __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
-    __shared__ uint32_t qcnt[2];
-    __shared__ uint32_t sm[40];
-    __shared__ float s_n[3];
-    __shared__ double s_th;
-    __shared__ uint32_t s_carry;
-    const int key = blockIdx.x;
-    if (action[key] != 1) return;
-    const uint32_t rk = rev_idx[key];
-    const uint32_t o0 = moff[key], M = moff[key + 1] - o0;
-    const float4 *pts = spts + o0;
+// After the exact z-sort: seeds, gf_iter x (plane fit, classification).  sortedV: sorted order (bin-local indices);
+// glist: scratch for the current ground list.  Templated so that LDS callers get ds_* instructions.
+template <class SV, class GL>
+__device__ __forceinline__ void rgpf_after_sort(const DP &P, const float4 *__restrict__ pts, uint32_t M, uint32_t o0, uint32_t rk, SV sortedV, GL glist,
+                                                uint32_t *sm, float *s_n, double *s_thp, double *s_lprp, uint32_t *s_carryp,
+                                                uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
+                                                uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
+                                                Counters *ctr) {
     const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6;
-    const bool local = M <= RG_LMAX;
-    // --- std::sort(src_copy, point_cmp) : erasor.cpp:239-240 ---
-    uint32_t *sortedV;  // sorted order (bin-local indices)
-    uint32_t *glist;    // current ground list (bin-local indices); reuses the key array
-    if (local) {
-        for (uint32_t i = tid; i < M; i += bs) {
-            sK[i] = esort::float_key(__float_as_uint(pts[i].z));
-            sV[i] = i;
-        }
-        __syncthreads();
-        esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
-                           &ctr->n_sort_fallback, &ctr->sort_qoverflow);
-        sortedV = sR;
-        glist = sK;
-    } else {
-        uint32_t *K = gsK + o0, *V = gsV + o0;
-        for (uint32_t i = tid; i < M; i += bs) {
-            K[i] = esort::float_key(__float_as_uint(pts[i].z));
-            V[i] = i;
-        }
-        __threadfence_block();
-        __syncthreads();
-        esort::block_esort(K, V, gsL + o0, gsR + o0, gsH + o0, gsK2 + o0, gsV2 + o0, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt,
-                           (uint32_t)(RG_LMAX / 16 + 2), &ctr->n_sort_fallback, &ctr->sort_qoverflow);
-        __threadfence_block();
-        __syncthreads();
-        sortedV = gsV2 + o0;
-        glist = K;
-    }
+    double &s_th = *s_thp;
+    double &s_lpr = *s_lprp;
+    uint32_t &s_carry = *s_carryp;
     // --- drop leading z < min_h (erasor.cpp:242-251); monotone in sorted order ---
     uint32_t cnt = 0;
     for (uint32_t k = tid; k < M; k += bs) cnt += ((double)pts[sortedV[k]].z < P.min_h) ? 1u : 0u;
@@ -1189,7 +1386,6 @@ __global__ __launch_bounds__(256) void k_rgpf(DP P, const uint8_t *__restrict__ 
     }
     const uint32_t drop = cnt, Ms = M - drop;
     // --- extract_initial_seeds_ (erasor.cpp:204-231) ---
-    __shared__ double s_lpr;
     if (tid == 0) {
         double sum = 0;
         int c = 0;
@@ -1226,7 +1422,10 @@ __global__ __launch_bounds__(256) void k_rgpf(DP P, const uint8_t *__restrict__ 
                 if (k < ng) mine = pts[glist[k]];
                 const uint32_t lim = min(64u, ng - base);
                 for (uint32_t j = 0; j < lim; ++j) {
-                    const float x = __shfl(mine.x, (int)j, 64), y = __shfl(mine.y, (int)j, 64), z = __shfl(mine.z, (int)j, 64);
+                    // j is wave-uniform: v_readlane_b32 (SGPR broadcast), not an LDS permute
+                    const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), (int)j));
+                    const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), (int)j));
+                    const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), (int)j));
                     // lane L owns accumulator L of PCL's accu[9]: xx xy xz yy yz zz x y z  (x*1.0f == x exactly)
                     const float A = ia == 0 ? x : (ia == 1 ? y : z);
                     const float Bv = ib == 0 ? x : (ib == 1 ? y : (ib == 2 ? z : 1.0f));
@@ -1310,43 +1509,69 @@ __global__ __launch_bounds__(256) void k_rgpf(DP P, const uint8_t *__restrict__ 
     if (tid == 0) ng_out[rk] = ng;
 }
 
+// gsK..gsH: global scratch arrays (capV [+1]) used when a bin has more than RG_LMAX points.
+__global__ __launch_bounds__(256) void k_rgpf(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
+                                               const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *gsK,
+                                               uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint8_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
+                                               uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
+                                               uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
+                                               Counters *ctr) {
+    __shared__ uint32_t sK[RG_LMAX], sV[RG_LMAX], sL[RG_LMAX], sR[RG_LMAX];
+    __shared__ uint8_t sH[RG_LMAX + 4];
+    __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
+    __shared__ uint32_t qcnt[2];
+    __shared__ uint32_t sm[40];
+    __shared__ float s_n[3];
+    __shared__ double s_th, s_lpr;
+    __shared__ uint32_t s_carry;
+    const int key = blockIdx.x;
+    if (action[key] != 1) return;
+    const uint32_t rk = rev_idx[key];
+    const uint32_t o0 = moff[key], M = moff[key + 1] - o0;
+    const float4 *pts = spts + o0;
+    const uint32_t tid = threadIdx.x, bs = blockDim.x;
+    // --- std::sort(src_copy, point_cmp) : erasor.cpp:239-240 ---
+    if (M <= RG_LMAX) {
+        for (uint32_t i = tid; i < M; i += bs) {
+            sK[i] = esort::float_key(__float_as_uint(pts[i].z));
+            sV[i] = i;
+        }
+        __syncthreads();
+        esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
+                           &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+        rgpf_after_sort(P, pts, M, o0, rk, sR, sK, sm, s_n, &s_th, &s_lpr, &s_carry, gflag, grank, glist_out, ng_out, plane_n, plane_d, ctr);
+    } else {
+        uint32_t *K = gsK + o0, *V = gsV + o0;
+        for (uint32_t i = tid; i < M; i += bs) {
+            K[i] = esort::float_key(__float_as_uint(pts[i].z));
+            V[i] = i;
+        }
+        __threadfence_block();
+        __syncthreads();
+        esort::block_esort(K, V, gsL + o0, gsR + o0, gsH + o0, gsK2 + o0, gsV2 + o0, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt,
+                           (uint32_t)(RG_LMAX / 16 + 2), &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+        __threadfence_block();
+        __syncthreads();
+        rgpf_after_sort(P, pts, M, o0, rk, gsV2 + o0, K, sm, s_n, &s_th, &s_lpr, &s_carry, gflag, grank, glist_out, ng_out, plane_n, plane_d, ctr);
+    }
+}
+
 // ================================================================================================
 // per-bin voxelize_preserving_labels(curr points + reverted ground, /erasor/map_voxel_size) —
 // erasor.cpp:523-528.  One workgroup per reverted bin.
 // ================================================================================================
 static constexpr uint32_t BV_LMAX = 2048;
 
-__global__ __launch_bounds__(256) void k_binvox(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
-                                                 const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
-                                                 const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq,
-                                                 const uint32_t *__restrict__ glist, const uint32_t *__restrict__ ng_arr,
-                                                 const uint32_t *__restrict__ vox_off, uint32_t *gsK, uint32_t *gsV, uint32_t *gsL,
-                                                 uint32_t *gsR, uint8_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
-                                                 float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr) {
-    __shared__ uint32_t sK[BV_LMAX], sV[BV_LMAX], sL[BV_LMAX], sR[BV_LMAX];
-    __shared__ uint8_t sH[BV_LMAX + 4];
-    __shared__ float4 sC[BV_LMAX];
-    __shared__ esort::Seg qa[BV_LMAX / 16 + 2], qb[BV_LMAX / 16 + 2];
-    __shared__ uint32_t qcnt[2];
-    __shared__ uint32_t sm[40];
-    __shared__ uint32_t sbb[6];
-    __shared__ uint32_t s_carry;
-    const int key = blockIdx.x;
-    if (action[key] != 1) return;
-    const uint32_t rk = rev_idx[key];
+// body of k_binvox, templated on the scratch pointers so that the LDS instantiation compiles to ds_* instructions
+template <class KP, class VP, class K2P, class V2P, class CP, class PP, class HP>
+__device__ __forceinline__ void binvox_core(const DP &P, uint32_t m, uint32_t nc, const float4 *__restrict__ sqb, const float4 *__restrict__ sptb,
+                                            const uint32_t *__restrict__ glb, KP K, VP V, K2P K2, V2P V2, CP C, PP posL, PP posR, HP head,
+                                            esort::Seg *qa, esort::Seg *qb, uint32_t *qcnt, uint32_t *sm, uint32_t *sbb, uint32_t *s_carryp,
+                                            float4 *__restrict__ vout, uint32_t *__restrict__ nvox_slot, Counters *ctr) {
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
-    const uint32_t mo = moff[key], qo = qoff[key];
-    const uint32_t nc = qoff[key + 1] - qo, ngr = ng_arr[rk];
-    const uint32_t m = nc + ngr;
-    if (nc == 0) {  // selected = bin_curr with is_occupied == false: r_pod2pc skips the bin
-        if (tid == 0) nvox_out[rk] = 0;
-        return;
-    }
-    const uint32_t vo = vox_off[rk];
-    const bool local = m <= BV_LMAX;
+    uint32_t &s_carry = *s_carryp;
     // input cloud of this call: curr bin points (scan order) then the reverted ground (source order)
-    float4 *C = local ? sC : (gsC + vo);
-    for (uint32_t j = tid; j < m; j += bs) C[j] = j < nc ? sq[qo + j] : spts[mo + glist[mo + (j - nc)]];
+    for (uint32_t j = tid; j < m; j += bs) C[j] = j < nc ? sqb[j] : sptb[glb[j - nc]];
     if (tid < 3) sbb[tid] = 0xFFFFFFFFu;
     if (tid >= 3 && tid < 6) sbb[tid] = 0u;
     __threadfence_block();
@@ -1376,12 +1601,10 @@ __global__ __launch_bounds__(256) void k_binvox(DP P, const uint8_t *__restrict_
         if (tid == 0) {
             atomicAdd(&ctr->n_voxel_overflow, 1u);
             ctr->err = 1;
-            nvox_out[rk] = 0;
+            *nvox_slot = 0;
         }
         return;
     }
-    uint32_t *K = local ? sK : (gsK + vo), *V = local ? sV : (gsV + vo);
-    uint32_t *K2 = local ? sL : (gsK2 + vo), *V2 = local ? sR : (gsV2 + vo);
     for (uint32_t j = tid; j < m; j += bs) {
         const float4 p = C[j];
         K[j] = vox_index(g, p.x, p.y, p.z);
@@ -1389,43 +1612,37 @@ __global__ __launch_bounds__(256) void k_binvox(DP P, const uint8_t *__restrict_
     }
     __threadfence_block();
     __syncthreads();
-    if (local)
-        esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, m, 2 * esort::lg2_floor(m), qa, qb, qcnt, (uint32_t)(BV_LMAX / 16 + 2),
-                           &ctr->n_sort_fallback, &ctr->sort_qoverflow);
-    else
-        esort::block_esort(K, V, gsL + vo, gsR + vo, gsH + vo, K2, V2, 0u, m, 2 * esort::lg2_floor(m), qa, qb, qcnt,
-                           (uint32_t)(BV_LMAX / 16 + 2), &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+    esort::block_esort(K, V, posL, posR, head, K2, V2, 0u, m, 2 * esort::lg2_floor(m), qa, qb, qcnt, (uint32_t)(BV_LMAX / 16 + 2),
+                       &ctr->n_sort_fallback, &ctr->sort_qoverflow);
     __threadfence_block();
     __syncthreads();
-    // phase A: runs -> centroids (CentroidPoint float sums in sorted order).  K / V are dead: reuse as cx / cy, head bytes
-    // are dead too but too small, so cz goes to the position array slot of the voxel (written after its last read).
-    float *CX = reinterpret_cast<float *>(K), *CY = reinterpret_cast<float *>(V);
+    // phase A: runs -> centroids (CentroidPoint float sums in sorted order).  K / V are dead: reuse their storage for the
+    // centroid x / y of voxel v (v <= position of its run head, and slots below the current tile are no longer read);
+    // cz is parked in the output slot.
     if (tid == 0) s_carry = 0;
     __syncthreads();
     for (uint32_t base = 0; base < m; base += bs) {
         const uint32_t i = base + tid;
-        const bool head = i < m && (i == 0 || K2[i] != K2[i - 1]);
+        const bool hd = i < m && (i == 0 || (uint32_t)K2[i] != (uint32_t)K2[i - 1]);
         uint32_t tot;
-        const uint32_t pre = block_excl_scan(head ? 1u : 0u, sm, tot);
+        const uint32_t pre = block_excl_scan(hd ? 1u : 0u, sm, tot);
         const uint32_t c0 = s_carry;
-        if (head) {
-            float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        if (hd) {
+            float sx = 0.f, sy = 0.f, sz = 0.f;
             uint32_t e = i;
             const uint32_t kk = K2[i];
-            while (e < m && K2[e] == kk) {
+            while (e < m && (uint32_t)K2[e] == kk) {
                 const float4 p = C[V2[e]];
                 sx += p.x;
                 sy += p.y;
-                sz += p.z;
-                si += p.w;
+                sz += p.z;  // the averaged intensity is overwritten by the nearest input point's label (utils.cpp:109)
                 ++e;
             }
             const float c = (float)(e - i);
-            const uint32_t v = c0 + pre;  // v <= i: slots of K/V below the current tile's heads are free
-            CX[v] = sx / c;
-            CY[v] = sy / c;
-            vox_out[vo + v].z = sz / c;
-            (void)si;  // the averaged intensity is overwritten by the nearest input point's label (utils.cpp:109)
+            const uint32_t v = c0 + pre;
+            K[v] = __float_as_uint(sx / c);
+            V[v] = __float_as_uint(sy / c);
+            vout[v].z = sz / c;
         }
         __syncthreads();
         if (tid == 0) s_carry = c0 + tot;
@@ -1436,7 +1653,7 @@ __global__ __launch_bounds__(256) void k_binvox(DP P, const uint8_t *__restrict_
     __syncthreads();
     // phase B: exact 1-NN of every centroid over all inputs of this call (lowest index on float ties)
     for (uint32_t v = tid; v < nv; v += bs) {
-        const float cx = CX[v], cy = CY[v], cz = vox_out[vo + v].z;
+        const float cx = __uint_as_float(K[v]), cy = __uint_as_float(V[v]), cz = vout[v].z;
         float best = __int_as_float(0x7F800000);
         uint32_t best_j = 0;
         for (uint32_t j = 0; j < m; ++j) {
@@ -1447,9 +1664,44 @@ __global__ __launch_bounds__(256) void k_binvox(DP P, const uint8_t *__restrict_
                 best_j = j;
             }
         }
-        vox_out[vo + v] = make_float4(cx, cy, cz, C[best_j].w);
+        const float4 pb = C[best_j];
+        vout[v] = make_float4(cx, cy, cz, pb.w);
     }
-    if (tid == 0) nvox_out[rk] = nv;
+    if (tid == 0) *nvox_slot = nv;
+}
+
+__global__ __launch_bounds__(256) void k_binvox(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
+                                                 const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
+                                                 const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq,
+                                                 const uint32_t *__restrict__ glist, const uint32_t *__restrict__ ng_arr,
+                                                 const uint32_t *__restrict__ vox_off, uint32_t *gsK, uint32_t *gsV, uint32_t *gsL,
+                                                 uint32_t *gsR, uint8_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
+                                                 float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr) {
+    __shared__ uint32_t sK[BV_LMAX], sV[BV_LMAX], sL[BV_LMAX], sR[BV_LMAX];
+    __shared__ uint8_t sH[BV_LMAX + 4];
+    __shared__ float4 sC[BV_LMAX];
+    __shared__ esort::Seg qa[BV_LMAX / 16 + 2], qb[BV_LMAX / 16 + 2];
+    __shared__ uint32_t qcnt[2];
+    __shared__ uint32_t sm[40];
+    __shared__ uint32_t sbb[6];
+    __shared__ uint32_t s_carry;
+    const int key = blockIdx.x;
+    if (action[key] != 1) return;
+    const uint32_t rk = rev_idx[key];
+    const uint32_t mo = moff[key], qo = qoff[key];
+    const uint32_t nc = qoff[key + 1] - qo, ngr = ng_arr[rk];
+    const uint32_t m = nc + ngr;
+    if (nc == 0) {  // selected = bin_curr with is_occupied == false: r_pod2pc skips the bin
+        if (threadIdx.x == 0) nvox_out[rk] = 0;
+        return;
+    }
+    const uint32_t vo = vox_off[rk];
+    if (m <= BV_LMAX)
+        binvox_core(P, m, nc, sq + qo, spts + mo, glist + mo, sK, sV, sL, sR, sC, sL, sR, sH, qa, qb, qcnt, sm, sbb, &s_carry, vox_out + vo,
+                    nvox_out + rk, ctr);
+    else
+        binvox_core(P, m, nc, sq + qo, spts + mo, glist + mo, gsK + vo, gsV + vo, gsK2 + vo, gsV2 + vo, gsC + vo, gsL + vo, gsR + vo, gsH + vo, qa, qb,
+                    qcnt, sm, sbb, &s_carry, vox_out + vo, nvox_out + rk, ctr);
 }
 
 // ================================================================================================
@@ -1601,6 +1853,7 @@ __global__ __launch_bounds__(256) void k_assemble_bins(DP P, Xf Tb2o, const uint
 // label counters over a float4 cloud (parse_dynamic_obj as counters, utils.cpp:57-78)
 __global__ __launch_bounds__(256) void k_count_labels4(const float4 *__restrict__ pts, uint32_t n_host, const uint32_t *n_dev,
                                                         unsigned long long *n_static, unsigned long long *n_dynamic) {
+    __shared__ uint32_t sd[4], ss[4];
     const uint32_t n = n_dev ? *n_dev : n_host;
     uint32_t d = 0, s = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -1611,8 +1864,14 @@ __global__ __launch_bounds__(256) void k_count_labels4(const float4 *__restrict_
         s += __shfl_down(s, o, 64);
     }
     if ((threadIdx.x & 63u) == 0) {
-        if (d) atomicAdd(n_dynamic, (unsigned long long)d);
-        if (s) atomicAdd(n_static, (unsigned long long)s);
+        sd[threadIdx.x >> 6] = d;
+        ss[threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one device-scope atomic per block and counter
+        const uint32_t td = sd[0] + sd[1] + sd[2] + sd[3], ts = ss[0] + ss[1] + ss[2] + ss[3];
+        if (td) atomicAdd(n_dynamic, (unsigned long long)td);
+        if (ts) atomicAdd(n_static, (unsigned long long)ts);
     }
 }
 
