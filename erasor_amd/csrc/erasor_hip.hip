@@ -74,16 +74,17 @@ struct erasor_hip_handle {
     // ---- query ----
     DBuf<float4> scan, cent, query, sq, curr_rejected;
     DBuf<uint32_t> bb, qk_a, qk_b, qv_a, qv_b, qposL, qposR, qflag, qpl, qtops, run_begin, ukeys, qkey;
-    DBuf<uint8_t> qhead;
+    DBuf<uint32_t> qhead;
     DBuf<esort::Seg> esq0, esq1, esq2, essmall;
     DBuf<EsQueues> esqs;
+    DBuf<unsigned long long> dbg_stamps;  // optional cycle stamps of the first finished segment (ERASOR_HIP_SORT_STAMPS)
     DBuf<WideSeg> wseg0, wseg1;
     DBuf<WideState> wstate;
     DBuf<uint32_t> wtileL, wtileR;
     DBuf<VoxGrid> qgrid;
     // ---- per-bin scratch (R-GPF / bin voxelise global paths) ----
     DBuf<uint32_t> gsK, gsV, gsL, gsR, gsK2, gsV2;
-    DBuf<uint8_t> gsH;
+    DBuf<uint32_t> gsH;
     DBuf<float4> gsC, vox_out;
     // ---- state ----
     DBuf<DevState> d_st;
@@ -308,7 +309,8 @@ int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
     rc |= ensure(h, h->scan, S) | ensure(h, h->cent, S) | ensure(h, h->query, S) | ensure(h, h->sq, S) | ensure(h, h->curr_rejected, S);
     rc |= ensure(h, h->qk_a, S) | ensure(h, h->qk_b, S) | ensure(h, h->qv_a, S) | ensure(h, h->qv_b, S) | ensure(h, h->qposL, S) | ensure(h, h->qposR, S);
     rc |= ensure(h, h->qflag, S) | ensure(h, h->qpl, S) | ensure(h, h->qtops, S / 1024 + 4) | ensure(h, h->run_begin, S + 1) | ensure(h, h->ukeys, S);
-    rc |= ensure(h, h->qkey, S) | ensure(h, h->qhead, S + 4);
+    rc |= ensure(h, h->qkey, S) | ensure(h, h->qhead, S / 32 + 8);
+    if (getenv("ERASOR_HIP_SORT_STAMPS")) rc |= ensure(h, h->dbg_stamps, 32);
     rc |= ensure(h, h->wseg0, WSEG_MAX) | ensure(h, h->wseg1, WSEG_MAX) | ensure(h, h->wstate, 1) | ensure(h, h->wtileL, WTILES_MAX) | ensure(h, h->wtileR, WTILES_MAX);
     rc |= ensure(h, h->esq0, 65536) | ensure(h, h->esq1, 65536) | ensure(h, h->esq2, 65536) | ensure(h, h->essmall, 65536);
     return rc ? ERASOR_E_NO_DEVICE : 0;
@@ -319,7 +321,7 @@ int alloc_step(erasor_hip_handle *h, uint32_t n_voi, uint32_t nq) {
     const size_t G = (size_t)n_voi + nq + 8;
     int rc = 0;
     rc |= ensure(h, h->gsK, G) | ensure(h, h->gsV, G) | ensure(h, h->gsL, G) | ensure(h, h->gsR, G) | ensure(h, h->gsK2, G) | ensure(h, h->gsV2, G);
-    rc |= ensure(h, h->gsH, G) | ensure(h, h->gsC, G) | ensure(h, h->vox_out, G);
+    rc |= ensure(h, h->gsH, G / 32 + 2 * (size_t)h->B + 16) | ensure(h, h->gsC, G) | ensure(h, h->vox_out, G);
     const size_t needF = 2 * (size_t)n_voi + nq + 64;
     rc |= ensure(h, h->F[h->curF ^ 1], needF);
     return rc ? ERASOR_E_NO_DEVICE : 0;
@@ -521,8 +523,8 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
     }
     const int bigcur = nlev % 3;
     esort::Seg *qs3[3] = {h->esq0.p, h->esq1.p, h->esq2.p};
-    LAUNCH(h, "q_esort_final", k_esort_final, 256, 256, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->qhead.p, h->qk_b.p, h->qv_b.p,
-           (const esort::Seg *)h->essmall.p, (const esort::Seg *)qs3[bigcur], h->esqs.p, bigcur, dc);
+    LAUNCH(h, "q_esort_final", k_esort_final, 256, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->qhead.p, h->qk_b.p, h->qv_b.p,
+           (const esort::Seg *)h->essmall.p, (const esort::Seg *)qs3[bigcur], h->esqs.p, bigcur, dc, h->dbg_stamps.p);
 }
 
 // ---- exact voxelisation of the cloud in h->scan[0..n): fills run_begin / cent / ukeys, d_st->q_nvox -------------------
@@ -681,11 +683,11 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     // ---- Scan Ratio Test, R-GPF, per-bin voxelisation (erasor.cpp:332-571) ----
     LAUNCH(h, "srt", k_srt, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)h->ccnt.p,
            (const float *)h->cmin.p, (const float *)h->cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
-    LAUNCH(h, "rgpf", k_rgpf, B, 256, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->moff.p,
+    LAUNCH(h, "rgpf", k_rgpf, B, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->moff.p,
            (const float4 *)h->spts.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p, h->gflag.p, h->grank.p, h->glist.p,
            h->ng.p, h->plane_n.p, h->plane_d.p, dc);
     if (P.version == 3)
-        LAUNCH(h, "bin_voxelize", k_binvox, B, 256, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->moff.p,
+        LAUNCH(h, "bin_voxelize", k_binvox, B, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->moff.p,
                (const float4 *)h->spts.p, (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->glist.p,
                (const uint32_t *)h->ng.p, (const uint32_t *)h->vox_off.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p,
                h->gsC.p, h->vox_out.p, h->nvox.p, dc);
@@ -1046,6 +1048,14 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
         return ERASOR_E_INTERNAL;
     }
     if (n_fallback) *n_fallback = c.n_sort_fallback;
+    if (h->dbg_stamps.p) {
+        unsigned long long t[32];
+        (void)hipMemcpy(t, h->dbg_stamps.p, sizeof(t), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[esort stamps n=%u] phase1 %llu, queue %llu, finalize %llu cycles; levels:", ns, t[1] - t[0], t[2] - t[1], t[3] - t[2]);
+        for (int i = 4; i < 15; ++i) fprintf(stderr, " %llu", t[i + 1] > t[i] ? t[i + 1] - t[i] : 0ull);
+        fprintf(stderr, "\n");
+        (void)hipMemset(h->dbg_stamps.p, 0, sizeof(t));
+    }
     if (ns) {
         HIPC(h, hipMemcpy(keys, h->qk_b.p, (size_t)ns * 4, hipMemcpyDeviceToHost));
         HIPC(h, hipMemcpy(vals, h->qv_b.p, (size_t)ns * 4, hipMemcpyDeviceToHost));

@@ -71,6 +71,90 @@ __device__ __forceinline__ uint32_t wave_partition(KP K, VP V, PP posL, PP posR,
     return cut;
 }
 
+// The whole introsort subtree of a segment of <= 64 keys, one key per lane, in registers: every partition is two
+// ballots, a scalar loop over the stop masks (pairs L[k] <-> R[k]) and ONE permute.  Leaves (<= 16 keys) are marked in
+// head[] for the caller's stable leaf ranking.  Exactly the same swaps as wave_partition / the sequential algorithm.
+template <class KP, class VP, class HP>
+__device__ __forceinline__ void wave_small_subtree(KP K, VP V, HP head, uint32_t first, uint32_t last, int32_t depth, uint32_t *n_fallback) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = last - first;  // 17..64
+    uint32_t k = lane < n ? (uint32_t)K[first + lane] : 0xFFFFFFFFu;
+    uint32_t v = lane < n ? (uint32_t)V[first + lane] : 0u;
+    uint64_t heads = 0;  // bit i: a leaf starts at lane i (i > 0)
+    // pending sub-ranges (lane indices), at most 64/17 = 3 alive at once
+    uint32_t sf[4], se[4];
+    int32_t sd[4];
+    int sp = 0;
+    sf[0] = 0; se[0] = n; sd[0] = depth; sp = 1;
+    while (sp > 0) {
+        --sp;
+        uint32_t f = sf[0], e = se[0];
+        int32_t d = sd[0];
+#pragma unroll
+        for (int t = 1; t < 4; ++t)
+            if (sp == t) { f = sf[t]; e = se[t]; d = sd[t]; }
+        if (d == 0) {
+            // depth budget exhausted: exact heapsort of this sub-range through memory (rare)
+            if (lane < n) { K[first + lane] = k; V[first + lane] = v; }
+            wave_sync();
+            if (lane == 0) {
+                heapsort_exact(K, V, first + f, first + e);
+                atomicAdd(n_fallback, 1u);
+            }
+            wave_sync();
+            if (lane < n) { k = K[first + lane]; v = V[first + lane]; }
+            for (uint32_t i = f + 1; i < e; ++i) heads |= 1ull << i;  // fully sorted: every key its own leaf
+            continue;
+        }
+        // __move_median_to_first(f, f+1, mid, e-1)
+        const uint32_t a = f + 1, b = f + (e - f) / 2, c = e - 1;
+        const uint32_t ka = __builtin_amdgcn_readlane(k, a), kb = __builtin_amdgcn_readlane(k, b), kc = __builtin_amdgcn_readlane(k, c);
+        uint32_t mp;
+        if (ka < kb) mp = (kb < kc) ? b : ((ka < kc) ? c : a);
+        else mp = (ka < kc) ? a : ((kb < kc) ? c : b);
+        const uint32_t kf = __builtin_amdgcn_readlane(k, f), vf = __builtin_amdgcn_readlane(v, f);
+        const uint32_t p = __builtin_amdgcn_readlane(k, mp), vm = __builtin_amdgcn_readlane(v, mp);
+        if (lane == f) { k = p; v = vm; }
+        if (lane == mp) { k = kf; v = vf; }
+        const bool inr = lane > f && lane < e;
+        uint64_t ml = __ballot(inr && !(k < p)), mr = __ballot(inr && !(p < k));
+        uint32_t src = lane, cut = 0xFFFFFFFFu, lastb = 0xFFFFFFFFu;
+        while (ml != 0ull && mr != 0ull) {
+            const uint32_t la = (uint32_t)__builtin_ctzll(ml), rb = 63u - (uint32_t)__builtin_clzll(mr);
+            if (!(la < rb)) break;
+            if (lane == la) src = rb;
+            if (lane == rb) src = la;
+            ml &= ml - 1ull;
+            mr &= ~(1ull << rb);
+            lastb = rb;
+        }
+        if (ml != 0ull) cut = (uint32_t)__builtin_ctzll(ml);
+        if (lastb < cut) cut = lastb;
+        k = __shfl(k, (int)src, 64);
+        v = __shfl(v, (int)src, 64);
+        heads |= 1ull << cut;
+        // children (order irrelevant): [f,cut) and [cut,e)
+        if (cut - f > (uint32_t)kThreshold) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (sp == t) { sf[t] = f; se[t] = cut; sd[t] = d - 1; }
+            ++sp;
+        }
+        if (e - cut > (uint32_t)kThreshold) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (sp == t) { sf[t] = cut; se[t] = e; sd[t] = d - 1; }
+            ++sp;
+        }
+    }
+    if (lane < n) {
+        K[first + lane] = k;
+        V[first + lane] = v;
+        if (lane > 0 && ((heads >> lane) & 1ull)) atomicOr(&head[(first + lane) >> 5], 1u << ((first + lane) & 31u));
+    }
+    wave_sync();
+}
+
 template <int EPT, class KP, class VP, class PP>
 __device__ __forceinline__ uint32_t block_partition(KP K, VP V, PP posL, PP posR, uint32_t first, uint32_t last, uint32_t *sm,
                                                     bool median_done = false);
@@ -85,11 +169,27 @@ static constexpr uint32_t kBlockMin = 768;  // inside block_esort, segments long
 template <class KP, class VP, class PP, class HP, class K2P, class V2P>
 __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP head, K2P K2, V2P V2, uint32_t seg_first, uint32_t seg_last,
                             int32_t depth, Seg *qa, Seg *qb, uint32_t *qcnt, uint32_t qcap, uint32_t *n_fallback,
-                            uint32_t *overflow_flag) {
+                            uint32_t *overflow_flag, unsigned long long *tstamp = nullptr) {
+#define ESORT_STAMP(i) do { if (tstamp && threadIdx.x == 0) tstamp[i] = clock64(); } while (0)
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
     const uint32_t wave = tid >> 6, nwaves = bs >> 6, lane = tid & 63u;
     const uint32_t n = seg_last - seg_first;
-    for (uint32_t i = seg_first + tid; i <= seg_last; i += bs) head[i] = (i == seg_first || i == seg_last) ? 1 : 0;
+    // head flags: one bit per element index (word e>>5, bit e&31); a set bit starts a leaf.  Words are shared with the
+    // neighbouring segments at the boundaries, so everything goes through atomics on whole words.
+    for (uint32_t w = (seg_first >> 5) + tid; w <= (seg_last >> 5); w += bs) {
+        // clear only the bits strictly inside (seg_first, seg_last): boundary bits are shared with the neighbours
+        const uint32_t lo_e = max(seg_first + 1u, w << 5), hi_e = min(seg_last, (w << 5) + 32u);
+        if (lo_e < hi_e) {
+            const uint32_t hb = hi_e - (w << 5), lb = lo_e - (w << 5);
+            const uint32_t m = (hb == 32u ? 0xFFFFFFFFu : ((1u << hb) - 1u)) & ~((1u << lb) - 1u);
+            atomicAnd(&head[w], ~m);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        atomicOr(&head[seg_first >> 5], 1u << (seg_first & 31u));
+        atomicOr(&head[seg_last >> 5], 1u << (seg_last & 31u));
+    }
     if (tid == 0) {
         qcnt[0] = 0;
         qcnt[1] = 0;
@@ -101,6 +201,7 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
         }
     }
     __syncthreads();
+    ESORT_STAMP(0);
     // phase 1: long segments are partitioned by the WHOLE workgroup, one after the other (a short stack); their
     // children go back on the stack or, once short enough, to the wavefront-per-segment queue of phase 2.
     {
@@ -128,7 +229,7 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
             if (tid == 0) --sp;
             const uint32_t cut = block_partition<4>(K, V, posL, posR, sg.first, sg.last, sm_bp);
             if (tid == 0) {
-                head[cut] = 1;
+                atomicOr(&head[cut >> 5], 1u << (cut & 31u));
                 const Seg ch[2] = {{sg.first, cut, sg.depth - 1}, {cut, sg.last, sg.depth - 1}};
                 for (int t = 0; t < 2; ++t) {
                     const uint32_t len = ch[t].last - ch[t].first;
@@ -147,10 +248,14 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
             __syncthreads();
         }
     }
+    ESORT_STAMP(1);
     int cur = 0;
+    int lvl_ = 0;
     for (;;) {
         const uint32_t nseg = qcnt[cur];
         if (nseg == 0) break;
+        if (lvl_ < 12) ESORT_STAMP(4 + lvl_);
+        ++lvl_;
         Seg *q = cur ? qb : qa;
         Seg *qn = cur ? qa : qb;
         for (uint32_t s = wave; s < nseg; s += nwaves) {
@@ -159,14 +264,18 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
                 if (lane == 0) {
                     heapsort_exact(K, V, sg.first, sg.last);
                     // a heapsorted segment is fully sorted: make every element its own leaf
-                    for (uint32_t i = sg.first; i < sg.last; ++i) head[i] = 1;
+                    for (uint32_t i = sg.first; i < sg.last; ++i) atomicOr(&head[i >> 5], 1u << (i & 31u));
                     atomicAdd(n_fallback, 1u);
                 }
                 continue;
             }
+            if (sg.last - sg.first <= 64u) {  // whole subtree in registers, no children to queue
+                wave_small_subtree(K, V, head, sg.first, sg.last, sg.depth, n_fallback);
+                continue;
+            }
             const uint32_t cut = wave_partition(K, V, posL, posR, sg.first, sg.last);
             if (lane == 0) {
-                head[cut] = 1;
+                atomicOr(&head[cut >> 5], 1u << (cut & 31u));
                 if (cut - sg.first > (uint32_t)kThreshold) {
                     const uint32_t at = atomicAdd(&qcnt[cur ^ 1], 1u);
                     if (at < qcap) {
@@ -196,18 +305,37 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
         cur ^= 1;
     }
     __syncthreads();
+    ESORT_STAMP(2);
     // leaves -> stable ranks.  Results go to registers first because K2/V2 may alias posL/posR only,
     // never K/V, so a direct write is safe.
     for (uint32_t i = seg_first + tid; i < seg_last; i += bs) {
-        uint32_t a = i;
-        while (!head[a]) --a;
-        uint32_t b = i + 1;
-        while (!head[b]) ++b;
-        const uint32_t r = leaf_rank(K, a, b, i);
-        K2[a + r] = K[i];
+        // leaf [a,b) of element i from the head bitmask: a = highest set bit <= i, b = lowest set bit > i (leaves are
+        // <= 16 long, so both lie within 16 positions: at most two 32-bit words each)
+        const uint32_t wi = i >> 5, bi = i & 31u;
+        const uint32_t w0 = head[wi];
+        const uint32_t lowm = w0 & ((2u << bi) - 1u);  // bits <= bi
+        uint32_t a, b;
+        if (lowm) a = (wi << 5) + (31u - (uint32_t)__builtin_clz(lowm));
+        else a = ((wi - 1) << 5) + (31u - (uint32_t)__builtin_clz(head[wi - 1]));
+        const uint32_t highm = bi == 31u ? 0u : (w0 & ~((2u << bi) - 1u));  // bits > bi
+        if (highm) b = (wi << 5) + (uint32_t)__builtin_ctz(highm);
+        else b = ((wi + 1) << 5) + (uint32_t)__builtin_ctz(head[wi + 1]);
+        // stable rank inside the leaf: 16 independent loads, predicated
+        const uint32_t ki = K[i];
+        uint32_t r = 0;
+#pragma unroll
+        for (int t = 0; t < kThreshold; ++t) {
+            const uint32_t j = a + t;
+            const bool valid = j < b;
+            const uint32_t kj = valid ? (uint32_t)K[j] : 0u;
+            r += (valid && ((kj < ki) || (kj == ki && j < i))) ? 1u : 0u;
+        }
+        K2[a + r] = ki;
         V2[a + r] = V[i];
     }
     __syncthreads();
+    ESORT_STAMP(3);
+#undef ESORT_STAMP
 }
 
 // One workgroup performs ONE partition of the global-memory segment [first,last).  sm: >= 2*nwaves+4 uint32.

@@ -929,11 +929,11 @@ __global__ __launch_bounds__(1024) void k_esort_level(uint32_t *K, uint32_t *V, 
 
 // final: every remaining segment (any size) is sorted to completion by one workgroup.
 // Segments <= ES_LMAX run in LDS; larger ones (only if the level budget ran out) run in place in global memory.
-__global__ __launch_bounds__(256) void k_esort_final(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, uint8_t *head,
+__global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, uint32_t *head,
                                                       uint32_t *K2, uint32_t *V2, const esort::Seg *smallq, const esort::Seg *bigq,
-                                                      EsQueues *qs, int bigcur, Counters *ctr) {  // bigcur: queue index (0..2) still holding big segments
+                                                      EsQueues *qs, int bigcur, Counters *ctr, unsigned long long *dbg) {  // bigcur: queue index (0..2) still holding big segments
     __shared__ uint32_t sK[ES_LMAX], sV[ES_LMAX], sL[ES_LMAX], sR[ES_LMAX];
-    __shared__ uint8_t sH[ES_LMAX + 4];
+    __shared__ uint32_t sH[ES_LMAX / 32 + 2];
     __shared__ esort::Seg qa[ES_LMAX / 16 + 2], qb[ES_LMAX / 16 + 2];
     __shared__ uint32_t qcnt[2];
     const uint32_t nsmall = qs->small_cnt, nbig = qs->cnt[bigcur];
@@ -947,7 +947,7 @@ __global__ __launch_bounds__(256) void k_esort_final(uint32_t *K, uint32_t *V, u
             }
             __syncthreads();
             esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, len, sg.depth, qa, qb, qcnt, (uint32_t)(ES_LMAX / 16 + 2),
-                               &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+                               &ctr->n_sort_fallback, &ctr->sort_qoverflow, (s == 0 && dbg) ? dbg : nullptr);
             for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
                 K2[sg.first + i] = sL[i];
                 V2[sg.first + i] = sR[i];
@@ -1069,6 +1069,19 @@ __global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts
                 for (int ii = ci - rho; ii <= ci + rho; ++ii) {
                     if (ii < 0 || ii >= dx) continue;
                     if (!shell_jk && abs(ii - ci) < rho) continue;  // interior cells were visited by earlier stages (rho-1, ..., 0)
+                    {   // a cell whose nearest corner/face is farther than the current best cannot hold a closer or tied point
+                        const int cell[3] = {ii, jj, kk};
+                        const double cc3[3] = {(double)c.x, (double)c.y, (double)c.z};
+                        double d2c = 0.0;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const double lo_a = (double)(g.min_b[a] + cell[a]) * L, hi_a = (double)(g.min_b[a] + cell[a] + 1) * L;
+                            const double margin = 1e-3 * L + 1e-6 * fabs(cc3[a]);
+                            const double da = fmax(0.0, fmax(lo_a - cc3[a], cc3[a] - hi_a) - margin);
+                            d2c += da * da;
+                        }
+                        if (d2c > (double)best) continue;
+                    }
                     const uint32_t q = (uint32_t)ii + (uint32_t)jj * (uint32_t)dx + (uint32_t)kk * (uint32_t)dx * (uint32_t)dy;
                     uint32_t lo = 0, hi = nv;  // lower_bound
                     while (lo < hi) {
@@ -1510,14 +1523,14 @@ __device__ __forceinline__ void rgpf_after_sort(const DP &P, const float4 *__res
 }
 
 // gsK..gsH: global scratch arrays (capV [+1]) used when a bin has more than RG_LMAX points.
-__global__ __launch_bounds__(256) void k_rgpf(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
+__global__ __launch_bounds__(1024) void k_rgpf(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
                                                const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *gsK,
-                                               uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint8_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
+                                               uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
                                                uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
                                                uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
                                                Counters *ctr) {
     __shared__ uint32_t sK[RG_LMAX], sV[RG_LMAX], sL[RG_LMAX], sR[RG_LMAX];
-    __shared__ uint8_t sH[RG_LMAX + 4];
+    __shared__ uint32_t sH[RG_LMAX / 32 + 2];
     __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
     __shared__ uint32_t qcnt[2];
     __shared__ uint32_t sm[40];
@@ -1548,7 +1561,7 @@ __global__ __launch_bounds__(256) void k_rgpf(DP P, const uint8_t *__restrict__ 
         }
         __threadfence_block();
         __syncthreads();
-        esort::block_esort(K, V, gsL + o0, gsR + o0, gsH + o0, gsK2 + o0, gsV2 + o0, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt,
+        esort::block_esort(K, V, gsL + o0, gsR + o0, gsH + (o0 >> 5) + 2 * key, gsK2 + o0, gsV2 + o0, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt,
                            (uint32_t)(RG_LMAX / 16 + 2), &ctr->n_sort_fallback, &ctr->sort_qoverflow);
         __threadfence_block();
         __syncthreads();
@@ -1670,15 +1683,15 @@ __device__ __forceinline__ void binvox_core(const DP &P, uint32_t m, uint32_t nc
     if (tid == 0) *nvox_slot = nv;
 }
 
-__global__ __launch_bounds__(256) void k_binvox(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
+__global__ __launch_bounds__(1024) void k_binvox(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
                                                  const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
                                                  const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq,
                                                  const uint32_t *__restrict__ glist, const uint32_t *__restrict__ ng_arr,
                                                  const uint32_t *__restrict__ vox_off, uint32_t *gsK, uint32_t *gsV, uint32_t *gsL,
-                                                 uint32_t *gsR, uint8_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
+                                                 uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
                                                  float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr) {
     __shared__ uint32_t sK[BV_LMAX], sV[BV_LMAX], sL[BV_LMAX], sR[BV_LMAX];
-    __shared__ uint8_t sH[BV_LMAX + 4];
+    __shared__ uint32_t sH[BV_LMAX / 32 + 2];
     __shared__ float4 sC[BV_LMAX];
     __shared__ esort::Seg qa[BV_LMAX / 16 + 2], qb[BV_LMAX / 16 + 2];
     __shared__ uint32_t qcnt[2];
@@ -1700,7 +1713,7 @@ __global__ __launch_bounds__(256) void k_binvox(DP P, const uint8_t *__restrict_
         binvox_core(P, m, nc, sq + qo, spts + mo, glist + mo, sK, sV, sL, sR, sC, sL, sR, sH, qa, qb, qcnt, sm, sbb, &s_carry, vox_out + vo,
                     nvox_out + rk, ctr);
     else
-        binvox_core(P, m, nc, sq + qo, spts + mo, glist + mo, gsK + vo, gsV + vo, gsK2 + vo, gsV2 + vo, gsC + vo, gsL + vo, gsR + vo, gsH + vo, qa, qb,
+        binvox_core(P, m, nc, sq + qo, spts + mo, glist + mo, gsK + vo, gsV + vo, gsK2 + vo, gsV2 + vo, gsC + vo, gsL + vo, gsR + vo, gsH + (vo >> 5) + 2 * rk, qa, qb,
                     qcnt, sm, sbb, &s_carry, vox_out + vo, nvox_out + rk, ctr);
 }
 
