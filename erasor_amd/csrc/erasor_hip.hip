@@ -238,20 +238,22 @@ int scan_u32(erasor_hip_handle *h, const uint32_t *in, uint32_t *out_local, uint
     return 0;
 }
 
-// stable LSD radix sort of keys[0..n) (n known on the host); returns pointers to the sorted keys / permutation
-int radix_sort(erasor_hip_handle *h, const uint32_t *keys_in, uint32_t n, int bits, uint32_t *ka, uint32_t *kb, uint32_t *va,
-               uint32_t *vb, const uint32_t **skeys, const uint32_t **sperm, const char *tag) {
-    const uint32_t nblk = std::max(1u, cdiv(n, RTILE));
+// stable LSD radix sort of keys[0..n): n = *n_dev when given (n_ub is then only an upper bound that sizes grids and
+// scratch), else n_ub itself.  Returns pointers to the sorted keys / permutation.
+int radix_sort(erasor_hip_handle *h, const uint32_t *keys_in, uint32_t n_ub, const uint32_t *n_dev, int bits, uint32_t *ka, uint32_t *kb,
+               uint32_t *va, uint32_t *vb, const uint32_t **skeys, const uint32_t **sperm, const char *tag) {
+    const uint32_t nblk = std::max(1u, cdiv(n_ub, RTILE));
     const uint32_t nhist = 256u * nblk;
     if (ensure(h, h->hist, nhist) || ensure(h, h->hist_l, nhist) || ensure(h, h->hist_t, cdiv(nhist, 1024) + 2)) return ERASOR_E_NO_DEVICE;
     const uint32_t *kin = keys_in;
     const uint32_t *vin = nullptr;
     uint32_t *kout = ka, *vout = va;
+    uint32_t *nhist_dev = h->dn.p + 8;
     for (int shift = 0; shift < bits; shift += 8) {
-        LAUNCH(h, tag, k_radix_hist, nblk, 256, kin, n, (const uint32_t *)nullptr, shift, h->hist.p);
-        scan_u32(h, h->hist.p, h->hist_l.p, h->hist_t.p, nhist, nhist, nullptr, nullptr, tag);
-        LAUNCH(h, tag, k_radix_scatter, nblk, 256, kin, vin, n, (const uint32_t *)nullptr, shift, (const uint32_t *)h->hist_l.p,
-               (const uint32_t *)h->hist_t.p, kout, vout);
+        LAUNCH(h, tag, k_radix_hist, nblk, 256, kin, n_ub, n_dev, shift, h->hist.p, nhist_dev);
+        scan_u32(h, h->hist.p, h->hist_l.p, h->hist_t.p, nhist, nhist, n_dev ? (const uint32_t *)nhist_dev : nullptr, nullptr, tag);
+        LAUNCH(h, tag, k_radix_scatter, nblk, 256, kin, vin, n_ub, n_dev, shift, (const uint32_t *)h->hist_l.p, (const uint32_t *)h->hist_t.p,
+               kout, vout);
         kin = kout;
         vin = vout;
         kout = (kout == ka) ? kb : ka;
@@ -581,7 +583,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     }
     rc = push_state(h);
     if (rc) return rc;
-    LAUNCH(h, "step_begin", k_step_begin, 1, 1, ds, dc);
+    LAUNCH(h, "step_begin", k_step_begin, 1, 1, ds, dc, (flags & STEP_QUERY_PREVOXELIZED) ? ns : 0u);
     if (ns) HIPC(h, hipMemcpyAsync(h->scan.p, scan_src, (size_t)ns * sizeof(float4), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
 
     // ---- query voxelisation, part 1 (OMU.cpp:238) ----
@@ -608,18 +610,10 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
                nchunks, nFchunks, ds);
     }
-    // ---- mid-step read-back: VoI size and query voxel count size the remaining launches ----
-    HIPC(h, hipMemcpyAsync(&h->st, ds, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
-    HIPC(h, hipStreamSynchronize(h->stream));
-    const uint32_t n_voi = h->st.voi_total, nq = prevox ? ns : h->st.q_nvox;
-    if (!prevox) {
-        VoxGrid g;
-        HIPC(h, hipMemcpy(&g, h->qgrid.p, sizeof(g), hipMemcpyDeviceToHost));
-        if (ns && g.overflow) {
-            h->err = "VoxelGrid index overflow on the query scan (reference returns the input unvoxelised): not supported on device";
-            return ERASOR_E_UNSUPPORTED;
-        }
-    }
+    // No mid-step read-back: everything below is launched on upper-bound grids and reads the actual counts
+    // (st->voi_total, st->q_nvox) from device memory.  n_voi <= logical map size, nq <= n_scan.
+    const uint32_t n_voi = (uint32_t)std::min<uint64_t>(n_map_in, 0xFFFFFFF0ull), nq = ns;  // upper bounds from here on
+    const uint32_t *nvoi_dev = &ds->voi_total, *nq_dev = &ds->q_nvox;
     rc = alloc_step(h, n_voi, nq);
     if (rc) return rc;
 
@@ -636,7 +630,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     }
     const int bits = key_bits(B + 1);
     // the radix ping-pong buffers are shared by the query and the map side (capV >= capS is not guaranteed -> use q buffers)
-    radix_sort(h, h->qkey.p, nq, bits, h->qk_a.p, h->qposL.p, h->qv_a.p, h->qposR.p, &sq_keys, &sq_perm, "q_bucket");
+    radix_sort(h, h->qkey.p, nq, nq_dev, bits, h->qk_a.p, h->qposL.p, h->qv_a.p, h->qposR.p, &sq_keys, &sq_perm, "q_bucket");
     if (g_debug_sync && nq) {
         std::vector<uint32_t> tk(nq), tq(nq);
         (void)hipMemcpy(tk.data(), sq_keys, (size_t)nq * 4, hipMemcpyDeviceToHost);
@@ -657,9 +651,9 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
                 ++shown;
             }
     }
-    if (nq) LAUNCH(h, "q_bucket", k_gather, cdiv(nq, 256), 256, (const float4 *)h->query.p, (const uint32_t *)nullptr, sq_perm, nq,
-                   (const uint32_t *)nullptr, h->sq.p, (uint32_t *)nullptr);
-    LAUNCH(h, "q_bucket", k_bin_offsets, cdiv((uint64_t)std::max(nq, B + 2) + 1, 256), 256, sq_keys, nq, (const uint32_t *)nullptr, B + 1, h->qoff.p);
+    if (nq) LAUNCH(h, "q_bucket", k_gather, cdiv(nq, 256), 256, (const float4 *)h->query.p, (const uint32_t *)nullptr, sq_perm, nq, nq_dev,
+                   h->sq.p, (uint32_t *)nullptr);
+    LAUNCH(h, "q_bucket", k_bin_offsets, cdiv((uint64_t)std::max(nq, B + 2) + 1, 256), 256, sq_keys, nq, nq_dev, B + 1, h->qoff.p);
     LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->sq.p, (const uint32_t *)h->qoff.p, B, h->ccnt.p,
            h->cmin.p, h->cmax.p);
 
@@ -672,11 +666,10 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
                h->voi_ego.p, h->voi_key.p, h->voi_src.p);
     }
     const uint32_t *sm_keys = nullptr, *sm_perm = nullptr;
-    radix_sort(h, h->voi_key.p, n_voi, bits, h->rk_a.p, h->rk_b.p, h->rv_a.p, h->rv_b.p, &sm_keys, &sm_perm, "voi_bucket");
+    radix_sort(h, h->voi_key.p, n_voi, nvoi_dev, bits, h->rk_a.p, h->rk_b.p, h->rv_a.p, h->rv_b.p, &sm_keys, &sm_perm, "voi_bucket");
     if (n_voi) LAUNCH(h, "voi_bucket", k_gather, cdiv(n_voi, 256), 256, (const float4 *)h->voi_ego.p, (const uint32_t *)h->voi_src.p, sm_perm, n_voi,
-                      (const uint32_t *)nullptr, h->spts.p, h->ssrc.p);
-    LAUNCH(h, "voi_bucket", k_bin_offsets, cdiv((uint64_t)std::max(n_voi, B + 2) + 1, 256), 256, sm_keys, n_voi, (const uint32_t *)nullptr, B + 1,
-           h->moff.p);
+                      nvoi_dev, h->spts.p, h->ssrc.p);
+    LAUNCH(h, "voi_bucket", k_bin_offsets, cdiv((uint64_t)std::max(n_voi, B + 2) + 1, 256), 256, sm_keys, n_voi, nvoi_dev, B + 1, h->moff.p);
     LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->spts.p, (const uint32_t *)h->moff.p, B, h->mcnt.p,
            h->mmin.p, h->mmax.p);
 
@@ -701,13 +694,13 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         LAUNCH(h, "assemble", k_assemble_map<true>, cdiv(n_voi, 256), 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
                sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p, (const uint32_t *)h->ccnt.p,
                (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p,
-               (const uint32_t *)h->rej_off.p, (const DevState *)ds, n_voi, Fnew, h->rejected.p, h->rejected_src.p);
+               (const uint32_t *)h->rej_off.p, (const DevState *)ds, Fnew, h->rejected.p, h->rejected_src.p);
     LAUNCH(h, "assemble", k_assemble_bins<true>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
            (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
            (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, Fnew, h->curr_rejected.p);
     LAUNCH(h, "count_labels", k_count_labels4, std::max(1u, std::min<uint32_t>(cdiv(2 * (uint64_t)n_voi + nq, 1024), 512)), 256,
            (const float4 *)Fnew, 0u, (const uint32_t *)&ds->nF_new, &ds->F_static, &ds->F_dynamic);
-    LAUNCH(h, "step_end", k_step_end, 1, 1, ds);
+    LAUNCH(h, "step_end", k_step_end, 1, 1, ds, (const Counters *)dc);
     HIPC(h, hipMemcpyAsync(&h->st, ds, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipMemcpyAsync(&h->ctr, dc, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
@@ -717,26 +710,35 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         return ERASOR_E_NO_DEVICE;
     }
     if (h->ctr.err || h->ctr.sort_qoverflow) {
-        h->err = h->ctr.sort_qoverflow ? "exact-sort segment queue overflow" : "per-bin VoxelGrid index overflow (unsupported on device)";
-        return ERASOR_E_INTERNAL;
+        // nothing was committed on the device (k_voi_gather / k_step_end bail out); restore the host mirror of the state
+        h->st.nF = h->nF;
+        h->st.o_begin = h->o_begin;
+        if (h->ctr.sort_qoverflow) {
+            h->err = "exact-sort segment queue overflow";
+            return ERASOR_E_INTERNAL;
+        }
+        h->err = h->ctr.err == 2 ? "VoxelGrid index overflow on the query scan (reference returns the input unvoxelised): not supported on device"
+                                 : "per-bin VoxelGrid index overflow (unsupported on device)";
+        return ERASOR_E_UNSUPPORTED;
     }
-    // commit
+    // commit (from here on n_voi / nq are the actual sizes)
+    const uint32_t n_voi_act = h->st.voi_total, nq_act = h->st.q_nvox;
     h->curF ^= 1;
     h->nF = h->st.nF;
     h->o_begin = h->st.o_begin;
-    const uint64_t n_out = (uint64_t)(h->o_valid) - (n_voi - h->st.voiF) + h->st.n_leaving;
+    const uint64_t n_out = (uint64_t)(h->o_valid) - (n_voi_act - h->st.voiF) + h->st.n_leaving;
     h->o_valid = n_out;
-    h->last_n_voi = n_voi;
-    h->last_nq = nq;
+    h->last_n_voi = n_voi_act;
+    h->last_nq = nq_act;
     h->last_n_scan = ns;
     h->last_skeys = sm_keys;
     h->have_step = true;
     erasor_step_result r;
     memset(&r, 0, sizeof(r));
     r.n_map_in = n_map_in;
-    r.n_voi = n_voi;
+    r.n_voi = n_voi_act;
     r.n_outskirts = n_out;
-    r.n_query = nq;
+    r.n_query = nq_act;
     r.n_static_estimate = h->st.n_static_est;
     r.n_complement = h->st.n_compl;
     r.n_map_rejected = h->st.n_rejected;
@@ -839,7 +841,7 @@ int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap
                        (const uint32_t *)h->rev_idx.p, h->last_skeys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p,
                        (const uint32_t *)h->moff.p, (const uint32_t *)h->ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p,
                        (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p, (const uint32_t *)h->rej_off.p,
-                       (const DevState *)h->d_st.p, n_voi, tmp, (float4 *)nullptr, (uint32_t *)nullptr);
+                       (const DevState *)h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr);
             LAUNCH(h, "get_cloud", k_assemble_bins<false>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
                    (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
                    (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, tmp, (float4 *)nullptr);
@@ -928,7 +930,7 @@ int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
     if (ns) HIPC(h, hipMemcpyAsync(h->scan.p, src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-    LAUNCH(h, "step_begin", k_step_begin, 1, 1, h->d_st.p, h->d_ctr.p);
+    LAUNCH(h, "step_begin", k_step_begin, 1, 1, h->d_st.p, h->d_ctr.p, 0u);
     voxelize_query_part1(h, ns, (float)leaf_size);
     DevState st;
     VoxGrid g;
@@ -1033,7 +1035,7 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
     const uint32_t ns = (uint32_t)n;
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
-    LAUNCH(h, "step_begin", k_step_begin, 1, 1, h->d_st.p, h->d_ctr.p);
+    LAUNCH(h, "step_begin", k_step_begin, 1, 1, h->d_st.p, h->d_ctr.p, 0u);
     if (ns) {
         HIPC(h, hipMemcpyAsync(h->qk_a.p, keys, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
         HIPC(h, hipMemcpyAsync(h->qv_a.p, vals, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
@@ -1088,7 +1090,7 @@ int erasor_hip_radix_sort_u32(erasor_hip_handle *h, const uint32_t *keys, size_t
     if (rc) return rc;
     if (ns) HIPC(h, hipMemcpyAsync(h->qkey.p, keys, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
     const uint32_t *sk = nullptr, *sp = nullptr;
-    rc = radix_sort(h, h->qkey.p, ns, bits, h->qk_a.p, h->qposL.p, h->qv_a.p, h->qposR.p, &sk, &sp, "radix_test");
+    rc = radix_sort(h, h->qkey.p, ns, nullptr, bits, h->qk_a.p, h->qposL.p, h->qv_a.p, h->qposR.p, &sk, &sp, "radix_test");
     if (rc) return rc;
     HIPC(h, hipStreamSynchronize(h->stream));
     if (ns) {

@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
                                                      const uint32_t *__restrict__ toph, Xf To2b, DP P, DevState *st,
                                                      Counters *ctr, float4 *__restrict__ voi_ego, uint32_t *__restrict__ voi_key,
                                                      uint32_t *__restrict__ voi_src) {
+    if (ctr->err) return;  // an earlier stage of this step failed: do not touch the map store
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -422,10 +423,11 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
 }
 
 __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t *__restrict__ keys, uint32_t n_host, const uint32_t *n_dev,
-                                                     int shift, uint32_t *__restrict__ hist /* [256][nblk] */) {
+                                                     int shift, uint32_t *__restrict__ hist /* [256][nblk] */, uint32_t *nhist_out) {
     __shared__ uint32_t wcnt[4][256];
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t nblk = (n + RTILE - 1) / RTILE;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nhist_out) *nhist_out = 256u * nblk;  // number of histogram entries to scan
     if (blockIdx.x >= nblk) return;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint64_t lt = lanemask_lt();
@@ -650,7 +652,10 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4 *__restrict__ p
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         *gout = g;
-        if (g.overflow) atomicAdd(&ctr->n_voxel_overflow, 1u);
+        if (g.overflow && n) {
+            atomicAdd(&ctr->n_voxel_overflow, 1u);
+            ctr->err = 2;  // VoxelGrid pass-through (reference returns the input unvoxelised): unsupported on device
+        }
     }
     if (i >= n) return;
     const float4 p = pts[i];
@@ -1376,12 +1381,13 @@ __device__ void jacobi_svd3(const float cov[9], float U[9], float sv[3]) {
 }
 
 static constexpr uint32_t RG_LMAX = 4096;
+static constexpr uint32_t RG_CH = 1024;  // covariance products are staged in LDS in chunks of this many list elements
 
 // After the exact z-sort: seeds, gf_iter x (plane fit, classification).  sortedV: sorted order (bin-local indices);
 // glist: scratch for the current ground list.  Templated so that LDS callers get ds_* instructions.
 template <class SV, class GL>
 __device__ __forceinline__ void rgpf_after_sort(const DP &P, const float4 *__restrict__ pts, uint32_t M, uint32_t o0, uint32_t rk, SV sortedV, GL glist,
-                                                uint32_t *sm, float *s_n, double *s_thp, double *s_lprp, uint32_t *s_carryp,
+                                                uint32_t *sm, float *sProd, float *s_n, double *s_thp, double *s_lprp, uint32_t *s_carryp,
                                                 uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
                                                 uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
                                                 Counters *ctr) {
@@ -1425,27 +1431,33 @@ __device__ __forceinline__ void rgpf_after_sort(const DP &P, const float4 *__res
     __syncthreads();
     for (int it = 0; it < P.gf_iter; ++it) {
         // --- estimate_plane_: pcl::computeMeanAndCovarianceMatrix, nine float32 accumulators in list order ---
-        if (wave == 0) {
-            float acc = 0.f;
-            const int ia = lane < 3 ? 0 : (lane < 5 ? 1 : (lane == 5 ? 2 : (int)lane - 6));
-            const int ib = lane < 3 ? (int)lane : (lane < 5 ? (int)lane - 2 : (lane == 5 ? 2 : 3));
-            for (uint32_t base = 0; base < ng; base += 64) {
-                const uint32_t k = base + lane;
-                float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < ng) mine = pts[glist[k]];
-                const uint32_t lim = min(64u, ng - base);
-                for (uint32_t j = 0; j < lim; ++j) {
-                    // j is wave-uniform: v_readlane_b32 (SGPR broadcast), not an LDS permute
-                    const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), (int)j));
-                    const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), (int)j));
-                    const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), (int)j));
-                    // lane L owns accumulator L of PCL's accu[9]: xx xy xz yy yz zz x y z  (x*1.0f == x exactly)
-                    const float A = ia == 0 ? x : (ia == 1 ? y : z);
-                    const float Bv = ib == 0 ? x : (ib == 1 ? y : (ib == 2 ? z : 1.0f));
-                    const float term = A * Bv;
-                    acc += term;
-                }
+        // The nine products of every list element are formed by ALL threads (parallel, order-free) into LDS; then lane a
+        // of wave 0 adds row a strictly in list order — the only part that has to be sequential (float32 addition order
+        // is what PCL's result depends on).  x*x etc. are single IEEE multiplies either way.
+        float acc = 0.f;
+        for (uint32_t cb = 0; cb < ng; cb += RG_CH) {
+            const uint32_t cn = min(RG_CH, ng - cb);
+            for (uint32_t t = tid; t < cn; t += bs) {
+                const float4 q = pts[glist[cb + t]];
+                sProd[0 * RG_CH + t] = q.x * q.x;
+                sProd[1 * RG_CH + t] = q.x * q.y;
+                sProd[2 * RG_CH + t] = q.x * q.z;
+                sProd[3 * RG_CH + t] = q.y * q.y;
+                sProd[4 * RG_CH + t] = q.y * q.z;
+                sProd[5 * RG_CH + t] = q.z * q.z;
+                sProd[6 * RG_CH + t] = q.x;
+                sProd[7 * RG_CH + t] = q.y;
+                sProd[8 * RG_CH + t] = q.z;
             }
+            __syncthreads();
+            if (wave == 0 && lane < 9) {
+                const float *row = sProd + lane * RG_CH;
+#pragma unroll 8
+                for (uint32_t k = 0; k < cn; ++k) acc += row[k];
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
             float a[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) a[k] = __shfl(acc, k, 64);
@@ -1534,6 +1546,7 @@ __global__ __launch_bounds__(1024) void k_rgpf(DP P, const uint8_t *__restrict__
     __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
     __shared__ uint32_t qcnt[2];
     __shared__ uint32_t sm[40];
+    __shared__ float sProd[9 * RG_CH];
     __shared__ float s_n[3];
     __shared__ double s_th, s_lpr;
     __shared__ uint32_t s_carry;
@@ -1552,7 +1565,7 @@ __global__ __launch_bounds__(1024) void k_rgpf(DP P, const uint8_t *__restrict__
         __syncthreads();
         esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
                            &ctr->n_sort_fallback, &ctr->sort_qoverflow);
-        rgpf_after_sort(P, pts, M, o0, rk, sR, sK, sm, s_n, &s_th, &s_lpr, &s_carry, gflag, grank, glist_out, ng_out, plane_n, plane_d, ctr);
+        rgpf_after_sort(P, pts, M, o0, rk, sR, sK, sm, sProd, s_n, &s_th, &s_lpr, &s_carry, gflag, grank, glist_out, ng_out, plane_n, plane_d, ctr);
     } else {
         uint32_t *K = gsK + o0, *V = gsV + o0;
         for (uint32_t i = tid; i < M; i += bs) {
@@ -1565,7 +1578,7 @@ __global__ __launch_bounds__(1024) void k_rgpf(DP P, const uint8_t *__restrict__
                            (uint32_t)(RG_LMAX / 16 + 2), &ctr->n_sort_fallback, &ctr->sort_qoverflow);
         __threadfence_block();
         __syncthreads();
-        rgpf_after_sort(P, pts, M, o0, rk, gsV2 + o0, K, sm, s_n, &s_th, &s_lpr, &s_carry, gflag, grank, glist_out, ng_out, plane_n, plane_d, ctr);
+        rgpf_after_sort(P, pts, M, o0, rk, gsV2 + o0, K, sm, sProd, s_n, &s_th, &s_lpr, &s_carry, gflag, grank, glist_out, ng_out, plane_n, plane_d, ctr);
     }
 }
 
@@ -1798,11 +1811,11 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
                                                        const uint32_t *__restrict__ moff, const uint32_t *__restrict__ ccnt,
                                                        const uint8_t *__restrict__ gflag, const uint32_t *__restrict__ grank,
                                                        const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ ground_off,
-                                                       const uint32_t *__restrict__ rej_off, const DevState *st, uint32_t n_voi,
+                                                       const uint32_t *__restrict__ rej_off, const DevState *st,
                                                        float4 *__restrict__ Fnew, float4 *__restrict__ rejected,
                                                        uint32_t *__restrict__ rejected_src) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_voi) return;
+    if (i >= st->voi_total) return;
     const uint32_t key = skeys[i];
     const float4 p = spts[i];
     const float4 w = XFORM ? xform(Tb2o, p) : p;
@@ -1888,13 +1901,15 @@ __global__ __launch_bounds__(256) void k_count_labels4(const float4 *__restrict_
     }
 }
 
-__global__ void k_step_begin(DevState *st, Counters *ctr) {
+__global__ void k_step_begin(DevState *st, Counters *ctr, uint32_t q_nvox_init) {
+    st->q_nvox = q_nvox_init;
     ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
     ctr->sort_qoverflow = ctr->err = 0;
     st->F_static = st->F_dynamic = 0;
     st->n_rev = 0;
 }
-__global__ void k_step_end(DevState *st) {
+__global__ void k_step_end(DevState *st, const Counters *ctr) {
+    if (ctr->err || ctr->sort_qoverflow) return;
     st->nF = st->nF_new;
     st->o_begin = st->o_new_begin;
 }
