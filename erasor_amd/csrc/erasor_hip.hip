@@ -509,7 +509,7 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
             const int cur = l & 1;
             LAUNCH(h, "q_esort_wide", k_esort_wide_mark, 256, 256, (const uint32_t *)h->qk_a.p, h->qposL.p, h->qposR.p,
                    (const WideSeg *)(cur ? h->wseg1.p : h->wseg0.p), (const WideState *)h->wstate.p, cur, h->wtileL.p, h->wtileR.p);
-            LAUNCH(h, "q_esort_wide", k_esort_wide_swap, 128, 256, h->qk_a.p, h->qv_a.p, (const uint32_t *)h->qposL.p, (const uint32_t *)h->qposR.p,
+            LAUNCH(h, "q_esort_wide", k_esort_wide_swap, 256, 256, h->qk_a.p, h->qv_a.p, (const uint32_t *)h->qposL.p, (const uint32_t *)h->qposR.p,
                    cur ? h->wseg1.p : h->wseg0.p, (const WideState *)h->wstate.p, cur, (const uint32_t *)h->wtileL.p, (const uint32_t *)h->wtileR.p);
             LAUNCH(h, "q_esort_wide", k_esort_wide_children, 1, 64, h->qk_a.p, h->qv_a.p, (const WideSeg *)(cur ? h->wseg1.p : h->wseg0.p),
                    cur ? h->wseg0.p : h->wseg1.p, h->wstate.p, cur, h->esq0.p, h->essmall.p, h->esqs.p, 65536u, l == wl - 1 ? 1 : 0, dc);
@@ -630,7 +630,14 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     }
     const int bits = key_bits(B + 1);
     // the radix ping-pong buffers are shared by the query and the map side (capV >= capS is not guaranteed -> use q buffers)
-    radix_sort(h, h->qkey.p, nq, nq_dev, bits, h->qk_a.p, h->qposL.p, h->qv_a.p, h->qposR.p, &sq_keys, &sq_perm, "q_bucket");
+    if (nq <= 8192) {  // tiny inputs: one single-workgroup launch instead of ten (slower than the multi-block path beyond ~10 k keys)
+        LAUNCH(h, "q_bucket", k_radix_small, 1, 1024, (const uint32_t *)h->qkey.p, nq, nq_dev, bits, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p);
+        const int passes = (bits + 7) / 8;
+        sq_keys = (passes & 1) ? h->qk_a.p : h->qposL.p;
+        sq_perm = (passes & 1) ? h->qv_a.p : h->qposR.p;
+    } else {
+        radix_sort(h, h->qkey.p, nq, nq_dev, bits, h->qk_a.p, h->qposL.p, h->qv_a.p, h->qposR.p, &sq_keys, &sq_perm, "q_bucket");
+    }
     if (g_debug_sync && nq) {
         std::vector<uint32_t> tk(nq), tq(nq);
         (void)hipMemcpy(tk.data(), sq_keys, (size_t)nq * 4, hipMemcpyDeviceToHost);

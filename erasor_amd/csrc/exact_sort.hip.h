@@ -159,7 +159,7 @@ template <int EPT, class KP, class VP, class PP>
 __device__ __forceinline__ uint32_t block_partition(KP K, VP V, PP posL, PP posR, uint32_t first, uint32_t last, uint32_t *sm,
                                                     bool median_done = false);
 
-static constexpr uint32_t kBlockMin = 768;  // inside block_esort, segments longer than this are partitioned by the whole workgroup
+static constexpr uint32_t kBlockMin = 2048;  // inside block_esort, segments longer than this are partitioned by the whole workgroup
 
 // Whole-subtree sort of K[base..base+n) by one workgroup.  All pointers index the same space
 // (element e lives at K[e]); the segment handled is [seg_first, seg_last) with introsort depth

@@ -506,6 +506,72 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t *__restric
     }
 }
 
+// One-launch stable LSD radix sort for small inputs (the voxelised query, ~20 k keys): a single 1024-thread workgroup,
+// every wavefront owns a contiguous strip (stability), digit counters per wavefront in LDS, ping-pong through L2.
+__global__ __launch_bounds__(1024) void k_radix_small(const uint32_t *__restrict__ keys_in, uint32_t n_host, const uint32_t *n_dev, int bits,
+                                                       uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb) {
+    __shared__ uint32_t wcnt[16][256];
+    __shared__ uint32_t wbase[16][256];
+    __shared__ uint32_t sm[40];
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint64_t lt = lanemask_lt();
+    const uint32_t per = ((n + 16 * 64 - 1) / (16 * 64)) * 64;  // strip length per wavefront, multiple of 64
+    const uint32_t s0 = wave * per, s1 = min(s0 + per, n);
+    const uint32_t *kin = keys_in;
+    const uint32_t *vin = nullptr;
+    uint32_t *kout = ka, *vout = va;
+    for (int shift = 0; shift < bits; shift += 8) {
+        for (uint32_t i = tid; i < 16 * 256; i += 1024) (&wcnt[0][0])[i] = 0;
+        __syncthreads();
+        for (uint32_t base = s0; base < s1; base += 64) {
+            const uint32_t i = base + lane;
+            const bool valid = i < s1;
+            const uint32_t d = valid ? ((kin[i] >> shift) & 0xFFu) : 0u;
+            const uint64_t peers = match_digit(d, valid);
+            if (valid && (peers & lt) == 0) wcnt[wave][d] += __popcll(peers);
+            esort::wave_sync();
+        }
+        __syncthreads();
+        // exclusive prefix in (digit-major, wavefront) order: thread d < 256 owns digit d
+        uint32_t tot = 0;
+        if (tid < 256)
+            for (int w = 0; w < 16; ++w) tot += wcnt[w][tid];
+        uint32_t all;
+        const uint32_t pre = block_excl_scan(tid < 256 ? tot : 0u, sm, all);
+        if (tid < 256) {
+            uint32_t b = pre;
+            for (int w = 0; w < 16; ++w) {
+                wbase[w][tid] = b;
+                b += wcnt[w][tid];
+            }
+        }
+        __syncthreads();
+        for (uint32_t base = s0; base < s1; base += 64) {
+            const uint32_t i = base + lane;
+            const bool valid = i < s1;
+            const uint32_t k = valid ? kin[i] : 0u;
+            const uint32_t v = valid ? (vin ? vin[i] : i) : 0u;
+            const uint32_t d = (k >> shift) & 0xFFu;
+            const uint64_t peers = match_digit(d, valid);
+            if (valid) {
+                const uint32_t pos = wbase[wave][d] + __popcll(peers & lt);
+                kout[pos] = k;
+                vout[pos] = v;
+            }
+            esort::wave_sync();
+            if (valid && (peers & lt) == 0) wbase[wave][d] += __popcll(peers);
+            esort::wave_sync();
+        }
+        __threadfence_block();
+        __syncthreads();
+        kin = kout;
+        vin = vout;
+        kout = (kout == ka) ? kb : ka;
+        vout = (vout == va) ? vb : va;
+    }
+}
+
 // gather points (and optionally a uint32 side array) into sorted order
 __global__ __launch_bounds__(256) void k_gather(const float4 *__restrict__ src, const uint32_t *__restrict__ src_aux,
                                                  const uint32_t *__restrict__ perm, uint32_t n_host, const uint32_t *n_dev,
@@ -733,6 +799,7 @@ __global__ __launch_bounds__(256) void k_esort_wide_mark(const uint32_t *__restr
         while (si + 1 < nseg && gt >= wseg[si + 1].tile0) ++si;
         const WideSeg sg = wseg[si];
         const uint32_t t = gt - sg.tile0;
+        if (t >= sg.ntiles) continue;  // tile ids of children that were routed to the level queue instead
         const uint32_t p = K[sg.first];
         const uint32_t lo = sg.first + 1 + t * WTILE;
         const uint32_t hi = min(lo + WTILE, sg.last);
@@ -781,8 +848,10 @@ __global__ __launch_bounds__(256) void k_esort_wide_swap(uint32_t *K, uint32_t *
     __shared__ uint32_t s_lo, s_hi;
     const uint32_t nseg = ws->nseg[cur];
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
-    for (uint32_t w = blockIdx.x; w < nseg * WPARTS; w += gridDim.x) {
-        const uint32_t si = w / WPARTS, part = w % WPARTS;
+    if (nseg == 0) return;
+    const uint32_t parts = max(1u, gridDim.x / nseg);  // workgroups sharing one segment's swaps (all of the grid at level 0)
+    for (uint32_t w = blockIdx.x; w < nseg * parts; w += gridDim.x) {
+        const uint32_t si = w / parts, part = w % parts;
         const WideSeg sg = wseg[si];
         const uint32_t nt = sg.ntiles, base = sg.first + 1;
         // tile prefixes (exclusive), entry nt = total
@@ -844,7 +913,7 @@ __global__ __launch_bounds__(256) void k_esort_wide_swap(uint32_t *K, uint32_t *
             }
             wseg[si].cut = cut;
         }
-        const uint32_t k_begin = (uint32_t)(((uint64_t)m * part) / WPARTS), k_end = (uint32_t)(((uint64_t)m * (part + 1)) / WPARTS);
+        const uint32_t k_begin = (uint32_t)(((uint64_t)m * part) / parts), k_end = (uint32_t)(((uint64_t)m * (part + 1)) / parts);
         for (uint32_t k = k_begin + tid; k < k_end; k += bs) {
             const uint32_t a = wide_lookup(preL, nt, posL, base, k), b = wide_lookup(preR, nt, posR, base, nR - 1 - k);
             esort::swap_kv(K, V, a, b);
@@ -853,42 +922,55 @@ __global__ __launch_bounds__(256) void k_esort_wide_swap(uint32_t *K, uint32_t *
     }
 }
 
-// single workgroup: route the children of every wide segment of this level
+// single workgroup, one thread per wide segment: route its two children (queue order is irrelevant, slots by atomics)
 __global__ __launch_bounds__(64) void k_esort_wide_children(uint32_t *K, uint32_t *V, const WideSeg *wcur, WideSeg *wnext, WideState *ws,
                                                              int cur, esort::Seg *q0, esort::Seg *smallq, EsQueues *qs, uint32_t qcap,
                                                              int last_level, Counters *ctr) {
-    if (threadIdx.x != 0) return;
+    __shared__ uint32_t s_nn, s_nt;
     const uint32_t nseg = ws->nseg[cur];
-    uint32_t nn = 0, nt_tot = 0;
-    for (uint32_t si = 0; si < nseg; ++si) {
+    if (threadIdx.x == 0) {
+        s_nn = 0;
+        s_nt = 0;
+    }
+    __syncthreads();
+    for (uint32_t si = threadIdx.x; si < nseg; si += blockDim.x) {
         const WideSeg sg = wcur[si];
         const esort::Seg ch[2] = {{sg.first, sg.cut, sg.depth - 1}, {sg.cut, sg.last, sg.depth - 1}};
         for (int t = 0; t < 2; ++t) {
             const uint32_t len = ch[t].last - ch[t].first;
             if (len == 0) continue;
             const uint32_t nt = len > 1 ? (len - 1 + WTILE - 1) / WTILE : 0;
-            if (ch[t].depth > 0 && len >= WIDE_MIN && !last_level && nn < WSEG_MAX && nt_tot + nt <= WTILES_MAX) {
+            bool wide = ch[t].depth > 0 && len >= WIDE_MIN && !last_level;
+            uint32_t slot = 0, t0 = 0;
+            if (wide) {
+                slot = atomicAdd(&s_nn, 1u);
+                t0 = atomicAdd(&s_nt, nt);
+                if (slot >= WSEG_MAX || t0 + nt > WTILES_MAX) wide = false;  // over capacity: the level queue takes it (counters only over-count)
+            }
+            if (wide) {
                 esort::move_median_to_first(K, V, ch[t].first, ch[t].last);
-                wnext[nn].first = ch[t].first;
-                wnext[nn].last = ch[t].last;
-                wnext[nn].depth = ch[t].depth;
-                wnext[nn].tile0 = nt_tot;
-                wnext[nn].ntiles = nt;
-                ++nn;
-                nt_tot += nt;
+                wnext[slot].first = ch[t].first;
+                wnext[slot].last = ch[t].last;
+                wnext[slot].depth = ch[t].depth;
+                wnext[slot].tile0 = t0;
+                wnext[slot].ntiles = nt;
             } else if (len > ES_LMAX && ch[t].depth > 0) {
-                const uint32_t at = qs->cnt[0]++;
+                const uint32_t at = atomicAdd(&qs->cnt[0], 1u);
                 if (at < qcap) q0[at] = ch[t]; else ctr->sort_qoverflow = 1;
             } else {
-                const uint32_t at = qs->small_cnt++;
+                const uint32_t at = atomicAdd(&qs->small_cnt, 1u);
                 if (at < qcap) smallq[at] = ch[t]; else ctr->sort_qoverflow = 1;
             }
         }
     }
-    ws->nseg[cur ^ 1] = nn;
-    ws->ntiles[cur ^ 1] = nt_tot;
-    ws->nseg[cur] = 0;
-    ws->ntiles[cur] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // capacity overflow would leave holes in wnext: only possible beyond WSEG_MAX / WTILES_MAX, which the init sizing excludes
+        ws->nseg[cur ^ 1] = min(s_nn, WSEG_MAX);
+        ws->ntiles[cur ^ 1] = min(s_nt, WTILES_MAX);
+        ws->nseg[cur] = 0;
+        ws->ntiles[cur] = 0;
+    }
 }
 
 // one level: each workgroup takes big segments of queue[cur] and performs one partition
