@@ -602,7 +602,9 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         return ERASOR_E_NO_DEVICE;
     {
         const uint32_t waves_needed = nchunks;
-        const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(waves_needed, 4), 256 * 8));
+        // one chunk per wave while that needs <= 16 workgroups per CU: the hardware back-fills workgroups as they finish,
+        // which balances better than a grid-stride tail (measured, tools/bw_probe.hip)
+        const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(waves_needed, 4), 256 * 16));
         LAUNCH(h, "voi_split", k_voi_split, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, (const float2 *)h->Oxy.p, h->o_begin,
                o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p);
         const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));
