@@ -60,7 +60,11 @@ def main():
     from erasor_amd import dist as ed
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    dist, world_size, rank, local_rank = ed.init("nccl")  # "nccl" is RCCL on ROCm
+    # "nccl" is RCCL on ROCm.  ERASOR_BENCH_BACKEND / ERASOR_BENCH_ONE_DEVICE exist only to smoke-test the multi-rank
+    # control flow on a single-GPU box (RCCL refuses two ranks on one device).
+    dist, world_size, rank, local_rank = ed.init(os.environ.get("ERASOR_BENCH_BACKEND", "nccl"))
+    if os.environ.get("ERASOR_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

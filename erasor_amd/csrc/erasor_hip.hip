@@ -56,6 +56,12 @@ struct erasor_hip_handle {
     int curF = 0;
     DBuf<float2> Oxy, Ozi;
     uint32_t nF = 0, o_begin = 0;  // host mirrors
+    // large-scale mode (OMU.cpp:332-379): everything outside the current submap
+    DBuf<float4> Cbuf;
+    uint32_t nC = 0;
+    bool submap_not_initialized = true;
+    double submap_cx = 0, submap_cy = 0;
+    uint32_t n_reassign = 0;
     uint64_t o_valid = 0;          // live outskirts entries
     // ---- VoI split ----
     DBuf<unsigned long long> vmask, hmask;
@@ -365,6 +371,104 @@ int rebuild_outskirts(erasor_hip_handle *h, uint32_t min_front_room) {
     return 0;
 }
 
+int push_state(erasor_hip_handle *h);
+
+// set_submap (OMU.cpp:360-379) over [F | outskirts | complement] in that (logical) order: stable partition by the box test
+// into the new submap (stored as outskirts, F empty) and the new complement.  Rare (every ~submap_size/2 of travel).
+int split_submap(erasor_hip_handle *h, double x, double y) {
+    const uint64_t total64 = (uint64_t)h->nF + h->o_valid + h->nC;
+    if (total64 > 0x7FFFFFF0ull) {
+        h->err = "map too large for 32-bit indexing";
+        return ERASOR_E_INVALID;
+    }
+    const uint32_t total = (uint32_t)total64;
+    DBuf<float4> G, newC;
+    DBuf<uint32_t> flag, pl, tops;
+    if (ensure(h, G, (size_t)total + 1) || ensure(h, flag, (size_t)total + 1) || ensure(h, pl, (size_t)total + 1) ||
+        ensure(h, tops, total / 1024 + 4))
+        return ERASOR_E_NO_DEVICE;
+    // logical global map = *map_arranged_ + *map_arranged_complement_ (OMU.cpp:349)
+    if (h->nF) HIPC(h, hipMemcpyAsync(G.p, h->F[h->curF].p, (size_t)h->nF * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    const uint32_t span = h->capO - h->o_begin;
+    if (span && h->o_valid) {
+        DBuf<uint32_t> f2, p2, t2;
+        if (ensure(h, f2, span + 1) || ensure(h, p2, span + 1) || ensure(h, t2, span / 1024 + 4)) return ERASOR_E_NO_DEVICE;
+        LAUNCH(h, "submap", k_o_valid, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, h->o_begin, h->capO, f2.p);
+        scan_u32(h, f2.p, p2.p, t2.p, span, span, nullptr, nullptr, "submap");
+        LAUNCH(h, "submap", k_o_compact, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, (const float2 *)h->Ozi.p, h->o_begin, h->capO,
+               (const uint32_t *)f2.p, (const uint32_t *)p2.p, (const uint32_t *)t2.p, G.p + h->nF);
+        HIPC(h, hipStreamSynchronize(h->stream));
+        release(f2);
+        release(p2);
+        release(t2);
+    }
+    if (h->nC) HIPC(h, hipMemcpyAsync(G.p + h->nF + h->o_valid, h->Cbuf.p, (size_t)h->nC * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    uint32_t n_sub = 0;
+    if (total) {
+        LAUNCH(h, "submap", k_box_flag, cdiv(total, 256), 256, (const float4 *)G.p, total, x, y, h->P.submap_size, flag.p);
+        scan_u32(h, flag.p, pl.p, tops.p, total, total, nullptr, h->dn.p, "submap");
+        HIPC(h, hipMemcpyAsync(&n_sub, h->dn.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+    }
+    const uint32_t n_cmp = total - n_sub;
+    const uint32_t needO = rup((uint64_t)n_sub + std::max<uint64_t>(n_sub / 2, 1u << 20), CHUNK);
+    if (needO > h->capO) {  // nothing to preserve: the region is rewritten from G
+        HIPC(h, hipStreamSynchronize(h->stream));
+        release(h->Oxy);
+        release(h->Ozi);
+        if (ensure(h, h->Oxy, needO) || ensure(h, h->Ozi, needO)) return ERASOR_E_NO_DEVICE;
+        h->capO = needO;
+    }
+    if (ensure(h, newC, (size_t)n_cmp + 1)) return ERASOR_E_NO_DEVICE;
+    const uint32_t dst0 = h->capO - n_sub;
+    if (total)
+        LAUNCH(h, "submap", k_box_partition, cdiv(total, 256), 256, (const float4 *)G.p, total, (const uint32_t *)flag.p, (const uint32_t *)pl.p,
+               (const uint32_t *)tops.p, h->Oxy.p, h->Ozi.p, dst0, newC.p);
+    h->nF = 0;
+    h->o_begin = dst0;
+    h->o_valid = n_sub;
+    memset(&h->st, 0, sizeof(h->st));
+    int rc = push_state(h);
+    if (rc) return rc;
+    if (n_sub) {
+        DevState *ds = h->d_st.p;
+        LAUNCH(h, "submap", k_count_labels_zi, std::min<uint32_t>(cdiv(n_sub, 256), 1024), 256, (const float2 *)(h->Ozi.p + dst0), n_sub,
+               &ds->O_static, &ds->O_dynamic);
+    }
+    HIPC(h, hipMemcpyAsync(&h->st, h->d_st.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    release(h->Cbuf);
+    h->Cbuf = newC;
+    h->nC = n_cmp;
+    release(G);
+    release(flag);
+    release(pl);
+    release(tops);
+    ++h->n_reassign;
+    return 0;
+}
+
+// reassign_submap (OMU.cpp:332-358)
+int reassign_submap(erasor_hip_handle *h, double pose_x, double pose_y) {
+    if (h->submap_not_initialized) {
+        int rc = split_submap(h, pose_x, pose_y);
+        if (rc) return rc;
+        h->submap_cx = pose_x;
+        h->submap_cy = pose_y;
+        h->submap_not_initialized = false;
+    } else {
+        const double diff_x = fabs(h->submap_cx - pose_x), diff_y = fabs(h->submap_cy - pose_y);
+        const double half_size = h->P.submap_size / 2.0;
+        if ((diff_x > half_size) || (diff_y > half_size)) {
+            int rc = split_submap(h, pose_x, pose_y);
+            if (rc) return rc;
+            h->submap_cx = pose_x;
+            h->submap_cy = pose_y;
+        }
+    }
+    return 0;
+}
+
 int push_state(erasor_hip_handle *h) {
     h->st.nF = h->nF;
     h->st.o_begin = h->o_begin;
@@ -401,6 +505,8 @@ int erasor_hip_params_default(erasor_params *p) {
     p->query_voxel_size = 0.05;  // OMU.cpp:66
     p->removal_interval = 2;     // OMU.cpp:69
     p->voi_max_range = 0.0;
+    p->is_large_scale = 0;   // OMU.cpp:75
+    p->submap_size = 200.0;  // OMU.cpp:76
     return ERASOR_OK;
 }
 
@@ -411,6 +517,7 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
     if (p->gf_iter < 1 || p->gf_iter > 64) return ERASOR_E_INVALID;
     if (p->version != 2 && p->version != 3) return ERASOR_E_UNSUPPORTED;  // OMU.cpp:273-275 "Other version is not implemented!"
     if (!(p->max_range > 0) || !(p->map_voxel_size > 0) || !(p->query_voxel_size > 0)) return ERASOR_E_INVALID;
+    if (p->is_large_scale && !(p->submap_size > 0)) return ERASOR_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return ERASOR_E_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return ERASOR_E_NO_DEVICE;
@@ -440,7 +547,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     prof_collect(h);
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
-    release(h->F[0]); release(h->F[1]); release(h->Oxy); release(h->Ozi);
+    release(h->Cbuf); release(h->F[0]); release(h->F[1]); release(h->Oxy); release(h->Ozi);
     release(h->vmask); release(h->hmask); release(h->cinfo); release(h->pvl); release(h->phl); release(h->topv); release(h->toph);
     release(h->voi_ego); release(h->spts); release(h->rejected); release(h->voi_key); release(h->voi_src); release(h->ssrc);
     release(h->rejected_src); release(h->grank); release(h->glist); release(h->gflag);
@@ -476,6 +583,8 @@ static int set_map_common(erasor_hip_handle *h, const void *src, size_t n, bool 
     h->curF = 0;
     h->o_begin = h->capO - (uint32_t)n;
     h->o_valid = n;
+    h->nC = 0;
+    h->submap_not_initialized = true;
     if (n) LAUNCH(h, "set_map", k_store_outskirts, cdiv(n, 256), 256, (const float4 *)h->voi_ego.p, (uint32_t)n, h->Oxy.p, h->Ozi.p, h->o_begin);
     memset(&h->st, 0, sizeof(h->st));
     rc = push_state(h);
@@ -571,6 +680,10 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     const DP &P = h->dp;
     const uint32_t B = h->B;
 
+    if (h->P.is_large_scale) {  // OMU.cpp:249-251
+        rc = reassign_submap(h, xc, yc);
+        if (rc) return rc;
+    }
     // room for the points that may leave the VoI-resident region (upper bound nF)
     if ((uint64_t)h->o_begin < (uint64_t)h->nF + CHUNK || (uint64_t)(h->capO - h->o_begin) > 2 * h->o_valid + (1u << 20)) {
         rc = rebuild_outskirts(h, h->nF + CHUNK);
@@ -779,7 +892,7 @@ int erasor_hip_step_device(erasor_hip_handle *h, const void *d_scan_xyzi, size_t
 int erasor_hip_map_size(erasor_hip_handle *h, size_t *n) {
     if (!h || !n) return ERASOR_E_INVALID;
     if (!h->have_map) return ERASOR_E_STATE;
-    *n = (size_t)h->nF + (size_t)h->o_valid;
+    *n = (size_t)h->nF + (size_t)h->o_valid + (size_t)h->nC;  // large-scale: *map_arranged_ + *map_arranged_complement_ (OMU.cpp:181)
     return ERASOR_OK;
 }
 
@@ -796,10 +909,11 @@ int erasor_hip_get_map(erasor_hip_handle *h, float *dst, size_t cap, size_t *n) 
     if (!h) return ERASOR_E_INVALID;
     if (!h->have_map) return ERASOR_E_STATE;
     HIPC(h, hipSetDevice(h->device));
-    const size_t total = (size_t)h->nF + (size_t)h->o_valid;
+    const size_t total = (size_t)h->nF + (size_t)h->o_valid + (size_t)h->nC;
     if (n) *n = total;
     if (!dst) return ERASOR_OK;
     if (total > cap) return ERASOR_E_CAPACITY;
+    if (h->nC) HIPC(h, hipMemcpy(dst + ((size_t)h->nF + h->o_valid) * 4, h->Cbuf.p, (size_t)h->nC * sizeof(float4), hipMemcpyDeviceToHost));
     if (h->nF) HIPC(h, hipMemcpy(dst, h->F[h->curF].p, (size_t)h->nF * sizeof(float4), hipMemcpyDeviceToHost));
     const uint32_t span = h->capO - h->o_begin;
     if (span && h->o_valid) {

@@ -2038,6 +2038,56 @@ __global__ __launch_bounds__(256) void k_o_compact(const float2 *__restrict__ Ox
     dst[pl[i] + tops[i >> 10]] = make_float4(a.x, a.y, b.x, b.y);
 }
 
+// ---- large-scale mode: set_submap (OMU.cpp:360-379) ------------------------------------------------
+// flag[i] = 1 iff |x - pt.x| < submap_size && |y - pt.y| < submap_size (doubles, strict)
+__global__ __launch_bounds__(256) void k_box_flag(const float4 *__restrict__ g, uint32_t n, double x, double y, double S,
+                                                   uint32_t *__restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = g[i];
+    const double dx = fabs(x - (double)p.x), dy = fabs(y - (double)p.y);
+    flag[i] = ((dx < S) && (dy < S)) ? 1u : 0u;
+}
+// stable partition: submap points -> outskirts layout at O[dst0 + rank], the rest -> C[i - rank]
+__global__ __launch_bounds__(256) void k_box_partition(const float4 *__restrict__ g, uint32_t n, const uint32_t *__restrict__ flag,
+                                                        const uint32_t *__restrict__ pl, const uint32_t *__restrict__ tops,
+                                                        float2 *__restrict__ Oxy, float2 *__restrict__ Ozi, uint32_t dst0,
+                                                        float4 *__restrict__ C) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = g[i];
+    const uint32_t r = pl[i] + tops[i >> 10];
+    if (flag[i]) {
+        Oxy[dst0 + r] = make_float2(p.x, p.y);
+        Ozi[dst0 + r] = make_float2(p.z, p.w);
+    } else {
+        C[i - r] = p;
+    }
+}
+// label counters over the {z,intensity} half of the outskirts layout
+__global__ __launch_bounds__(256) void k_count_labels_zi(const float2 *__restrict__ zi, uint32_t n, unsigned long long *n_static,
+                                                          unsigned long long *n_dynamic) {
+    __shared__ uint32_t sd[4], ss[4];
+    uint32_t d = 0, s = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (is_dynamic_label(zi[i].y)) ++d; else ++s;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        d += __shfl_down(d, o, 64);
+        s += __shfl_down(s, o, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        sd[threadIdx.x >> 6] = d;
+        ss[threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t td = sd[0] + sd[1] + sd[2] + sd[3], ts = ss[0] + ss[1] + ss[2] + ss[3];
+        if (td) atomicAdd(n_dynamic, (unsigned long long)td);
+        if (ts) atomicAdd(n_static, (unsigned long long)ts);
+    }
+}
+
 // device libm probe: sqrt / div / atan2 in double, as the binning uses them (tests pin these vs host libm)
 __global__ void k_probe_math(const double *x, const double *y, uint32_t n, double *o_sqrt, double *o_div, double *o_atan2) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -231,7 +231,8 @@ namespace erasor {
 
 OfflineMapUpdater::OfflineMapUpdater(const Config &cfg) : cfg_(cfg) {
     if (cfg_.environment == "indoor") throw std::invalid_argument("This `indoor` mode is not perfect!");  // OMU.cpp:149
-    if (cfg_.is_large_scale) throw std::invalid_argument("large-scale (submap) mode is not implemented in the HIP path yet");
+    cfg_.params.is_large_scale = cfg_.is_large_scale ? 1 : 0;  // /large_scale/is_large_scale, /large_scale/submap_size (OMU.cpp:75-76)
+    if (cfg_.is_large_scale) cfg_.params.submap_size = cfg_.submap_size;
     geometry_msgs::Pose l2b;
     l2b.position.x = cfg_.lidar2body[0]; l2b.position.y = cfg_.lidar2body[1]; l2b.position.z = cfg_.lidar2body[2];
     l2b.orientation.x = cfg_.lidar2body[3]; l2b.orientation.y = cfg_.lidar2body[4]; l2b.orientation.z = cfg_.lidar2body[5];

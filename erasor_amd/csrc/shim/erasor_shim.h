@@ -66,7 +66,8 @@ public:
         double lidar2body[7] = {0, 0, 0, 0, 0, 0, 1};          // /tf/lidar2body: x y z qx qy qz qw (OMU.cpp:89-104)
         std::string environment = "outdoor";                   // /MapUpdater/env
         std::string initial_map_path, save_path = ".", data_name = "00";
-        bool is_large_scale = false;                           // /large_scale/is_large_scale (not supported yet: rejected)
+        bool is_large_scale = false;                           // /large_scale/is_large_scale (OMU.cpp:75)
+        double submap_size = 200.0;                            // /large_scale/submap_size   (OMU.cpp:76)
         bool verbose = false;
         int device = 0;
     };

@@ -68,7 +68,12 @@ typedef struct erasor_params {
     /* VoI radius used by fetch_VoI: /erasor/max_range read a second time with a
      * different default (60.0, OMU.cpp:78).  <=0 means "same as max_range". */
     double  voi_max_range;
-    int32_t reserved_[7];
+    /* /large_scale/... (OMU.cpp:75-76): map_arranged_ becomes a submap |dx|,|dy| < submap_size around the pose,
+     * re-centred when the pose moves more than submap_size/2 (OMU.cpp:332-379); save = submap + complement */
+    int32_t is_large_scale;        /* default false */
+    int32_t reserved0_;
+    double  submap_size;           /* default 200.0 */
+    int32_t reserved_[3];
 } erasor_params;
 
 /* Per-step result: the sizes the reference prints (OMU.cpp:431-433,452-464) plus

@@ -861,6 +861,53 @@ struct Updater {
     erasor_params P;
     Erasor er;
     Cloud map_arranged;
+    // large-scale mode (OMU.cpp:75-76, 332-379): map_arranged is the submap, the rest lives here
+    Cloud map_arranged_global, map_arranged_complement;
+    bool is_submap_not_initialized = true;
+    double submap_center_x = 0, submap_center_y = 0;
+    uint32_t n_reassign = 0;
+
+    // OMU.cpp:360-379
+    static void set_submap(const Cloud &map_global, Cloud &submap, Cloud &submap_complement, double x, double y, double submap_size) {
+        submap.clear();
+        submap_complement.clear();
+        for (const Pt &pt : map_global) {
+            const double diff_x = fabs(x - pt.x);
+            const double diff_y = fabs(y - pt.y);
+            if ((diff_x < submap_size) && (diff_y < submap_size))
+                submap.push_back(pt);
+            else
+                submap_complement.push_back(pt);
+        }
+    }
+    // OMU.cpp:332-358
+    void reassign_submap(double pose_x, double pose_y) {
+        if (is_submap_not_initialized) {
+            set_submap(map_arranged_global, map_arranged, map_arranged_complement, pose_x, pose_y, P.submap_size);
+            submap_center_x = pose_x;
+            submap_center_y = pose_y;
+            is_submap_not_initialized = false;
+            ++n_reassign;
+        } else {
+            const double diff_x = fabs(submap_center_x - pose_x);
+            const double diff_y = fabs(submap_center_y - pose_y);
+            const double half_size = P.submap_size / 2.0;
+            if ((diff_x > half_size) || (diff_y > half_size)) {
+                map_arranged_global = map_arranged;
+                map_arranged_global.insert(map_arranged_global.end(), map_arranged_complement.begin(), map_arranged_complement.end());
+                set_submap(map_arranged_global, map_arranged, map_arranged_complement, pose_x, pose_y, P.submap_size);
+                submap_center_x = pose_x;
+                submap_center_y = pose_y;
+                ++n_reassign;
+            }
+        }
+    }
+    // what save_static_map starts from (OMU.cpp:179-184)
+    Cloud full_map() const {
+        Cloud m = map_arranged;
+        if (P.is_large_scale) m.insert(m.end(), map_arranged_complement.begin(), map_arranged_complement.end());
+        return m;
+    }
     // last-step products
     Cloud query_voi, map_voi, map_outskirts, static_estimate, complement, map_rejected, curr_rejected, ground_viz;
     std::vector<uint64_t> voi_src, rejected_src;
@@ -871,6 +918,7 @@ struct Updater {
     void step(const Cloud &scan, const float T_l2b[16], const float T_b2o[16], const float T_o2b[16]) {
         memset(&res, 0, sizeof(res));
         er.n_neg_sector = er.n_degenerate_plane = er.n_voxel_overflow = er.n_ambiguous = 0;
+        if (P.is_large_scale) reassign_submap((double)T_b2o[3], (double)T_b2o[7]);  // OMU.cpp:246-251
         res.n_map_in = map_arranged.size();
         // 1. query (OMU.cpp:237-241)
         Cloud q_vox;
@@ -978,6 +1026,8 @@ void orc_params_default(erasor_params *p) {
     p->query_voxel_size = 0.05;
     p->removal_interval = 2;
     p->voi_max_range = 0.0;
+    p->is_large_scale = 0;   // OMU.cpp:75
+    p->submap_size = 200.0;  // OMU.cpp:76
 }
 
 void orc_geopose2eigen(const double pose7[7], float T[16]) { geoPose2eigen(pose7, T); }
@@ -1090,7 +1140,11 @@ void *orc_create(const erasor_params *p) {
 }
 void orc_destroy(void *h) { delete (Updater *)h; }
 int orc_set_map(void *h, const float *xyzi, size_t n) {
-    to_cloud(xyzi, n, ((Updater *)h)->map_arranged);
+    Updater *u = (Updater *)h;
+    to_cloud(xyzi, n, u->map_arranged);
+    u->map_arranged_global = u->map_arranged;  // OMU.cpp:133-140
+    u->map_arranged_complement.clear();
+    u->is_submap_not_initialized = true;
     return 0;
 }
 int orc_step(void *h, const float *scan, size_t n, const float T_l2b[16], const float T_b2o[16], const float T_o2b[16], erasor_step_result *res) {
@@ -1103,10 +1157,15 @@ int orc_step(void *h, const float *scan, size_t n, const float T_l2b[16], const 
     return 0;
 }
 int orc_map_size(void *h, size_t *n) {
+    Updater *u = (Updater *)h;
+    *n = u->map_arranged.size() + (u->P.is_large_scale ? u->map_arranged_complement.size() : 0);
+    return 0;
+}
+int orc_get_map(void *h, float *dst, size_t cap, size_t *n) { return from_cloud(((Updater *)h)->full_map(), dst, cap, n); }
+int orc_submap_size(void *h, size_t *n) {
     *n = ((Updater *)h)->map_arranged.size();
     return 0;
 }
-int orc_get_map(void *h, float *dst, size_t cap, size_t *n) { return from_cloud(((Updater *)h)->map_arranged, dst, cap, n); }
 int orc_get_cloud(void *h, int which, float *dst, size_t cap, size_t *n) {
     Updater *u = (Updater *)h;
     switch (which) {
@@ -1117,7 +1176,7 @@ int orc_get_cloud(void *h, int which, float *dst, size_t cap, size_t *n) {
         case ERASOR_CLOUD_MAP_REJECTED: return from_cloud(u->map_rejected, dst, cap, n);
         case ERASOR_CLOUD_CURR_REJECTED: return from_cloud(u->curr_rejected, dst, cap, n);
         case ERASOR_CLOUD_GROUND_VIZ: return from_cloud(u->ground_viz, dst, cap, n);
-        case ERASOR_CLOUD_MAP: return from_cloud(u->map_arranged, dst, cap, n);
+        case ERASOR_CLOUD_MAP: return from_cloud(u->full_map(), dst, cap, n);
     }
     return ERASOR_E_INVALID;
 }

@@ -24,7 +24,8 @@ class Params(C.Structure):
         ("gf_th_seeds_height", C.c_double), ("map_voxel_size", C.c_double),
         ("version", C.c_int32), ("query_voxel_size", C.c_double),
         ("removal_interval", C.c_int32), ("voi_max_range", C.c_double),
-        ("reserved_", C.c_int32 * 7),
+        ("is_large_scale", C.c_int32), ("reserved0_", C.c_int32), ("submap_size", C.c_double),
+        ("reserved_", C.c_int32 * 3),
     ]
 
 

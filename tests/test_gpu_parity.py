@@ -159,6 +159,23 @@ def test_step_parity_on_synthetic_sequences(gpu_mod, seq, version, steps):
         compare_step(g, o, rg, ro)
 
 
+@pytest.mark.parametrize("submap_size", [25.0, 8.0, 500.0])
+def test_large_scale_submap_mode(gpu_mod, submap_size):
+    """/large_scale/is_large_scale (OMU.cpp:332-379): submap re-centring, save = submap + complement"""
+    import copy
+    sc = scenarios.small()
+    p = copy.copy(sc["params"])
+    p.is_large_scale, p.submap_size = 1, submap_size
+    g, o = make_pair(gpu_mod, p)
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    for f in range(12):
+        ro = o.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        rg = g.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        assert g.map_size() == o.map_size()
+        compare_step(g, o, rg, ro, full=(f < 2))
+
+
 def test_outskirts_rebuild_is_invisible(gpu_mod):
     """tombstones + front growth are an HBM layout detail: forcing the compaction must not change anything"""
     sc = scenarios.small()

@@ -367,3 +367,33 @@ def test_unsupported_version_is_rejected():
     o.set_map(np.zeros((1, 4), np.float32))
     with pytest.raises(RuntimeError):
         o.step(np.zeros((0, 4), np.float32), I4, I4, I4)
+
+
+# ---------------------------------------------------------------------------------------------
+# large-scale (submap) mode: OMU.cpp:332-379
+# ---------------------------------------------------------------------------------------------
+def test_large_scale_submap_semantics():
+    from scenarios import small
+    sc = small()
+    p = params(is_large_scale=1, submap_size=25.0)
+    o = orc.Oracle(p)
+    o.set_map(sc["map"])
+    n0 = len(sc["map"])
+    x0, y0 = float(sc["T_b2o"][0][3]), float(sc["T_b2o"][0][7])
+    r = o.step(sc["scans"][0], sc["T_l2b"], sc["T_b2o"][0], sc["T_o2b"][0])
+    m = sc["map"]
+    box = (np.abs(x0 - m[:, 0].astype(np.float64)) < 25.0) & (np.abs(y0 - m[:, 1].astype(np.float64)) < 25.0)   # full submap_size, not half
+    assert r.n_map_in == box.sum()                                   # map_arranged_ is the submap
+    full = o.get_map()                                               # save = submap + complement (OMU.cpp:181)
+    assert len(full) == r.n_map_out + (n0 - box.sum())
+    assert np.array_equal(full[r.n_map_out:], m[~box])               # complement: untouched, original order
+    # re-centring only after moving more than submap_size / 2 (OMU.cpp:342-345)
+    sizes = []
+    for f in range(1, 12):
+        r = o.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        sizes.append(o.map_size())
+        moved = max(abs(float(sc["T_b2o"][f][3]) - x0), abs(float(sc["T_b2o"][f][7]) - y0))
+        if moved > 12.5:
+            break
+    assert moved > 12.5, "scenario does not travel far enough to re-centre the submap"
+    assert r.n_static + r.n_dynamic == r.n_map_out                   # counters are over the submap only
