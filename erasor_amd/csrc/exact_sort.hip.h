@@ -316,10 +316,20 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
         const uint32_t lowm = w0 & ((2u << bi) - 1u);  // bits <= bi
         uint32_t a, b;
         if (lowm) a = (wi << 5) + (31u - (uint32_t)__builtin_clz(lowm));
-        else a = ((wi - 1) << 5) + (31u - (uint32_t)__builtin_clz(head[wi - 1]));
+        else {
+            const uint32_t wp = wi > (seg_first >> 5) ? head[wi - 1] : 0u;
+            a = wp ? ((wi - 1) << 5) + (31u - (uint32_t)__builtin_clz(wp)) : seg_first;
+        }
         const uint32_t highm = bi == 31u ? 0u : (w0 & ~((2u << bi) - 1u));  // bits > bi
         if (highm) b = (wi << 5) + (uint32_t)__builtin_ctz(highm);
-        else b = ((wi + 1) << 5) + (uint32_t)__builtin_ctz(head[wi + 1]);
+        else {
+            const uint32_t wn = wi < (seg_last >> 5) ? head[wi + 1] : 0u;
+            b = wn ? ((wi + 1) << 5) + (uint32_t)__builtin_ctz(wn) : seg_last;
+        }
+        // only reachable after a segment-queue overflow (already flagged as an error): stay inside the segment
+        if (a < seg_first) a = seg_first;
+        if (b > seg_last) b = seg_last;
+        if (i >= a + (uint32_t)kThreshold) a = i - (uint32_t)kThreshold + 1u;
         // stable rank inside the leaf: 16 independent loads, predicated
         const uint32_t ki = K[i];
         uint32_t r = 0;

@@ -757,8 +757,8 @@ struct EsQueues {
 //   children : one workgroup: children -> next wide list (median move done here) / level queue / final queue
 static constexpr uint32_t WIDE_MIN = 16384;  // segments at least this long use the wide path
 static constexpr uint32_t WTILE = 2048;      // 256 threads x 8 keys
-static constexpr uint32_t WSEG_MAX = 64;     // wide segments per level
-static constexpr uint32_t WTILES_MAX = 2048; // tiles per level (all wide segments together) -> n up to ~4 M keys
+static constexpr uint32_t WSEG_MAX = 1024;   // wide segments per level (n / WIDE_MIN: ~16 M keys)
+static constexpr uint32_t WTILES_MAX = 8192; // tiles per level (all wide segments together) -> n up to ~16 M keys
 static constexpr uint32_t WPARTS = 8;        // workgroups sharing one segment's swaps
 static constexpr int32_t MED_DONE = 0x40000000;  // flag in Seg::depth: median already moved to `first`
 
@@ -807,13 +807,21 @@ __global__ __launch_bounds__(256) void k_esort_wide_mark(const uint32_t *__restr
                                                           const WideState *ws, int cur, uint32_t *__restrict__ tileL,
                                                           uint32_t *__restrict__ tileR) {
     __shared__ uint32_t sm[40];
+    __shared__ uint32_t s_si;
     const uint32_t nseg = ws->nseg[cur], ntot = ws->ntiles[cur];
     for (uint32_t gt = blockIdx.x; gt < ntot; gt += gridDim.x) {
-        uint32_t si = 0;
-        while (si + 1 < nseg && gt >= wseg[si + 1].tile0) ++si;
+        // which segment owns tile gt?  (slots and tile ranges are handed out by atomics: no ordering to rely on)
+        if (threadIdx.x == 0) s_si = 0xFFFFFFFFu;
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < nseg; c += blockDim.x) {
+            const uint32_t t0 = wseg[c].tile0;
+            if (gt >= t0 && gt < t0 + wseg[c].ntiles) s_si = c;
+        }
+        __syncthreads();
+        const uint32_t si = s_si;
+        if (si == 0xFFFFFFFFu) continue;  // tile ids of children that were routed to the level queue instead
         const WideSeg sg = wseg[si];
         const uint32_t t = gt - sg.tile0;
-        if (t >= sg.ntiles) continue;  // tile ids of children that were routed to the level queue instead
         const uint32_t p = K[sg.first];
         const uint32_t lo = sg.first + 1 + t * WTILE;
         const uint32_t hi = min(lo + WTILE, sg.last);

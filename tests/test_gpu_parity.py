@@ -311,3 +311,15 @@ def test_full_size_parity_and_properties(gpu_mod):
         n_prev = rg.n_map_out
         ro = o.step(s, Tl, Tb, To)
         compare_step(g, o, rg, ro, full=(k == 0))
+
+
+def test_whole_map_save_voxelisation(gpu_mod):
+    """save_static_map's voxelize_preserving_labels over a multi-million-point map (OMU.cpp:186): the exact sort's
+    multi-workgroup levels, thousands of wide segments, label NN at scale"""
+    from oracle import orc
+    w = synth.World(seed=20210305 + 5, length=600.0, n_streets=3, street_gap=50.0)
+    m = w.sample_map(spacing=0.2, frames=range(0, 100, 2))
+    assert len(m) > 3_000_000
+    g = gpu_mod.Erasor(gpu_mod.params_default())
+    for leaf in (0.2, 0.4):
+        same(g.voxelize_preserving_labels(m, leaf), orc.voxelize_preserving_labels(m, leaf), "saved map, leaf %.1f" % leaf)
