@@ -181,7 +181,7 @@ void prof_collect(erasor_hip_handle *h) {
 #define LAUNCH(h, name, kern, grid, block, ...)                                   \
     do {                                                                          \
         PendingEvt pe_;                                                           \
-        const bool prof_ = (h)->prof == 1 || ((h)->prof == 2 && strcmp(name, "voi_split") == 0); \
+        const bool prof_ = (h)->prof == 1 || ((h)->prof == 2 && strncmp(name, "voi_split", 9) == 0); \
         if (prof_) {                                                              \
             pe_.name_id = prof_id((h), name);                                     \
             pe_.a = get_evt(h);                                                   \
@@ -718,6 +718,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         // one chunk per wave while that needs <= 16 workgroups per CU: the hardware back-fills workgroups as they finish,
         // which balances better than a grid-stride tail (measured, tools/bw_probe.hip)
         const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(waves_needed, 4), 256 * 16));
+        if (h->prof == 2) hipLaunchKernelGGL(k_null, dim3(1), dim3(64), 0, h->stream);  // same predecessor state for both brackets
+        if (h->prof == 2) LAUNCH(h, "voi_split_event_calib", k_null, 1, 64);
         LAUNCH(h, "voi_split", k_voi_split, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, (const float2 *)h->Oxy.p, h->o_begin,
                o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p);
         const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));

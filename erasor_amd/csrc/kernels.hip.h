@@ -2005,6 +2005,9 @@ __global__ __launch_bounds__(256) void k_count_labels4(const float4 *__restrict_
     }
 }
 
+// empty kernel: bracketed by HIP events exactly like k_voi_split to measure the bracket's own overhead
+__global__ void k_null() {}
+
 __global__ void k_step_begin(DevState *st, Counters *ctr, uint32_t q_nvox_init) {
     st->q_nvox = q_nvox_init;
     ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
