@@ -8,10 +8,10 @@ from oracle import orc
 
 
 @functools.lru_cache(maxsize=8)
-def small(seq="05", n_frames=12, az=500, length=200.0, version=3, seed=20210310):
+def small(seq="05", n_frames=12, az=500, length=200.0, version=3, seed=20210310, lidar="hdl64"):
     """~70 k-pt accumulated map, ~28 k-pt scans, seq-shaped parameters."""
     w = synth.World(seed=seed, length=length)
-    lid = synth.Lidar.hdl64(az)
+    lid = synth.Lidar.hdl64(az) if lidar == "hdl64" else synth.Lidar.ouster128(az)
     frames = list(range(0, 2 * n_frames, 2))
     m, scans, poses = w.accumulate_map(frames, lid, step=1.0)
     p = orc.params_default()

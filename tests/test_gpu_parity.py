@@ -159,6 +159,51 @@ def test_step_parity_on_synthetic_sequences(gpu_mod, seq, version, steps):
         compare_step(g, o, rg, ro)
 
 
+def test_baseline_config_shapes(gpu_mod):
+    """BASELINE.json configs 3-5 at test size: seq 02 thresholds; config/large_scale_05.yaml parameters with
+    /large_scale/is_large_scale (submap 160 m, launch/run_erasor_in_large_scale.launch:4-5); an Ouster-128 stream
+    (config/your_own_env_ouster.yaml: 20 m / 20 x 60 / lidar2body identity, 262 k rays per scan)"""
+    import copy
+    from oracle import orc
+    cases = [(scenarios.small(seq="02"), {}, 3),
+             (scenarios.small(seq="large_scale_05"), {"is_large_scale": 1, "submap_size": 160.0}, 3),
+             (scenarios.small(seq="ouster", lidar="ouster128", az=2048, n_frames=4, length=120.0), {}, 3)]
+    for sc, over, steps in cases:
+        p = copy.copy(sc["params"])
+        for k, v in over.items():
+            setattr(p, k, v)
+        Tl = sc["T_l2b"] if sc["seq"] != "ouster" else orc.geopose2eigen([0, 0, 0, 0, 0, 0, 1])  # your_own_env_ouster.yaml:33
+        g, o = make_pair(gpu_mod, p)
+        g.set_map(sc["map"])
+        o.set_map(sc["map"])
+        for f in range(steps):
+            ro = o.step(sc["scans"][f], Tl, sc["T_b2o"][f], sc["T_o2b"][f])
+            rg = g.step(sc["scans"][f], Tl, sc["T_b2o"][f], sc["T_o2b"][f])
+            compare_step(g, o, rg, ro, full=(f == 0))
+
+
+def test_pr_rr_end_to_end(gpu_mod):
+    """the metric's quality half: PR / RR of the saved static map (voxelised at 0.2 like save_static_map, OMU.cpp:186)
+    against the labelled initial map, GPU and oracle, with the evaluator that is pinned to scripts/analysis_runner.py"""
+    from oracle import orc
+    from erasor_amd import evalmap
+    sc = scenarios.small()
+    g, o = make_pair(gpu_mod, sc["params"])
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    for f in range(12):
+        o.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        g.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+    saved_g = g.voxelize_preserving_labels(g.get_map(), 0.2)
+    saved_o = orc.voxelize_preserving_labels(o.get_map(), 0.2)
+    same(saved_g, saved_o, "saved static map")
+    gt = orc.voxelize_preserving_labels(sc["map"], 0.2)
+    rg, ro = evalmap.evaluate_clouds(gt, saved_g, 0.2), evalmap.evaluate_clouds(gt, saved_o, 0.2)
+    assert rg == ro
+    before = evalmap.evaluate_clouds(gt, gt, 0.2)
+    assert before["RR"] == 0.0 and rg["RR"] > 50.0 and rg["PR"] > 90.0, rg   # dynamic trails go, static structure stays
+
+
 @pytest.mark.parametrize("submap_size", [25.0, 8.0, 500.0])
 def test_large_scale_submap_mode(gpu_mod, submap_size):
     """/large_scale/is_large_scale (OMU.cpp:332-379): submap re-centring, save = submap + complement"""
