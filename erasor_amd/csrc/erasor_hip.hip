@@ -627,14 +627,14 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
     if (n > ES_LMAX) {
         // level queue: one workgroup per segment, one partition per launch.  Segments that are still big after `nlev`
         // levels are finished (slowly, in global memory) by the final kernel, so any nlev is correct.
-        nlev = std::min(2 * esort::lg2_floor(n), n >= WIDE_MIN ? 6 : 12);
+        nlev = std::min(2 * esort::lg2_floor(n), n >= WIDE_MIN ? (n > (1u << 21) ? 12 : 2) : 12);
         for (int l = 0; l < nlev; ++l)
             LAUNCH(h, "q_esort", k_esort_level, 48, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->esq0.p, h->esq1.p, h->esq2.p,
                    h->essmall.p, h->esqs.p, l, 65536u, dc);
     }
     const int bigcur = nlev % 3;
     esort::Seg *qs3[3] = {h->esq0.p, h->esq1.p, h->esq2.p};
-    LAUNCH(h, "q_esort_final", k_esort_final, 256, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->qhead.p, h->qk_b.p, h->qv_b.p,
+    LAUNCH(h, "q_esort_final", k_esort_final, 2048, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->qhead.p, h->qk_b.p, h->qv_b.p,
            (const esort::Seg *)h->essmall.p, (const esort::Seg *)qs3[bigcur], h->esqs.p, bigcur, dc, h->dbg_stamps.p);
 }
 

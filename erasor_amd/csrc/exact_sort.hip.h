@@ -75,12 +75,16 @@ __device__ __forceinline__ uint32_t wave_partition(KP K, VP V, PP posL, PP posR,
 // ballots, a scalar loop over the stop masks (pairs L[k] <-> R[k]) and ONE permute.  Leaves (<= 16 keys) are marked in
 // head[] for the caller's stable leaf ranking.  Exactly the same swaps as wave_partition / the sequential algorithm.
 template <class KP, class VP, class HP>
-__device__ __forceinline__ void wave_small_subtree(KP K, VP V, HP head, uint32_t first, uint32_t last, int32_t depth, uint32_t *n_fallback) {
+__device__ __forceinline__ void wave_small_subtree(KP K, VP V, HP head, uint32_t first, uint32_t last, int32_t depth, uint32_t *n_fallback,
+                                                   uint32_t *wsc /* 128 uint32 of LDS owned by this wavefront */) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n = last - first;  // 17..64
+    const uint64_t lt = lanemask_lt();
+    const uint64_t gt = ~(lt | (1ull << lane));  // lanes above this one
+    const uint32_t n = last - first;             // 17..64
     uint32_t k = lane < n ? (uint32_t)K[first + lane] : 0xFFFFFFFFu;
     uint32_t v = lane < n ? (uint32_t)V[first + lane] : 0u;
     uint64_t heads = 0;  // bit i: a leaf starts at lane i (i > 0)
+    uint32_t *wsL = wsc, *wsR = wsc + 64;
     // pending sub-ranges (lane indices), at most 64/17 = 3 alive at once
     uint32_t sf[4], se[4];
     int32_t sd[4];
@@ -117,19 +121,26 @@ __device__ __forceinline__ void wave_small_subtree(KP K, VP V, HP head, uint32_t
         if (lane == f) { k = p; v = vm; }
         if (lane == mp) { k = kf; v = vf; }
         const bool inr = lane > f && lane < e;
-        uint64_t ml = __ballot(inr && !(k < p)), mr = __ballot(inr && !(p < k));
-        uint32_t src = lane, cut = 0xFFFFFFFFu, lastb = 0xFFFFFFFFu;
-        while (ml != 0ull && mr != 0ull) {
-            const uint32_t la = (uint32_t)__builtin_ctzll(ml), rb = 63u - (uint32_t)__builtin_clzll(mr);
-            if (!(la < rb)) break;
-            if (lane == la) src = rb;
-            if (lane == rb) src = la;
-            ml &= ml - 1ull;
-            mr &= ~(1ull << rb);
-            lastb = rb;
+        const bool isL = inr && !(k < p), isR = inr && !(p < k);
+        const uint64_t ml = __ballot(isL), mr = __ballot(isR);
+        // rank tables: wsL[k] = k-th left stop (ascending), wsR[k] = k-th right stop counted from the top
+        const uint32_t rkL = (uint32_t)__popcll(ml & lt), rkR = (uint32_t)__popcll(mr & gt);
+        if (isL) wsL[rkL] = lane;
+        if (isR) wsR[rkR] = lane;
+        wave_sync();
+        const uint32_t nL = (uint32_t)__popcll(ml), nR = (uint32_t)__popcll(mr), lim = nL < nR ? nL : nR;
+        const uint32_t lk = lane < nL ? wsL[lane] : 0xFFFFFFFFu, rk = lane < nR ? wsR[lane] : 0u;
+        const uint32_t m = (uint32_t)__popcll(__ballot(lane < lim && lk < rk));  // monotone predicate: count == first false
+        uint32_t cut = 0xFFFFFFFFu;
+        if (m < nL) cut = __builtin_amdgcn_readlane(lk, m);
+        if (m > 0) {
+            const uint32_t r = __builtin_amdgcn_readlane(rk, m - 1);
+            if (r < cut) cut = r;
         }
-        if (ml != 0ull) cut = (uint32_t)__builtin_ctzll(ml);
-        if (lastb < cut) cut = lastb;
+        uint32_t src = lane;
+        if (isL && rkL < m) src = wsR[rkL];
+        if (isR && rkR < m) src = wsL[rkR];
+        wave_sync();  // the tables are rewritten by the next partition
         k = __shfl(k, (int)src, 64);
         v = __shfl(v, (int)src, 64);
         heads |= 1ull << cut;
@@ -200,6 +211,7 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
             qcnt[0] = 1;
         }
     }
+    __shared__ uint32_t s_wsc[16][128];  // per-wavefront rank tables of wave_small_subtree
     __syncthreads();
     ESORT_STAMP(0);
     // phase 1: long segments are partitioned by the WHOLE workgroup, one after the other (a short stack); their
@@ -270,7 +282,7 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
                 continue;
             }
             if (sg.last - sg.first <= 64u) {  // whole subtree in registers, no children to queue
-                wave_small_subtree(K, V, head, sg.first, sg.last, sg.depth, n_fallback);
+                wave_small_subtree(K, V, head, sg.first, sg.last, sg.depth, n_fallback, &s_wsc[wave][0]);
                 continue;
             }
             const uint32_t cut = wave_partition(K, V, posL, posR, sg.first, sg.last);

@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4 *__restrict__ p
 }
 
 // ---- exact std::sort of the (idx, point) pairs, global memory -----------------------------------
-static constexpr uint32_t ES_LMAX = 4096;   // segments up to this size are finished inside LDS
+static constexpr uint32_t ES_LMAX = 2048;   // segments up to this size are finished inside LDS
 struct EsQueues {
     uint32_t cnt[3];      // three rotating level queues: level l reads [l%3], appends to [(l+1)%3], clears [(l+2)%3]
     uint32_t small_cnt;   // segments handed to the final kernel
@@ -755,7 +755,7 @@ struct EsQueues {
 //   swap     : WPARTS workgroups per segment: tile prefix, m by a block-wide multiway search over the two-level
 //              stop lists, cut, then the m swaps split between the workgroups
 //   children : one workgroup: children -> next wide list (median move done here) / level queue / final queue
-static constexpr uint32_t WIDE_MIN = 16384;  // segments at least this long use the wide path
+static constexpr uint32_t WIDE_MIN = ES_LMAX + 1;  // segments at least this long use the wide path (everything the LDS finisher cannot take)
 static constexpr uint32_t WTILE = 2048;      // 256 threads x 8 keys
 static constexpr uint32_t WSEG_MAX = 1024;   // wide segments per level (n / WIDE_MIN: ~16 M keys)
 static constexpr uint32_t WTILES_MAX = 8192; // tiles per level (all wide segments together) -> n up to ~16 M keys
