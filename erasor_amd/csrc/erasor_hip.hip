@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -45,7 +47,14 @@ struct erasor_hip_handle {
     erasor_params P;
     DP dp;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // main stream: query chain, SRT .. write-back
+    hipStream_t stream2 = nullptr;  // map chain of a step (VoI split .. bin stats), concurrent with the query chain
+    hipStream_t cur = nullptr;      // stream LAUNCH() currently targets
+    hipEvent_t ev_fork = nullptr, ev_keys = nullptr, ev_join = nullptr;
+    const float4 *scan_in = nullptr;  // scan of the step in flight (the caller's device buffer, or h->scan)
+    HostOut *pin = nullptr;         // pinned host block k_step_end reports into
+    bool forked = false;            // ev_join has been recorded at least once
+    int bank = 0;                   // scratch bank of scan/radix helpers (0: main stream, 1: stream2)
     std::string err;
     bool have_map = false, have_step = false;
 
@@ -71,7 +80,7 @@ struct erasor_hip_handle {
     DBuf<uint32_t> voi_key, voi_src, ssrc, rejected_src, grank, glist;
     DBuf<uint8_t> gflag;
     // ---- radix ----
-    DBuf<uint32_t> rk_a, rk_b, rv_a, rv_b, hist, hist_l, hist_t, dn;
+    DBuf<uint32_t> rk_a, rk_b, rv_a, rv_b, hist, hist_l, hist_t, hist2, hist2_l, hist2_t, dn;
     // ---- bins ----
     DBuf<uint32_t> moff, mcnt, qoff, ccnt, rev_idx, rev_list, vox_off, nvox, ng, out_off, ground_off, rej_off, crej_off;
     DBuf<float> mmin, mmax, cmin, cmax, plane_n;
@@ -186,16 +195,16 @@ void prof_collect(erasor_hip_handle *h) {
             pe_.name_id = prof_id((h), name);                                     \
             pe_.a = get_evt(h);                                                   \
             pe_.b = get_evt(h);                                                   \
-            (void)hipEventRecord(pe_.a, (h)->stream);                             \
+            (void)hipEventRecord(pe_.a, (h)->cur);                                \
         }                                                                         \
         if (g_debug_sync) fprintf(stderr, "[erasor_hip] launch %s grid=%u\n", name, (unsigned)(grid)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (h)->stream, __VA_ARGS__); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (h)->cur, __VA_ARGS__); \
         if (g_debug_sync) {                                                       \
-            hipError_t e2_ = hipStreamSynchronize((h)->stream);                   \
+            hipError_t e2_ = hipStreamSynchronize((h)->cur);                      \
             if (e2_ != hipSuccess) fprintf(stderr, "[erasor_hip]   -> %s\n", hipGetErrorString(e2_)); \
         }                                                                         \
         if (prof_) {                                                              \
-            (void)hipEventRecord(pe_.b, (h)->stream);                             \
+            (void)hipEventRecord(pe_.b, (h)->cur);                                \
             (h)->pending.push_back(pe_);                                          \
         }                                                                         \
     } while (0)
@@ -250,15 +259,16 @@ int radix_sort(erasor_hip_handle *h, const uint32_t *keys_in, uint32_t n_ub, con
                uint32_t *va, uint32_t *vb, const uint32_t **skeys, const uint32_t **sperm, const char *tag) {
     const uint32_t nblk = std::max(1u, cdiv(n_ub, RTILE));
     const uint32_t nhist = 256u * nblk;
-    if (ensure(h, h->hist, nhist) || ensure(h, h->hist_l, nhist) || ensure(h, h->hist_t, cdiv(nhist, 1024) + 2)) return ERASOR_E_NO_DEVICE;
+    DBuf<uint32_t> &H = h->bank ? h->hist2 : h->hist, &HL = h->bank ? h->hist2_l : h->hist_l, &HT = h->bank ? h->hist2_t : h->hist_t;
+    if (ensure(h, H, nhist) || ensure(h, HL, nhist) || ensure(h, HT, cdiv(nhist, 1024) + 2)) return ERASOR_E_NO_DEVICE;
     const uint32_t *kin = keys_in;
     const uint32_t *vin = nullptr;
     uint32_t *kout = ka, *vout = va;
-    uint32_t *nhist_dev = h->dn.p + 8;
+    uint32_t *nhist_dev = h->dn.p + 8 + h->bank;
     for (int shift = 0; shift < bits; shift += 8) {
-        LAUNCH(h, tag, k_radix_hist, nblk, 256, kin, n_ub, n_dev, shift, h->hist.p, nhist_dev);
-        scan_u32(h, h->hist.p, h->hist_l.p, h->hist_t.p, nhist, nhist, n_dev ? (const uint32_t *)nhist_dev : nullptr, nullptr, tag);
-        LAUNCH(h, tag, k_radix_scatter, nblk, 256, kin, vin, n_ub, n_dev, shift, (const uint32_t *)h->hist_l.p, (const uint32_t *)h->hist_t.p,
+        LAUNCH(h, tag, k_radix_hist, nblk, 256, kin, n_ub, n_dev, shift, H.p, nhist_dev);
+        scan_u32(h, H.p, HL.p, HT.p, nhist, nhist, n_dev ? (const uint32_t *)nhist_dev : nullptr, nullptr, tag);
+        LAUNCH(h, tag, k_radix_scatter, nblk, 256, kin, vin, n_ub, n_dev, shift, (const uint32_t *)HL.p, (const uint32_t *)HT.p,
                kout, vout);
         kin = kout;
         vin = vout;
@@ -529,10 +539,16 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
     memset(&h->st, 0, sizeof(h->st));
     memset(&h->ctr, 0, sizeof(h->ctr));
     memset(&h->last_res, 0, sizeof(h->last_res));
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_keys, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void **)&h->pin, sizeof(HostOut), hipHostMallocDefault) != hipSuccess) {
         delete h;
         return ERASOR_E_NO_DEVICE;
     }
+    h->cur = h->stream;
     if (alloc_bins(h)) {
         erasor_hip_destroy(h);
         return ERASOR_E_NO_DEVICE;
@@ -551,7 +567,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->vmask); release(h->hmask); release(h->cinfo); release(h->pvl); release(h->phl); release(h->topv); release(h->toph);
     release(h->voi_ego); release(h->spts); release(h->rejected); release(h->voi_key); release(h->voi_src); release(h->ssrc);
     release(h->rejected_src); release(h->grank); release(h->glist); release(h->gflag);
-    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->dn);
+    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn);
     release(h->moff); release(h->mcnt); release(h->qoff); release(h->ccnt); release(h->rev_idx); release(h->rev_list); release(h->vox_off);
     release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
     release(h->mmin); release(h->mmax); release(h->cmin); release(h->cmax); release(h->plane_n); release(h->plane_d);
@@ -562,6 +578,14 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->wseg0); release(h->wseg1); release(h->wstate); release(h->wtileL); release(h->wtileR); release(h->esq0); release(h->esq1); release(h->esq2); release(h->essmall); release(h->esqs); release(h->qgrid);
     release(h->gsK); release(h->gsV); release(h->gsL); release(h->gsR); release(h->gsK2); release(h->gsV2); release(h->gsH); release(h->gsC);
     release(h->vox_out); release(h->d_st); release(h->d_ctr);
+    if (h->stream2) {
+        (void)hipStreamSynchronize(h->stream2);
+        (void)hipStreamDestroy(h->stream2);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_keys) (void)hipEventDestroy(h->ev_keys);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->pin) (void)hipHostFree(h->pin);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -639,13 +663,14 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
 }
 
 // ---- exact voxelisation of the cloud in h->scan[0..n): fills run_begin / cent / ukeys, d_st->q_nvox -------------------
-static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf) {
+static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf, const std::function<void()> &after_keys) {
     DevState *ds = h->d_st.p;
     Counters *dc = h->d_ctr.p;
-    LAUNCH(h, "q_bbox", k_bbox_init, 1, 64, h->bb.p);
-    if (n) LAUNCH(h, "q_bbox", k_bbox, std::min<uint32_t>(cdiv(n, 256), 1024), 256, (const float4 *)h->scan.p, n, h->bb.p);
-    LAUNCH(h, "q_keys", k_voxel_keys, std::max(1u, cdiv(n, 256)), 256, (const float4 *)h->scan.p, n, (const uint32_t *)h->bb.p, leaf, h->qk_a.p,
+    // (the bounding box was reset by k_step_begin)
+    if (n) LAUNCH(h, "q_bbox", k_bbox, std::min<uint32_t>(cdiv(n, 256), 1024), 256, h->scan_in, n, h->bb.p);
+    LAUNCH(h, "q_keys", k_voxel_keys, std::max(1u, cdiv(n, 256)), 256, h->scan_in, n, (const uint32_t *)h->bb.p, leaf, h->qk_a.p,
            h->qv_a.p, h->qgrid.p, dc);
+    after_keys();  // ctr->err (VoxelGrid overflow) is final from here on: the caller may fork work that depends on it
     // exact std::sort: a few global levels (one workgroup per big segment), then per-segment completion in LDS
     run_exact_sort(h, n);
     // runs
@@ -668,6 +693,12 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     if (!T_l2b || !T_b2o || !T_o2b || (!scan_src && n_scan) || n_scan > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
     prof_collect(h);
+    const auto t_host0 = std::chrono::steady_clock::now();
+    static const bool host_timing = getenv("ERASOR_HIP_HOST_TIMING") != nullptr;
+    std::vector<std::pair<const char *, double>> marks;
+    auto MARK = [&](const char *what) {
+        if (host_timing) marks.emplace_back(what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count());
+    };
     const uint32_t ns = (uint32_t)n_scan;
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
@@ -694,17 +725,18 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         h->err = "map grew beyond the capacity reserved at set_map";
         return ERASOR_E_CAPACITY;
     }
-    rc = push_state(h);
-    if (rc) return rc;
-    LAUNCH(h, "step_begin", k_step_begin, 1, 1, ds, dc, (flags & STEP_QUERY_PREVOXELIZED) ? ns : 0u);
-    if (ns) HIPC(h, hipMemcpyAsync(h->scan.p, scan_src, (size_t)ns * sizeof(float4), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_step_begin
+    h->st.o_begin = h->o_begin;
+    if (h->forked) (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);  // a previous step that bailed out between fork and join
+    LAUNCH(h, "step_begin", k_step_begin, 1, 64, ds, dc, (flags & STEP_QUERY_PREVOXELIZED) ? ns : 0u, h->st, 1, h->bb.p);
+    // a device-resident scan is read in place (the call is synchronous: the caller's buffer outlives every kernel of the step)
+    if (ns && !src_is_device) HIPC(h, hipMemcpyAsync(h->scan.p, scan_src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    h->scan_in = src_is_device && ns ? (const float4 *)scan_src : (const float4 *)h->scan.p;
 
-    // ---- query voxelisation, part 1 (OMU.cpp:238) ----
+    MARK("prologue+upload");
+    // ---- sizes, scratch ----
     const bool prevox = (flags & STEP_QUERY_PREVOXELIZED) != 0;
-    if (!prevox) voxelize_query_part1(h, ns, P.leaf_query);
     const double voi_r2 = (flags & STEP_VOI_EVERYTHING) ? HUGE_VAL : P.voi_r2;
-
-    // ---- VoI split (OMU.cpp:254 fetch_VoI membership) ----
     const uint32_t nFchunks = cdiv(h->nF, CHUNK);
     const uint32_t o_chunk0 = h->o_begin / CHUNK;
     const uint32_t nOchunks = h->capO / CHUNK - o_chunk0;
@@ -713,39 +745,82 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         ensure(h, h->cinfo, nchunks + 8) || ensure(h, h->pvl, nchunks + 8) || ensure(h, h->phl, nchunks + 8) ||
         ensure(h, h->topv, nchunks / 1024 + 8) || ensure(h, h->toph, nchunks / 1024 + 8))
         return ERASOR_E_NO_DEVICE;
-    {
-        const uint32_t waves_needed = nchunks;
-        // one chunk per wave while that needs <= 16 workgroups per CU: the hardware back-fills workgroups as they finish,
-        // which balances better than a grid-stride tail (measured, tools/bw_probe.hip)
-        const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(waves_needed, 4), 256 * 16));
-        if (h->prof == 2) hipLaunchKernelGGL(k_null, dim3(1), dim3(64), 0, h->stream);  // same predecessor state for both brackets
-        if (h->prof == 2) LAUNCH(h, "voi_split_event_calib", k_null, 1, 64);
-        LAUNCH(h, "voi_split", k_voi_split, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, (const float2 *)h->Oxy.p, h->o_begin,
-               o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p);
-        const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));
-        LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p);
-        LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
-               nchunks, nFchunks, ds);
-    }
-    // No mid-step read-back: everything below is launched on upper-bound grids and reads the actual counts
+    // No mid-step read-back: everything is launched on upper-bound grids and reads the actual counts
     // (st->voi_total, st->q_nvox) from device memory.  n_voi <= logical map size, nq <= n_scan.
     const uint32_t n_voi = (uint32_t)std::min<uint64_t>(n_map_in, 0xFFFFFFF0ull), nq = ns;  // upper bounds from here on
     const uint32_t *nvoi_dev = &ds->voi_total, *nq_dev = &ds->q_nvox;
     rc = alloc_step(h, n_voi, nq);
     if (rc) return rc;
+    const int bits = key_bits(B + 1);
+    {   // make sure both scratch banks of the bucket sort exist before the streams fork
+        const uint32_t nb_q = 256u * std::max(1u, cdiv(nq, RTILE)), nb_m = 256u * std::max(1u, cdiv(n_voi, RTILE));
+        if (ensure(h, h->hist, nb_q) || ensure(h, h->hist_l, nb_q) || ensure(h, h->hist_t, cdiv(nb_q, 1024) + 2) || ensure(h, h->hist2, nb_m) ||
+            ensure(h, h->hist2_l, nb_m) || ensure(h, h->hist2_t, cdiv(nb_m, 1024) + 2))
+            return ERASOR_E_NO_DEVICE;
+    }
+    const uint32_t *sm_keys = nullptr, *sm_perm = nullptr;
+    HIPC(h, hipEventRecord(h->ev_fork, h->stream));  // state pushed, counters cleared, scan uploaded
 
+    // ---- map chain, on stream2, concurrent with the query chain (they only meet at the Scan Ratio Test) ----
+    auto enqueue_map_chain = [&]() {
+        MARK("  mapchain_begin");
+        h->cur = h->stream2;
+        h->bank = 1;
+        (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
+        {   // VoI split (OMU.cpp:254 fetch_VoI membership)
+            // one chunk per wave while that needs <= 16 workgroups per CU: the hardware back-fills workgroups as they finish,
+            // which balances better than a grid-stride tail (measured, tools/bw_probe.hip)
+            const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nchunks, 4), 256 * 16));
+            if (h->prof == 2) hipLaunchKernelGGL(k_null, dim3(1), dim3(64), 0, h->cur);  // same predecessor state for both brackets
+            if (h->prof == 2) LAUNCH(h, "voi_split_event_calib", k_null, 1, 64);
+            LAUNCH(h, "voi_split", k_voi_split, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, (const float2 *)h->Oxy.p, h->o_begin,
+                   o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p);
+            const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));
+            LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p);
+            LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
+                   nchunks, nFchunks, ds);
+        }
+        (void)hipStreamWaitEvent(h->stream2, h->ev_keys, 0);  // k_voi_gather must see the query side's error flag
+        {   // VoI gather + egocentric transform + R-POD key (OMU.cpp:435-437; erasor.cpp:124-139)
+            const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nchunks, 4), 256 * 8));
+            LAUNCH(h, "voi_gather", k_voi_gather, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, h->Oxy.p, h->Ozi.p, o_chunk0,
+                   nOchunks, (const unsigned long long *)h->vmask.p, (const unsigned long long *)h->hmask.p, (const uint32_t *)h->cinfo.p,
+                   (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p, (const uint32_t *)h->topv.p, (const uint32_t *)h->toph.p, h->To2b, P, ds,
+                   dc, h->voi_ego.p, h->voi_key.p, h->voi_src.p);
+        }
+        radix_sort(h, h->voi_key.p, n_voi, nvoi_dev, bits, h->rk_a.p, h->rk_b.p, h->rv_a.p, h->rv_b.p, &sm_keys, &sm_perm, "voi_bucket");
+        if (n_voi) LAUNCH(h, "voi_bucket", k_gather, cdiv(n_voi, 256), 256, (const float4 *)h->voi_ego.p, (const uint32_t *)h->voi_src.p, sm_perm,
+                          n_voi, nvoi_dev, h->spts.p, h->ssrc.p);
+        LAUNCH(h, "voi_bucket", k_bin_offsets, cdiv((uint64_t)std::max(n_voi, B + 2) + 1, 256), 256, sm_keys, n_voi, nvoi_dev, B + 1, h->moff.p);
+        LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->spts.p, (const uint32_t *)h->moff.p, B, h->mcnt.p,
+               h->mmin.p, h->mmax.p);
+        (void)hipEventRecord(h->ev_join, h->stream2);
+        MARK("  mapchain_end");
+        h->forked = true;
+        h->cur = h->stream;
+        h->bank = 0;
+    };
+
+    MARK("alloc");
+    // ---- query voxelisation, part 1 (OMU.cpp:238); the map chain is forked right after the voxel keys ----
+    // Host enqueue order matters: the main stream's (long) sort chain goes into its queue first, so that it never idles
+    // while the host is still busy enqueueing the map chain; the event right after the voxel keys is what stream2 waits for.
+    if (!prevox) voxelize_query_part1(h, ns, P.leaf_query, [&] { (void)hipEventRecord(h->ev_keys, h->stream); });
+    else (void)hipEventRecord(h->ev_keys, h->stream);
+    enqueue_map_chain();
+
+    MARK("part1+mapchain");
     // ---- query voxelisation, part 2: centroids, label NN, lidar->body, R-POD key ----
     const uint32_t *sq_keys = nullptr, *sq_perm = nullptr;
     if (prevox) {
-        if (nq) LAUNCH(h, "q_direct", k_query_direct, cdiv(nq, 256), 256, (const float4 *)h->scan.p, nq, P, dc, h->query.p, h->qkey.p);
+        if (nq) LAUNCH(h, "q_direct", k_query_direct, cdiv(nq, 256), 256, h->scan_in, nq, P, dc, h->query.p, h->qkey.p);
     } else if (nq) {
-        LAUNCH(h, "q_centroids", k_centroids, cdiv(nq, 256), 256, (const float4 *)h->scan.p, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
+        LAUNCH(h, "q_centroids", k_centroids, cdiv(nq, 256), 256, h->scan_in, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
                (const uint32_t *)h->run_begin.p, (const uint32_t *)&ds->q_nvox, h->cent.p, h->ukeys.p);
-        LAUNCH(h, "q_nn", k_query_nn, cdiv(nq, 256), 256, (const float4 *)h->scan.p, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
+        LAUNCH(h, "q_nn", k_query_nn, cdiv(nq, 256), 256, h->scan_in, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
                (const uint32_t *)h->ukeys.p, (const float4 *)h->cent.p, (const uint32_t *)&ds->q_nvox, (const VoxGrid *)h->qgrid.p, h->Tl2b, P, dc,
                h->query.p, h->qkey.p);
     }
-    const int bits = key_bits(B + 1);
     // the radix ping-pong buffers are shared by the query and the map side (capV >= capS is not guaranteed -> use q buffers)
     if (nq <= 8192) {  // tiny inputs: one single-workgroup launch instead of ten (slower than the multi-block path beyond ~10 k keys)
         LAUNCH(h, "q_bucket", k_radix_small, 1, 1024, (const uint32_t *)h->qkey.p, nq, nq_dev, bits, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p);
@@ -781,21 +856,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->sq.p, (const uint32_t *)h->qoff.p, B, h->ccnt.p,
            h->cmin.p, h->cmax.p);
 
-    // ---- VoI gather + egocentric transform + R-POD key (OMU.cpp:435-437; erasor.cpp:124-139) ----
-    {
-        const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nchunks, 4), 256 * 8));
-        LAUNCH(h, "voi_gather", k_voi_gather, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, h->Oxy.p, h->Ozi.p, o_chunk0, nOchunks,
-               (const unsigned long long *)h->vmask.p, (const unsigned long long *)h->hmask.p, (const uint32_t *)h->cinfo.p,
-               (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p, (const uint32_t *)h->topv.p, (const uint32_t *)h->toph.p, h->To2b, P, ds, dc,
-               h->voi_ego.p, h->voi_key.p, h->voi_src.p);
-    }
-    const uint32_t *sm_keys = nullptr, *sm_perm = nullptr;
-    radix_sort(h, h->voi_key.p, n_voi, nvoi_dev, bits, h->rk_a.p, h->rk_b.p, h->rv_a.p, h->rv_b.p, &sm_keys, &sm_perm, "voi_bucket");
-    if (n_voi) LAUNCH(h, "voi_bucket", k_gather, cdiv(n_voi, 256), 256, (const float4 *)h->voi_ego.p, (const uint32_t *)h->voi_src.p, sm_perm, n_voi,
-                      nvoi_dev, h->spts.p, h->ssrc.p);
-    LAUNCH(h, "voi_bucket", k_bin_offsets, cdiv((uint64_t)std::max(n_voi, B + 2) + 1, 256), 256, sm_keys, n_voi, nvoi_dev, B + 1, h->moff.p);
-    LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->spts.p, (const uint32_t *)h->moff.p, B, h->mcnt.p,
-           h->mmin.p, h->mmax.p);
+    MARK("part2");
+    HIPC(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));  // join: bins of the map are ready
 
     // ---- Scan Ratio Test, R-GPF, per-bin voxelisation (erasor.cpp:332-571) ----
     LAUNCH(h, "srt", k_srt, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)h->ccnt.p,
@@ -815,19 +877,34 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     // ---- map write-back (OMU.cpp:281-290) ----
     float4 *Fnew = h->F[h->curF ^ 1].p;
     if (n_voi)
-        LAUNCH(h, "assemble", k_assemble_map<true>, cdiv(n_voi, 256), 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
+        LAUNCH(h, "assemble", k_assemble_map<true>, std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
                sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p, (const uint32_t *)h->ccnt.p,
                (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p,
-               (const uint32_t *)h->rej_off.p, (const DevState *)ds, Fnew, h->rejected.p, h->rejected_src.p);
+               (const uint32_t *)h->rej_off.p, (const DevState *)ds, Fnew, h->rejected.p, h->rejected_src.p, ds);
     LAUNCH(h, "assemble", k_assemble_bins<true>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
            (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
-           (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, Fnew, h->curr_rejected.p);
-    LAUNCH(h, "count_labels", k_count_labels4, std::max(1u, std::min<uint32_t>(cdiv(2 * (uint64_t)n_voi + nq, 1024), 512)), 256,
-           (const float4 *)Fnew, 0u, (const uint32_t *)&ds->nF_new, &ds->F_static, &ds->F_dynamic);
-    LAUNCH(h, "step_end", k_step_end, 1, 1, ds, (const Counters *)dc);
-    HIPC(h, hipMemcpyAsync(&h->st, ds, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
-    HIPC(h, hipMemcpyAsync(&h->ctr, dc, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+           (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, Fnew, h->curr_rejected.p, ds);
+    // (label counters of the new VoI-resident region are accumulated by the two assemble kernels)
+    LAUNCH(h, "step_end", k_step_end, 1, 1, ds, (const Counters *)dc, h->pin);
+    const auto t_host1 = std::chrono::steady_clock::now();
     HIPC(h, hipStreamSynchronize(h->stream));
+    h->st = h->pin->st;
+    h->ctr = h->pin->ctr;
+    if (host_timing) {
+        for (auto &m : marks) fprintf(stderr, "   %-20s %.1f us\n", m.first, m.second);
+        const auto t_host2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[step host] enqueue %.1f us, wait %.1f us\n", std::chrono::duration<double, std::micro>(t_host1 - t_host0).count(),
+                std::chrono::duration<double, std::micro>(t_host2 - t_host1).count());
+    }
+    if (h->dbg_stamps.p) {
+        unsigned long long t[32];
+        (void)hipMemcpy(t, h->dbg_stamps.p, sizeof(t), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[esort slowest segment: len %llu depth %llu of %llu segments] phase1 %llu, queue %llu, finalize %llu cycles; levels:", t[30] >> 32,
+                t[30] & 0xFFFFFFFFull, t[29], t[1] - t[0], t[2] - t[1], t[3] - t[2]);
+        for (int i = 4; i < 15; ++i) fprintf(stderr, " %llu", t[i + 1] > t[i] ? t[i + 1] - t[i] : 0ull);
+        fprintf(stderr, "\n");
+        (void)hipMemset(h->dbg_stamps.p, 0, sizeof(t));
+    }
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
         h->err = std::string("kernel launch: ") + hipGetErrorString(le);
@@ -962,14 +1039,14 @@ int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap
             const DP &P = h->dp;
             const uint32_t B = h->B, n_voi = h->last_n_voi;
             if (n_voi)
-                LAUNCH(h, "get_cloud", k_assemble_map<false>, cdiv(n_voi, 256), 256, P, h->Tb2o, (const uint8_t *)h->action.p,
+                LAUNCH(h, "get_cloud", k_assemble_map<false>, std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p,
                        (const uint32_t *)h->rev_idx.p, h->last_skeys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p,
                        (const uint32_t *)h->moff.p, (const uint32_t *)h->ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p,
                        (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p, (const uint32_t *)h->rej_off.p,
-                       (const DevState *)h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr);
+                       (const DevState *)h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr, (DevState *)nullptr);
             LAUNCH(h, "get_cloud", k_assemble_bins<false>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
                    (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
-                   (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, tmp, (float4 *)nullptr);
+                   (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, tmp, (float4 *)nullptr, (DevState *)nullptr);
             HIPC(h, hipStreamSynchronize(h->stream));
             const size_t off = which == ERASOR_CLOUD_STATIC_ESTIMATE ? 0 : (which == ERASOR_CLOUD_COMPLEMENT ? s.n_static_est : s.total_bins);
             if (cnt) HIPC(h, hipMemcpy(dst, tmp + off, cnt * sizeof(float4), hipMemcpyDeviceToHost));
@@ -1055,8 +1132,9 @@ int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
     if (ns) HIPC(h, hipMemcpyAsync(h->scan.p, src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-    LAUNCH(h, "step_begin", k_step_begin, 1, 1, h->d_st.p, h->d_ctr.p, 0u);
-    voxelize_query_part1(h, ns, (float)leaf_size);
+    h->scan_in = (const float4 *)h->scan.p;
+    LAUNCH(h, "step_begin", k_step_begin, 1, 64, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p);
+    voxelize_query_part1(h, ns, (float)leaf_size, [] {});
     DevState st;
     VoxGrid g;
     HIPC(h, hipMemcpyAsync(&st, h->d_st.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
@@ -1072,9 +1150,9 @@ int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src
         // identity lidar->body; the R-POD key output is ignored
         const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
         // x*1 + y*0 + z*0 + 0 reproduces x exactly (0*finite = 0, x+0 = x; -0.0 would become +0.0, irrelevant for a centroid)
-        LAUNCH(h, "q_centroids", k_centroids, cdiv(nq, 256), 256, (const float4 *)h->scan.p, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
+        LAUNCH(h, "q_centroids", k_centroids, cdiv(nq, 256), 256, h->scan_in, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
                (const uint32_t *)h->run_begin.p, (const uint32_t *)&h->d_st.p->q_nvox, h->cent.p, h->ukeys.p);
-        LAUNCH(h, "q_nn", k_query_nn, cdiv(nq, 256), 256, (const float4 *)h->scan.p, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
+        LAUNCH(h, "q_nn", k_query_nn, cdiv(nq, 256), 256, h->scan_in, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
                (const uint32_t *)h->ukeys.p, (const float4 *)h->cent.p, (const uint32_t *)&h->d_st.p->q_nvox, (const VoxGrid *)h->qgrid.p, to_xf(I),
                h->dp, h->d_ctr.p, h->query.p, h->qkey.p);
         HIPC(h, hipStreamSynchronize(h->stream));
@@ -1160,7 +1238,7 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
     const uint32_t ns = (uint32_t)n;
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
-    LAUNCH(h, "step_begin", k_step_begin, 1, 1, h->d_st.p, h->d_ctr.p, 0u);
+    LAUNCH(h, "step_begin", k_step_begin, 1, 64, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p);
     if (ns) {
         HIPC(h, hipMemcpyAsync(h->qk_a.p, keys, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
         HIPC(h, hipMemcpyAsync(h->qv_a.p, vals, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));

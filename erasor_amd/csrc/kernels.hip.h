@@ -1055,8 +1055,18 @@ __global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, 
                 sV[i] = V[sg.first + i];
             }
             __syncthreads();
+            __shared__ unsigned long long s_stamps[20];
+            const unsigned long long t_a = clock64();
             esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, len, sg.depth, qa, qb, qcnt, (uint32_t)(ES_LMAX / 16 + 2),
-                               &ctr->n_sort_fallback, &ctr->sort_qoverflow, (s == 0 && dbg) ? dbg : nullptr);
+                               &ctr->n_sort_fallback, &ctr->sort_qoverflow, dbg ? s_stamps : nullptr);
+            if (dbg && threadIdx.x == 0) {  // diagnostics: keep the stamps of the slowest segment
+                const unsigned long long dur = clock64() - t_a;
+                if (atomicMax(&dbg[31], dur) < dur) {
+                    for (int i = 0; i < 16; ++i) dbg[i] = s_stamps[i];
+                    dbg[30] = ((unsigned long long)len << 32) | (unsigned)sg.depth;
+                    dbg[29] = (unsigned long long)(nsmall + nbig);
+                }
+            }
             for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
                 K2[sg.first + i] = sL[i];
                 V2[sg.first + i] = sR[i];
@@ -1908,6 +1918,31 @@ __global__ __launch_bounds__(1024) void k_layout(DP P, const uint8_t *__restrict
 
 // one thread per sorted VoI point.  XFORM: apply tf_body2origin_ (map write-back) or keep egocentric
 // coordinates (the clouds get_static_estimate / get_outliers hand out).
+// parse_dynamic_obj as counters (utils.cpp:57-78) over the points a workgroup wrote to Fnew: per-thread tallies (d, s),
+// one pair of device-scope atomics per workgroup (same-address atomics serialise: keep them few)
+__device__ __forceinline__ void block_commit_labels(uint32_t d, uint32_t s, DevState *cnt) {
+    __shared__ uint32_t sd[16], ss[16];
+    if (!cnt) return;
+    for (int o = 32; o > 0; o >>= 1) {
+        d += __shfl_down(d, o, 64);
+        s += __shfl_down(s, o, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        sd[threadIdx.x >> 6] = d;
+        ss[threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t td = 0, ts = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
+            td += sd[w];
+            ts += ss[w];
+        }
+        if (td) atomicAdd(&cnt->F_dynamic, (unsigned long long)td);
+        if (ts) atomicAdd(&cnt->F_static, (unsigned long long)ts);
+    }
+}
+
 template <bool XFORM>
 __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8_t *__restrict__ action,
                                                        const uint32_t *__restrict__ rev_idx, const uint32_t *__restrict__ skeys,
@@ -1917,35 +1952,47 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
                                                        const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ ground_off,
                                                        const uint32_t *__restrict__ rej_off, const DevState *st,
                                                        float4 *__restrict__ Fnew, float4 *__restrict__ rejected,
-                                                       uint32_t *__restrict__ rejected_src) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= st->voi_total) return;
-    const uint32_t key = skeys[i];
-    const float4 p = spts[i];
-    const float4 w = XFORM ? xform(Tb2o, p) : p;
-    if (key == (uint32_t)P.B) {
-        Fnew[st->n_static_est + (i - moff[P.B])] = w;
-        return;
-    }
-    const uint8_t act = action[key];
-    const uint32_t r = i - moff[key];
-    if (act == 1) {
-        const uint32_t rk = rev_idx[key];
-        const uint32_t gr = grank[i];
-        if (gflag[i]) {
-            Fnew[st->total_bins + ground_off[rk] + gr] = w;                              // ground_viz copy
-            if (P.version == 2 && ccnt[key] > 0) Fnew[out_off[key] + ccnt[key] + gr] = w;  // v2: inside the bin too
-        } else if (rejected) {
-            rejected[rej_off[rk] + gr] = xform(Tb2o, p);  // map_rejected_ is handed out in the map frame (OMU.cpp:287)
-            rejected_src[rej_off[rk] + gr] = ssrc[i];
+                                                       uint32_t *__restrict__ rejected_src, DevState *cnt) {
+    uint32_t nd = 0, nst = 0;  // label tallies of the copies this thread wrote to Fnew
+    const uint32_t n_act = st->voi_total;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_act; i += gridDim.x * blockDim.x) {
+        uint32_t nwr = 0;
+        const uint32_t key = skeys[i];
+        const float4 p = spts[i];
+        const float4 w = XFORM ? xform(Tb2o, p) : p;
+        if (key == (uint32_t)P.B) {
+            Fnew[st->n_static_est + (i - moff[P.B])] = w;
+            nwr = 1;
+        } else {
+            const uint8_t act = action[key];
+            const uint32_t r = i - moff[key];
+            if (act == 1) {
+                const uint32_t rk = rev_idx[key];
+                const uint32_t gr = grank[i];
+                if (gflag[i]) {
+                    Fnew[st->total_bins + ground_off[rk] + gr] = w;  // ground_viz copy
+                    nwr = 1;
+                    if (P.version == 2 && ccnt[key] > 0) {
+                        Fnew[out_off[key] + ccnt[key] + gr] = w;  // v2: inside the bin too
+                        nwr = 2;
+                    }
+                } else if (rejected) {
+                    rejected[rej_off[rk] + gr] = xform(Tb2o, p);  // map_rejected_ is handed out in the map frame (OMU.cpp:287)
+                    rejected_src[rej_off[rk] + gr] = ssrc[i];
+                }
+            } else if (act == 2) {
+                Fnew[out_off[key] + ccnt[key] + r] = w;  // merged bin: curr points first
+                nwr = 1;
+            } else if (act == 3) {
+                // map bin empty by construction
+            } else {
+                Fnew[out_off[key] + r] = w;
+                nwr = 1;
+            }
         }
-    } else if (act == 2) {
-        Fnew[out_off[key] + ccnt[key] + r] = w;  // merged bin: curr points first
-    } else if (act == 3) {
-        // map bin empty by construction
-    } else {
-        Fnew[out_off[key] + r] = w;
+        if (is_dynamic_label(p.w)) nd += nwr; else nst += nwr;
     }
+    block_commit_labels(nd, nst, cnt);
 }
 
 // scan-side contributions: v3 voxelised reverted bins; v2 curr points of reverted / merged / curr-only bins
@@ -1955,11 +2002,12 @@ __global__ __launch_bounds__(256) void k_assemble_bins(DP P, Xf Tb2o, const uint
                                                         const float4 *__restrict__ sq, const uint32_t *__restrict__ nvox,
                                                         const uint32_t *__restrict__ vox_off, const float4 *__restrict__ vox_out,
                                                         const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ crej_off,
-                                                        float4 *__restrict__ Fnew, float4 *__restrict__ curr_rejected) {
+                                                        float4 *__restrict__ Fnew, float4 *__restrict__ curr_rejected, DevState *cnt) {
     const int key = blockIdx.x;
     const uint8_t act = action[key];
-    if (act == 0) return;
+    if (act == 0) return;  // (block-uniform exits: no thread reaches the tally's barrier)
     const uint32_t qo = qoff[key], cc = qoff[key + 1] - qo;
+    uint32_t nd = 0, nst = 0;
     if (act == 1 && P.version == 3) {
         if (cc == 0) return;
         const uint32_t rk = rev_idx[key];
@@ -1967,6 +2015,7 @@ __global__ __launch_bounds__(256) void k_assemble_bins(DP P, Xf Tb2o, const uint
         for (uint32_t v = threadIdx.x; v < nv; v += blockDim.x) {
             const float4 p = vox_out[vo + v];
             Fnew[oo + v] = XFORM ? xform(Tb2o, p) : p;
+            if (is_dynamic_label(p.w)) ++nd; else ++nst;
         }
     } else if (act == 4) {
         if (curr_rejected)
@@ -1976,8 +2025,10 @@ __global__ __launch_bounds__(256) void k_assemble_bins(DP P, Xf Tb2o, const uint
         for (uint32_t j = threadIdx.x; j < cc; j += blockDim.x) {
             const float4 p = sq[qo + j];
             Fnew[oo + j] = XFORM ? xform(Tb2o, p) : p;
+            if (is_dynamic_label(p.w)) ++nd; else ++nst;
         }
     }
+    block_commit_labels(nd, nst, cnt);
 }
 
 // label counters over a float4 cloud (parse_dynamic_obj as counters, utils.cpp:57-78)
@@ -2008,17 +2059,37 @@ __global__ __launch_bounds__(256) void k_count_labels4(const float4 *__restrict_
 // empty kernel: bracketed by HIP events exactly like k_voi_split to measure the bracket's own overhead
 __global__ void k_null() {}
 
-__global__ void k_step_begin(DevState *st, Counters *ctr, uint32_t q_nvox_init) {
-    st->q_nvox = q_nvox_init;
-    ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
-    ctr->sort_qoverflow = ctr->err = 0;
-    st->F_static = st->F_dynamic = 0;
-    st->n_rev = 0;
+// result block in pinned host memory: k_step_end stores the step's state and counters there, so the host needs no D2H copies
+struct HostOut {
+    DevState st;
+    Counters ctr;
+};
+
+// `init` != nullptr semantics are by value: when use_init is set the whole device state is replaced by the host's mirror
+// (nF / o_begin may have been changed by host-side map maintenance); bb != nullptr also resets the query bounding box.
+__global__ void k_step_begin(DevState *st, Counters *ctr, uint32_t q_nvox_init, DevState init, int use_init, uint32_t *bb) {
+    if (threadIdx.x == 0) {
+        if (use_init) *st = init;
+        st->q_nvox = q_nvox_init;
+        ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
+        ctr->sort_qoverflow = ctr->err = 0;
+        st->F_static = st->F_dynamic = 0;
+        st->n_rev = 0;
+    }
+    if (bb) {
+        if (threadIdx.x < 3) bb[threadIdx.x] = 0xFFFFFFFFu;
+        if (threadIdx.x >= 3 && threadIdx.x < 6) bb[threadIdx.x] = 0u;
+    }
 }
-__global__ void k_step_end(DevState *st, const Counters *ctr) {
-    if (ctr->err || ctr->sort_qoverflow) return;
-    st->nF = st->nF_new;
-    st->o_begin = st->o_new_begin;
+__global__ void k_step_end(DevState *st, const Counters *ctr, HostOut *out) {
+    if (!(ctr->err || ctr->sort_qoverflow)) {
+        st->nF = st->nF_new;
+        st->o_begin = st->o_new_begin;
+    }
+    if (out) {
+        out->st = *st;
+        out->ctr = *ctr;
+    }
 }
 
 // ---- map store maintenance ---------------------------------------------------------------------
