@@ -51,6 +51,8 @@ struct erasor_hip_handle {
     hipStream_t stream2 = nullptr;  // map chain of a step (VoI split .. bin stats), concurrent with the query chain
     hipStream_t cur = nullptr;      // stream LAUNCH() currently targets
     hipEvent_t ev_fork = nullptr, ev_keys = nullptr, ev_join = nullptr;
+    DBuf<uint32_t> qb_tot;            // [B + 1] bucket totals of the same
+    DBuf<uint32_t> qb_hist;           // [B + 1][tiles] histogram of the query counting sort
     const float4 *scan_in = nullptr;  // scan of the step in flight (the caller's device buffer, or h->scan)
     HostOut *pin = nullptr;         // pinned host block k_step_end reports into
     bool forked = false;            // ev_join has been recorded at least once
@@ -295,7 +297,7 @@ int alloc_bins(erasor_hip_handle *h) {
     rc |= ensure(h, h->vox_off, B) | ensure(h, h->nvox, B) | ensure(h, h->ng, B) | ensure(h, h->out_off, B) | ensure(h, h->ground_off, B);
     rc |= ensure(h, h->rej_off, B) | ensure(h, h->crej_off, B);
     rc |= ensure(h, h->plane_n, B * (size_t)std::max(h->P.gf_iter, 1) * 3) | ensure(h, h->plane_d, B * (size_t)std::max(h->P.gf_iter, 1));
-    rc |= ensure(h, h->d_st, 1) | ensure(h, h->d_ctr, 1) | ensure(h, h->dn, 16) | ensure(h, h->bb, 8) | ensure(h, h->qgrid, 1) | ensure(h, h->esqs, 1);
+    rc |= ensure(h, h->d_st, 1) | ensure(h, h->d_ctr, 1) | ensure(h, h->dn, 16) | ensure(h, h->bb, 8) | ensure(h, h->qgrid, 1) | ensure(h, h->esqs, 1) | ensure(h, h->qb_tot, B + 2);
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
 
@@ -567,7 +569,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->vmask); release(h->hmask); release(h->cinfo); release(h->pvl); release(h->phl); release(h->topv); release(h->toph);
     release(h->voi_ego); release(h->spts); release(h->rejected); release(h->voi_key); release(h->voi_src); release(h->ssrc);
     release(h->rejected_src); release(h->grank); release(h->glist); release(h->gflag);
-    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn);
+    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->qb_hist); release(h->qb_tot);
     release(h->moff); release(h->mcnt); release(h->qoff); release(h->ccnt); release(h->rev_idx); release(h->rev_list); release(h->vox_off);
     release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
     release(h->mmin); release(h->mmax); release(h->cmin); release(h->cmax); release(h->plane_n); release(h->plane_d);
@@ -728,7 +730,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_step_begin
     h->st.o_begin = h->o_begin;
     if (h->forked) (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);  // a previous step that bailed out between fork and join
-    LAUNCH(h, "step_begin", k_step_begin, 1, 64, ds, dc, (flags & STEP_QUERY_PREVOXELIZED) ? ns : 0u, h->st, 1, h->bb.p);
+    LAUNCH(h, "step_begin", k_step_begin, 1, 256, ds, dc, (flags & STEP_QUERY_PREVOXELIZED) ? ns : 0u, h->st, 1, h->bb.p,
+           B + 1 <= QB_NB_MAX ? h->qb_tot.p : (uint32_t *)nullptr, B + 1 <= QB_NB_MAX ? B + 1 : 0u);
     // a device-resident scan is read in place (the call is synchronous: the caller's buffer outlives every kernel of the step)
     if (ns && !src_is_device) HIPC(h, hipMemcpyAsync(h->scan.p, scan_src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     h->scan_in = src_is_device && ns ? (const float4 *)scan_src : (const float4 *)h->scan.p;
@@ -752,6 +755,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     rc = alloc_step(h, n_voi, nq);
     if (rc) return rc;
     const int bits = key_bits(B + 1);
+    if (B + 1 <= QB_NB_MAX && ensure(h, h->qb_hist, (size_t)(B + 1) * std::max(1u, cdiv(nq, QB_TILE)) + 8)) return ERASOR_E_NO_DEVICE;
     {   // make sure both scratch banks of the bucket sort exist before the streams fork
         const uint32_t nb_q = 256u * std::max(1u, cdiv(nq, RTILE)), nb_m = 256u * std::max(1u, cdiv(n_voi, RTILE));
         if (ensure(h, h->hist, nb_q) || ensure(h, h->hist_l, nb_q) || ensure(h, h->hist_t, cdiv(nb_q, 1024) + 2) || ensure(h, h->hist2, nb_m) ||
@@ -821,38 +825,18 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
                (const uint32_t *)h->ukeys.p, (const float4 *)h->cent.p, (const uint32_t *)&ds->q_nvox, (const VoxGrid *)h->qgrid.p, h->Tl2b, P, dc,
                h->query.p, h->qkey.p);
     }
-    // the radix ping-pong buffers are shared by the query and the map side (capV >= capS is not guaranteed -> use q buffers)
-    if (nq <= 8192) {  // tiny inputs: one single-workgroup launch instead of ten (slower than the multi-block path beyond ~10 k keys)
-        LAUNCH(h, "q_bucket", k_radix_small, 1, 1024, (const uint32_t *)h->qkey.p, nq, nq_dev, bits, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p);
-        const int passes = (bits + 7) / 8;
-        sq_keys = (passes & 1) ? h->qk_a.p : h->qposL.p;
-        sq_perm = (passes & 1) ? h->qv_a.p : h->qposR.p;
-    } else {
+    if (B + 1 <= QB_NB_MAX) {  // one-digit stable counting sort with the gather and the bucket offsets folded in
+        const uint32_t ntile_ub = std::max(1u, cdiv(nq, QB_TILE));
+        LAUNCH(h, "q_bucket", k_qb_hist, ntile_ub, 1024, (const uint32_t *)h->qkey.p, nq, nq_dev, B + 1, h->qb_hist.p, h->qb_tot.p);
+        LAUNCH(h, "q_bucket", k_qb_scan, 1, 1024, (const uint32_t *)h->qb_tot.p, B + 1, h->qoff.p);
+        LAUNCH(h, "q_bucket", k_qb_scatter, ntile_ub, 1024, (const uint32_t *)h->qkey.p, (const float4 *)h->query.p, nq, nq_dev, B + 1, bits,
+               (const uint32_t *)h->qb_hist.p, (const uint32_t *)h->qoff.p, h->sq.p);
+    } else {  // very fine R-POD grids: LSD radix passes
         radix_sort(h, h->qkey.p, nq, nq_dev, bits, h->qk_a.p, h->qposL.p, h->qv_a.p, h->qposR.p, &sq_keys, &sq_perm, "q_bucket");
+        if (nq) LAUNCH(h, "q_bucket", k_gather, cdiv(nq, 256), 256, (const float4 *)h->query.p, (const uint32_t *)nullptr, sq_perm, nq, nq_dev,
+                       h->sq.p, (uint32_t *)nullptr);
+        LAUNCH(h, "q_bucket", k_bin_offsets, cdiv((uint64_t)std::max(nq, B + 2) + 1, 256), 256, sq_keys, nq, nq_dev, B + 1, h->qoff.p);
     }
-    if (g_debug_sync && nq) {
-        std::vector<uint32_t> tk(nq), tq(nq);
-        (void)hipMemcpy(tk.data(), sq_keys, (size_t)nq * 4, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(tq.data(), h->qkey.p, (size_t)nq * 4, hipMemcpyDeviceToHost);
-        uint32_t mx = 0, mxq = 0, unsorted = 0;
-        for (uint32_t i = 0; i < nq; ++i) {
-            mx = std::max(mx, tk[i]);
-            mxq = std::max(mxq, tq[i]);
-            if (i && tk[i] < tk[i - 1]) ++unsorted;
-        }
-        fprintf(stderr, "[erasor_hip] debug: nq=%u bits=%d B=%u max sorted key=%u max raw key=%u unsorted=%u\n", nq, bits, B, mx, mxq, unsorted);
-        std::vector<float> qp((size_t)nq * 4);
-        (void)hipMemcpy(qp.data(), h->query.p, (size_t)nq * 16, hipMemcpyDeviceToHost);
-        int shown = 0;
-        for (uint32_t i = 0; i < nq && shown < 12; ++i)
-            if (tq[i] > B) {
-                fprintf(stderr, "   bad key[%u]=%u (0x%08x) pt=(%.9g %.9g %.9g %.9g)\n", i, tq[i], tq[i], qp[4 * i], qp[4 * i + 1], qp[4 * i + 2], qp[4 * i + 3]);
-                ++shown;
-            }
-    }
-    if (nq) LAUNCH(h, "q_bucket", k_gather, cdiv(nq, 256), 256, (const float4 *)h->query.p, (const uint32_t *)nullptr, sq_perm, nq, nq_dev,
-                   h->sq.p, (uint32_t *)nullptr);
-    LAUNCH(h, "q_bucket", k_bin_offsets, cdiv((uint64_t)std::max(nq, B + 2) + 1, 256), 256, sq_keys, nq, nq_dev, B + 1, h->qoff.p);
     LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->sq.p, (const uint32_t *)h->qoff.p, B, h->ccnt.p,
            h->cmin.p, h->cmax.p);
 
@@ -1133,7 +1117,7 @@ int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src
     if (rc) return rc;
     if (ns) HIPC(h, hipMemcpyAsync(h->scan.p, src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     h->scan_in = (const float4 *)h->scan.p;
-    LAUNCH(h, "step_begin", k_step_begin, 1, 64, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p);
+    LAUNCH(h, "step_begin", k_step_begin, 1, 256, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p, (uint32_t *)nullptr, 0u);
     voxelize_query_part1(h, ns, (float)leaf_size, [] {});
     DevState st;
     VoxGrid g;
@@ -1238,7 +1222,7 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
     const uint32_t ns = (uint32_t)n;
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
-    LAUNCH(h, "step_begin", k_step_begin, 1, 64, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p);
+    LAUNCH(h, "step_begin", k_step_begin, 1, 256, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p, (uint32_t *)nullptr, 0u);
     if (ns) {
         HIPC(h, hipMemcpyAsync(h->qk_a.p, keys, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
         HIPC(h, hipMemcpyAsync(h->qv_a.p, vals, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));

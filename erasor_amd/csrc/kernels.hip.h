@@ -599,6 +599,101 @@ __global__ __launch_bounds__(256) void k_gather(const float4 *__restrict__ src, 
 }
 
 // off[k] = first sorted position with key >= k, for k in [0, nkeys]; off[nkeys] = n  (nkeys = B+1 buckets -> B+2 entries)
+// ---- stable one-digit counting sort of the query voxels by R-POD key ------------------------------
+// The key range (B + 1 buckets) fits an LDS table, so the bucketing is one histogram / scan / scatter round with the
+// bucket offsets (k_bin_offsets' product) and the point gather (k_gather) folded in: 3 launches instead of 12.
+// Tile-major inside a bucket + index order inside a tile == the stable order of the LSD radix path.
+static constexpr uint32_t QB_TILE = 1024;
+static constexpr uint32_t QB_NB_MAX = 12288;  // buckets (B + 1) the LDS table holds
+
+__global__ __launch_bounds__(1024) void k_qb_hist(const uint32_t *__restrict__ keys, uint32_t n_host, const uint32_t *n_dev, uint32_t nb,
+                                                   uint32_t *__restrict__ hist /* [tile][nb] */, uint32_t *__restrict__ tot /* [nb] */) {
+    __shared__ uint32_t cnt[QB_NB_MAX];
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t ntile = (n + QB_TILE - 1) / QB_TILE;
+    if (blockIdx.x >= ntile) return;
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * QB_TILE + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[min(keys[i], nb - 1)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+        const uint32_t c = cnt[b];
+        hist[(size_t)blockIdx.x * nb + b] = c;
+        if (c) atomicAdd(&tot[b], c);  // bucket totals (integer: order-independent); zeroed by k_step_begin
+    }
+}
+
+// single workgroup, one thread per bucket: exclusive scan of the bucket totals -> off[b]; off[nb] = n
+__global__ __launch_bounds__(1024) void k_qb_scan(const uint32_t *__restrict__ tot, uint32_t nb, uint32_t *__restrict__ off) {
+    __shared__ uint32_t sm[40];
+    constexpr int ROUNDS = QB_NB_MAX / 1024;
+    uint32_t s[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const uint32_t b = r * 1024 + threadIdx.x;
+        s[r] = b < nb ? tot[b] : 0u;
+    }
+    uint32_t carry = 0;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if ((uint32_t)r * 1024 >= nb) break;  // block-uniform
+        const uint32_t b = r * 1024 + threadIdx.x;
+        uint32_t t;
+        const uint32_t ex = block_excl_scan(s[r], sm, t);
+        if (b < nb) off[b] = carry + ex;
+        carry += t;
+    }
+    if (threadIdx.x == 0) off[nb] = carry;
+}
+
+__global__ __launch_bounds__(1024) void k_qb_scatter(const uint32_t *__restrict__ keys, const float4 *__restrict__ src, uint32_t n_host,
+                                                      const uint32_t *n_dev, uint32_t nb, int bits, const uint32_t *__restrict__ hist,
+                                                      const uint32_t *__restrict__ off, float4 *__restrict__ dst) {
+    __shared__ uint32_t cnt[QB_NB_MAX];
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t ntile = (n + QB_TILE - 1) / QB_TILE;
+    if (blockIdx.x >= ntile) return;
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * QB_TILE + threadIdx.x;
+    const bool valid = i < n;
+    const uint32_t k = valid ? min(keys[i], nb - 1) : 0u;
+    const uint32_t wave = threadIdx.x >> 6;
+    // start of (bucket k, this tile): bucket offset + the earlier tiles' share of the bucket
+    uint32_t pre = 0;
+    if (valid) {
+        uint32_t a0 = off[k], a1 = 0, a2 = 0, a3 = 0;
+        uint32_t t = 0;
+        for (; t + 4 <= blockIdx.x; t += 4) {  // four independent loads in flight
+            a0 += hist[(size_t)t * nb + k];
+            a1 += hist[(size_t)(t + 1) * nb + k];
+            a2 += hist[(size_t)(t + 2) * nb + k];
+            a3 += hist[(size_t)(t + 3) * nb + k];
+        }
+        for (; t < blockIdx.x; ++t) a0 += hist[(size_t)t * nb + k];
+        pre = (a0 + a1) + (a2 + a3);
+    }
+    // lanes of this wave that hold the same key
+    uint64_t peers = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+        const bool bit = (k >> b) & 1u;
+        const uint64_t m = __ballot(valid && bit);
+        peers &= bit ? m : ~m;
+    }
+    const uint64_t lt = lanemask_lt();
+    uint32_t r = 0;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {  // waves take their turn in index order
+        if (wave == w && valid) {
+            r = cnt[k] + (uint32_t)__popcll(peers & lt);
+            esort::wave_sync();
+            if ((peers >> (threadIdx.x & 63u)) >> 1 == 0) cnt[k] += (uint32_t)__popcll(peers);  // highest lane of the group
+        }
+        __syncthreads();
+    }
+    if (valid) dst[pre + r] = src[i];
+}
+
 __global__ __launch_bounds__(256) void k_bin_offsets(const uint32_t *__restrict__ skeys, uint32_t n_host, const uint32_t *n_dev,
                                                       uint32_t nbuckets, uint32_t *__restrict__ off) {
     const uint32_t n = n_dev ? *n_dev : n_host;
@@ -2067,7 +2162,9 @@ struct HostOut {
 
 // `init` != nullptr semantics are by value: when use_init is set the whole device state is replaced by the host's mirror
 // (nF / o_begin may have been changed by host-side map maintenance); bb != nullptr also resets the query bounding box.
-__global__ void k_step_begin(DevState *st, Counters *ctr, uint32_t q_nvox_init, DevState init, int use_init, uint32_t *bb) {
+__global__ void k_step_begin(DevState *st, Counters *ctr, uint32_t q_nvox_init, DevState init, int use_init, uint32_t *bb, uint32_t *qb_tot,
+                             uint32_t qb_n) {
+    for (uint32_t b = threadIdx.x; b < qb_n; b += blockDim.x) qb_tot[b] = 0;  // bucket totals of the query counting sort
     if (threadIdx.x == 0) {
         if (use_init) *st = init;
         st->q_nvox = q_nvox_init;
