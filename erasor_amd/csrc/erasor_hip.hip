@@ -639,7 +639,9 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
     if (n >= WIDE_MIN && (n - 1 + WTILE - 1) / WTILE <= WTILES_MAX) {
         // wide levels: segments >= WIDE_MIN keys, many workgroups each.  A segment halves (roughly) per level, so
         // lg(n / WIDE_MIN) + slack levels empty the wide list; whatever is left is routed to the level queue.
-        const int wl = std::min(esort::lg2_floor(n / WIDE_MIN) + 4, 16);
+        // ERASOR_HIP_SORT_LEVEL_CAP (test hook): cut the level budget short so that the final kernel meets long segments
+        static const int level_cap = getenv("ERASOR_HIP_SORT_LEVEL_CAP") ? atoi(getenv("ERASOR_HIP_SORT_LEVEL_CAP")) : 1 << 20;
+        const int wl = std::min(std::min(esort::lg2_floor(n / WIDE_MIN) + 4, 16), level_cap);
         for (int l = 0; l < wl; ++l) {
             const int cur = l & 1;
             LAUNCH(h, "q_esort_wide", k_esort_wide_mark, 256, 256, (const uint32_t *)h->qk_a.p, h->qposL.p, h->qposR.p,
@@ -653,7 +655,8 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
     if (n > ES_LMAX) {
         // level queue: one workgroup per segment, one partition per launch.  Segments that are still big after `nlev`
         // levels are finished (slowly, in global memory) by the final kernel, so any nlev is correct.
-        nlev = std::min(2 * esort::lg2_floor(n), n >= WIDE_MIN ? (n > (1u << 21) ? 12 : 2) : 12);
+        static const int level_cap2 = getenv("ERASOR_HIP_SORT_LEVEL_CAP") ? atoi(getenv("ERASOR_HIP_SORT_LEVEL_CAP")) : 1 << 20;
+        nlev = std::min(std::min(2 * esort::lg2_floor(n), n >= WIDE_MIN ? (n > (1u << 21) ? 12 : 2) : 12), level_cap2);
         for (int l = 0; l < nlev; ++l)
             LAUNCH(h, "q_esort", k_esort_level, 48, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->esq0.p, h->esq1.p, h->esq2.p,
                    h->essmall.p, h->esqs.p, l, 65536u, dc);
@@ -886,8 +889,11 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         fprintf(stderr, "[esort slowest segment: len %llu depth %llu of %llu segments] phase1 %llu, queue %llu, finalize %llu cycles; levels:", t[30] >> 32,
                 t[30] & 0xFFFFFFFFull, t[29], t[1] - t[0], t[2] - t[1], t[3] - t[2]);
         for (int i = 4; i < 15; ++i) fprintf(stderr, " %llu", t[i + 1] > t[i] ? t[i + 1] - t[i] : 0ull);
-        fprintf(stderr, "\n");
-        (void)hipMemset(h->dbg_stamps.p, 0, sizeof(t));
+        fprintf(stderr, "; kernel span: first start -> last working end %.1f us, -> last end %.1f us\n", (double)(t[26] - t[28]) / 100.0,
+                (double)(t[27] - t[28]) / 100.0);
+        memset(t, 0, sizeof(t));
+        t[28] = ~0ull;
+        (void)hipMemcpy(h->dbg_stamps.p, t, sizeof(t), hipMemcpyHostToDevice);
     }
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
@@ -899,7 +905,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         h->st.nF = h->nF;
         h->st.o_begin = h->o_begin;
         if (h->ctr.sort_qoverflow) {
-            h->err = "exact-sort segment queue overflow";
+            h->err = "exact-sort segment queue overflow (site " + std::to_string(h->ctr.sort_qoverflow) + ")";
             return ERASOR_E_INTERNAL;
         }
         h->err = h->ctr.err == 2 ? "VoxelGrid index overflow on the query scan (reference returns the input unvoxelised): not supported on device"
@@ -1242,8 +1248,11 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
         (void)hipMemcpy(t, h->dbg_stamps.p, sizeof(t), hipMemcpyDeviceToHost);
         fprintf(stderr, "[esort stamps n=%u] phase1 %llu, queue %llu, finalize %llu cycles; levels:", ns, t[1] - t[0], t[2] - t[1], t[3] - t[2]);
         for (int i = 4; i < 15; ++i) fprintf(stderr, " %llu", t[i + 1] > t[i] ? t[i + 1] - t[i] : 0ull);
-        fprintf(stderr, "\n");
-        (void)hipMemset(h->dbg_stamps.p, 0, sizeof(t));
+        fprintf(stderr, "; kernel span: first start -> last working end %.1f us, -> last end %.1f us\n", (double)(t[26] - t[28]) / 100.0,
+                (double)(t[27] - t[28]) / 100.0);
+        memset(t, 0, sizeof(t));
+        t[28] = ~0ull;
+        (void)hipMemcpy(h->dbg_stamps.p, t, sizeof(t), hipMemcpyHostToDevice);
     }
     if (ns) {
         HIPC(h, hipMemcpy(keys, h->qk_b.p, (size_t)ns * 4, hipMemcpyDeviceToHost));

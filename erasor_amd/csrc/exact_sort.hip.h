@@ -216,53 +216,78 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
     ESORT_STAMP(0);
     // phase 1: long segments are partitioned by the WHOLE workgroup, one after the other (a short stack); their
     // children go back on the stack or, once short enough, to the wavefront-per-segment queue of phase 2.
-    {
-        __shared__ Seg stk[48];
-        __shared__ uint32_t sm_bp[40];
-        __shared__ int sp;
-        __shared__ Seg cur_sg;
+    // The queue holds one level of pairwise disjoint segments longer than kThreshold, i.e. at most n / 17 + 1 entries:
+    // while n <= 16 * (qcap - 2) every short piece joins ONE queue run at the end (most parallel); a longer segment
+    // (only reachable on the global-memory paths) runs the queue once per <= kBlockMin piece instead, which keeps every
+    // run within kBlockMin / 17 + 1 <= qcap entries -- no input can overflow it.
+    __shared__ Seg stk[72];  // DFS: one sibling per level, depth <= 2 lg n <= 64
+    __shared__ uint32_t sm_bp[40];
+    __shared__ int sp, s_mode;
+    __shared__ Seg cur_sg;
+    const bool seq_pieces = n > 16u * (qcap - 2u) || qcap < kBlockMin / 16u + 2u;
+    enum { M_EXIT = 0, M_PART = 1, M_QUEUE = 2 };
+    if (tid == 0) {
+        sp = 0;
+        if ((n > kBlockMin && depth > 0) || (seq_pieces && n > (uint32_t)kThreshold)) {
+            stk[0].first = seg_first;
+            stk[0].last = seg_last;
+            stk[0].depth = depth;
+            sp = 1;
+            qcnt[0] = 0;
+        }
+    }
+    __syncthreads();
+    bool drained = false;  // block-uniform
+    int lvl_ = 0;
+    for (;;) {
         if (tid == 0) {
-            sp = 0;
-            if (n > kBlockMin && depth > 0) {
-                stk[0].first = seg_first;
-                stk[0].last = seg_last;
-                stk[0].depth = depth;
-                sp = 1;
-                qcnt[0] = 0;
-            }
+            if (sp > 0) {
+                cur_sg = stk[--sp];
+                const uint32_t len = cur_sg.last - cur_sg.first;
+                if (len > kBlockMin && cur_sg.depth > 0) s_mode = M_PART;
+                else {  // a short (or depth-exhausted) piece on its own: only in seq_pieces mode
+                    qa[0] = cur_sg;
+                    qcnt[0] = 1;
+                    qcnt[1] = 0;
+                    s_mode = M_QUEUE;
+                }
+            } else
+                s_mode = drained ? M_EXIT : M_QUEUE;
         }
         __syncthreads();
-        for (;;) {
-            if (tid == 0 && sp > 0) cur_sg = stk[sp - 1];
-            __syncthreads();
-            if (sp == 0) break;
-            const Seg sg = cur_sg;
-            __syncthreads();
-            if (tid == 0) --sp;
-            const uint32_t cut = block_partition<4>(K, V, posL, posR, sg.first, sg.last, sm_bp);
+        const int mode = s_mode;
+        const Seg sg0 = cur_sg;
+        const bool stack_empty = sp == 0;
+        __syncthreads();
+        if (mode == M_EXIT) break;
+        if (mode == M_PART) {
+            const uint32_t cut = block_partition<4>(K, V, posL, posR, sg0.first, sg0.last, sm_bp);
             if (tid == 0) {
                 atomicOr(&head[cut >> 5], 1u << (cut & 31u));
-                const Seg ch[2] = {{sg.first, cut, sg.depth - 1}, {cut, sg.last, sg.depth - 1}};
+                const Seg ch[2] = {{sg0.first, cut, sg0.depth - 1}, {cut, sg0.last, sg0.depth - 1}};
                 for (int t = 0; t < 2; ++t) {
                     const uint32_t len = ch[t].last - ch[t].first;
-                    if (len > kBlockMin && ch[t].depth > 0 && sp < 48) {
-                        stk[sp++] = ch[t];
-                    } else if (len > (uint32_t)kThreshold) {
+                    if (len <= (uint32_t)kThreshold) continue;
+                    if ((len > kBlockMin && ch[t].depth > 0) || seq_pieces) {
+                        if (sp < 72) stk[sp++] = ch[t];
+                        else *overflow_flag = 4;
+                    } else {
                         const uint32_t at = qcnt[0];
                         if (at < qcap) {
                             qa[at] = ch[t];
                             qcnt[0] = at + 1;
                         } else
-                            *overflow_flag = 1;
+                            *overflow_flag = 3;
                     }
                 }
             }
             __syncthreads();
+            continue;
         }
-    }
-    ESORT_STAMP(1);
-    int cur = 0;
-    int lvl_ = 0;
+        if (stack_empty && mode == M_QUEUE) drained = true;  // this run also takes whatever phase 1 queued: nothing is left after it
+        if (lvl_ == 0) ESORT_STAMP(1);
+        // phase 2: level-synchronous queue, one wavefront per segment
+        int cur = 0;
     for (;;) {
         const uint32_t nseg = qcnt[cur];
         if (nseg == 0) break;
@@ -295,7 +320,7 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
                         qn[at].last = cut;
                         qn[at].depth = sg.depth - 1;
                     } else
-                        *overflow_flag = 1;
+                        *overflow_flag = 3;
                 }
                 if (sg.last - cut > (uint32_t)kThreshold) {
                     const uint32_t at = atomicAdd(&qcnt[cur ^ 1], 1u);
@@ -304,7 +329,7 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
                         qn[at].last = sg.last;
                         qn[at].depth = sg.depth - 1;
                     } else
-                        *overflow_flag = 1;
+                        *overflow_flag = 3;
                 }
             }
         }
@@ -315,6 +340,7 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
         }
         __syncthreads();
         cur ^= 1;
+    }
     }
     __syncthreads();
     ESORT_STAMP(2);

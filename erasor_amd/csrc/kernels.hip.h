@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(1024) void k_esort_level(uint32_t *K, uint32_t *V, 
         if (sg.depth == 0) {  // hand over: the final kernel runs the exact heapsort
             if (threadIdx.x == 0) {
                 const uint32_t at = atomicAdd(&qs->small_cnt, 1u);
-                if (at < qcap) smallq[at] = sg; else ctr->sort_qoverflow = 1;
+                if (at < qcap) smallq[at] = sg; else ctr->sort_qoverflow = 2;
             }
             continue;
         }
@@ -1120,10 +1120,10 @@ __global__ __launch_bounds__(1024) void k_esort_level(uint32_t *K, uint32_t *V, 
                 if (len == 0) continue;
                 if (len > ES_LMAX) {
                     const uint32_t at = atomicAdd(&qs->cnt[nxt], 1u);
-                    if (at < qcap) qnext[at] = ch[t]; else ctr->sort_qoverflow = 1;
+                    if (at < qcap) qnext[at] = ch[t]; else ctr->sort_qoverflow = 2;
                 } else {
                     const uint32_t at = atomicAdd(&qs->small_cnt, 1u);
-                    if (at < qcap) smallq[at] = ch[t]; else ctr->sort_qoverflow = 1;
+                    if (at < qcap) smallq[at] = ch[t]; else ctr->sort_qoverflow = 2;
                 }
             }
         }
@@ -1141,6 +1141,7 @@ __global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, 
     __shared__ esort::Seg qa[ES_LMAX / 16 + 2], qb[ES_LMAX / 16 + 2];
     __shared__ uint32_t qcnt[2];
     const uint32_t nsmall = qs->small_cnt, nbig = qs->cnt[bigcur];
+    if (dbg && threadIdx.x == 0) atomicMin(&dbg[28], wall_clock64());  // diagnostics: first workgroup start (100 MHz ticks)
     for (uint32_t s = blockIdx.x; s < nsmall + nbig; s += gridDim.x) {
         const esort::Seg sg = s < nsmall ? smallq[s] : bigq[s - nsmall];
         const uint32_t len = sg.last - sg.first;
@@ -1173,7 +1174,9 @@ __global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, 
             esort::block_esort(K, V, posL, posR, head, K2, V2, sg.first, sg.last, sg.depth, qa, qb, qcnt,
                                (uint32_t)(ES_LMAX / 16 + 2), &ctr->n_sort_fallback, &ctr->sort_qoverflow);
         }
+        if (dbg && threadIdx.x == 0) atomicMax(&dbg[26], wall_clock64());  // last working workgroup end
     }
+    if (dbg && threadIdx.x == 0) atomicMax(&dbg[27], wall_clock64());  // last workgroup (working or not) end
 }
 
 // run heads of the sorted voxel keys

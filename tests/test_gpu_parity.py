@@ -5,6 +5,8 @@ BASELINE.json:north_star states (asserted) — and in fact bit-identical (also a
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -116,6 +118,29 @@ def test_exact_sort_heapsort_fallback_on_median_of_3_killer(gpu_mod):
         same(gk, ok)
         same(gv, ov)
         assert nf > 0, "depth limit was never hit: the fallback is not exercised"
+
+
+def test_exact_sort_long_segments_reach_the_final_kernel(gpu_mod):
+    """With the level budget cut to one wide level (test hook), segments of tens of thousands of keys reach the final
+    kernel's global-memory path: its bounded per-piece queue must neither overflow nor change the permutation."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, erasor_amd\n"
+        "from oracle import orc\n"
+        "g = erasor_amd.Erasor(erasor_amd.params_default())\n"
+        "for n, kr in ((200000, 3000), (150001, 1 << 32), (40000, 17)):\n"
+        "    k = np.random.default_rng(n).integers(0, kr, n).astype(np.uint32)\n"
+        "    v = np.arange(n, dtype=np.uint32)\n"
+        "    gk, gv, _ = g.exact_sort_u32(k, v)\n"
+        "    ok, ov = orc.std_sort_u32(k, v)\n"
+        "    assert np.array_equal(gk, ok) and np.array_equal(gv, ov), (n, kr)\n"
+        "print('LONG-SEGMENTS-OK')\n"
+    )
+    env = dict(os.environ, ERASOR_HIP_SORT_LEVEL_CAP="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert "LONG-SEGMENTS-OK" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.parametrize("n,B", [(0, 900), (5, 900), (12453, 900), (100000, 2160), (300001, 2160)])
