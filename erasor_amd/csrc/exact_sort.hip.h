@@ -220,6 +220,9 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
     // while n <= 16 * (qcap - 2) every short piece joins ONE queue run at the end (most parallel); a longer segment
     // (only reachable on the global-memory paths) runs the queue once per <= kBlockMin piece instead, which keeps every
     // run within kBlockMin / 17 + 1 <= qcap entries -- no input can overflow it.
+    __shared__ Seg s_small[4096 / 16 + 2];  // segments of <= 64 keys, finished by wave_small_subtree after the level loop
+    __shared__ uint32_t s_nsmall, s_small_next;
+    const uint32_t small_cap = qcap < (uint32_t)(4096 / 16 + 2) ? qcap : (uint32_t)(4096 / 16 + 2);
     __shared__ Seg stk[72];  // DFS: one sibling per level, depth <= 2 lg n <= 64
     __shared__ uint32_t sm_bp[40];
     __shared__ int sp, s_mode;
@@ -286,7 +289,14 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
         }
         if (stack_empty && mode == M_QUEUE) drained = true;  // this run also takes whatever phase 1 queued: nothing is left after it
         if (lvl_ == 0) ESORT_STAMP(1);
-        // phase 2: level-synchronous queue, one wavefront per segment
+        // phase 2: level-synchronous queue, one wavefront per segment.  Segments of <= 64 keys do not take part in the
+        // levels (a register-resident subtree costs several partitions' worth of time and would stall every level it
+        // appears in): they are set aside and handed out to the wavefronts, dynamically, once the levels are done.
+        if (tid == 0) {
+            s_nsmall = 0;
+            s_small_next = 0;
+        }
+        __syncthreads();
         int cur = 0;
     for (;;) {
         const uint32_t nseg = qcnt[cur];
@@ -306,30 +316,27 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
                 }
                 continue;
             }
-            if (sg.last - sg.first <= 64u) {  // whole subtree in registers, no children to queue
-                wave_small_subtree(K, V, head, sg.first, sg.last, sg.depth, n_fallback, &s_wsc[wave][0]);
+            if (sg.last - sg.first <= 64u) {  // (a short initial segment) whole subtree in registers, later
+                if (lane == 0) {
+                    const uint32_t at = atomicAdd(&s_nsmall, 1u);
+                    if (at < small_cap) s_small[at] = sg; else *overflow_flag = 3;
+                }
                 continue;
             }
             const uint32_t cut = wave_partition(K, V, posL, posR, sg.first, sg.last);
             if (lane == 0) {
                 atomicOr(&head[cut >> 5], 1u << (cut & 31u));
-                if (cut - sg.first > (uint32_t)kThreshold) {
-                    const uint32_t at = atomicAdd(&qcnt[cur ^ 1], 1u);
-                    if (at < qcap) {
-                        qn[at].first = sg.first;
-                        qn[at].last = cut;
-                        qn[at].depth = sg.depth - 1;
-                    } else
-                        *overflow_flag = 3;
-                }
-                if (sg.last - cut > (uint32_t)kThreshold) {
-                    const uint32_t at = atomicAdd(&qcnt[cur ^ 1], 1u);
-                    if (at < qcap) {
-                        qn[at].first = cut;
-                        qn[at].last = sg.last;
-                        qn[at].depth = sg.depth - 1;
-                    } else
-                        *overflow_flag = 3;
+                const Seg ch[2] = {{sg.first, cut, sg.depth - 1}, {cut, sg.last, sg.depth - 1}};
+                for (int t = 0; t < 2; ++t) {
+                    const uint32_t len = ch[t].last - ch[t].first;
+                    if (len <= (uint32_t)kThreshold) continue;
+                    if (len <= 64u && ch[t].depth > 0) {
+                        const uint32_t at = atomicAdd(&s_nsmall, 1u);
+                        if (at < small_cap) s_small[at] = ch[t]; else *overflow_flag = 3;
+                    } else {
+                        const uint32_t at = atomicAdd(&qcnt[cur ^ 1], 1u);
+                        if (at < qcap) qn[at] = ch[t]; else *overflow_flag = 3;
+                    }
                 }
             }
         }
@@ -341,6 +348,18 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
         __syncthreads();
         cur ^= 1;
     }
+        {   // the set-aside short segments, one wavefront each, handed out dynamically (their cost varies 4x with the length)
+            const uint32_t ns = s_nsmall < small_cap ? s_nsmall : small_cap;
+            for (;;) {
+                uint32_t i = 0;
+                if (lane == 0) i = atomicAdd(&s_small_next, 1u);
+                i = __shfl(i, 0, 64);
+                if (i >= ns) break;
+                const Seg sg = s_small[i];
+                wave_small_subtree(K, V, head, sg.first, sg.last, sg.depth, n_fallback, &s_wsc[wave][0]);
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();
     ESORT_STAMP(2);
