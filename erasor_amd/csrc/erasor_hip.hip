@@ -51,6 +51,7 @@ struct erasor_hip_handle {
     hipStream_t stream2 = nullptr;  // map chain of a step (VoI split .. bin stats), concurrent with the query chain
     hipStream_t cur = nullptr;      // stream LAUNCH() currently targets
     hipEvent_t ev_fork = nullptr, ev_keys = nullptr, ev_join = nullptr;
+    DBuf<unsigned long long> lab_slots;  // [16][8] label tallies of the assemble kernels (one cache line per slot)
     DBuf<uint32_t> qb_tot;            // [B + 1] bucket totals of the same
     DBuf<uint32_t> qb_hist;           // [B + 1][tiles] histogram of the query counting sort
     const float4 *scan_in = nullptr;  // scan of the step in flight (the caller's device buffer, or h->scan)
@@ -297,7 +298,7 @@ int alloc_bins(erasor_hip_handle *h) {
     rc |= ensure(h, h->vox_off, B) | ensure(h, h->nvox, B) | ensure(h, h->ng, B) | ensure(h, h->out_off, B) | ensure(h, h->ground_off, B);
     rc |= ensure(h, h->rej_off, B) | ensure(h, h->crej_off, B);
     rc |= ensure(h, h->plane_n, B * (size_t)std::max(h->P.gf_iter, 1) * 3) | ensure(h, h->plane_d, B * (size_t)std::max(h->P.gf_iter, 1));
-    rc |= ensure(h, h->d_st, 1) | ensure(h, h->d_ctr, 1) | ensure(h, h->dn, 16) | ensure(h, h->bb, 8) | ensure(h, h->qgrid, 1) | ensure(h, h->esqs, 1) | ensure(h, h->qb_tot, B + 2);
+    rc |= ensure(h, h->d_st, 1) | ensure(h, h->d_ctr, 1) | ensure(h, h->dn, 16) | ensure(h, h->bb, 8) | ensure(h, h->qgrid, 1) | ensure(h, h->esqs, 1) | ensure(h, h->qb_tot, B + 2) | ensure(h, h->lab_slots, 128);
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
 
@@ -569,7 +570,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->vmask); release(h->hmask); release(h->cinfo); release(h->pvl); release(h->phl); release(h->topv); release(h->toph);
     release(h->voi_ego); release(h->spts); release(h->rejected); release(h->voi_key); release(h->voi_src); release(h->ssrc);
     release(h->rejected_src); release(h->grank); release(h->glist); release(h->gflag);
-    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->qb_hist); release(h->qb_tot);
+    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->qb_hist); release(h->qb_tot); release(h->lab_slots);
     release(h->moff); release(h->mcnt); release(h->qoff); release(h->ccnt); release(h->rev_idx); release(h->rev_list); release(h->vox_off);
     release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
     release(h->mmin); release(h->mmax); release(h->cmin); release(h->cmax); release(h->plane_n); release(h->plane_d);
@@ -734,7 +735,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     h->st.o_begin = h->o_begin;
     if (h->forked) (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);  // a previous step that bailed out between fork and join
     LAUNCH(h, "step_begin", k_step_begin, 1, 256, ds, dc, (flags & STEP_QUERY_PREVOXELIZED) ? ns : 0u, h->st, 1, h->bb.p,
-           B + 1 <= QB_NB_MAX ? h->qb_tot.p : (uint32_t *)nullptr, B + 1 <= QB_NB_MAX ? B + 1 : 0u);
+           B + 1 <= QB_NB_MAX ? h->qb_tot.p : (uint32_t *)nullptr, B + 1 <= QB_NB_MAX ? B + 1 : 0u, h->lab_slots.p);
     // a device-resident scan is read in place (the call is synchronous: the caller's buffer outlives every kernel of the step)
     if (ns && !src_is_device) HIPC(h, hipMemcpyAsync(h->scan.p, scan_src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     h->scan_in = src_is_device && ns ? (const float4 *)scan_src : (const float4 *)h->scan.p;
@@ -867,12 +868,12 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         LAUNCH(h, "assemble", k_assemble_map<true>, std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
                sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p, (const uint32_t *)h->ccnt.p,
                (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p,
-               (const uint32_t *)h->rej_off.p, (const DevState *)ds, Fnew, h->rejected.p, h->rejected_src.p, ds);
+               (const uint32_t *)h->rej_off.p, (const DevState *)ds, Fnew, h->rejected.p, h->rejected_src.p, h->lab_slots.p);
     LAUNCH(h, "assemble", k_assemble_bins<true>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
            (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
-           (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, Fnew, h->curr_rejected.p, ds);
+           (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, Fnew, h->curr_rejected.p, h->lab_slots.p);
     // (label counters of the new VoI-resident region are accumulated by the two assemble kernels)
-    LAUNCH(h, "step_end", k_step_end, 1, 1, ds, (const Counters *)dc, h->pin);
+    LAUNCH(h, "step_end", k_step_end, 1, 1, ds, (const Counters *)dc, h->pin, (const unsigned long long *)h->lab_slots.p);
     const auto t_host1 = std::chrono::steady_clock::now();
     HIPC(h, hipStreamSynchronize(h->stream));
     h->st = h->pin->st;
@@ -1033,10 +1034,10 @@ int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap
                        (const uint32_t *)h->rev_idx.p, h->last_skeys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p,
                        (const uint32_t *)h->moff.p, (const uint32_t *)h->ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p,
                        (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p, (const uint32_t *)h->rej_off.p,
-                       (const DevState *)h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr, (DevState *)nullptr);
+                       (const DevState *)h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr);
             LAUNCH(h, "get_cloud", k_assemble_bins<false>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
                    (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
-                   (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, tmp, (float4 *)nullptr, (DevState *)nullptr);
+                   (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, tmp, (float4 *)nullptr, (unsigned long long *)nullptr);
             HIPC(h, hipStreamSynchronize(h->stream));
             const size_t off = which == ERASOR_CLOUD_STATIC_ESTIMATE ? 0 : (which == ERASOR_CLOUD_COMPLEMENT ? s.n_static_est : s.total_bins);
             if (cnt) HIPC(h, hipMemcpy(dst, tmp + off, cnt * sizeof(float4), hipMemcpyDeviceToHost));
@@ -1123,7 +1124,7 @@ int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src
     if (rc) return rc;
     if (ns) HIPC(h, hipMemcpyAsync(h->scan.p, src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     h->scan_in = (const float4 *)h->scan.p;
-    LAUNCH(h, "step_begin", k_step_begin, 1, 256, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p, (uint32_t *)nullptr, 0u);
+    LAUNCH(h, "step_begin", k_step_begin, 1, 256, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p, (uint32_t *)nullptr, 0u, (unsigned long long *)nullptr);
     voxelize_query_part1(h, ns, (float)leaf_size, [] {});
     DevState st;
     VoxGrid g;
@@ -1228,7 +1229,7 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
     const uint32_t ns = (uint32_t)n;
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
-    LAUNCH(h, "step_begin", k_step_begin, 1, 256, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p, (uint32_t *)nullptr, 0u);
+    LAUNCH(h, "step_begin", k_step_begin, 1, 256, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p, (uint32_t *)nullptr, 0u, (unsigned long long *)nullptr);
     if (ns) {
         HIPC(h, hipMemcpyAsync(h->qk_a.p, keys, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
         HIPC(h, hipMemcpyAsync(h->qv_a.p, vals, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));

@@ -2018,7 +2018,7 @@ __global__ __launch_bounds__(1024) void k_layout(DP P, const uint8_t *__restrict
 // coordinates (the clouds get_static_estimate / get_outliers hand out).
 // parse_dynamic_obj as counters (utils.cpp:57-78) over the points a workgroup wrote to Fnew: per-thread tallies (d, s),
 // one pair of device-scope atomics per workgroup (same-address atomics serialise: keep them few)
-__device__ __forceinline__ void block_commit_labels(uint32_t d, uint32_t s, DevState *cnt) {
+__device__ __forceinline__ void block_commit_labels(uint32_t d, uint32_t s, unsigned long long *cnt /* [16][8]: {static, dynamic, pad} */) {
     __shared__ uint32_t sd[16], ss[16];
     if (!cnt) return;
     for (int o = 32; o > 0; o >>= 1) {
@@ -2036,8 +2036,10 @@ __device__ __forceinline__ void block_commit_labels(uint32_t d, uint32_t s, DevS
             td += sd[w];
             ts += ss[w];
         }
-        if (td) atomicAdd(&cnt->F_dynamic, (unsigned long long)td);
-        if (ts) atomicAdd(&cnt->F_static, (unsigned long long)ts);
+        // 16 slots, one cache line each: same-address atomics serialise (~6 ns apiece), k_step_end adds the slots up
+        unsigned long long *slot = cnt + (blockIdx.x & 15u) * 8u;
+        if (td) atomicAdd(slot + 1, (unsigned long long)td);
+        if (ts) atomicAdd(slot, (unsigned long long)ts);
     }
 }
 
@@ -2050,7 +2052,7 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
                                                        const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ ground_off,
                                                        const uint32_t *__restrict__ rej_off, const DevState *st,
                                                        float4 *__restrict__ Fnew, float4 *__restrict__ rejected,
-                                                       uint32_t *__restrict__ rejected_src, DevState *cnt) {
+                                                       uint32_t *__restrict__ rejected_src, unsigned long long *cnt) {
     uint32_t nd = 0, nst = 0;  // label tallies of the copies this thread wrote to Fnew
     const uint32_t n_act = st->voi_total;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_act; i += gridDim.x * blockDim.x) {
@@ -2100,7 +2102,7 @@ __global__ __launch_bounds__(256) void k_assemble_bins(DP P, Xf Tb2o, const uint
                                                         const float4 *__restrict__ sq, const uint32_t *__restrict__ nvox,
                                                         const uint32_t *__restrict__ vox_off, const float4 *__restrict__ vox_out,
                                                         const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ crej_off,
-                                                        float4 *__restrict__ Fnew, float4 *__restrict__ curr_rejected, DevState *cnt) {
+                                                        float4 *__restrict__ Fnew, float4 *__restrict__ curr_rejected, unsigned long long *cnt) {
     const int key = blockIdx.x;
     const uint8_t act = action[key];
     if (act == 0) return;  // (block-uniform exits: no thread reaches the tally's barrier)
@@ -2166,7 +2168,8 @@ struct HostOut {
 // `init` != nullptr semantics are by value: when use_init is set the whole device state is replaced by the host's mirror
 // (nF / o_begin may have been changed by host-side map maintenance); bb != nullptr also resets the query bounding box.
 __global__ void k_step_begin(DevState *st, Counters *ctr, uint32_t q_nvox_init, DevState init, int use_init, uint32_t *bb, uint32_t *qb_tot,
-                             uint32_t qb_n) {
+                             uint32_t qb_n, unsigned long long *lab_slots) {
+    if (lab_slots && threadIdx.x < 128) lab_slots[threadIdx.x] = 0;
     for (uint32_t b = threadIdx.x; b < qb_n; b += blockDim.x) qb_tot[b] = 0;  // bucket totals of the query counting sort
     if (threadIdx.x == 0) {
         if (use_init) *st = init;
@@ -2181,7 +2184,16 @@ __global__ void k_step_begin(DevState *st, Counters *ctr, uint32_t q_nvox_init, 
         if (threadIdx.x >= 3 && threadIdx.x < 6) bb[threadIdx.x] = 0u;
     }
 }
-__global__ void k_step_end(DevState *st, const Counters *ctr, HostOut *out) {
+__global__ void k_step_end(DevState *st, const Counters *ctr, HostOut *out, const unsigned long long *lab_slots) {
+    if (lab_slots) {
+        unsigned long long ns = 0, nd = 0;
+        for (int i = 0; i < 16; ++i) {
+            ns += lab_slots[i * 8];
+            nd += lab_slots[i * 8 + 1];
+        }
+        st->F_static = ns;
+        st->F_dynamic = nd;
+    }
     if (!(ctr->err || ctr->sort_qoverflow)) {
         st->nF = st->nF_new;
         st->o_begin = st->o_new_begin;
