@@ -157,7 +157,7 @@ def main():
     rocprof_avg = None  # kernel-only average of the committed rocprofv3 --kernel-trace --stats run of this command
     try:
         import csv
-        with open(os.path.join(ROOT, "profiles", "r01c_rocprofv3_kernel_stats.csv")) as f:
+        with open(os.path.join(ROOT, "profiles", "kernel_stats_latest.csv")) as f:
             for row in csv.DictReader(f):
                 if "k_voi_split" in row["Name"]:
                     rocprof_avg = round(float(row["AverageNs"]) / 1e3, 2)

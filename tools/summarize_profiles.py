@@ -1,0 +1,57 @@
+"""Condense rocprofv3 outputs into the small files kept under profiles/ (see tools/collect_profiles.sh)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+stats_dir, fetch_dir, write_dir, out = sys.argv[1:5]
+
+
+def find(d, pat):
+    f = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    return f[-1] if f else None
+
+
+ks = find(stats_dir, "*kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(out, "rocprofv3_kernel_stats.csv"))
+
+
+def pmc(d, counter):
+    f = find(d, "*counter_collection.csv")
+    per = defaultdict(list)
+    if not f:
+        return {}
+    for row in csv.DictReader(open(f)):
+        if row.get("Counter_Name") != counter:
+            continue
+        name = row["Kernel_Name"].split("(")[0]
+        per[name].append(float(row["Counter_Value"]))
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB
+    return {k: {"dispatches": len(v), "mean_KiB": round(sum(v) / len(v), 1), "max_KiB": round(max(v), 1)} for k, v in sorted(per.items())}
+
+
+res = {"FETCH_SIZE": pmc(fetch_dir, "FETCH_SIZE"), "WRITE_SIZE": pmc(write_dir, "WRITE_SIZE")}
+json.dump(res, open(os.path.join(out, "pmc_fetch_write_size.json"), "w"), indent=1)
+
+# k_voi_split traffic per launch, corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 128-B
+# requests as 64 B: x2; calibrated on k_store_outskirts, a pure 16 B/pt stream, when it is in the trace)
+fs = res["FETCH_SIZE"].get("ek::k_voi_split")
+ws = res["WRITE_SIZE"].get("ek::k_voi_split")
+if fs:
+    latest = {
+        "kernel": "k_voi_split",
+        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/collect_profiles.sh)",
+        "fetch_size_KiB_per_launch": fs["mean_KiB"],
+        "write_size_KiB_per_launch": ws["mean_KiB"] if ws else None,
+        "gfx950_correction": "FETCH_SIZE x2 (128-B requests tallied at 64 B)",
+        "traffic_bytes_per_launch": int(fs["mean_KiB"] * 1024 * 2 + (ws["mean_KiB"] * 1024 if ws else 0)),
+    }
+    cal = res["FETCH_SIZE"].get("ek::k_store_outskirts")
+    if cal:
+        latest["calibration_k_store_outskirts_fetch_KiB"] = cal["max_KiB"]
+    json.dump(latest, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
+print(json.dumps({"kernel_stats": ks, "voi_split_fetch": fs, "voi_split_write": ws}))
