@@ -542,8 +542,11 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
     memset(&h->st, 0, sizeof(h->st));
     memset(&h->ctr, 0, sizeof(h->ctr));
     memset(&h->last_res, 0, sizeof(h->last_res));
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+    // the query chain is the critical path of a step: its stream gets the highest priority, the map chain's the lowest
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_keys, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
