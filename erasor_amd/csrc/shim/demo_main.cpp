@@ -54,17 +54,56 @@ static int erasor_class_mode(int argc, char **argv) {
     return 0;
 }
 
+// --config <rosparam.yaml> [n_frames]: the reference's own driver, main_in_your_env.cpp:61-127, without ROS:
+//   <data_dir>/poses_lidar2body.csv, <data_dir>/pcds/%06d.pcd from init_idx on, every node through
+//   OfflineMapUpdater::callback_node (pose -> eigen2geoPose -> node.odom), then save_static_map(0.2).
+// The initial map is /MapUpdater/initial_map_path, or <data_dir>/dense_global_map.pcd when that key is absent.
+static int config_mode(int argc, char **argv) {
+    if (argc < 3) return 2;
+    erasor::OfflineMapUpdater::Config cfg;
+    erasor_hip_params_default(&cfg.params);
+    cfg.params.query_voxel_size = 0.05;  // OMU.cpp:66
+    cfg.params.removal_interval = 2;     // OMU.cpp:69
+    cfg.verbose = true;                  // OMU.cpp:83
+    erasor::DriverConfig drv;
+    if (!erasor::load_config_yaml(argv[2], cfg, &drv)) {
+        fprintf(stderr, "cannot read %s\n", argv[2]);
+        return 3;
+    }
+    const int max_frames = argc > 3 ? atoi(argv[3]) : 1 << 30;
+    if (cfg.initial_map_path.empty() || cfg.initial_map_path == "/") cfg.initial_map_path = drv.data_dir + "/dense_global_map.pcd";
+    if (cfg.save_path == "/" || cfg.save_path == ".") cfg.save_path = drv.data_dir;
+    erasor::OfflineMapUpdater updater(cfg);
+    std::vector<Eigen::Matrix4f> poses;
+    if (!erasor::load_all_poses(drv.data_dir + "/poses_lidar2body.csv", poses)) {
+        fprintf(stderr, "cannot read %s/poses_lidar2body.csv\n", drv.data_dir.c_str());
+        return 3;
+    }
+    printf("Total %zu poses are loaded\n", poses.size() + 1);  // main_in_your_env.cpp:58 counts the header line too
+    int done = 0;
+    for (int i = drv.init_idx; i < (int)poses.size() && done < max_frames; ++i, ++done) {
+        char name[64];
+        snprintf(name, sizeof(name), "/pcds/%06d.pcd", i);
+        pcl::PointCloud<pcl::PointXYZI> scan;
+        if (erasor_utils::load_pcd(drv.data_dir + name, scan) == -1) return 3;
+        updater.callback_node(i, erasor_utils::eigen2geoPose(poses[i]), scan);
+    }
+    updater.save_static_map(0.2f);  // main_in_your_env.cpp:123
+    printf("Static map building complete!\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
-    if (argc >= 2 && std::string(argv[1]) == "--erasor-class") {
+    if (argc >= 2 && (std::string(argv[1]) == "--erasor-class" || std::string(argv[1]) == "--config")) {
         try {
-            return erasor_class_mode(argc, argv);
+            return std::string(argv[1]) == "--config" ? config_mode(argc, argv) : erasor_class_mode(argc, argv);
         } catch (const std::exception &e) {
             fprintf(stderr, "error: %s\n", e.what());
             return 1;
         }
     }
     if (argc < 3) {
-        fprintf(stderr, "usage: %s <data_dir> <n_frames> [version] [removal_interval]\n", argv[0]);
+        fprintf(stderr, "usage: %s <data_dir> <n_frames> [version] [removal_interval]\n       %s --config <rosparam.yaml> [n_frames]\n", argv[0], argv[0]);
         return 2;
     }
     const std::string dir = argv[1];

@@ -116,71 +116,6 @@ void count_stat_dyn(const Cloud &cloudIn, int &num_static, int &num_dynamic) {
     num_dynamic = d;
 }
 
-int load_pcd(const std::string &pcd_name, Cloud &dst) {
-    std::ifstream f(pcd_name, std::ios::binary);
-    if (!f) {
-        fprintf(stderr, "Couldn't read file!!! \n");
-        return -1;
-    }
-    std::string line, mode;
-    std::vector<std::string> fields;
-    size_t npts = 0;
-    while (std::getline(f, line)) {
-        if (line.empty() || line[0] == '#') continue;
-        std::istringstream ss(line);
-        std::string key;
-        ss >> key;
-        if (key == "FIELDS") {
-            std::string t;
-            while (ss >> t) fields.push_back(t);
-        } else if (key == "POINTS") {
-            ss >> npts;
-        } else if (key == "DATA") {
-            ss >> mode;
-            break;
-        }
-    }
-    int ix = -1, iy = -1, iz = -1, ii = -1;
-    for (size_t k = 0; k < fields.size(); ++k) {
-        if (fields[k] == "x") ix = (int)k;
-        if (fields[k] == "y") iy = (int)k;
-        if (fields[k] == "z") iz = (int)k;
-        if (fields[k] == "intensity") ii = (int)k;
-    }
-    if (ix < 0 || iy < 0 || iz < 0 || fields.empty()) return -1;
-    dst.points.resize(npts);
-    const size_t nf = fields.size();
-    std::vector<float> row(nf);
-    if (mode == "ascii") {
-        for (size_t i = 0; i < npts; ++i) {
-            for (size_t k = 0; k < nf; ++k)
-                if (!(f >> row[k])) return -1;
-            dst.points[i].x = row[ix]; dst.points[i].y = row[iy]; dst.points[i].z = row[iz];
-            dst.points[i].intensity = ii >= 0 ? row[ii] : 0.f;
-        }
-    } else if (mode == "binary") {  // all-float32 fields only
-        for (size_t i = 0; i < npts; ++i) {
-            if (!f.read(reinterpret_cast<char *>(row.data()), (std::streamsize)(nf * 4))) return -1;
-            dst.points[i].x = row[ix]; dst.points[i].y = row[iy]; dst.points[i].z = row[iz];
-            dst.points[i].intensity = ii >= 0 ? row[ii] : 0.f;
-        }
-    } else {
-        return -1;
-    }
-    dst.width = (unsigned)npts;
-    dst.height = 1;
-    return 0;
-}
-
-int save_pcd_ascii(const std::string &pcd_name, const Cloud &src) {
-    FILE *fp = fopen(pcd_name.c_str(), "w");
-    if (!fp) return -1;
-    fprintf(fp, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n");
-    fprintf(fp, "WIDTH %zu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %zu\nDATA ascii\n", src.size(), src.size());
-    for (const auto &p : src.points) fprintf(fp, "%.8g %.8g %.8g %.8g\n", p.x, p.y, p.z, p.intensity);
-    fclose(fp);
-    return 0;
-}
 }  // namespace erasor_utils
 
 // ------------------------------------------------------------------------------------------------

@@ -27,10 +27,14 @@ Eigen::Matrix4f inverse(const Eigen::Matrix4f &T);
 void parse_dynamic_obj(const Cloud &cloudIn, Cloud &dynamicOut, Cloud &staticOut);
 // utils.cpp:116-138
 void count_stat_dyn(const Cloud &cloudIn, int &num_static, int &num_dynamic);
-// utils.hpp:75-93 — ASCII or binary .pcd with fields x y z intensity; returns -1 on failure like the reference
+// utils.cpp:6-33 (tf::Matrix3x3::getRotation in double)
+geometry_msgs::Pose eigen2geoPose(const Eigen::Matrix4f &pose);
+// utils.hpp:75-93 — .pcd with fields x y z [intensity] (ASCII, binary with any SIZE/TYPE/COUNT layout,
+// binary_compressed); returns -1 on failure like the reference
 int load_pcd(const std::string &pcd_name, Cloud &dst);
-// pcl::io::savePCDFileASCII as used at OMU.cpp:193
+// pcl::io::savePCDFileASCII as used at OMU.cpp:193 (PCL's default: 8 significant digits), and the lossless binary form
 int save_pcd_ascii(const std::string &pcd_name, const Cloud &src);
+int save_pcd_binary(const std::string &pcd_name, const Cloud &src);
 }  // namespace erasor_utils
 
 // class ERASOR (erasor.h:43-228).  Inputs of set_inputs are egocentric clouds, as in the reference.
@@ -89,5 +93,16 @@ private:
     Eigen::Matrix4f tf_lidar2body_, tf_body2origin_;
     int stack_count_ = 0;
 };
+// main_in_your_env.cpp:66-70: the driver's own rosparams
+struct DriverConfig {
+    std::string data_dir = "/";
+    double voxel_size = 0.075;
+    int init_idx = 0, interval = 2;
+};
+// Reads a rosparam YAML file in the reference's layout (config/*.yaml).  Keys that are absent keep the values already
+// in cfg (fill it with the reference's defaults first: erasor_hip_params_default + OMU.cpp:66-83).
+bool load_config_yaml(const std::string &path, OfflineMapUpdater::Config &cfg, DriverConfig *drv = nullptr);
+// main_in_your_env.cpp:33-59: poses_lidar2body.csv -> 4x4 float transforms (one per line after the header)
+bool load_all_poses(const std::string &txt, std::vector<Eigen::Matrix4f> &poses);
 }  // namespace erasor
 #endif

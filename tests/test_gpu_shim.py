@@ -103,3 +103,55 @@ def test_erasor_class_on_egocentric_clouds(tmp_path, version):
     bad = subprocess.run([DEMO, "--erasor-class", os.path.join(d, "map_voi.bin"), os.path.join(d, "query_voi.bin"), os.path.join(d, "o2"), "4"],
                          capture_output=True, text=True, timeout=600)
     assert bad.returncode == 1 and "not implemented" in bad.stderr   # std::invalid_argument, as OMU.cpp:274
+
+
+def test_config_driver_like_main_in_your_env(tmp_path):
+    """erasor_offline_demo --config <rosparam.yaml>: the reference's own driver flow (main_in_your_env.cpp:61-127) —
+    YAML in the reference's layout, <data_dir>/poses_lidar2body.csv (float parse, Quaternionf -> matrix ->
+    eigen2geoPose -> node.odom -> geoPose2eigen), <data_dir>/pcds/%06d.pcd from init_idx, save_static_map(0.2)."""
+    import ctypes as C
+    from oracle import orc
+    from erasor_amd import synth
+    ensure_demo()
+    sc = scenarios.small()
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "pcds"))
+    os.makedirs(os.path.join(d, "out"))
+    write_pcd_binary(os.path.join(d, "dense_global_map.pcd"), sc["map"])
+    n, init_idx = 6, 1
+    with open(os.path.join(d, "poses_lidar2body.csv"), "w") as f:
+        f.write("index, timestamp, x, y, z, qx, qy, qz, qw\n")
+        for k in range(n):
+            write_pcd_binary(os.path.join(d, "pcds", "%06d.pcd" % k), sc["scans"][k])
+            f.write("%d, %.2f, %s\n" % (k, 0.1 * k, ", ".join("%.9f" % v for v in sc["poses"][k])))
+    sp = synth.SEQ_PARAMS["05"]
+    with open(os.path.join(d, "cfg.yaml"), "w") as f:
+        f.write("erasor:\n")
+        for key in ("max_range", "num_rings", "num_sectors", "min_h", "max_h", "th_bin_max_h", "scan_ratio_threshold", "minimum_num_pts",
+                    "gf_dist_thr", "gf_iter", "gf_num_lpr", "gf_th_seeds_height"):
+            f.write("    %s: %s # from config/seq_05.yaml\n" % (key, sp[key]))
+        f.write("    rejection_ratio: 0\n    version: 3\n\nMapUpdater:\n    data_name: \"05\"\n    env: \"outdoor\"\n")
+        f.write("    save_path: \"%s\"\n    query_voxel_size: 0.2\n    map_voxel_size: 0.05\n    removal_interval: 1\n\n" % os.path.join(d, "out"))
+        f.write("data_dir: \"%s\"\ninit_idx: %d\ninterval: 2\nvoxel_size: 0.075\n" % (d, init_idx))
+        f.write("tf:\n     lidar2body: [0.0, 0.0, %s, 0, 0.0, 0.0, 1.0] # xyz q_x, q_y, q_z, q_w in order\n\nverbose: true\n" % synth.LIDAR_HEIGHT)
+    out = subprocess.run([DEMO, "--config", os.path.join(d, "cfg.yaml")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Static map building complete!" in out.stdout
+    # the oracle, fed with the transforms the driver derives from the csv
+    shim = C.CDLL(os.path.join(ROOT, "erasor_amd", "liberasor_shim.so"))
+    shim.erasor_shim_load_poses.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+    shim.erasor_shim_load_poses.restype = C.c_long
+    T = np.zeros((n, 16), np.float32)
+    geo = np.zeros((n, 7), np.float64)
+    R = np.zeros((n, 16), np.float32)
+    assert shim.erasor_shim_load_poses(os.path.join(d, "poses_lidar2body.csv").encode(), T.ctypes.data, geo.ctypes.data, R.ctypes.data, n) == n
+    o = orc.Oracle(sc["params"])
+    o.set_map(sc["map"])
+    for k in range(init_idx, n):
+        Tb = np.ascontiguousarray(R[k].reshape(4, 4))
+        o.step(sc["scans"][k], sc["T_l2b"], Tb, orc.invert4(Tb))
+    ref = orc.voxelize_preserving_labels(o.get_map(), 0.2)
+    saved = np.loadtxt(os.path.join(d, "out", "05_result.pcd"), skiprows=11, dtype=np.float64).reshape(-1, 4)
+    assert saved.shape == ref.shape
+    # ASCII PCD with PCL's 8 significant digits (OMU.cpp:193)
+    assert np.allclose(saved[:, :3], ref[:, :3], rtol=2e-7, atol=1e-7) and np.array_equal(saved[:, 3], ref[:, 3].astype(np.float64))

@@ -1,0 +1,290 @@
+"""Host-side file code of the C++ shim: rosparam YAML in the reference's layout, poses csv and
+the pose -> node.odom round trip, .pcd readers/writers.  CPU only: no kernel is launched."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def shim():
+    import erasor_amd
+    erasor_amd.build()
+    lib = C.CDLL(os.path.join(ROOT, "erasor_amd", "liberasor_shim.so"))
+    lib.erasor_shim_dump_config.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    lib.erasor_shim_dump_config.restype = C.c_int
+    lib.erasor_shim_load_pcd.argtypes = [C.c_char_p, C.c_void_p, C.c_long]
+    lib.erasor_shim_load_pcd.restype = C.c_long
+    lib.erasor_shim_save_pcd.argtypes = [C.c_char_p, C.c_void_p, C.c_long, C.c_int]
+    lib.erasor_shim_save_pcd.restype = C.c_int
+    lib.erasor_shim_load_poses.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+    lib.erasor_shim_load_poses.restype = C.c_long
+    return lib
+
+
+def dump_config(shim, path):
+    buf = C.create_string_buffer(8192)
+    n = shim.erasor_shim_dump_config(str(path).encode(), buf, 8192)
+    assert n > 0
+    return dict(line.split("=", 1) for line in buf.value.decode().strip().split("\n"))
+
+
+YAML_FULL = """idx: 450
+erasor: 
+    max_range: 80.0
+    num_rings: 20
+    num_sectors: 108
+    min_h: -1.3 # [m] depends on the body frame height
+    max_h: 3.0 # [m]
+    th_bin_max_h: 0.2 # [m]
+    scan_ratio_threshold: 0.2 # The Larger, the more aggressive!!
+    minimum_num_pts: 6
+    rejection_ratio: 0
+    gf_dist_thr: 0.25
+    gf_iter: 3
+    gf_num_lpr: 20
+    gf_th_seeds_height: 0.5
+    map_voxel_size: 0.2
+    version: 3 # 2: R-GPF / 3: R-GPF w/ blocking
+
+
+MapUpdater:
+    data_name: "00"
+    initial_map_path: "/data/my maps/00_0_to_4540_w_interval2_voxel_0.200000.pcd"
+    env: "outdoor"
+    save_path: '/data/out#1'
+    query_voxel_size: 0.2
+    map_voxel_size: 0.2  
+    voxelization_interval: 2
+    removal_interval: 4
+
+large_scale:
+    is_large_scale: true
+    submap_size: 160.0
+
+tf:
+     lidar2body: [0.0, 0.0, 1.73, 0, 0.0, 0.0, 1.0] # xyz q_x, q_y, q_z, q_w in order
+
+verbose: false
+"""
+
+YAML_OWN_ENV = """erasor:
+    max_range: 9.5
+    num_rings: 8
+    th_bin_max_h: -1.0
+    version: 2
+data_dir: "/data/bongeunsa"
+voxel_size: 0.075
+init_idx: 130
+interval: 2
+tf:
+     lidar2body: [0.1, -0.2, 0.3, 0, 0.0, 0.7071, 0.7071]
+"""
+
+
+def test_rosparam_yaml_in_the_reference_layout(shim, tmp_path):
+    p = tmp_path / "large_scale.yaml"
+    p.write_text(YAML_FULL)
+    d = dump_config(shim, p)
+    assert float(d["max_range"]) == 80.0 and int(d["num_rings"]) == 20 and int(d["num_sectors"]) == 108
+    assert float(d["min_h"]) == -1.3 and float(d["max_h"]) == 3.0 and float(d["th_bin_max_h"]) == 0.2
+    assert float(d["scan_ratio_threshold"]) == 0.2 and int(d["minimum_num_pts"]) == 6 and float(d["rejection_ratio"]) == 0.0
+    assert float(d["gf_dist_thr"]) == 0.25 and int(d["gf_iter"]) == 3 and int(d["gf_num_lpr"]) == 20
+    assert float(d["gf_th_seeds_height"]) == 0.5 and float(d["map_voxel_size"]) == 0.2 and int(d["version"]) == 3
+    assert int(d["num_lowest_pts"]) == 5  # absent: erasor.h:54 default
+    assert float(d["query_voxel_size"]) == 0.2 and int(d["removal_interval"]) == 4
+    assert d["data_name"] == "00" and d["env"] == "outdoor"
+    assert d["initial_map_path"] == "/data/my maps/00_0_to_4540_w_interval2_voxel_0.200000.pcd"
+    assert d["save_path"] == "/data/out#1"  # '#' inside quotes is not a comment
+    assert d["is_large_scale"] == "1" and float(d["submap_size"]) == 160.0 and d["verbose"] == "0"
+    assert [float(x) for x in d["lidar2body"].split(",")] == [0.0, 0.0, 1.73, 0.0, 0.0, 0.0, 1.0]
+
+
+def test_rosparam_defaults_are_the_references(shim, tmp_path):
+    p = tmp_path / "own.yaml"
+    p.write_text(YAML_OWN_ENV)
+    d = dump_config(shim, p)
+    assert float(d["max_range"]) == 9.5 and int(d["num_rings"]) == 8 and float(d["th_bin_max_h"]) == -1.0 and int(d["version"]) == 2
+    # everything else: nh.param defaults of erasor.h:47-61 and OMU.cpp:66-83
+    assert int(d["num_sectors"]) == 60 and float(d["max_h"]) == 3.0 and float(d["min_h"]) == 0.0
+    assert float(d["scan_ratio_threshold"]) == 0.22 and int(d["num_lowest_pts"]) == 5 and int(d["minimum_num_pts"]) == 4
+    assert float(d["rejection_ratio"]) == 0.33 and float(d["gf_dist_thr"]) == 0.05 and int(d["gf_num_lpr"]) == 10
+    assert float(d["query_voxel_size"]) == 0.05 and int(d["removal_interval"]) == 2
+    assert d["is_large_scale"] == "0" and float(d["submap_size"]) == 200.0
+    assert d["data_dir"] == "/data/bongeunsa" and float(d["voxel_size"]) == 0.075 and int(d["init_idx"]) == 130 and int(d["interval"]) == 2
+    assert [float(x) for x in d["lidar2body"].split(",")] == [0.1, -0.2, 0.3, 0.0, 0.0, 0.7071, 0.7071]
+
+
+def load_pcd(shim, path, cap=1 << 20):
+    buf = np.zeros((cap, 4), np.float32)
+    n = shim.erasor_shim_load_pcd(str(path).encode(), buf.ctypes.data, cap)
+    return n, buf[:max(n, 0)]
+
+
+def test_pcd_ascii_and_binary_round_trip(shim, tmp_path):
+    rng = np.random.default_rng(5)
+    pts = (rng.standard_normal((1000, 4)) * 37.123).astype(np.float32)
+    pts[:, 3] = rng.integers(0, 1 << 20, 1000).astype(np.float32)  # labels (instance << 16 | class) as floats
+    pts[0] = [1e-30, -0.0, 3.4e38, 16777215.0]
+    for binary in (0, 1):
+        f = tmp_path / ("c%d.pcd" % binary)
+        assert shim.erasor_shim_save_pcd(str(f).encode(), pts.ctypes.data, len(pts), binary) == 0
+        n, back = load_pcd(shim, f)
+        assert n == len(pts)
+        if binary:
+            assert np.array_equal(back.view(np.uint32), pts.view(np.uint32))
+        else:  # savePCDFileASCII keeps 8 significant digits (PCL's default precision), like the reference's output
+            want = np.array([[np.float32(float("%.8g" % v)) for v in row] for row in pts], np.float32)
+            assert np.array_equal(back.view(np.uint32), want.view(np.uint32))
+    assert shim.erasor_shim_load_pcd(str(tmp_path / "missing.pcd").encode(), None, 0) == -1  # utils.hpp:80 returns -1
+
+
+def test_pcd_binary_with_a_mixed_field_layout(shim, tmp_path):
+    # x y z float32, intensity uint16... as a real sensor driver writes them: t float64, ring uint16, rgb-like count 3
+    n = 257
+    rng = np.random.default_rng(6)
+    xyz = rng.standard_normal((n, 3)).astype(np.float32)
+    inten = rng.integers(0, 65535, n).astype(np.uint16)
+    t = rng.random(n)
+    ring = rng.integers(0, 128, n).astype(np.uint16)
+    hdr = ("# .PCD v0.7\nVERSION 0.7\nFIELDS x y z t intensity ring normal\nSIZE 4 4 4 8 2 2 4\nTYPE F F F F U U F\n"
+           "COUNT 1 1 1 1 1 1 3\nWIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary\n" % (n, n))
+    body = b"".join(struct.pack("<fffdHHfff", *xyz[i], t[i], inten[i], ring[i], 0.0, 0.0, 1.0) for i in range(n))
+    f = tmp_path / "mixed.pcd"
+    f.write_bytes(hdr.encode() + body)
+    m, back = load_pcd(shim, f)
+    assert m == n
+    assert np.array_equal(back[:, :3], xyz) and np.array_equal(back[:, 3], inten.astype(np.float32))
+
+
+def lzf_compress(data: bytes) -> bytes:
+    """Greedy LZF encoder (format of liblzf / pcl::lzfCompress): literal runs <= 32 bytes, back references of
+    3..264 bytes at offsets <= 8192.  Brute-force matching: test inputs are small."""
+    out = bytearray()
+    lit = bytearray()
+    i, n = 0, len(data)
+
+    def flush():
+        while lit:
+            chunk = lit[:32]
+            out.append(len(chunk) - 1)
+            out.extend(chunk)
+            del lit[:32]
+
+    while i < n:
+        best_len, best_off = 0, 0
+        lo = max(0, i - 8192)
+        if i + 3 <= n:
+            key = data[i:i + 3]
+            j = data.rfind(key, lo, i + 2)
+            while j != -1 and j < i:
+                ln = 3
+                while i + ln < n and ln < 264 and data[j + ln] == data[i + ln]:
+                    ln += 1
+                if ln > best_len:
+                    best_len, best_off = ln, i - j
+                j = data.rfind(key, lo, j + 2) if j > lo else -1
+        if best_len >= 3:
+            flush()
+            ln, off = best_len - 2, best_off - 1
+            if ln < 7:
+                out.append((ln << 5) | (off >> 8))
+            else:
+                out.append((7 << 5) | (off >> 8))
+                out.append(ln - 7)
+            out.append(off & 0xFF)
+            i += best_len
+        else:
+            lit.append(data[i])
+            i += 1
+    flush()
+    return bytes(out)
+
+
+def test_pcd_binary_compressed(shim, tmp_path):
+    n = 600
+    rng = np.random.default_rng(7)
+    x = np.round(rng.standard_normal(n) * 10, 1).astype(np.float32)
+    y = np.repeat(np.float32(2.5), n)              # long runs -> back references
+    z = np.tile(np.arange(6, dtype=np.float32), n // 6)
+    inten = rng.integers(40, 44, n).astype(np.float32)
+    soa = x.tobytes() + y.tobytes() + z.tobytes() + inten.tobytes()  # binary_compressed stores field after field
+    comp = lzf_compress(soa)
+    assert len(comp) < len(soa) // 2
+    hdr = ("# .PCD v0.7\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH %d\nHEIGHT 1\n"
+           "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary_compressed\n" % (n, n))
+    f = tmp_path / "comp.pcd"
+    f.write_bytes(hdr.encode() + struct.pack("<II", len(comp), len(soa)) + comp)
+    m, back = load_pcd(shim, f)
+    assert m == n
+    assert np.array_equal(back, np.stack([x, y, z, inten], axis=1))
+    # a truncated stream must fail cleanly
+    f.write_bytes(hdr.encode() + struct.pack("<II", len(comp) - 5, len(soa)) + comp[:-5])
+    assert shim.erasor_shim_load_pcd(str(f).encode(), None, 0) == -1
+
+
+def test_poses_csv_and_the_pose_to_odom_round_trip(shim, tmp_path):
+    from oracle import orc
+    rng = np.random.default_rng(8)
+    n = 50
+    q = rng.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[0] = [0, 0, 0, 1]
+    q[1] = [1, 0, 0, 0]          # trace < 0 branches of getRotation
+    q[2] = [0, 1, 0, 0]
+    q[3] = [0, 0, 1, 0]
+    xyz = rng.standard_normal((n, 3)) * 100
+    lines = ["index, timestamp, x, y, z, qx, qy, qz, qw"]
+    for i in range(n):
+        lines.append("%d, %.3f, %.9f, %.9f, %.9f, %.9f, %.9f, %.9f, %.9f" % (i, 0.1 * i, *xyz[i], *q[i]))
+    f = tmp_path / "poses_lidar2body.csv"
+    f.write_text("\n".join(lines) + "\n")
+    T = np.zeros((n, 16), np.float32)
+    geo = np.zeros((n, 7), np.float64)
+    R = np.zeros((n, 16), np.float32)
+    assert shim.erasor_shim_load_poses(str(f).encode(), T.ctypes.data, geo.ctypes.data, R.ctypes.data, n) == n
+    f32 = np.float32
+    for i in range(n):
+        v = [f32(t) for t in lines[i + 1].split(",")]  # stof
+        x, y, z, w = v[5], v[6], v[7], v[8]
+        # Eigen::Quaternionf::toRotationMatrix, float32 operation by operation
+        tx, ty, tz = f32(2) * x, f32(2) * y, f32(2) * z
+        twx, twy, twz = tx * w, ty * w, tz * w
+        txx, txy, txz = tx * x, ty * x, tz * x
+        tyy, tyz, tzz = ty * y, tz * y, tz * z
+        M = np.array([[f32(1) - (tyy + tzz), txy - twz, txz + twy, v[2]],
+                      [txy + twz, f32(1) - (txx + tzz), tyz - twx, v[3]],
+                      [txz - twy, tyz + twx, f32(1) - (txx + tyy), v[4]],
+                      [0, 0, 0, 1]], np.float32)
+        assert np.array_equal(T[i].reshape(4, 4).view(np.uint32), M.view(np.uint32)), i
+        # tf::Matrix3x3::getRotation in double
+        m = M[:3, :3].astype(np.float64)
+        tr = m[0, 0] + m[1, 1] + m[2, 2]
+        t = [0.0] * 4
+        if tr > 0:
+            s = np.sqrt(tr + 1.0)
+            t[3] = s * 0.5
+            s = 0.5 / s
+            t[0] = (m[2, 1] - m[1, 2]) * s
+            t[1] = (m[0, 2] - m[2, 0]) * s
+            t[2] = (m[1, 0] - m[0, 1]) * s
+        else:
+            a = (2 if m[1, 1] < m[2, 2] else 1) if m[0, 0] < m[1, 1] else (2 if m[0, 0] < m[2, 2] else 0)
+            b, c = (a + 1) % 3, (a + 2) % 3
+            s = np.sqrt(m[a, a] - m[b, b] - m[c, c] + 1.0)
+            t[a] = s * 0.5
+            s = 0.5 / s
+            t[3] = (m[c, b] - m[b, c]) * s
+            t[b] = (m[b, a] + m[a, b]) * s
+            t[c] = (m[c, a] + m[a, c]) * s
+        want = np.array([M[0, 3], M[1, 3], M[2, 3], *t], np.float64)
+        assert np.array_equal(geo[i], want), (i, geo[i], want)
+        # the rotation survives the round trip to ~1 ulp of float32, and q == +-q_in
+        assert abs(abs(np.dot(geo[i, 3:], q[i])) - 1.0) < 1e-6
+        # callback_node's matrix (OMU.cpp:219) is geoPose2eigen of that odom: same as the oracle's helper
+        assert np.array_equal(R[i].view(np.uint32), np.asarray(orc.geopose2eigen(geo[i]), np.float32).reshape(16).view(np.uint32))
+        assert np.allclose(R[i], T[i], atol=2e-6 * max(1.0, np.abs(T[i]).max()))
