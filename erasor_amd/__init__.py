@@ -230,6 +230,33 @@ class Erasor:
                                                                 C.c_size_t(len(out)), C.byref(n)))
         return out[: n.value].copy()
 
+    # -- mapgen (src/mapgen/mapgen.hpp) --
+    def mapgen_begin(self, leafsize, is_large_scale=False):
+        self._check(lib().erasor_hip_mapgen_begin(self._h, C.c_double(leafsize), C.c_int(int(is_large_scale))))
+
+    def mapgen_accum(self, scan, T_pose, T_lidar2origin=None):
+        scan = _f32(scan).reshape(-1, 4)
+        tp = _f32(T_pose).reshape(16)
+        tl = _f32(T_lidar2origin).reshape(16) if T_lidar2origin is not None else None
+        n = C.c_size_t(0)
+        self._check(lib().erasor_hip_mapgen_accum(self._h, _p(scan), C.c_size_t(len(scan)), _p(tp), _p(tl) if tl is not None else None,
+                                                  C.byref(n)))
+        return n.value
+
+    def mapgen_get(self, which):
+        n = C.c_size_t(0)
+        self._check(lib().erasor_hip_mapgen_get(self._h, C.c_int(which), None, C.c_size_t(0), C.byref(n)))
+        out = np.empty((max(n.value, 1), 4), np.float32)
+        self._check(lib().erasor_hip_mapgen_get(self._h, C.c_int(which), _p(out), C.c_size_t(len(out)), C.byref(n)))
+        return out[: n.value].copy()
+
+    def mapgen_save(self):
+        n = C.c_size_t(0)
+        self._check(lib().erasor_hip_mapgen_get(self._h, C.c_int(2), None, C.c_size_t(0), C.byref(n)))
+        out = np.empty((max(n.value, 1), 4), np.float32)
+        self._check(lib().erasor_hip_mapgen_save(self._h, _p(out), C.c_size_t(len(out)), C.byref(n)))
+        return out[: n.value].copy()
+
     def count_static_dynamic(self):
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._check(lib().erasor_hip_count_static_dynamic(self._h, C.byref(a), C.byref(b)))

@@ -51,6 +51,12 @@ struct erasor_hip_handle {
     hipStream_t stream2 = nullptr;  // map chain of a step (VoI split .. bin stats), concurrent with the query chain
     hipStream_t cur = nullptr;      // stream LAUNCH() currently targets
     hipEvent_t ev_fork = nullptr, ev_keys = nullptr, ev_join = nullptr;
+    // mapgen state (mapgen.hpp:27-46): cloud_curr, cloud_map, the finished submaps (cloud_maps, concatenated)
+    DBuf<float4> mg_curr, mg_map, mg_done, mg_tmp;
+    uint64_t mg_ncurr = 0, mg_nmap = 0, mg_ndone = 0;
+    double mg_leaf = 0.05;
+    bool mg_large = false, mg_initial = true, mg_active = false;
+    uint64_t mg_cnt_voxel = 0, mg_accum = 0;
     DBuf<unsigned long long> lab_slots;  // [16][8] label tallies of the assemble kernels (one cache line per slot)
     DBuf<uint32_t> qb_tot;            // [B + 1] bucket totals of the same
     DBuf<uint32_t> qb_hist;           // [B + 1][tiles] histogram of the query counting sort
@@ -573,7 +579,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->vmask); release(h->hmask); release(h->cinfo); release(h->pvl); release(h->phl); release(h->topv); release(h->toph);
     release(h->voi_ego); release(h->spts); release(h->rejected); release(h->voi_key); release(h->voi_src); release(h->ssrc);
     release(h->rejected_src); release(h->grank); release(h->glist); release(h->gflag);
-    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->qb_hist); release(h->qb_tot); release(h->lab_slots);
+    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->qb_hist); release(h->qb_tot); release(h->lab_slots); release(h->mg_curr); release(h->mg_map); release(h->mg_done); release(h->mg_tmp);
     release(h->moff); release(h->mcnt); release(h->qoff); release(h->ccnt); release(h->rev_idx); release(h->rev_list); release(h->vox_off);
     release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
     release(h->mmin); release(h->mmax); release(h->cmin); release(h->cmax); release(h->plane_n); release(h->plane_d);
@@ -1117,16 +1123,12 @@ int erasor_hip_get_planes(erasor_hip_handle *h, uint32_t *bin_index, float *norm
     return ERASOR_OK;
 }
 
-int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src, size_t n, double leaf_size, float *dst, size_t cap,
-                                          size_t *n_out) {
-    if (!h || (!src && n) || !(leaf_size > 0) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
-    HIPC(h, hipSetDevice(h->device));
-    prof_collect(h);
-    const uint32_t ns = (uint32_t)n;
+// erasor_utils::voxelize_preserving_labels (utils.cpp:80-114) of a DEVICE cloud; the result is h->query[0..*nq_out).
+// d_src may be any device buffer except the scan-side scratch itself.
+static int voxelize_device(erasor_hip_handle *h, const float4 *d_src, uint32_t ns, double leaf_size, uint32_t *nq_out) {
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
-    if (ns) HIPC(h, hipMemcpyAsync(h->scan.p, src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-    h->scan_in = (const float4 *)h->scan.p;
+    h->scan_in = d_src;
     LAUNCH(h, "step_begin", k_step_begin, 1, 256, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p, (uint32_t *)nullptr, 0u, (unsigned long long *)nullptr);
     voxelize_query_part1(h, ns, (float)leaf_size, [] {});
     DevState st;
@@ -1139,7 +1141,7 @@ int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src
         return ERASOR_E_UNSUPPORTED;
     }
     const uint32_t nq = st.q_nvox;
-    if (n_out) *n_out = nq;
+    *nq_out = nq;
     if (nq) {
         // identity lidar->body; the R-POD key output is ignored
         const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -1154,13 +1156,163 @@ int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src
     Counters c;
     HIPC(h, hipMemcpy(&c, h->d_ctr.p, sizeof(c), hipMemcpyDeviceToHost));
     if (c.sort_qoverflow) {
-        h->err = "exact-sort segment queue overflow";
+        h->err = "exact-sort segment queue overflow (site " + std::to_string(c.sort_qoverflow) + ")";
         return ERASOR_E_INTERNAL;
     }
+    return ERASOR_OK;
+}
+
+int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src, size_t n, double leaf_size, float *dst, size_t cap,
+                                          size_t *n_out) {
+    if (!h || (!src && n) || !(leaf_size > 0) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
+    HIPC(h, hipSetDevice(h->device));
+    prof_collect(h);
+    const uint32_t ns = (uint32_t)n;
+    int rc = alloc_scan(h, std::max(ns, 1u));
+    if (rc) return rc;
+    if (ns) HIPC(h, hipMemcpyAsync(h->scan.p, src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    uint32_t nq = 0;
+    rc = voxelize_device(h, (const float4 *)h->scan.p, ns, leaf_size, &nq);
+    if (rc) return rc;
+    if (n_out) *n_out = nq;
     if (!dst) return ERASOR_OK;
     if (nq > cap) return ERASOR_E_CAPACITY;
     if (nq) HIPC(h, hipMemcpy(dst, h->query.p, (size_t)nq * sizeof(float4), hipMemcpyDeviceToHost));
     return ERASOR_OK;
+}
+
+// ---- mapgen (src/mapgen/mapgen.hpp:187-305) ------------------------------------------------------
+static int mg_append(erasor_hip_handle *h, DBuf<float4> &dst, uint64_t &ndst, const float4 *src, uint64_t n) {
+    if (ndst + n > 0x3FFFFFF0ull) {
+        h->err = "mapgen: map too large for 32-bit indexing";
+        return ERASOR_E_CAPACITY;
+    }
+    if (ndst + n > dst.cap) {
+        DBuf<float4> bigger;
+        const size_t want = (size_t)std::max<uint64_t>((ndst + n) * 2, 1u << 20);
+        if (ensure(h, bigger, want)) return ERASOR_E_NO_DEVICE;
+        if (ndst) HIPC(h, hipMemcpyAsync(bigger.p, dst.p, (size_t)ndst * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+        release(dst);
+        dst = bigger;
+        bigger.p = nullptr;
+        bigger.cap = 0;
+    }
+    if (n) HIPC(h, hipMemcpyAsync(dst.p + ndst, src, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    ndst += n;
+    return ERASOR_OK;
+}
+
+int erasor_hip_mapgen_begin(erasor_hip_handle *h, double leafsize, int is_large_scale) {
+    if (!h || !(leafsize > 0)) return ERASOR_E_INVALID;
+    h->mg_leaf = leafsize;
+    h->mg_large = is_large_scale != 0;
+    h->mg_initial = true;
+    h->mg_active = true;
+    h->mg_ncurr = h->mg_nmap = h->mg_ndone = 0;
+    h->mg_cnt_voxel = h->mg_accum = 0;
+    return ERASOR_OK;
+}
+
+int erasor_hip_mapgen_accum(erasor_hip_handle *h, const float *scan_xyzi, size_t n, const float T_pose[16], const float T_lidar2origin[16],
+                            size_t *n_curr) {
+    if (!h || (!scan_xyzi && n) || !T_pose || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
+    if (!h->mg_active) {
+        h->err = "erasor_hip_mapgen_accum before erasor_hip_mapgen_begin";
+        return ERASOR_E_STATE;
+    }
+    HIPC(h, hipSetDevice(h->device));
+    prof_collect(h);
+    const uint32_t ns = (uint32_t)n;
+    int rc = alloc_scan(h, std::max(ns, 1u));
+    if (rc) return rc;
+    if (ensure(h, h->mg_tmp, (size_t)ns + 8)) return ERASOR_E_NO_DEVICE;
+    static const float L2O[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1.73f, 0, 0, 0, 1};  // mapgen.hpp:212-215
+    uint32_t n_kept = 0;
+    if (ns) {
+        HIPC(h, hipMemcpyAsync(h->scan.p, scan_xyzi, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+        const float max_dist_square = (float)pow(2.7, 2);  // CAR_BODY_SIZE, mapgen.hpp:8,221
+        LAUNCH(h, "mapgen", k_mapgen_flag, cdiv(ns, 256), 256, (const float4 *)h->scan.p, ns, max_dist_square, h->qflag.p);
+        scan_u32(h, h->qflag.p, h->qpl.p, h->qtops.p, ns, ns, nullptr, h->dn.p, "mapgen");
+        LAUNCH(h, "mapgen", k_mapgen_scatter, cdiv(ns, 256), 256, (const float4 *)h->scan.p, ns, (const uint32_t *)h->qflag.p,
+               (const uint32_t *)h->qpl.p, (const uint32_t *)h->qtops.p, to_xf(T_lidar2origin ? T_lidar2origin : L2O), to_xf(T_pose), h->mg_tmp.p);
+        HIPC(h, hipMemcpyAsync(&n_kept, h->dn.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+    }
+    uint32_t nq = 0;
+    rc = voxelize_device(h, (const float4 *)h->mg_tmp.p, n_kept, 0.2, &nq);  // cloud_curr (mapgen.hpp:239: fixed 0.2 m leaf)
+    if (rc) return rc;
+    h->mg_ncurr = 0;
+    rc = mg_append(h, h->mg_curr, h->mg_ncurr, (const float4 *)h->query.p, nq);
+    if (rc) return rc;
+    if (h->mg_initial) {  // :241-243
+        h->mg_nmap = 0;
+        rc = mg_append(h, h->mg_map, h->mg_nmap, (const float4 *)h->query.p, nq);
+        if (rc) return rc;
+        h->mg_initial = false;
+    } else {  // :244-256
+        rc = mg_append(h, h->mg_map, h->mg_nmap, (const float4 *)h->query.p, nq);
+        if (rc) return rc;
+        if (h->mg_large && (h->mg_cnt_voxel++ % 500 == 0)) {
+            HIPC(h, hipStreamSynchronize(h->stream));
+            uint32_t nv = 0;
+            rc = voxelize_device(h, (const float4 *)h->mg_map.p, (uint32_t)h->mg_nmap, h->mg_leaf, &nv);
+            if (rc) return rc;
+            rc = mg_append(h, h->mg_done, h->mg_ndone, (const float4 *)h->query.p, nv);  // cloud_maps.push_back
+            if (rc) return rc;
+            h->mg_nmap = 0;  // cloud_map.clear()
+        }
+        ++h->mg_accum;
+    }
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if (n_curr) *n_curr = h->mg_ncurr;
+    return ERASOR_OK;
+}
+
+int erasor_hip_mapgen_get(erasor_hip_handle *h, int which, float *dst, size_t cap, size_t *n_out) {
+    if (!h || which < 0 || which > 2) return ERASOR_E_INVALID;
+    if (!h->mg_active) return ERASOR_E_STATE;
+    HIPC(h, hipSetDevice(h->device));
+    const uint64_t n = which == 0 ? h->mg_ncurr : (which == 1 ? h->mg_nmap : (h->mg_large ? h->mg_ndone : 0) + h->mg_nmap);
+    if (n_out) *n_out = (size_t)n;
+    if (!dst) return ERASOR_OK;
+    if (n > cap) return ERASOR_E_CAPACITY;
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if (which == 0) {
+        if (n) HIPC(h, hipMemcpy(dst, h->mg_curr.p, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    } else if (which == 1) {
+        if (n) HIPC(h, hipMemcpy(dst, h->mg_map.p, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    } else {  // saveNaiveMap's cloud_src: previous submaps, then the remaining map (:267-279)
+        const uint64_t nd = h->mg_large ? h->mg_ndone : 0;
+        if (nd) HIPC(h, hipMemcpy(dst, h->mg_done.p, (size_t)nd * sizeof(float4), hipMemcpyDeviceToHost));
+        if (h->mg_nmap) HIPC(h, hipMemcpy(dst + 4 * nd, h->mg_map.p, (size_t)h->mg_nmap * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    return ERASOR_OK;
+}
+
+int erasor_hip_mapgen_save(erasor_hip_handle *h, float *dst, size_t cap, size_t *n_out) {
+    if (!h) return ERASOR_E_INVALID;
+    if (!h->mg_active) return ERASOR_E_STATE;
+    HIPC(h, hipSetDevice(h->device));
+    prof_collect(h);
+    const uint64_t nd = h->mg_large ? h->mg_ndone : 0, total = nd + h->mg_nmap;
+    if (total > 0x3FFFFFFFull) return ERASOR_E_CAPACITY;
+    DBuf<float4> src;
+    if (ensure(h, src, (size_t)total + 8)) return ERASOR_E_NO_DEVICE;
+    if (nd) HIPC(h, hipMemcpyAsync(src.p, h->mg_done.p, (size_t)nd * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    if (h->mg_nmap) HIPC(h, hipMemcpyAsync(src.p + nd, h->mg_map.p, (size_t)h->mg_nmap * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    uint32_t nq = 0;
+    int rc = voxelize_device(h, (const float4 *)src.p, (uint32_t)total, h->mg_leaf, &nq);  // :291
+    if (rc == ERASOR_OK) {
+        if (n_out) *n_out = nq;
+        if (dst) {
+            if (nq > cap) rc = ERASOR_E_CAPACITY;
+            else if (nq && hipMemcpy(dst, h->query.p, (size_t)nq * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) rc = ERASOR_E_NO_DEVICE;
+        }
+    }
+    (void)hipStreamSynchronize(h->stream);
+    release(src);
+    return rc;
 }
 
 int erasor_hip_count_static_dynamic(erasor_hip_handle *h, uint64_t *n_static, uint64_t *n_dynamic) {

@@ -2204,6 +2204,27 @@ __global__ void k_step_end(DevState *st, const Counters *ctr, HostOut *out, cons
     }
 }
 
+// ---- mapgen (src/mapgen/mapgen.hpp:198-257): per-scan preparation ----------------------------------------------
+// keep flag of the self-filter (mapgen.hpp:219-228): a point is dropped when pow(x,2) + pow(y,2) (double) is below
+// max_dist_square, a FLOAT holding pow(CAR_BODY_SIZE, 2)
+__global__ __launch_bounds__(256) void k_mapgen_flag(const float4 *__restrict__ pts, uint32_t n, float max_dist_square,
+                                                      uint32_t *__restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const double dx = (double)p.x, dy = (double)p.y;
+    const double dist_square = dx * dx + dy * dy;  // squares of floats are exact in double, like pow(x, 2)
+    flag[i] = (dist_square < (double)max_dist_square) ? 0u : 1u;
+}
+// stable compaction of the kept points, then lidar->origin-of-body and the pose (two pcl::transformPointCloud, :231-237)
+__global__ __launch_bounds__(256) void k_mapgen_scatter(const float4 *__restrict__ pts, uint32_t n, const uint32_t *__restrict__ flag,
+                                                         const uint32_t *__restrict__ pl, const uint32_t *__restrict__ tops, Xf T1, Xf T2,
+                                                         float4 *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    out[pl[i] + tops[i >> 10]] = xform(T2, xform(T1, pts[i]));
+}
+
 // ---- map store maintenance ---------------------------------------------------------------------
 // split an AoS float4 cloud into the outskirts layout at O[dst0 ...]
 __global__ __launch_bounds__(256) void k_store_outskirts(const float4 *__restrict__ src, uint32_t n, float2 *__restrict__ Oxy,

@@ -93,7 +93,41 @@ static int config_mode(int argc, char **argv) {
     return 0;
 }
 
+// --mapgen <data_dir> <n_frames> <voxelsize> <is_large_scale>: src/mapgen/main.cpp:41-64 without ROS — every node of
+// <data_dir>/poses_lidar2body.csv + pcds/%06d.pcd through mapgen::accumPointCloud, then saveNaiveMap
+static int mapgen_mode(int argc, char **argv) {
+    if (argc < 6) return 2;
+    const std::string dir = argv[2];
+    const int n = atoi(argv[3]);
+    mapgen gen;
+    gen.setValue(dir, (float)atof(argv[4]), "05", "0", std::to_string(n - 1), 1, atoi(argv[5]) != 0);
+    std::vector<Eigen::Matrix4f> poses;
+    if (!erasor::load_all_poses(dir + "/poses_lidar2body.csv", poses)) return 3;
+    for (int i = 0; i < n && i < (int)poses.size(); ++i) {
+        char name[64];
+        snprintf(name, sizeof(name), "/pcds/%06d.pcd", i);
+        pcl::PointCloud<pcl::PointXYZI> scan;
+        if (erasor_utils::load_pcd(dir + name, scan) == -1) return 3;
+        gen.accumPointCloud(erasor_utils::eigen2geoPose(poses[i]), scan);
+    }
+    pcl::PointCloud<pcl::PointXYZI> m, c;
+    gen.getPointClouds(m, c);
+    write_bin(dir + "/mapgen_cloud_map.bin", m);
+    write_bin(dir + "/mapgen_cloud_curr.bin", c);
+    gen.saveNaiveMap(dir + "/05_original.pcd", gen.map_file_name());
+    printf("[MAPGEN] map saved to %s\n", gen.map_file_name().c_str());
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 2 && std::string(argv[1]) == "--mapgen") {
+        try {
+            return mapgen_mode(argc, argv);
+        } catch (const std::exception &e) {
+            fprintf(stderr, "error: %s\n", e.what());
+            return 1;
+        }
+    }
     if (argc >= 2 && (std::string(argv[1]) == "--erasor-class" || std::string(argv[1]) == "--config")) {
         try {
             return std::string(argv[1]) == "--config" ? config_mode(argc, argv) : erasor_class_mode(argc, argv);

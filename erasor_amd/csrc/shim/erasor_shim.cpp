@@ -162,6 +162,61 @@ void ERASOR::get_outliers(Cloud &map_rejected, Cloud &curr_rejected) {
 double ERASOR::get_max_range() { return P_.max_range; }
 
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+mapgen::mapgen(int device) {
+    erasor_params p;
+    erasor_hip_params_default(&p);
+    check(nullptr, erasor_hip_create(&p, device, &h_), "erasor_hip_create");
+}
+mapgen::~mapgen() {
+    if (h_) erasor_hip_destroy(h_);
+}
+void mapgen::setValue(std::string pcd_save_path, float voxelsize, std::string sequence, std::string init_time_stamp,
+                      std::string final_time_stamp, int frame_interval, bool is_map_large_scale) {
+    save_path_ = pcd_save_path;
+    leafsize_ = voxelsize;
+    seq_ = sequence;
+    init_stamp_ = init_time_stamp;
+    final_stamp_ = final_time_stamp;
+    interval_ = frame_interval;
+    (void)std::stoi(final_stamp_);  // mapgen.hpp:190-191 (throws on a malformed bag name, like the reference)
+    (void)std::stoi(init_stamp_);
+    is_large_scale_ = is_map_large_scale;
+    check(h_, erasor_hip_mapgen_begin(h_, (double)leafsize_, is_large_scale_ ? 1 : 0), "erasor_hip_mapgen_begin");
+}
+void mapgen::accumPointCloud(const geometry_msgs::Pose &odom, const Cloud &lidar) {
+    float Tp[16];
+    mat16(erasor_utils::geoPose2eigen(odom), Tp);  // mapgen.hpp:234
+    const std::vector<float> s = to_xyzi(lidar);
+    size_t n = 0;
+    check(h_, erasor_hip_mapgen_accum(h_, s.data(), lidar.size(), Tp, nullptr, &n), "erasor_hip_mapgen_accum");
+}
+static void mapgen_fetch(erasor_hip_handle *h, int which, Cloud &dst) {
+    size_t n = 0;
+    check(h, erasor_hip_mapgen_get(h, which, nullptr, 0, &n), "erasor_hip_mapgen_get");
+    std::vector<float> v(n * 4 + 4);
+    check(h, erasor_hip_mapgen_get(h, which, v.data(), n, &n), "erasor_hip_mapgen_get");
+    from_xyzi(v, n, dst);
+}
+void mapgen::getPointClouds(Cloud &map_out, Cloud &curr_out) {
+    mapgen_fetch(h_, 1, map_out);
+    mapgen_fetch(h_, 0, curr_out);
+}
+void mapgen::saveNaiveMap(const std::string &original_dir, const std::string &map_dir) {
+    Cloud cloud_src, cloud_out;
+    mapgen_fetch(h_, 2, cloud_src);
+    if (erasor_utils::save_pcd_ascii(original_dir, cloud_src) != 0) throw std::runtime_error("cannot write " + original_dir);  // :281
+    size_t n = cloud_src.size();
+    std::vector<float> v(n * 4 + 4);
+    check(h_, erasor_hip_mapgen_save(h_, v.data(), n, &n), "erasor_hip_mapgen_save");
+    from_xyzi(v, n, cloud_out);
+    if (erasor_utils::save_pcd_ascii(map_dir, cloud_out) != 0) throw std::runtime_error("cannot write " + map_dir);  // :299
+}
+std::string mapgen::map_file_name() const {
+    return save_path_ + "/" + seq_ + "_" + init_stamp_ + "_to_" + final_stamp_ + "_w_interval" + std::to_string(interval_) + "_voxel_" +
+           std::to_string(leafsize_) + ".pcd";
+}
+
 namespace erasor {
 
 OfflineMapUpdater::OfflineMapUpdater(const Config &cfg) : cfg_(cfg) {

@@ -61,6 +61,28 @@ private:
     pcl::PointCloud<pcl::PointXYZI> map_voi_, query_voi_, arranged_;
 };
 
+// class mapgen (src/mapgen/mapgen.hpp:27-305): builds the naive accumulated map that OfflineMapUpdater later loads.
+// Same public methods; the erasor::node message is passed as (odom pose, lidar cloud), nav_msgs::Path is dropped.
+class mapgen {
+public:
+    explicit mapgen(int device = 0);
+    ~mapgen();
+    void setValue(std::string pcd_save_path, float voxelsize, std::string sequence, std::string init_time_stamp, std::string final_time_stamp,
+                  int frame_interval, bool is_map_large_scale);                                                   // mapgen.hpp:182-196
+    void accumPointCloud(const geometry_msgs::Pose &odom, const pcl::PointCloud<pcl::PointXYZI> &lidar);         // :198-257
+    void getPointClouds(pcl::PointCloud<pcl::PointXYZI> &map_out, pcl::PointCloud<pcl::PointXYZI> &curr_out);   // :258-262
+    void saveNaiveMap(const std::string &original_dir, const std::string &map_dir);                              // :264-303
+    // main.cpp:34-38: <save_path>/<seq>_<from>_to_<to>_w_interval<k>_voxel_<leaf>.pcd
+    std::string map_file_name() const;
+
+private:
+    erasor_hip_handle *h_ = nullptr;
+    float leafsize_ = 0.05f;
+    std::string seq_, init_stamp_, final_stamp_, save_path_;
+    int interval_ = 1;
+    bool is_large_scale_ = false;
+};
+
 namespace erasor {
 // erasor::OfflineMapUpdater (OfflineMapUpdater.h:9-151): owns the (device-resident) map, one callback per node.
 class OfflineMapUpdater {

@@ -183,6 +183,23 @@ int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src
                                           double leaf_size, float *dst_xyzi, size_t cap_points,
                                           size_t *n_out);
 
+/* ---- mapgen: the step BEFORE the hot path (src/mapgen/mapgen.hpp), device-resident accumulation ----
+ * replaces: mapgen::setValue + constructor (mapgen.hpp:182-196): leafsize = /map/voxelsize, is_large_scale */
+int erasor_hip_mapgen_begin(erasor_hip_handle *h, double leafsize, int is_large_scale);
+/* replaces: mapgen::accumPointCloud (mapgen.hpp:198-257) for one erasor::node: self-filter of points closer than
+ * CAR_BODY_SIZE (2.7 m, :219-228), lidar->origin-of-body then pose (two pcl::transformPointCloud, :231-237; pass
+ * T_lidar2origin = NULL for the reference's constant, z + 1.73), voxelize_preserving_labels at 0.2 m -> cloud_curr
+ * (:239), cloud_map += cloud_curr, and in large-scale mode the re-voxelisation of the accumulated submap on the
+ * first and every 500th accumulated scan (:247-255).  T_pose = geoPose2eigen(node.odom), row-major. */
+int erasor_hip_mapgen_accum(erasor_hip_handle *h, const float *scan_xyzi, size_t n, const float T_pose[16],
+                            const float T_lidar2origin[16], size_t *n_curr);
+/* replaces: mapgen::getPointClouds (:258-262) and saveNaiveMap's un-voxelised cloud_src (:267-279).
+ * which: 0 cloud_curr, 1 cloud_map, 2 all finished submaps followed by cloud_map.  dst may be NULL (size query). */
+int erasor_hip_mapgen_get(erasor_hip_handle *h, int which, float *dst_xyzi, size_t cap_points, size_t *n_out);
+/* replaces: saveNaiveMap's voxelize_preserving_labels(cloud_src, leafsize) (:281-299): the map that is saved as
+ * <seq>_<from>_to_<to>_w_interval<k>_voxel_<leaf>.pcd and later loaded by OfflineMapUpdater::load_global_map */
+int erasor_hip_mapgen_save(erasor_hip_handle *h, float *dst_xyzi, size_t cap_points, size_t *n_out);
+
 /* replaces: erasor_utils::parse_dynamic_obj as counters (utils.cpp:57-78) over the current map */
 int erasor_hip_count_static_dynamic(erasor_hip_handle *h, uint64_t *n_static, uint64_t *n_dynamic);
 

@@ -264,3 +264,52 @@ class Oracle:
         if n.value:
             lib().orc_get_voi_codes(self.h, _p(code), _p(src), C.c_size_t(n.value), C.byref(n))
         return code, src
+
+
+class Mapgen:
+    """CPU restatement of class mapgen (src/mapgen/mapgen.hpp:27-305) over the oracle's C functions.
+    TEST INFRASTRUCTURE ONLY, like the rest of oracle/ (parity unpinned: the reference has no mapgen fixtures)."""
+
+    CAR_BODY_SIZE = 2.7  # mapgen.hpp:8
+
+    def __init__(self, leafsize, is_large_scale=False):  # setValue, mapgen.hpp:182-196
+        self.leafsize = leafsize
+        self.is_large_scale = is_large_scale
+        self.is_initial = True
+        self.cloud_curr = np.zeros((0, 4), np.float32)
+        self.cloud_map = np.zeros((0, 4), np.float32)
+        self.cloud_maps = []
+        self.cnt_voxel = 0  # the function-local static of accumPointCloud (:248)
+        self.accum_count = 0
+
+    def accum(self, scan, T_pose, T_lidar2origin=None):  # accumPointCloud, mapgen.hpp:198-257
+        scan = np.ascontiguousarray(scan, np.float32).reshape(-1, 4)
+        if T_lidar2origin is None:
+            T_lidar2origin = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 1.73], [0, 0, 0, 1]], np.float32)  # :212-215
+        # :219-228  float max_dist_square = pow(CAR_BODY_SIZE, 2); double dist_square = pow(pt.x, 2) + pow(pt.y, 2)
+        max_dist_square = np.float32(self.CAR_BODY_SIZE ** 2)
+        x, y = scan[:, 0].astype(np.float64), scan[:, 1].astype(np.float64)
+        dist_square = x * x + y * y
+        outliers = scan[~(dist_square < np.float64(max_dist_square))]
+        world = transform(transform(outliers, T_lidar2origin), T_pose)  # :231-237
+        self.cloud_curr = voxelize_preserving_labels(world, 0.2)  # :239
+        if self.is_initial:
+            self.cloud_map = self.cloud_curr.copy()
+            self.is_initial = False
+        else:
+            self.cloud_map = np.concatenate([self.cloud_map, self.cloud_curr])
+            if self.is_large_scale:
+                if self.cnt_voxel % 500 == 0:  # :248-255
+                    self.cloud_maps.append(voxelize_preserving_labels(self.cloud_map, self.leafsize))
+                    self.cloud_map = np.zeros((0, 4), np.float32)
+                self.cnt_voxel += 1
+            self.accum_count += 1
+        return len(self.cloud_curr)
+
+    def naive_map(self):  # saveNaiveMap's cloud_src, :267-279
+        if self.is_large_scale:
+            return np.concatenate(self.cloud_maps + [self.cloud_map]) if (self.cloud_maps or len(self.cloud_map)) else self.cloud_map
+        return self.cloud_map
+
+    def save(self):  # :281-299
+        return voxelize_preserving_labels(self.naive_map(), self.leafsize)

@@ -393,3 +393,32 @@ def test_whole_map_save_voxelisation(gpu_mod):
     g = gpu_mod.Erasor(gpu_mod.params_default())
     for leaf in (0.2, 0.4):
         same(g.voxelize_preserving_labels(m, leaf), orc.voxelize_preserving_labels(m, leaf), "saved map, leaf %.1f" % leaf)
+
+
+@pytest.mark.parametrize("large", [False, True])
+def test_mapgen_accumulation_matches_oracle(gpu_mod, large):
+    """mapgen::accumPointCloud / saveNaiveMap (src/mapgen/mapgen.hpp:198-305) on the device: self-filter, two
+    transforms, label-preserving voxelisation, accumulation, (large-scale) submap re-voxelisation, final map."""
+    from oracle import orc
+    sc = scenarios.small()
+    g = gpu_mod.Erasor(gpu_mod.params_default())
+    o = orc.Mapgen(0.1, large)
+    g.mapgen_begin(0.1, large)
+    rng = np.random.default_rng(3)
+    for k in range(6):
+        scan = sc["scans"][k].copy()
+        # lidar-frame returns from the vehicle itself: inside / exactly on / just outside CAR_BODY_SIZE
+        near = np.zeros((40, 4), np.float32)
+        ang = rng.random(40) * 2 * np.pi
+        rad = np.concatenate([rng.random(30) * 3.2, np.float32([2.7, 2.6999998, 2.7000003, 0.0, 2.7, 2.7, 2.7, 2.7, 2.7, 2.7])]).astype(np.float32)
+        near[:, 0], near[:, 1], near[:, 2], near[:, 3] = rad * np.cos(ang), rad * np.sin(ang), -1.0, 40.0
+        scan = np.concatenate([scan[: len(scan) // 2], near, scan[len(scan) // 2:]])
+        T = np.asarray(sc["T_b2o"][k], np.float32).reshape(4, 4)
+        nc = g.mapgen_accum(scan, T)
+        assert nc == o.accum(scan, T)
+        same(g.mapgen_get(0), o.cloud_curr, "cloud_curr, scan %d" % k)
+        same(g.mapgen_get(1), o.cloud_map, "cloud_map, scan %d" % k)
+    same(g.mapgen_get(2), o.naive_map(), "naive map")
+    same(g.mapgen_save(), o.save(), "saved (voxelised) map")
+    if large:
+        assert len(o.cloud_maps) == 1  # the first accumulated scan closes a submap (cnt_voxel == 0)

@@ -155,3 +155,45 @@ def test_config_driver_like_main_in_your_env(tmp_path):
     assert saved.shape == ref.shape
     # ASCII PCD with PCL's 8 significant digits (OMU.cpp:193)
     assert np.allclose(saved[:, :3], ref[:, :3], rtol=2e-7, atol=1e-7) and np.array_equal(saved[:, 3], ref[:, 3].astype(np.float64))
+
+
+@pytest.mark.parametrize("large", [0, 1])
+def test_mapgen_class_and_driver(tmp_path, large):
+    """class mapgen of the shim (setValue / accumPointCloud / getPointClouds / saveNaiveMap, mapgen.hpp:182-303) driven
+    like src/mapgen/main.cpp: the saved map is what OfflineMapUpdater::load_global_map reads next."""
+    import ctypes as C
+    from oracle import orc
+    ensure_demo()
+    sc = scenarios.small()
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "pcds"))
+    n = 5
+    with open(os.path.join(d, "poses_lidar2body.csv"), "w") as f:
+        f.write("index, timestamp, x, y, z, qx, qy, qz, qw\n")
+        for k in range(n):
+            write_pcd_binary(os.path.join(d, "pcds", "%06d.pcd" % k), sc["scans"][k])
+            f.write("%d, %.2f, %s\n" % (k, 0.1 * k, ", ".join("%.9f" % v for v in sc["poses"][k])))
+    out = subprocess.run([DEMO, "--mapgen", d, str(n), "0.2", str(large)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    shim = C.CDLL(os.path.join(ROOT, "erasor_amd", "liberasor_shim.so"))
+    shim.erasor_shim_load_poses.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+    shim.erasor_shim_load_poses.restype = C.c_long
+    T = np.zeros((n, 16), np.float32)
+    geo = np.zeros((n, 7), np.float64)
+    R = np.zeros((n, 16), np.float32)
+    assert shim.erasor_shim_load_poses(os.path.join(d, "poses_lidar2body.csv").encode(), T.ctypes.data, geo.ctypes.data, R.ctypes.data, n) == n
+    o = orc.Mapgen(np.float32(0.2), bool(large))
+    for k in range(n):
+        o.accum(sc["scans"][k], R[k].reshape(4, 4))
+    got_map = np.fromfile(os.path.join(d, "mapgen_cloud_map.bin"), np.float32).reshape(-1, 4)
+    got_curr = np.fromfile(os.path.join(d, "mapgen_cloud_curr.bin"), np.float32).reshape(-1, 4)
+    assert np.array_equal(got_map.view(np.uint32), o.cloud_map.view(np.uint32))
+    assert np.array_equal(got_curr.view(np.uint32), o.cloud_curr.view(np.uint32))
+    name = os.path.join(d, "05_0_to_%d_w_interval1_voxel_0.200000.pcd" % (n - 1))  # main.cpp:34-38
+    assert os.path.exists(name), os.listdir(d)
+    saved = np.loadtxt(name, skiprows=11, dtype=np.float64).reshape(-1, 4)
+    ref = o.save()
+    assert saved.shape == ref.shape
+    assert np.allclose(saved[:, :3], ref[:, :3], rtol=2e-7, atol=1e-7) and np.array_equal(saved[:, 3], ref[:, 3].astype(np.float64))
+    naive = np.loadtxt(os.path.join(d, "05_original.pcd"), skiprows=11, dtype=np.float64).reshape(-1, 4)
+    assert naive.shape == o.naive_map().shape
