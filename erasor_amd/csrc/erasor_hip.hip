@@ -57,6 +57,8 @@ struct erasor_hip_handle {
     double mg_leaf = 0.05;
     bool mg_large = false, mg_initial = true, mg_active = false;
     uint64_t mg_cnt_voxel = 0, mg_accum = 0;
+    DBuf<uint32_t> hkey, hval;        // voxel key -> voxel id hash of the scan voxelisation (k_centroids fills, k_query_nn probes)
+    int hbits = 10;
     DBuf<unsigned long long> lab_slots;  // [16][8] label tallies of the assemble kernels (one cache line per slot)
     DBuf<uint32_t> qb_tot;            // [B + 1] bucket totals of the same
     DBuf<uint32_t> qb_hist;           // [B + 1][tiles] histogram of the query counting sort
@@ -337,6 +339,9 @@ int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
     rc |= ensure(h, h->qk_a, S) | ensure(h, h->qk_b, S) | ensure(h, h->qv_a, S) | ensure(h, h->qv_b, S) | ensure(h, h->qposL, S) | ensure(h, h->qposR, S);
     rc |= ensure(h, h->qflag, S) | ensure(h, h->qpl, S) | ensure(h, h->qtops, S / 1024 + 4) | ensure(h, h->run_begin, S + 1) | ensure(h, h->ukeys, S);
     rc |= ensure(h, h->qkey, S) | ensure(h, h->qhead, S / 32 + 8);
+    h->hbits = 10;  // voxel hash table: >= 2 slots per possible voxel
+    while ((1ull << h->hbits) < 2ull * S) ++h->hbits;
+    rc |= ensure(h, h->hkey, (size_t)1 << h->hbits) | ensure(h, h->hval, (size_t)1 << h->hbits);
     if (getenv("ERASOR_HIP_SORT_STAMPS")) rc |= ensure(h, h->dbg_stamps, 32);
     rc |= ensure(h, h->wseg0, WSEG_MAX) | ensure(h, h->wseg1, WSEG_MAX) | ensure(h, h->wstate, 1) | ensure(h, h->wtileL, WTILES_MAX) | ensure(h, h->wtileR, WTILES_MAX);
     rc |= ensure(h, h->esq0, 65536) | ensure(h, h->esq1, 65536) | ensure(h, h->esq2, 65536) | ensure(h, h->essmall, 65536);
@@ -579,7 +584,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->vmask); release(h->hmask); release(h->cinfo); release(h->pvl); release(h->phl); release(h->topv); release(h->toph);
     release(h->voi_ego); release(h->spts); release(h->rejected); release(h->voi_key); release(h->voi_src); release(h->ssrc);
     release(h->rejected_src); release(h->grank); release(h->glist); release(h->gflag);
-    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->qb_hist); release(h->qb_tot); release(h->lab_slots); release(h->mg_curr); release(h->mg_map); release(h->mg_done); release(h->mg_tmp);
+    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->qb_hist); release(h->qb_tot); release(h->lab_slots); release(h->hkey); release(h->hval); release(h->mg_curr); release(h->mg_map); release(h->mg_done); release(h->mg_tmp);
     release(h->moff); release(h->mcnt); release(h->qoff); release(h->ccnt); release(h->rev_idx); release(h->rev_list); release(h->vox_off);
     release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
     release(h->mmin); release(h->mmax); release(h->cmin); release(h->cmax); release(h->plane_n); release(h->plane_d);
@@ -684,7 +689,7 @@ static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf, co
     // (the bounding box was reset by k_step_begin)
     if (n) LAUNCH(h, "q_bbox", k_bbox, std::min<uint32_t>(cdiv(n, 256), 1024), 256, h->scan_in, n, h->bb.p);
     LAUNCH(h, "q_keys", k_voxel_keys, std::max(1u, cdiv(n, 256)), 256, h->scan_in, n, (const uint32_t *)h->bb.p, leaf, h->qk_a.p,
-           h->qv_a.p, h->qgrid.p, dc);
+           h->qv_a.p, h->qgrid.p, dc, h->hkey.p, 1u << h->hbits);
     after_keys();  // ctr->err (VoxelGrid overflow) is final from here on: the caller may fork work that depends on it
     // exact std::sort: a few global levels (one workgroup per big segment), then per-segment completion in LDS
     run_exact_sort(h, n);
@@ -833,10 +838,10 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         if (nq) LAUNCH(h, "q_direct", k_query_direct, cdiv(nq, 256), 256, h->scan_in, nq, P, dc, h->query.p, h->qkey.p);
     } else if (nq) {
         LAUNCH(h, "q_centroids", k_centroids, cdiv(nq, 256), 256, h->scan_in, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
-               (const uint32_t *)h->run_begin.p, (const uint32_t *)&ds->q_nvox, h->cent.p, h->ukeys.p);
-        LAUNCH(h, "q_nn", k_query_nn, cdiv(nq, 256), 256, h->scan_in, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
+               (const uint32_t *)h->run_begin.p, (const uint32_t *)&ds->q_nvox, h->cent.p, h->ukeys.p, h->hkey.p, h->hval.p, h->hbits);
+        LAUNCH(h, "q_nn", k_query_nn, cdiv((uint64_t)nq * NN_SUB, 256), 256, h->scan_in, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
                (const uint32_t *)h->ukeys.p, (const float4 *)h->cent.p, (const uint32_t *)&ds->q_nvox, (const VoxGrid *)h->qgrid.p, h->Tl2b, P, dc,
-               h->query.p, h->qkey.p);
+               h->query.p, h->qkey.p, (const uint32_t *)h->hkey.p, (const uint32_t *)h->hval.p, h->hbits);
     }
     if (B + 1 <= QB_NB_MAX) {  // one-digit stable counting sort with the gather and the bucket offsets folded in
         const uint32_t ntile_ub = std::max(1u, cdiv(nq, QB_TILE));
@@ -1147,10 +1152,10 @@ static int voxelize_device(erasor_hip_handle *h, const float4 *d_src, uint32_t n
         const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
         // x*1 + y*0 + z*0 + 0 reproduces x exactly (0*finite = 0, x+0 = x; -0.0 would become +0.0, irrelevant for a centroid)
         LAUNCH(h, "q_centroids", k_centroids, cdiv(nq, 256), 256, h->scan_in, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
-               (const uint32_t *)h->run_begin.p, (const uint32_t *)&h->d_st.p->q_nvox, h->cent.p, h->ukeys.p);
-        LAUNCH(h, "q_nn", k_query_nn, cdiv(nq, 256), 256, h->scan_in, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
+               (const uint32_t *)h->run_begin.p, (const uint32_t *)&h->d_st.p->q_nvox, h->cent.p, h->ukeys.p, h->hkey.p, h->hval.p, h->hbits);
+        LAUNCH(h, "q_nn", k_query_nn, cdiv((uint64_t)nq * NN_SUB, 256), 256, h->scan_in, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
                (const uint32_t *)h->ukeys.p, (const float4 *)h->cent.p, (const uint32_t *)&h->d_st.p->q_nvox, (const VoxGrid *)h->qgrid.p, to_xf(I),
-               h->dp, h->d_ctr.p, h->query.p, h->qkey.p);
+               h->dp, h->d_ctr.p, h->query.p, h->qkey.p, (const uint32_t *)h->hkey.p, (const uint32_t *)h->hval.p, h->hbits);
         HIPC(h, hipStreamSynchronize(h->stream));
     }
     Counters c;

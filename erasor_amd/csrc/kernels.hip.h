@@ -820,7 +820,9 @@ __device__ __forceinline__ uint32_t vox_index(const VoxGrid &g, float x, float y
 
 __global__ __launch_bounds__(256) void k_voxel_keys(const float4 *__restrict__ pts, uint32_t n, const uint32_t *__restrict__ bb,
                                                      float leaf, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                     VoxGrid *gout, Counters *ctr) {
+                                                     VoxGrid *gout, Counters *ctr, uint32_t *__restrict__ hkey, uint32_t hsize) {
+    // (side job) empty the voxel hash table that k_centroids fills and k_query_nn probes
+    for (uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x; sl < hsize; sl += gridDim.x * blockDim.x) hkey[sl] = 0xFFFFFFFFu;
     const float mn[3] = {fkey_inv(bb[0]), fkey_inv(bb[1]), fkey_inv(bb[2])};
     const float mx[3] = {fkey_inv(bb[3]), fkey_inv(bb[4]), fkey_inv(bb[5])};
     const VoxGrid g = vox_grid_from_bbox(mn, mx, leaf);
@@ -1200,10 +1202,13 @@ __global__ __launch_bounds__(256) void k_run_begin(const uint32_t *__restrict__ 
     if (flag[i]) run_begin[pl[i] + tops[i >> 10]] = i;
 }
 
+__device__ __forceinline__ uint32_t vox_hash(uint32_t key, int hbits) { return (key * 2654435761u) >> (32 - hbits); }
+
 // CentroidPoint<PointXYZI>: float32 running sums in sorted order, each / (float)count
 __global__ __launch_bounds__(256) void k_centroids(const float4 *__restrict__ pts, const uint32_t *__restrict__ skeys,
                                                     const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ run_begin,
-                                                    const uint32_t *nv_dev, float4 *__restrict__ cent, uint32_t *__restrict__ ukeys) {
+                                                    const uint32_t *nv_dev, float4 *__restrict__ cent, uint32_t *__restrict__ ukeys,
+                                                    uint32_t *__restrict__ hkey, uint32_t *__restrict__ hval, int hbits) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= *nv_dev) return;
     const uint32_t s = run_begin[v], e = run_begin[v + 1];
@@ -1217,7 +1222,16 @@ __global__ __launch_bounds__(256) void k_centroids(const float4 *__restrict__ pt
     }
     const float c = (float)(e - s);
     cent[v] = make_float4(sx / c, sy / c, sz / c, si / c);
-    ukeys[v] = skeys[s];
+    const uint32_t key = skeys[s];
+    ukeys[v] = key;
+    // voxel key -> voxel id, open addressing (load factor <= 1/2; keys are unique, so the slot is ours once claimed)
+    uint32_t sl = vox_hash(key, hbits);
+    for (;;) {
+        const uint32_t old = atomicCAS(&hkey[sl], 0xFFFFFFFFu, key);
+        if (old == 0xFFFFFFFFu || old == key) break;
+        sl = (sl + 1) & ((1u << hbits) - 1u);
+    }
+    hval[sl] = v;
 }
 
 // FLANN L2_Simple: ((0 + dx*dx) + dy*dy) + dz*dz in float32
@@ -1234,39 +1248,53 @@ __device__ __forceinline__ float l2_simple(float ax, float ay, float az, float b
 
 // exact 1-NN of every centroid among the input points (lowest index on float ties), searched through
 // the sorted voxel runs; then tf_lidar2body and the query's R-POD key (OMU.cpp:240; erasor.cpp:100-115).
+// EIGHT LANES PER VOXEL: the points of a cell and the cells of a shell are dealt out to the lanes, neighbour cells are
+// found through the voxel hash (one or two probes instead of a 15-step binary search), and the lanes' candidates are
+// merged by (distance, index) -- the order in which candidates are looked at cannot change that minimum.
+static constexpr uint32_t NN_SUB = 8;
+__device__ __forceinline__ void nn_take(float dd, uint32_t pi, float &best, uint32_t &best_i) {
+    if (dd < best || (dd == best && pi < best_i)) {
+        best = dd;
+        best_i = pi;
+    }
+}
+__device__ __forceinline__ void nn_merge(float &best, uint32_t &best_i) {
+#pragma unroll
+    for (int o = NN_SUB / 2; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const uint32_t oi = __shfl_xor(best_i, o, 64);
+        nn_take(ob, oi, best, best_i);
+    }
+}
 __global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts, const uint32_t *__restrict__ sperm,
                                                    const uint32_t *__restrict__ run_begin, const uint32_t *__restrict__ ukeys,
                                                    const float4 *__restrict__ cent, const uint32_t *nv_dev, const VoxGrid *gp, Xf Tl2b,
-                                                   DP P, Counters *ctr, float4 *__restrict__ query, uint32_t *__restrict__ qkey) {
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+                                                   DP P, Counters *ctr, float4 *__restrict__ query, uint32_t *__restrict__ qkey,
+                                                   const uint32_t *__restrict__ hkey, const uint32_t *__restrict__ hval, int hbits) {
+    const uint32_t v = (blockIdx.x * blockDim.x + threadIdx.x) / NN_SUB, sub = threadIdx.x & (NN_SUB - 1);
     const uint32_t nv = *nv_dev;
-    if (v >= nv) return;
+    if (v >= nv) return;  // the eight lanes of a voxel leave together
     const VoxGrid g = *gp;
     const float4 c = cent[v];
     const uint32_t key = ukeys[v];
     const int dx = g.div_b[0], dy = g.div_b[1], dz = g.div_b[2];
     const int ci = (int)(key % (uint32_t)dx), cj = (int)((key / (uint32_t)dx) % (uint32_t)dy), ck = (int)(key / ((uint32_t)dx * (uint32_t)dy));
     const double L = 1.0 / (double)g.inv_leaf;
+    const double cc[3] = {(double)c.x, (double)c.y, (double)c.z};
+    const int cidx[3] = {ci, cj, ck};
     float best = __int_as_float(0x7F800000);
     uint32_t best_i = 0xFFFFFFFFu;
     const int maxrho = max(dx, max(dy, dz));
     // stage 0: the voxel's own points.  If the best of them is closer than the centroid's distance to the walls of its
     // own cell, no point of any other cell can beat or tie it (single-point voxels end here with distance 0).
-    {
-        for (uint32_t li = run_begin[v]; li < run_begin[v + 1]; ++li) {
-            const uint32_t pi = sperm[li];
-            const float4 p = pts[pi];
-            const float dd = l2_simple(c.x, c.y, c.z, p.x, p.y, p.z);
-            if (dd < best || (dd == best && pi < best_i)) {
-                best = dd;
-                best_i = pi;
-            }
-        }
+    for (uint32_t li = run_begin[v] + sub; li < run_begin[v + 1]; li += NN_SUB) {
+        const uint32_t pi = sperm[li];
+        const float4 p = pts[pi];
+        nn_take(l2_simple(c.x, c.y, c.z, p.x, p.y, p.z), pi, best, best_i);
     }
+    nn_merge(best, best_i);
     bool done = false;
     {
-        const double cc[3] = {(double)c.x, (double)c.y, (double)c.z};
-        const int cidx[3] = {ci, cj, ck};
         double gmin = 1e300;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -1277,7 +1305,10 @@ __global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts
         }
         done = (gmin > 0.0 && (double)best <= gmin * gmin);
     }
+    const uint32_t hmask = (1u << hbits) - 1u;
     for (int rho = 1; !done; ++rho) {
+        const float shell_best = best;  // pruning bound for this shell (the same in all eight lanes; a looser bound only prunes less)
+        uint32_t turn = 0;
         for (int kk = ck - rho; kk <= ck + rho; ++kk) {
             if (kk < 0 || kk >= dz) continue;
             for (int jj = cj - rho; jj <= cj + rho; ++jj) {
@@ -1286,41 +1317,34 @@ __global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts
                 for (int ii = ci - rho; ii <= ci + rho; ++ii) {
                     if (ii < 0 || ii >= dx) continue;
                     if (!shell_jk && abs(ii - ci) < rho) continue;  // interior cells were visited by earlier stages (rho-1, ..., 0)
+                    if ((turn++ & (NN_SUB - 1)) != sub) continue;   // this cell belongs to another lane
                     {   // a cell whose nearest corner/face is farther than the current best cannot hold a closer or tied point
                         const int cell[3] = {ii, jj, kk};
-                        const double cc3[3] = {(double)c.x, (double)c.y, (double)c.z};
                         double d2c = 0.0;
 #pragma unroll
                         for (int a = 0; a < 3; ++a) {
                             const double lo_a = (double)(g.min_b[a] + cell[a]) * L, hi_a = (double)(g.min_b[a] + cell[a] + 1) * L;
-                            const double margin = 1e-3 * L + 1e-6 * fabs(cc3[a]);
-                            const double da = fmax(0.0, fmax(lo_a - cc3[a], cc3[a] - hi_a) - margin);
+                            const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
+                            const double da = fmax(0.0, fmax(lo_a - cc[a], cc[a] - hi_a) - margin);
                             d2c += da * da;
                         }
-                        if (d2c > (double)best) continue;
+                        if (d2c > (double)shell_best) continue;
                     }
                     const uint32_t q = (uint32_t)ii + (uint32_t)jj * (uint32_t)dx + (uint32_t)kk * (uint32_t)dx * (uint32_t)dy;
-                    uint32_t lo = 0, hi = nv;  // lower_bound
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (ukeys[mid] < q) lo = mid + 1; else hi = mid;
-                    }
-                    if (lo >= nv || ukeys[lo] != q) continue;
-                    for (uint32_t li = run_begin[lo]; li < run_begin[lo + 1]; ++li) {
+                    uint32_t sl = vox_hash(q, hbits), hk;
+                    while ((hk = hkey[sl]) != q && hk != 0xFFFFFFFFu) sl = (sl + 1) & hmask;
+                    if (hk != q) continue;  // empty cell
+                    const uint32_t w = hval[sl];
+                    for (uint32_t li = run_begin[w]; li < run_begin[w + 1]; ++li) {
                         const uint32_t pi = sperm[li];
                         const float4 p = pts[pi];
-                        const float dd = l2_simple(c.x, c.y, c.z, p.x, p.y, p.z);
-                        if (dd < best || (dd == best && pi < best_i)) {
-                            best = dd;
-                            best_i = pi;
-                        }
+                        nn_take(l2_simple(c.x, c.y, c.z, p.x, p.y, p.z), pi, best, best_i);
                     }
                 }
             }
         }
+        nn_merge(best, best_i);
         if (rho >= maxrho) break;
-        const double cc[3] = {(double)c.x, (double)c.y, (double)c.z};
-        const int cidx[3] = {ci, cj, ck};
         double gmin = 1e300;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -1332,6 +1356,7 @@ __global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts
         }
         if (best_i != 0xFFFFFFFFu && gmin > 0.0 && (double)best <= gmin * gmin) break;
     }
+    if (sub != 0) return;
     float4 o = c;
     o.w = pts[best_i].w;  // utils.cpp:109
     const float4 b = xform(Tl2b, o);
