@@ -837,7 +837,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     if (prevox) {
         if (nq) LAUNCH(h, "q_direct", k_query_direct, cdiv(nq, 256), 256, h->scan_in, nq, P, dc, h->query.p, h->qkey.p);
     } else if (nq) {
-        LAUNCH(h, "q_centroids", k_centroids, cdiv(nq, 256), 256, h->scan_in, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
+        LAUNCH(h, "q_centroids", k_centroids, cdiv((uint64_t)nq * 8, 256), 256, h->scan_in, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
                (const uint32_t *)h->run_begin.p, (const uint32_t *)&ds->q_nvox, h->cent.p, h->ukeys.p, h->hkey.p, h->hval.p, h->hbits);
         LAUNCH(h, "q_nn", k_query_nn, cdiv((uint64_t)nq * NN_SUB, 256), 256, h->scan_in, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
                (const uint32_t *)h->ukeys.p, (const float4 *)h->cent.p, (const uint32_t *)&ds->q_nvox, (const VoxGrid *)h->qgrid.p, h->Tl2b, P, dc,
@@ -1151,7 +1151,7 @@ static int voxelize_device(erasor_hip_handle *h, const float4 *d_src, uint32_t n
         // identity lidar->body; the R-POD key output is ignored
         const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
         // x*1 + y*0 + z*0 + 0 reproduces x exactly (0*finite = 0, x+0 = x; -0.0 would become +0.0, irrelevant for a centroid)
-        LAUNCH(h, "q_centroids", k_centroids, cdiv(nq, 256), 256, h->scan_in, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
+        LAUNCH(h, "q_centroids", k_centroids, cdiv((uint64_t)nq * 8, 256), 256, h->scan_in, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
                (const uint32_t *)h->run_begin.p, (const uint32_t *)&h->d_st.p->q_nvox, h->cent.p, h->ukeys.p, h->hkey.p, h->hval.p, h->hbits);
         LAUNCH(h, "q_nn", k_query_nn, cdiv((uint64_t)nq * NN_SUB, 256), 256, h->scan_in, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
                (const uint32_t *)h->ukeys.p, (const float4 *)h->cent.p, (const uint32_t *)&h->d_st.p->q_nvox, (const VoxGrid *)h->qgrid.p, to_xf(I),

@@ -1209,17 +1209,33 @@ __global__ __launch_bounds__(256) void k_centroids(const float4 *__restrict__ pt
                                                     const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ run_begin,
                                                     const uint32_t *nv_dev, float4 *__restrict__ cent, uint32_t *__restrict__ ukeys,
                                                     uint32_t *__restrict__ hkey, uint32_t *__restrict__ hval, int hbits) {
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= *nv_dev) return;
+    // Eight lanes per voxel: they FETCH eight points of the run at once (index, then point: two dependent loads per
+    // batch instead of two per point); the float32 sums stay a strictly sequential chain in run order -- every lane
+    // replays it from the batch's registers.
+    constexpr uint32_t SUB = 8;
+    const uint32_t v = (blockIdx.x * blockDim.x + threadIdx.x) / SUB, sub = threadIdx.x & (SUB - 1);
+    if (v >= *nv_dev) return;  // the eight lanes of a voxel leave together
+    const int lane0 = (int)((threadIdx.x & 63u) & ~(SUB - 1));
     const uint32_t s = run_begin[v], e = run_begin[v + 1];
     float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-    for (uint32_t li = s; li < e; ++li) {
-        const float4 p = pts[sperm[li]];
-        sx += p.x;
-        sy += p.y;
-        sz += p.z;
-        si += p.w;
+    for (uint32_t base = s; base < e; base += SUB) {
+        const uint32_t li = base + sub;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (li < e) p = pts[sperm[li]];
+        const uint32_t cnt = min(SUB, e - base);
+#pragma unroll
+        for (uint32_t j = 0; j < SUB; ++j) {
+            const float px = __shfl(p.x, lane0 + (int)j, 64), py = __shfl(p.y, lane0 + (int)j, 64);
+            const float pz = __shfl(p.z, lane0 + (int)j, 64), pw = __shfl(p.w, lane0 + (int)j, 64);
+            if (j < cnt) {
+                sx += px;
+                sy += py;
+                sz += pz;
+                si += pw;
+            }
+        }
     }
+    if (sub != 0) return;
     const float c = (float)(e - s);
     cent[v] = make_float4(sx / c, sy / c, sz / c, si / c);
     const uint32_t key = skeys[s];
