@@ -667,7 +667,15 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
                    cur ? h->wseg0.p : h->wseg1.p, h->wstate.p, cur, h->esq0.p, h->essmall.p, h->esqs.p, 65536u, l == wl - 1 ? 1 : 0, dc);
         }
     }
-    if (n > ES_LMAX) {
+    bool mid_done = false;
+    if (n >= WIDE_MIN && (n - 1 + WTILE - 1) / WTILE <= WTILES_MAX && !getenv("ERASOR_HIP_SORT_LEVEL_CAP")) {
+        // whatever is still longer than the finisher's LDS capacity after the wide levels (a few unbalanced subtrees):
+        // one workgroup per segment cuts it down, all of its partitions in this one launch
+        LAUNCH(h, "q_esort", k_esort_mid, 256, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, (const esort::Seg *)h->esq0.p, h->essmall.p,
+               h->esqs.p, 0, 65536u, dc);
+        mid_done = true;
+    }
+    if (n > ES_LMAX && !mid_done) {
         // level queue: one workgroup per segment, one partition per launch.  Segments that are still big after `nlev`
         // levels are finished (slowly, in global memory) by the final kernel, so any nlev is correct.
         static const int level_cap2 = getenv("ERASOR_HIP_SORT_LEVEL_CAP") ? atoi(getenv("ERASOR_HIP_SORT_LEVEL_CAP")) : 1 << 20;
@@ -676,7 +684,7 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
             LAUNCH(h, "q_esort", k_esort_level, 48, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->esq0.p, h->esq1.p, h->esq2.p,
                    h->essmall.p, h->esqs.p, l, 65536u, dc);
     }
-    const int bigcur = nlev % 3;
+    const int bigcur = mid_done ? 1 : nlev % 3;  // after k_esort_mid queue 0 is spent: hand the (empty) queue 1 to the final kernel
     esort::Seg *qs3[3] = {h->esq0.p, h->esq1.p, h->esq2.p};
     LAUNCH(h, "q_esort_final", k_esort_final, 2048, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->qhead.p, h->qk_b.p, h->qv_b.p,
            (const esort::Seg *)h->essmall.p, (const esort::Seg *)qs3[bigcur], h->esqs.p, bigcur, dc, h->dbg_stamps.p);
@@ -904,8 +912,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         fprintf(stderr, "[esort slowest segment: len %llu depth %llu of %llu segments] phase1 %llu, queue %llu, finalize %llu cycles; levels:", t[30] >> 32,
                 t[30] & 0xFFFFFFFFull, t[29], t[1] - t[0], t[2] - t[1], t[3] - t[2]);
         for (int i = 4; i < 15; ++i) fprintf(stderr, " %llu", t[i + 1] > t[i] ? t[i + 1] - t[i] : 0ull);
-        fprintf(stderr, "; kernel span: first start -> last working end %.1f us, -> last end %.1f us\n", (double)(t[26] - t[28]) / 100.0,
-                (double)(t[27] - t[28]) / 100.0);
+        fprintf(stderr, "; kernel span: first start -> last working end %.1f us, -> last end %.1f us; long segments left for the global path: %llu (longest %llu)\n",
+                (double)(t[26] - t[28]) / 100.0, (double)(t[27] - t[28]) / 100.0, t[25], t[24]);
         memset(t, 0, sizeof(t));
         t[28] = ~0ull;
         (void)hipMemcpy(h->dbg_stamps.p, t, sizeof(t), hipMemcpyHostToDevice);

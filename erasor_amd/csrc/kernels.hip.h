@@ -1133,6 +1133,73 @@ __global__ __launch_bounds__(1024) void k_esort_level(uint32_t *K, uint32_t *V, 
     }
 }
 
+// "mid" kernel: every segment still longer than ES_LMAX after the wide levels is cut down to LDS-finisher size by ONE
+// workgroup, depth-first, all of its block-wide partitions in one launch (in LDS when the segment fits: a partition costs
+// a few microseconds there, against ~10 us per partition-and-launch through k_esort_level).  Pieces go to the small queue.
+static constexpr uint32_t ES_MID_LMAX = 8192;
+__global__ __launch_bounds__(1024) void k_esort_mid(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, const esort::Seg *bigq,
+                                                     esort::Seg *smallq, EsQueues *qs, int bigcur, uint32_t qcap, Counters *ctr) {
+    __shared__ uint32_t sK[ES_MID_LMAX], sV[ES_MID_LMAX], sL[ES_MID_LMAX], sR[ES_MID_LMAX];
+    __shared__ uint32_t sm[40];
+    __shared__ esort::Seg stk[72];
+    __shared__ int sp;
+    __shared__ esort::Seg cur;
+    const uint32_t nbig = qs->cnt[bigcur];
+    for (uint32_t s = blockIdx.x; s < nbig; s += gridDim.x) {
+        const esort::Seg sg = bigq[s];
+        const uint32_t len = sg.last - sg.first;
+        if (sg.depth <= 0 || len <= ES_LMAX) {  // nothing to partition here: straight to the finisher
+            if (threadIdx.x == 0) {
+                const uint32_t at = atomicAdd(&qs->small_cnt, 1u);
+                if (at < qcap) smallq[at] = sg; else ctr->sort_qoverflow = 2;
+            }
+            continue;
+        }
+        const bool in_lds = len <= ES_MID_LMAX;
+        __syncthreads();
+        if (in_lds)
+            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+                sK[i] = K[sg.first + i];
+                sV[i] = V[sg.first + i];
+            }
+        if (threadIdx.x == 0) {
+            stk[0] = sg;
+            sp = 1;
+        }
+        for (;;) {
+            __syncthreads();
+            if (sp == 0) break;  // block-uniform
+            __syncthreads();
+            if (threadIdx.x == 0) cur = stk[--sp];
+            __syncthreads();
+            const esort::Seg c = cur;
+            uint32_t cut;
+            // the LDS copy is indexed relative to the segment's first key
+            if (in_lds) cut = esort::block_partition<4>(sK, sV, sL, sR, c.first - sg.first, c.last - sg.first, sm) + sg.first;
+            else cut = esort::block_partition<8>(K, V, posL, posR, c.first, c.last, sm);
+            if (threadIdx.x == 0) {
+                const esort::Seg ch[2] = {{c.first, cut, c.depth - 1}, {cut, c.last, c.depth - 1}};
+                for (int t = 0; t < 2; ++t) {
+                    const uint32_t l = ch[t].last - ch[t].first;
+                    if (l == 0) continue;
+                    if (l > ES_LMAX && ch[t].depth > 0 && sp < 72) {
+                        stk[sp++] = ch[t];
+                    } else {  // finisher size (or depth budget exhausted: the finisher runs the exact heapsort)
+                        const uint32_t at = atomicAdd(&qs->small_cnt, 1u);
+                        if (at < qcap) smallq[at] = ch[t]; else ctr->sort_qoverflow = 2;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (in_lds)
+            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+                K[sg.first + i] = sK[i];
+                V[sg.first + i] = sV[i];
+            }
+    }
+}
+
 // final: every remaining segment (any size) is sorted to completion by one workgroup.
 // Segments <= ES_LMAX run in LDS; larger ones (only if the level budget ran out) run in place in global memory.
 __global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, uint32_t *head,
@@ -1144,6 +1211,12 @@ __global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, 
     __shared__ uint32_t qcnt[2];
     const uint32_t nsmall = qs->small_cnt, nbig = qs->cnt[bigcur];
     if (dbg && threadIdx.x == 0) atomicMin(&dbg[28], wall_clock64());  // diagnostics: first workgroup start (100 MHz ticks)
+    if (dbg && threadIdx.x == 0 && blockIdx.x == 0) {
+        dbg[25] = nbig;
+        unsigned long long mx = 0;
+        for (uint32_t i = 0; i < nbig; ++i) mx = max(mx, (unsigned long long)(bigq[i].last - bigq[i].first));
+        dbg[24] = mx;
+    }
     for (uint32_t s = blockIdx.x; s < nsmall + nbig; s += gridDim.x) {
         const esort::Seg sg = s < nsmall ? smallq[s] : bigq[s - nsmall];
         const uint32_t len = sg.last - sg.first;
