@@ -656,7 +656,10 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
         // lg(n / WIDE_MIN) + slack levels empty the wide list; whatever is left is routed to the level queue.
         // ERASOR_HIP_SORT_LEVEL_CAP (test hook): cut the level budget short so that the final kernel meets long segments
         static const int level_cap = getenv("ERASOR_HIP_SORT_LEVEL_CAP") ? atoi(getenv("ERASOR_HIP_SORT_LEVEL_CAP")) : 1 << 20;
-        const int wl = std::min(std::min(esort::lg2_floor(n / WIDE_MIN) + 4, 16), level_cap);
+#ifndef ESORT_WIDE_SLACK
+#define ESORT_WIDE_SLACK 4
+#endif
+        const int wl = std::min(std::min(esort::lg2_floor(n / WIDE_MIN) + ESORT_WIDE_SLACK, 16), level_cap);
         for (int l = 0; l < wl; ++l) {
             const int cur = l & 1;
             LAUNCH(h, "q_esort_wide", k_esort_wide_mark, 256, 256, (const uint32_t *)h->qk_a.p, h->qposL.p, h->qposR.p,

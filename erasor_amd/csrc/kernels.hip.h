@@ -852,7 +852,10 @@ struct EsQueues {
 //   swap     : WPARTS workgroups per segment: tile prefix, m by a block-wide multiway search over the two-level
 //              stop lists, cut, then the m swaps split between the workgroups
 //   children : one workgroup: children -> next wide list (median move done here) / level queue / final queue
-static constexpr uint32_t WIDE_MIN = ES_LMAX + 1;  // segments at least this long use the wide path (everything the LDS finisher cannot take)
+#ifndef ESORT_WIDE_MIN
+#define ESORT_WIDE_MIN (ES_LMAX + 1)
+#endif
+static constexpr uint32_t WIDE_MIN = ESORT_WIDE_MIN;  // segments at least this long use the wide path (everything the LDS finisher cannot take)
 static constexpr uint32_t WTILE = 2048;      // 256 threads x 8 keys
 static constexpr uint32_t WSEG_MAX = 1024;   // wide segments per level (n / WIDE_MIN: ~16 M keys)
 static constexpr uint32_t WTILES_MAX = 8192; // tiles per level (all wide segments together) -> n up to ~16 M keys
