@@ -171,6 +171,16 @@ class Erasor:
         return self.get_cloud(CLOUD_MAP)
 
     # -- step --
+    def prefetch(self, scan, T_l2b):
+        """announce the next scan (host array): its query chain starts now, beside the step in flight"""
+        scan = _f32(scan).reshape(-1, 4)
+        self._keep = scan  # the step that follows must pass this very buffer
+        self._check(lib().erasor_hip_prefetch_scan(self._h, _p(scan), C.c_size_t(len(scan)), C.c_int(0), _p(_f32(T_l2b).reshape(16))))
+        return scan
+
+    def prefetch_device(self, d_ptr, n, T_l2b):
+        self._check(lib().erasor_hip_prefetch_scan(self._h, C.c_void_p(d_ptr), C.c_size_t(n), C.c_int(1), _p(_f32(T_l2b).reshape(16))))
+
     def step(self, scan, T_l2b, T_b2o, T_o2b):
         scan = _f32(scan).reshape(-1, 4)
         res = StepResult()

@@ -43,26 +43,63 @@ struct DBuf {
 
 }  // namespace
 
+// The query side of a step (see erasor_hip_handle::q)
+struct QSide {
+    uint32_t capS = 0;
+    DBuf<float4> scan, cent, query, sq;
+    const float4 *scan_in = nullptr;  // scan being voxelised (the caller's device buffer, or scan)
+    DBuf<uint32_t> bb, qk_a, qk_b, qv_a, qv_b, qposL, qposR, qflag, qpl, qtops, run_begin, ukeys, qkey;
+    DBuf<uint32_t> qhead;
+    DBuf<esort::Seg> esq0, esq1, esq2, essmall;
+    DBuf<EsQueues> esqs;
+    DBuf<WideSeg> wseg0, wseg1;
+    DBuf<WideState> wstate;
+    DBuf<uint32_t> wtileL, wtileR;
+    DBuf<VoxGrid> qgrid;
+    DBuf<uint32_t> hkey, hval;        // voxel key -> voxel id hash of the scan voxelisation (k_centroids fills, k_query_nn probes)
+    int hbits = 10;
+    DBuf<uint32_t> qb_tot;            // [B + 1] bucket totals of the query counting sort
+    DBuf<uint32_t> qb_hist;           // [tiles][B + 1] histogram of the same
+    DBuf<uint32_t> qoff, ccnt;        // bins of the query: offsets, counts, min / max z
+    DBuf<float> cmin, cmax;
+    DBuf<uint32_t> d_nvox;            // voxels of this scan (device word every downstream launch reads)
+    DBuf<Counters> d_qctr;            // counters / error flags of this scan's query chain (folded into the step's by k_step_end)
+    hipEvent_t ev_keys = nullptr;     // voxel keys (and the VoxelGrid overflow flag) are final
+    hipEvent_t ev_done = nullptr;     // the whole query chain of the scan is done
+    // bookkeeping of a chain that has been enqueued (erasor_hip_prefetch_scan) but not yet consumed by a step
+    const void *src = nullptr;
+    size_t src_n = 0;
+    float Tl[16] = {0};
+    uint32_t ns = 0;
+    bool used = false;                // ev_done has been recorded at least once
+};
+
 struct erasor_hip_handle {
     erasor_params P;
     DP dp;
     int device = 0;
-    hipStream_t stream = nullptr;   // main stream: query chain, SRT .. write-back
+    hipStream_t stream = nullptr;   // main stream: step begin, SRT .. write-back
     hipStream_t stream2 = nullptr;  // map chain of a step (VoI split .. bin stats), concurrent with the query chain
+    hipStream_t streamQ = nullptr;  // query chains (voxelisation + bucketing of a scan), one after the other
     hipStream_t cur = nullptr;      // stream LAUNCH() currently targets
-    hipEvent_t ev_fork = nullptr, ev_keys = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int pend[2] = {0, 0};           // query sides with a prefetched chain in flight, oldest first
+    int npend = 0;
+    // a scan announced by erasor_hip_prefetch_scan whose chain is not enqueued yet (the step in flight goes first)
+    struct {
+        bool valid = false, is_device = false;
+        const void *src = nullptr;
+        size_t n = 0;
+        float Tl[16] = {0};
+        int side = 0;
+    } ann;
     // mapgen state (mapgen.hpp:27-46): cloud_curr, cloud_map, the finished submaps (cloud_maps, concatenated)
     DBuf<float4> mg_curr, mg_map, mg_done, mg_tmp;
     uint64_t mg_ncurr = 0, mg_nmap = 0, mg_ndone = 0;
     double mg_leaf = 0.05;
     bool mg_large = false, mg_initial = true, mg_active = false;
     uint64_t mg_cnt_voxel = 0, mg_accum = 0;
-    DBuf<uint32_t> hkey, hval;        // voxel key -> voxel id hash of the scan voxelisation (k_centroids fills, k_query_nn probes)
-    int hbits = 10;
     DBuf<unsigned long long> lab_slots;  // [16][8] label tallies of the assemble kernels (one cache line per slot)
-    DBuf<uint32_t> qb_tot;            // [B + 1] bucket totals of the same
-    DBuf<uint32_t> qb_hist;           // [B + 1][tiles] histogram of the query counting sort
-    const float4 *scan_in = nullptr;  // scan of the step in flight (the caller's device buffer, or h->scan)
     HostOut *pin = nullptr;         // pinned host block k_step_end reports into
     bool forked = false;            // ev_join has been recorded at least once
     int bank = 0;                   // scratch bank of scan/radix helpers (0: main stream, 1: stream2)
@@ -70,7 +107,7 @@ struct erasor_hip_handle {
     bool have_map = false, have_step = false;
 
     // ---- map store ----
-    uint32_t capMap = 0, capF = 0, capO = 0, capV = 0, capS = 0, capG = 0;
+    uint32_t capMap = 0, capF = 0, capO = 0, capV = 0, capG = 0;
     uint32_t B = 0;
     DBuf<float4> F[2];
     int curF = 0;
@@ -93,21 +130,16 @@ struct erasor_hip_handle {
     // ---- radix ----
     DBuf<uint32_t> rk_a, rk_b, rv_a, rv_b, hist, hist_l, hist_t, hist2, hist2_l, hist2_t, dn;
     // ---- bins ----
-    DBuf<uint32_t> moff, mcnt, qoff, ccnt, rev_idx, rev_list, vox_off, nvox, ng, out_off, ground_off, rej_off, crej_off;
-    DBuf<float> mmin, mmax, cmin, cmax, plane_n;
+    DBuf<uint32_t> moff, mcnt, rev_idx, rev_list, vox_off, nvox, ng, out_off, ground_off, rej_off, crej_off;
+    DBuf<float> mmin, mmax, plane_n;
     DBuf<double> plane_d;
     DBuf<uint8_t> st1, status, action;
-    // ---- query ----
-    DBuf<float4> scan, cent, query, sq, curr_rejected;
-    DBuf<uint32_t> bb, qk_a, qk_b, qv_a, qv_b, qposL, qposR, qflag, qpl, qtops, run_begin, ukeys, qkey;
-    DBuf<uint32_t> qhead;
-    DBuf<esort::Seg> esq0, esq1, esq2, essmall;
-    DBuf<EsQueues> esqs;
+    // ---- query side: everything the voxelisation / bucketing of ONE scan owns.  Two sets, so that the query chain of the
+    // next scan (erasor_hip_prefetch_scan) can run while the current step is in its map-side stages ----
+    QSide q[2];
+    int qi = 0;                      // the set the calls below work on
+    DBuf<float4> curr_rejected;
     DBuf<unsigned long long> dbg_stamps;  // optional cycle stamps of the first finished segment (ERASOR_HIP_SORT_STAMPS)
-    DBuf<WideSeg> wseg0, wseg1;
-    DBuf<WideState> wstate;
-    DBuf<uint32_t> wtileL, wtileR;
-    DBuf<VoxGrid> qgrid;
     // ---- per-bin scratch (R-GPF / bin voxelise global paths) ----
     DBuf<uint32_t> gsK, gsV, gsL, gsR, gsK2, gsV2;
     DBuf<uint32_t> gsH;
@@ -129,6 +161,8 @@ struct erasor_hip_handle {
     std::vector<PendingEvt> pending;
     std::vector<hipEvent_t> evt_pool;
 };
+
+#define Q(h) ((h)->q[(h)->qi])
 
 namespace {
 
@@ -300,13 +334,20 @@ int key_bits(uint32_t nbuckets) {
 int alloc_bins(erasor_hip_handle *h) {
     const size_t B = h->B;
     int rc = 0;
-    rc |= ensure(h, h->moff, B + 2) | ensure(h, h->qoff, B + 2) | ensure(h, h->mcnt, B) | ensure(h, h->ccnt, B);
-    rc |= ensure(h, h->mmin, B) | ensure(h, h->mmax, B) | ensure(h, h->cmin, B) | ensure(h, h->cmax, B);
+    const int keep = h->qi;
+    for (h->qi = 0; h->qi < 2; ++h->qi) {
+        rc |= ensure(h, Q(h).qoff, B + 2) | ensure(h, Q(h).ccnt, B) | ensure(h, Q(h).cmin, B) | ensure(h, Q(h).cmax, B);
+        rc |= ensure(h, Q(h).bb, 8) | ensure(h, Q(h).qgrid, 1) | ensure(h, Q(h).esqs, 1) | ensure(h, Q(h).qb_tot, B + 2);
+        rc |= ensure(h, Q(h).d_nvox, 4) | ensure(h, Q(h).d_qctr, 1);
+    }
+    h->qi = keep;
+    rc |= ensure(h, h->moff, B + 2) | ensure(h, h->mcnt, B);
+    rc |= ensure(h, h->mmin, B) | ensure(h, h->mmax, B);
     rc |= ensure(h, h->st1, B) | ensure(h, h->status, B) | ensure(h, h->action, B) | ensure(h, h->rev_idx, B) | ensure(h, h->rev_list, B);
     rc |= ensure(h, h->vox_off, B) | ensure(h, h->nvox, B) | ensure(h, h->ng, B) | ensure(h, h->out_off, B) | ensure(h, h->ground_off, B);
     rc |= ensure(h, h->rej_off, B) | ensure(h, h->crej_off, B);
     rc |= ensure(h, h->plane_n, B * (size_t)std::max(h->P.gf_iter, 1) * 3) | ensure(h, h->plane_d, B * (size_t)std::max(h->P.gf_iter, 1));
-    rc |= ensure(h, h->d_st, 1) | ensure(h, h->d_ctr, 1) | ensure(h, h->dn, 16) | ensure(h, h->bb, 8) | ensure(h, h->qgrid, 1) | ensure(h, h->esqs, 1) | ensure(h, h->qb_tot, B + 2) | ensure(h, h->lab_slots, 128);
+    rc |= ensure(h, h->d_st, 1) | ensure(h, h->d_ctr, 1) | ensure(h, h->dn, 16) | ensure(h, h->lab_slots, 128);
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
 
@@ -331,20 +372,20 @@ int alloc_map(erasor_hip_handle *h, uint32_t n) {
 }
 
 int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
-    if (ns <= h->capS && h->capS) return 0;
+    if (ns <= Q(h).capS && Q(h).capS) return 0;
     const uint32_t S = ns + ns / 4 + 1024;
-    h->capS = S;
+    Q(h).capS = S;
     int rc = 0;
-    rc |= ensure(h, h->scan, S) | ensure(h, h->cent, S) | ensure(h, h->query, S) | ensure(h, h->sq, S) | ensure(h, h->curr_rejected, S);
-    rc |= ensure(h, h->qk_a, S) | ensure(h, h->qk_b, S) | ensure(h, h->qv_a, S) | ensure(h, h->qv_b, S) | ensure(h, h->qposL, S) | ensure(h, h->qposR, S);
-    rc |= ensure(h, h->qflag, S) | ensure(h, h->qpl, S) | ensure(h, h->qtops, S / 1024 + 4) | ensure(h, h->run_begin, S + 1) | ensure(h, h->ukeys, S);
-    rc |= ensure(h, h->qkey, S) | ensure(h, h->qhead, S / 32 + 8);
-    h->hbits = 10;  // voxel hash table: >= 2 slots per possible voxel
-    while ((1ull << h->hbits) < 2ull * S) ++h->hbits;
-    rc |= ensure(h, h->hkey, (size_t)1 << h->hbits) | ensure(h, h->hval, (size_t)1 << h->hbits);
+    rc |= ensure(h, Q(h).scan, S) | ensure(h, Q(h).cent, S) | ensure(h, Q(h).query, S) | ensure(h, Q(h).sq, S) | ensure(h, h->curr_rejected, S);
+    rc |= ensure(h, Q(h).qk_a, S) | ensure(h, Q(h).qk_b, S) | ensure(h, Q(h).qv_a, S) | ensure(h, Q(h).qv_b, S) | ensure(h, Q(h).qposL, S) | ensure(h, Q(h).qposR, S);
+    rc |= ensure(h, Q(h).qflag, S) | ensure(h, Q(h).qpl, S) | ensure(h, Q(h).qtops, S / 1024 + 4) | ensure(h, Q(h).run_begin, S + 1) | ensure(h, Q(h).ukeys, S);
+    rc |= ensure(h, Q(h).qkey, S) | ensure(h, Q(h).qhead, S / 32 + 8);
+    Q(h).hbits = 10;  // voxel hash table: >= 2 slots per possible voxel
+    while ((1ull << Q(h).hbits) < 2ull * S) ++Q(h).hbits;
+    rc |= ensure(h, Q(h).hkey, (size_t)1 << Q(h).hbits) | ensure(h, Q(h).hval, (size_t)1 << Q(h).hbits);
     if (getenv("ERASOR_HIP_SORT_STAMPS")) rc |= ensure(h, h->dbg_stamps, 32);
-    rc |= ensure(h, h->wseg0, WSEG_MAX) | ensure(h, h->wseg1, WSEG_MAX) | ensure(h, h->wstate, 1) | ensure(h, h->wtileL, WTILES_MAX) | ensure(h, h->wtileR, WTILES_MAX);
-    rc |= ensure(h, h->esq0, 65536) | ensure(h, h->esq1, 65536) | ensure(h, h->esq2, 65536) | ensure(h, h->essmall, 65536);
+    rc |= ensure(h, Q(h).wseg0, WSEG_MAX) | ensure(h, Q(h).wseg1, WSEG_MAX) | ensure(h, Q(h).wstate, 1) | ensure(h, Q(h).wtileL, WTILES_MAX) | ensure(h, Q(h).wtileR, WTILES_MAX);
+    rc |= ensure(h, Q(h).esq0, 65536) | ensure(h, Q(h).esq1, 65536) | ensure(h, Q(h).esq2, 65536) | ensure(h, Q(h).essmall, 65536);
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
 
@@ -557,9 +598,13 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->streamQ, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_keys, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->q[0].ev_keys, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->q[1].ev_keys, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->q[0].ev_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->q[1].ev_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&h->pin, sizeof(HostOut), hipHostMallocDefault) != hipSuccess) {
         delete h;
@@ -577,22 +622,29 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
 void erasor_hip_destroy(erasor_hip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->streamQ) (void)hipStreamSynchronize(h->streamQ);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     prof_collect(h);
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
+    for (h->qi = 0; h->qi < 2; ++h->qi) {  // both query sides
+        release(Q(h).d_nvox); release(Q(h).d_qctr); release(Q(h).qb_hist); release(Q(h).qb_tot); release(Q(h).hkey); release(Q(h).hval); release(Q(h).qoff); release(Q(h).ccnt); release(Q(h).cmin); release(Q(h).cmax); release(Q(h).scan); release(Q(h).cent); release(Q(h).query); release(Q(h).sq); release(Q(h).bb); release(Q(h).qk_a); release(Q(h).qk_b); release(Q(h).qv_a); release(Q(h).qv_b); release(Q(h).qposL); release(Q(h).qposR); release(Q(h).qflag); release(Q(h).qpl); release(Q(h).qtops); release(Q(h).run_begin); release(Q(h).ukeys); release(Q(h).qkey); release(Q(h).qhead); release(Q(h).wseg0); release(Q(h).wseg1); release(Q(h).wstate); release(Q(h).wtileL); release(Q(h).wtileR); release(Q(h).esq0); release(Q(h).esq1); release(Q(h).esq2); release(Q(h).essmall); release(Q(h).esqs); release(Q(h).qgrid);
+    }
+    h->qi = 0;
+       
     release(h->Cbuf); release(h->F[0]); release(h->F[1]); release(h->Oxy); release(h->Ozi);
     release(h->vmask); release(h->hmask); release(h->cinfo); release(h->pvl); release(h->phl); release(h->topv); release(h->toph);
     release(h->voi_ego); release(h->spts); release(h->rejected); release(h->voi_key); release(h->voi_src); release(h->ssrc);
     release(h->rejected_src); release(h->grank); release(h->glist); release(h->gflag);
-    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->qb_hist); release(h->qb_tot); release(h->lab_slots); release(h->hkey); release(h->hval); release(h->mg_curr); release(h->mg_map); release(h->mg_done); release(h->mg_tmp);
-    release(h->moff); release(h->mcnt); release(h->qoff); release(h->ccnt); release(h->rev_idx); release(h->rev_list); release(h->vox_off);
+    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->lab_slots); release(h->mg_curr); release(h->mg_map); release(h->mg_done); release(h->mg_tmp);
+    release(h->moff); release(h->mcnt); release(h->rev_idx); release(h->rev_list); release(h->vox_off);
     release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
-    release(h->mmin); release(h->mmax); release(h->cmin); release(h->cmax); release(h->plane_n); release(h->plane_d);
+    release(h->mmin); release(h->mmax); release(h->plane_n); release(h->plane_d);
     release(h->st1); release(h->status); release(h->action);
-    release(h->scan); release(h->cent); release(h->query); release(h->sq); release(h->curr_rejected);
-    release(h->bb); release(h->qk_a); release(h->qk_b); release(h->qv_a); release(h->qv_b); release(h->qposL); release(h->qposR);
-    release(h->qflag); release(h->qpl); release(h->qtops); release(h->run_begin); release(h->ukeys); release(h->qkey); release(h->qhead);
-    release(h->wseg0); release(h->wseg1); release(h->wstate); release(h->wtileL); release(h->wtileR); release(h->esq0); release(h->esq1); release(h->esq2); release(h->essmall); release(h->esqs); release(h->qgrid);
+    release(h->curr_rejected);
+   
+   
+   
     release(h->gsK); release(h->gsV); release(h->gsL); release(h->gsR); release(h->gsK2); release(h->gsV2); release(h->gsH); release(h->gsC);
     release(h->vox_out); release(h->d_st); release(h->d_ctr);
     if (h->stream2) {
@@ -600,7 +652,11 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
         (void)hipStreamDestroy(h->stream2);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_keys) (void)hipEventDestroy(h->ev_keys);
+    for (int k = 0; k < 2; ++k) {
+        if (h->q[k].ev_keys) (void)hipEventDestroy(h->q[k].ev_keys);
+        if (h->q[k].ev_done) (void)hipEventDestroy(h->q[k].ev_done);
+    }
+    if (h->streamQ) (void)hipStreamDestroy(h->streamQ);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -648,8 +704,8 @@ int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n
 // exact std::sort of (qk_a, qv_a)[0..n) -> (qk_b, qv_b): global levels (one workgroup per big segment, one partition per
 // launch), then every remaining segment is completed inside LDS by one workgroup.
 static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
-    Counters *dc = h->d_ctr.p;
-    LAUNCH(h, "q_esort", k_esort_init, 1, 1, h->qk_a.p, h->qv_a.p, h->esq0.p, h->essmall.p, h->esqs.p, h->wseg0.p, h->wstate.p, n);
+    Counters *dc = Q(h).d_qctr.p;
+    LAUNCH(h, "q_esort", k_esort_init, 1, 1, Q(h).qk_a.p, Q(h).qv_a.p, Q(h).esq0.p, Q(h).essmall.p, Q(h).esqs.p, Q(h).wseg0.p, Q(h).wstate.p, n);
     int nlev = 0;
     if (n >= WIDE_MIN && (n - 1 + WTILE - 1) / WTILE <= WTILES_MAX) {
         // wide levels: segments >= WIDE_MIN keys, many workgroups each.  A segment halves (roughly) per level, so
@@ -662,20 +718,20 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
         const int wl = std::min(std::min(esort::lg2_floor(n / WIDE_MIN) + ESORT_WIDE_SLACK, 16), level_cap);
         for (int l = 0; l < wl; ++l) {
             const int cur = l & 1;
-            LAUNCH(h, "q_esort_wide", k_esort_wide_mark, 256, 256, (const uint32_t *)h->qk_a.p, h->qposL.p, h->qposR.p,
-                   (const WideSeg *)(cur ? h->wseg1.p : h->wseg0.p), (const WideState *)h->wstate.p, cur, h->wtileL.p, h->wtileR.p);
-            LAUNCH(h, "q_esort_wide", k_esort_wide_swap, 256, 256, h->qk_a.p, h->qv_a.p, (const uint32_t *)h->qposL.p, (const uint32_t *)h->qposR.p,
-                   cur ? h->wseg1.p : h->wseg0.p, (const WideState *)h->wstate.p, cur, (const uint32_t *)h->wtileL.p, (const uint32_t *)h->wtileR.p);
-            LAUNCH(h, "q_esort_wide", k_esort_wide_children, 1, 64, h->qk_a.p, h->qv_a.p, (const WideSeg *)(cur ? h->wseg1.p : h->wseg0.p),
-                   cur ? h->wseg0.p : h->wseg1.p, h->wstate.p, cur, h->esq0.p, h->essmall.p, h->esqs.p, 65536u, l == wl - 1 ? 1 : 0, dc);
+            LAUNCH(h, "q_esort_wide", k_esort_wide_mark, 256, 256, (const uint32_t *)Q(h).qk_a.p, Q(h).qposL.p, Q(h).qposR.p,
+                   (const WideSeg *)(cur ? Q(h).wseg1.p : Q(h).wseg0.p), (const WideState *)Q(h).wstate.p, cur, Q(h).wtileL.p, Q(h).wtileR.p);
+            LAUNCH(h, "q_esort_wide", k_esort_wide_swap, 256, 256, Q(h).qk_a.p, Q(h).qv_a.p, (const uint32_t *)Q(h).qposL.p, (const uint32_t *)Q(h).qposR.p,
+                   cur ? Q(h).wseg1.p : Q(h).wseg0.p, (const WideState *)Q(h).wstate.p, cur, (const uint32_t *)Q(h).wtileL.p, (const uint32_t *)Q(h).wtileR.p);
+            LAUNCH(h, "q_esort_wide", k_esort_wide_children, 1, 64, Q(h).qk_a.p, Q(h).qv_a.p, (const WideSeg *)(cur ? Q(h).wseg1.p : Q(h).wseg0.p),
+                   cur ? Q(h).wseg0.p : Q(h).wseg1.p, Q(h).wstate.p, cur, Q(h).esq0.p, Q(h).essmall.p, Q(h).esqs.p, 65536u, l == wl - 1 ? 1 : 0, dc);
         }
     }
     bool mid_done = false;
     if (n >= WIDE_MIN && (n - 1 + WTILE - 1) / WTILE <= WTILES_MAX && !getenv("ERASOR_HIP_SORT_LEVEL_CAP")) {
         // whatever is still longer than the finisher's LDS capacity after the wide levels (a few unbalanced subtrees):
         // one workgroup per segment cuts it down, all of its partitions in this one launch
-        LAUNCH(h, "q_esort", k_esort_mid, 256, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, (const esort::Seg *)h->esq0.p, h->essmall.p,
-               h->esqs.p, 0, 65536u, dc);
+        LAUNCH(h, "q_esort", k_esort_mid, 256, 1024, Q(h).qk_a.p, Q(h).qv_a.p, Q(h).qposL.p, Q(h).qposR.p, (const esort::Seg *)Q(h).esq0.p, Q(h).essmall.p,
+               Q(h).esqs.p, 0, 65536u, dc);
         mid_done = true;
     }
     if (n > ES_LMAX && !mid_done) {
@@ -684,35 +740,136 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
         static const int level_cap2 = getenv("ERASOR_HIP_SORT_LEVEL_CAP") ? atoi(getenv("ERASOR_HIP_SORT_LEVEL_CAP")) : 1 << 20;
         nlev = std::min(std::min(2 * esort::lg2_floor(n), n >= WIDE_MIN ? (n > (1u << 21) ? 12 : 2) : 12), level_cap2);
         for (int l = 0; l < nlev; ++l)
-            LAUNCH(h, "q_esort", k_esort_level, 48, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->esq0.p, h->esq1.p, h->esq2.p,
-                   h->essmall.p, h->esqs.p, l, 65536u, dc);
+            LAUNCH(h, "q_esort", k_esort_level, 48, 1024, Q(h).qk_a.p, Q(h).qv_a.p, Q(h).qposL.p, Q(h).qposR.p, Q(h).esq0.p, Q(h).esq1.p, Q(h).esq2.p,
+                   Q(h).essmall.p, Q(h).esqs.p, l, 65536u, dc);
     }
     const int bigcur = mid_done ? 1 : nlev % 3;  // after k_esort_mid queue 0 is spent: hand the (empty) queue 1 to the final kernel
-    esort::Seg *qs3[3] = {h->esq0.p, h->esq1.p, h->esq2.p};
-    LAUNCH(h, "q_esort_final", k_esort_final, 2048, 1024, h->qk_a.p, h->qv_a.p, h->qposL.p, h->qposR.p, h->qhead.p, h->qk_b.p, h->qv_b.p,
-           (const esort::Seg *)h->essmall.p, (const esort::Seg *)qs3[bigcur], h->esqs.p, bigcur, dc, h->dbg_stamps.p);
+    esort::Seg *qs3[3] = {Q(h).esq0.p, Q(h).esq1.p, Q(h).esq2.p};
+    LAUNCH(h, "q_esort_final", k_esort_final, 2048, 1024, Q(h).qk_a.p, Q(h).qv_a.p, Q(h).qposL.p, Q(h).qposR.p, Q(h).qhead.p, Q(h).qk_b.p, Q(h).qv_b.p,
+           (const esort::Seg *)Q(h).essmall.p, (const esort::Seg *)qs3[bigcur], Q(h).esqs.p, bigcur, dc, h->dbg_stamps.p);
 }
 
-// ---- exact voxelisation of the cloud in h->scan[0..n): fills run_begin / cent / ukeys, d_st->q_nvox -------------------
+// ---- exact voxelisation of the cloud in Q(h).scan[0..n): fills run_begin / cent / ukeys, d_st->q_nvox -------------------
 static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf, const std::function<void()> &after_keys) {
-    DevState *ds = h->d_st.p;
-    Counters *dc = h->d_ctr.p;
-    // (the bounding box was reset by k_step_begin)
-    if (n) LAUNCH(h, "q_bbox", k_bbox, std::min<uint32_t>(cdiv(n, 256), 1024), 256, h->scan_in, n, h->bb.p);
-    LAUNCH(h, "q_keys", k_voxel_keys, std::max(1u, cdiv(n, 256)), 256, h->scan_in, n, (const uint32_t *)h->bb.p, leaf, h->qk_a.p,
-           h->qv_a.p, h->qgrid.p, dc, h->hkey.p, 1u << h->hbits);
+    Counters *dc = Q(h).d_qctr.p;
+    // (the bounding box was reset by k_query_begin)
+    if (n) LAUNCH(h, "q_bbox", k_bbox, std::min<uint32_t>(cdiv(n, 256), 1024), 256, Q(h).scan_in, n, Q(h).bb.p);
+    LAUNCH(h, "q_keys", k_voxel_keys, std::max(1u, cdiv(n, 256)), 256, Q(h).scan_in, n, (const uint32_t *)Q(h).bb.p, leaf, Q(h).qk_a.p,
+           Q(h).qv_a.p, Q(h).qgrid.p, dc, Q(h).hkey.p, 1u << Q(h).hbits);
     after_keys();  // ctr->err (VoxelGrid overflow) is final from here on: the caller may fork work that depends on it
     // exact std::sort: a few global levels (one workgroup per big segment), then per-segment completion in LDS
     run_exact_sort(h, n);
     // runs
-    if (n) LAUNCH(h, "q_runs", k_run_heads, cdiv(n, 256), 256, (const uint32_t *)h->qk_b.p, n, h->qflag.p);
-    scan_u32(h, h->qflag.p, h->qpl.p, h->qtops.p, n, n, nullptr, nullptr, "q_runs");
-    LAUNCH(h, "q_runs", k_run_begin, cdiv((uint64_t)n + 1, 256), 256, (const uint32_t *)h->qflag.p, (const uint32_t *)h->qpl.p,
-           (const uint32_t *)h->qtops.p, n, h->run_begin.p, &ds->q_nvox);
+    if (n) LAUNCH(h, "q_runs", k_run_heads, cdiv(n, 256), 256, (const uint32_t *)Q(h).qk_b.p, n, Q(h).qflag.p);
+    scan_u32(h, Q(h).qflag.p, Q(h).qpl.p, Q(h).qtops.p, n, n, nullptr, nullptr, "q_runs");
+    LAUNCH(h, "q_runs", k_run_begin, cdiv((uint64_t)n + 1, 256), 256, (const uint32_t *)Q(h).qflag.p, (const uint32_t *)Q(h).qpl.p,
+           (const uint32_t *)Q(h).qtops.p, n, Q(h).run_begin.p, Q(h).d_nvox.p);
     return 0;
 }
 
 enum { STEP_QUERY_PREVOXELIZED = 1, STEP_VOI_EVERYTHING = 2 };
+
+// restores the handle's active query side / target stream when a helper that switched them returns (also on errors)
+struct SideGuard {
+    erasor_hip_handle *h;
+    int qi;
+    hipStream_t cur;
+    explicit SideGuard(erasor_hip_handle *hh) : h(hh), qi(hh->qi), cur(hh->cur) {}
+    ~SideGuard() {
+        h->qi = qi;
+        h->cur = cur;
+    }
+};
+
+// The QUERY CHAIN of one scan, enqueued on streamQ into query side `side`: voxelize_preserving_labels (OMU.cpp:238),
+// lidar->body + R-POD key (OMU.cpp:240; erasor.cpp:100-115), bucketing and per-bin statistics of the query.  It depends
+// on the scan and the lidar->body transform only -- not on the map -- which is what lets erasor_hip_prefetch_scan run
+// it for scan k+1 while step k is still in its map-side stages.
+static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_src, uint32_t ns, bool src_is_device, const float T_l2b[16],
+                               bool prevox, bool staged = false) {
+    SideGuard guard(h);
+    h->qi = side;
+    h->cur = h->streamQ;
+    int rc = alloc_scan(h, std::max(ns, 1u));
+    if (rc) return rc;
+    const DP &P = h->dp;
+    const uint32_t B = h->B, nq = ns;  // nq: upper bound; the actual count lives in d_nvox
+    const int bits = key_bits(B + 1);
+    if (B + 1 <= QB_NB_MAX) {
+        if (ensure(h, Q(h).qb_hist, (size_t)(B + 1) * std::max(1u, cdiv(nq, QB_TILE)) + 8)) return ERASOR_E_NO_DEVICE;
+    } else {
+        const uint32_t nb_q = 256u * std::max(1u, cdiv(nq, RTILE));
+        if (ensure(h, h->hist, nb_q) || ensure(h, h->hist_l, nb_q) || ensure(h, h->hist_t, cdiv(nb_q, 1024) + 2)) return ERASOR_E_NO_DEVICE;
+    }
+    QSide &q = Q(h);
+    // a device-resident scan is read in place (it must stay valid until the step that consumes it has returned);
+    // a host scan is copied now (blocking copy: this side has no work in flight)
+    if (ns && !src_is_device && !staged) {
+        // the side may still be executing a chain that was dropped (a prefetch that no step claimed): its kernels read
+        // q.scan, and a scan that changes between the bounding-box pass and the voxel keys sends them astray
+        if (q.used) HIPC(h, hipEventSynchronize(q.ev_done));
+        HIPC(h, hipMemcpy(q.scan.p, scan_src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    q.scan_in = src_is_device && ns ? (const float4 *)scan_src : (const float4 *)q.scan.p;
+    Counters *qc = q.d_qctr.p;
+    const uint32_t *nq_dev = q.d_nvox.p;
+    LAUNCH(h, "q_begin", k_query_begin, 1, 256, qc, q.bb.p, B + 1 <= QB_NB_MAX ? q.qb_tot.p : (uint32_t *)nullptr, B + 1 <= QB_NB_MAX ? B + 1 : 0u,
+           q.d_nvox.p, prevox ? ns : 0u);
+    // ---- part 1: bounding box, voxel keys, exact std::sort, runs ----
+    if (!prevox) voxelize_query_part1(h, ns, P.leaf_query, [&] { (void)hipEventRecord(q.ev_keys, h->streamQ); });
+    else (void)hipEventRecord(q.ev_keys, h->streamQ);
+    // ---- part 2: centroids, label NN, lidar->body, R-POD key ----
+    const uint32_t *sq_keys = nullptr, *sq_perm = nullptr;
+    if (prevox) {
+        if (nq) LAUNCH(h, "q_direct", k_query_direct, cdiv(nq, 256), 256, q.scan_in, nq, P, qc, q.query.p, q.qkey.p);
+    } else if (nq) {
+        LAUNCH(h, "q_centroids", k_centroids, cdiv((uint64_t)nq * 8, 256), 256, q.scan_in, (const uint32_t *)q.qk_b.p, (const uint32_t *)q.qv_b.p,
+               (const uint32_t *)q.run_begin.p, nq_dev, q.cent.p, q.ukeys.p, q.hkey.p, q.hval.p, q.hbits);
+        LAUNCH(h, "q_nn", k_query_nn, cdiv((uint64_t)nq * NN_SUB, 256), 256, q.scan_in, (const uint32_t *)q.qv_b.p, (const uint32_t *)q.run_begin.p,
+               (const uint32_t *)q.ukeys.p, (const float4 *)q.cent.p, nq_dev, (const VoxGrid *)q.qgrid.p, to_xf(T_l2b), P, qc, q.query.p, q.qkey.p,
+               (const uint32_t *)q.hkey.p, (const uint32_t *)q.hval.p, q.hbits);
+    }
+    if (B + 1 <= QB_NB_MAX) {  // one-digit stable counting sort with the gather and the bucket offsets folded in
+        const uint32_t ntile_ub = std::max(1u, cdiv(nq, QB_TILE));
+        LAUNCH(h, "q_bucket", k_qb_hist, ntile_ub, 1024, (const uint32_t *)q.qkey.p, nq, nq_dev, B + 1, q.qb_hist.p, q.qb_tot.p);
+        LAUNCH(h, "q_bucket", k_qb_scan, 1, 1024, (const uint32_t *)q.qb_tot.p, B + 1, q.qoff.p);
+        LAUNCH(h, "q_bucket", k_qb_scatter, ntile_ub, 1024, (const uint32_t *)q.qkey.p, (const float4 *)q.query.p, nq, nq_dev, B + 1, bits,
+               (const uint32_t *)q.qb_hist.p, (const uint32_t *)q.qoff.p, q.sq.p);
+    } else {  // very fine R-POD grids: LSD radix passes
+        radix_sort(h, q.qkey.p, nq, nq_dev, bits, q.qk_a.p, q.qposL.p, q.qv_a.p, q.qposR.p, &sq_keys, &sq_perm, "q_bucket");
+        if (nq) LAUNCH(h, "q_bucket", k_gather, cdiv(nq, 256), 256, (const float4 *)q.query.p, (const uint32_t *)nullptr, sq_perm, nq, nq_dev, q.sq.p,
+                       (uint32_t *)nullptr);
+        LAUNCH(h, "q_bucket", k_bin_offsets, cdiv((uint64_t)std::max(nq, B + 2) + 1, 256), 256, sq_keys, nq, nq_dev, B + 1, q.qoff.p);
+    }
+    LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)q.sq.p, (const uint32_t *)q.qoff.p, B, q.ccnt.p, q.cmin.p,
+           q.cmax.p);
+    (void)hipEventRecord(q.ev_done, h->streamQ);
+    q.used = true;
+    q.src = scan_src;
+    q.src_n = ns;
+    q.ns = ns;
+    memcpy(q.Tl, T_l2b, sizeof(q.Tl));
+    return ERASOR_OK;
+}
+
+// the chain of the announced scan goes into its queue (after whatever the caller has just enqueued)
+static int flush_announced(erasor_hip_handle *h) {
+    if (!h->ann.valid) return ERASOR_OK;
+    h->ann.valid = false;
+    const int rc = enqueue_query_chain(h, h->ann.side, h->ann.src, (uint32_t)h->ann.n, h->ann.is_device, h->ann.Tl, false, /*staged=*/true);
+    if (rc) return rc;
+    h->pend[h->npend++] = h->ann.side;
+    return ERASOR_OK;
+}
+
+// standalone entry points (voxelize, mapgen, sort hooks, ERASOR-class runs) use the active query side as scratch:
+// forget prefetched chains and let streamQ run dry first
+static void q_drain(erasor_hip_handle *h) {
+    h->npend = 0;
+    h->ann.valid = false;
+    (void)hipStreamSynchronize(h->streamQ);
+}
+
 
 static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan, bool src_is_device, const float T_l2b[16],
                        const float T_b2o[16], const float T_o2b[16], erasor_step_result *res, int flags = 0) {
@@ -731,8 +888,36 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         if (host_timing) marks.emplace_back(what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count());
     };
     const uint32_t ns = (uint32_t)n_scan;
-    int rc = alloc_scan(h, std::max(ns, 1u));
-    if (rc) return rc;
+    const bool prevox = (flags & STEP_QUERY_PREVOXELIZED) != 0;
+    int rc = 0;
+    // ---- this scan's query chain: already in flight (erasor_hip_prefetch_scan), or enqueued now -- first, it is the long one ----
+    {
+        int side = -1;
+        if (h->npend == 0 && h->ann.valid && !prevox && h->ann.src == scan_src && h->ann.n == n_scan &&
+            memcmp(h->ann.Tl, T_l2b, sizeof(h->ann.Tl)) == 0) {
+            rc = flush_announced(h);  // announced, not yet started (first scan of a sequence): start it now, it is ours
+            if (rc) return rc;
+        }
+        if (h->npend > 0) {
+            const QSide &c = h->q[h->pend[0]];
+            if (!prevox && c.src == scan_src && c.src_n == n_scan && memcmp(c.Tl, T_l2b, sizeof(c.Tl)) == 0) {
+                side = h->pend[0];
+                h->pend[0] = h->pend[1];
+                --h->npend;
+            } else {
+                h->npend = 0;  // not the scan that was announced: the prefetched chains are dropped (they still run, harmlessly)
+                h->ann.valid = false;
+            }
+        }
+        if (side < 0) {
+            // (an announcement that is not this scan is the NEXT scan: it keeps the side it was staged into)
+            side = h->npend ? (h->pend[0] ^ 1) : (h->ann.valid ? (h->ann.side ^ 1) : (h->qi ^ 1));
+            rc = enqueue_query_chain(h, side, scan_src, ns, src_is_device, T_l2b, prevox);
+            if (rc) return rc;
+        }
+        h->qi = side;
+    }
+    MARK("query chain");
     h->Tl2b = to_xf(T_l2b);
     h->Tb2o = to_xf(T_b2o);
     h->To2b = to_xf(T_o2b);
@@ -759,15 +944,10 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_step_begin
     h->st.o_begin = h->o_begin;
     if (h->forked) (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);  // a previous step that bailed out between fork and join
-    LAUNCH(h, "step_begin", k_step_begin, 1, 256, ds, dc, (flags & STEP_QUERY_PREVOXELIZED) ? ns : 0u, h->st, 1, h->bb.p,
-           B + 1 <= QB_NB_MAX ? h->qb_tot.p : (uint32_t *)nullptr, B + 1 <= QB_NB_MAX ? B + 1 : 0u, h->lab_slots.p);
-    // a device-resident scan is read in place (the call is synchronous: the caller's buffer outlives every kernel of the step)
-    if (ns && !src_is_device) HIPC(h, hipMemcpyAsync(h->scan.p, scan_src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-    h->scan_in = src_is_device && ns ? (const float4 *)scan_src : (const float4 *)h->scan.p;
+    LAUNCH(h, "step_begin", k_step_begin, 1, 256, ds, dc, h->st, h->lab_slots.p);
 
-    MARK("prologue+upload");
+    MARK("prologue");
     // ---- sizes, scratch ----
-    const bool prevox = (flags & STEP_QUERY_PREVOXELIZED) != 0;
     const double voi_r2 = (flags & STEP_VOI_EVERYTHING) ? HUGE_VAL : P.voi_r2;
     const uint32_t nFchunks = cdiv(h->nF, CHUNK);
     const uint32_t o_chunk0 = h->o_begin / CHUNK;
@@ -780,21 +960,18 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     // No mid-step read-back: everything is launched on upper-bound grids and reads the actual counts
     // (st->voi_total, st->q_nvox) from device memory.  n_voi <= logical map size, nq <= n_scan.
     const uint32_t n_voi = (uint32_t)std::min<uint64_t>(n_map_in, 0xFFFFFFF0ull), nq = ns;  // upper bounds from here on
-    const uint32_t *nvoi_dev = &ds->voi_total, *nq_dev = &ds->q_nvox;
+    const uint32_t *nvoi_dev = &ds->voi_total;
     rc = alloc_step(h, n_voi, nq);
     if (rc) return rc;
     const int bits = key_bits(B + 1);
-    if (B + 1 <= QB_NB_MAX && ensure(h, h->qb_hist, (size_t)(B + 1) * std::max(1u, cdiv(nq, QB_TILE)) + 8)) return ERASOR_E_NO_DEVICE;
-    {   // make sure both scratch banks of the bucket sort exist before the streams fork
-        const uint32_t nb_q = 256u * std::max(1u, cdiv(nq, RTILE)), nb_m = 256u * std::max(1u, cdiv(n_voi, RTILE));
-        if (ensure(h, h->hist, nb_q) || ensure(h, h->hist_l, nb_q) || ensure(h, h->hist_t, cdiv(nb_q, 1024) + 2) || ensure(h, h->hist2, nb_m) ||
-            ensure(h, h->hist2_l, nb_m) || ensure(h, h->hist2_t, cdiv(nb_m, 1024) + 2))
-            return ERASOR_E_NO_DEVICE;
+    {   // the map chain's scratch bank of the bucket sort
+        const uint32_t nb_m = 256u * std::max(1u, cdiv(n_voi, RTILE));
+        if (ensure(h, h->hist2, nb_m) || ensure(h, h->hist2_l, nb_m) || ensure(h, h->hist2_t, cdiv(nb_m, 1024) + 2)) return ERASOR_E_NO_DEVICE;
     }
     const uint32_t *sm_keys = nullptr, *sm_perm = nullptr;
-    HIPC(h, hipEventRecord(h->ev_fork, h->stream));  // state pushed, counters cleared, scan uploaded
+    HIPC(h, hipEventRecord(h->ev_fork, h->stream));  // state pushed, counters cleared
 
-    // ---- map chain, on stream2, concurrent with the query chain (they only meet at the Scan Ratio Test) ----
+    // ---- map chain, on stream2, concurrent with the query chain(s) on streamQ (they only meet at the Scan Ratio Test) ----
     auto enqueue_map_chain = [&]() {
         MARK("  mapchain_begin");
         h->cur = h->stream2;
@@ -813,13 +990,13 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
             LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
                    nchunks, nFchunks, ds);
         }
-        (void)hipStreamWaitEvent(h->stream2, h->ev_keys, 0);  // k_voi_gather must see the query side's error flag
+        (void)hipStreamWaitEvent(h->stream2, Q(h).ev_keys, 0);  // k_voi_gather must see the query side's error flag
         {   // VoI gather + egocentric transform + R-POD key (OMU.cpp:435-437; erasor.cpp:124-139)
             const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nchunks, 4), 256 * 8));
             LAUNCH(h, "voi_gather", k_voi_gather, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, h->Oxy.p, h->Ozi.p, o_chunk0,
                    nOchunks, (const unsigned long long *)h->vmask.p, (const unsigned long long *)h->hmask.p, (const uint32_t *)h->cinfo.p,
                    (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p, (const uint32_t *)h->topv.p, (const uint32_t *)h->toph.p, h->To2b, P, ds,
-                   dc, h->voi_ego.p, h->voi_key.p, h->voi_src.p);
+                   dc, (const Counters *)Q(h).d_qctr.p, h->voi_ego.p, h->voi_key.p, h->voi_src.p);
         }
         radix_sort(h, h->voi_key.p, n_voi, nvoi_dev, bits, h->rk_a.p, h->rk_b.p, h->rv_a.p, h->rv_b.p, &sm_keys, &sm_perm, "voi_bucket");
         if (n_voi) LAUNCH(h, "voi_bucket", k_gather, cdiv(n_voi, 256), 256, (const float4 *)h->voi_ego.p, (const uint32_t *)h->voi_src.p, sm_perm,
@@ -834,71 +1011,48 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         h->bank = 0;
     };
 
-    MARK("alloc");
-    // ---- query voxelisation, part 1 (OMU.cpp:238); the map chain is forked right after the voxel keys ----
-    // Host enqueue order matters: the main stream's (long) sort chain goes into its queue first, so that it never idles
-    // while the host is still busy enqueueing the map chain; the event right after the voxel keys is what stream2 waits for.
-    if (!prevox) voxelize_query_part1(h, ns, P.leaf_query, [&] { (void)hipEventRecord(h->ev_keys, h->stream); });
-    else (void)hipEventRecord(h->ev_keys, h->stream);
     enqueue_map_chain();
-
-    MARK("part1+mapchain");
-    // ---- query voxelisation, part 2: centroids, label NN, lidar->body, R-POD key ----
-    const uint32_t *sq_keys = nullptr, *sq_perm = nullptr;
-    if (prevox) {
-        if (nq) LAUNCH(h, "q_direct", k_query_direct, cdiv(nq, 256), 256, h->scan_in, nq, P, dc, h->query.p, h->qkey.p);
-    } else if (nq) {
-        LAUNCH(h, "q_centroids", k_centroids, cdiv((uint64_t)nq * 8, 256), 256, h->scan_in, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
-               (const uint32_t *)h->run_begin.p, (const uint32_t *)&ds->q_nvox, h->cent.p, h->ukeys.p, h->hkey.p, h->hval.p, h->hbits);
-        LAUNCH(h, "q_nn", k_query_nn, cdiv((uint64_t)nq * NN_SUB, 256), 256, h->scan_in, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
-               (const uint32_t *)h->ukeys.p, (const float4 *)h->cent.p, (const uint32_t *)&ds->q_nvox, (const VoxGrid *)h->qgrid.p, h->Tl2b, P, dc,
-               h->query.p, h->qkey.p, (const uint32_t *)h->hkey.p, (const uint32_t *)h->hval.p, h->hbits);
-    }
-    if (B + 1 <= QB_NB_MAX) {  // one-digit stable counting sort with the gather and the bucket offsets folded in
-        const uint32_t ntile_ub = std::max(1u, cdiv(nq, QB_TILE));
-        LAUNCH(h, "q_bucket", k_qb_hist, ntile_ub, 1024, (const uint32_t *)h->qkey.p, nq, nq_dev, B + 1, h->qb_hist.p, h->qb_tot.p);
-        LAUNCH(h, "q_bucket", k_qb_scan, 1, 1024, (const uint32_t *)h->qb_tot.p, B + 1, h->qoff.p);
-        LAUNCH(h, "q_bucket", k_qb_scatter, ntile_ub, 1024, (const uint32_t *)h->qkey.p, (const float4 *)h->query.p, nq, nq_dev, B + 1, bits,
-               (const uint32_t *)h->qb_hist.p, (const uint32_t *)h->qoff.p, h->sq.p);
-    } else {  // very fine R-POD grids: LSD radix passes
-        radix_sort(h, h->qkey.p, nq, nq_dev, bits, h->qk_a.p, h->qposL.p, h->qv_a.p, h->qposR.p, &sq_keys, &sq_perm, "q_bucket");
-        if (nq) LAUNCH(h, "q_bucket", k_gather, cdiv(nq, 256), 256, (const float4 *)h->query.p, (const uint32_t *)nullptr, sq_perm, nq, nq_dev,
-                       h->sq.p, (uint32_t *)nullptr);
-        LAUNCH(h, "q_bucket", k_bin_offsets, cdiv((uint64_t)std::max(nq, B + 2) + 1, 256), 256, sq_keys, nq, nq_dev, B + 1, h->qoff.p);
-    }
-    LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->sq.p, (const uint32_t *)h->qoff.p, B, h->ccnt.p,
-           h->cmin.p, h->cmax.p);
-
-    MARK("part2");
+    MARK("map chain");
+    HIPC(h, hipStreamWaitEvent(h->stream, Q(h).ev_done, 0));  // join: the query's bins are ready
     HIPC(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));  // join: bins of the map are ready
 
     // ---- Scan Ratio Test, R-GPF, per-bin voxelisation (erasor.cpp:332-571) ----
-    LAUNCH(h, "srt", k_srt, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)h->ccnt.p,
-           (const float *)h->cmin.p, (const float *)h->cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
+    LAUNCH(h, "srt", k_srt, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
+           (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
     LAUNCH(h, "rgpf", k_rgpf, B, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->moff.p,
            (const float4 *)h->spts.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p, h->gflag.p, h->grank.p, h->glist.p,
            h->ng.p, h->plane_n.p, h->plane_d.p, dc);
     if (P.version == 3)
         LAUNCH(h, "bin_voxelize", k_binvox, B, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->moff.p,
-               (const float4 *)h->spts.p, (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->glist.p,
+               (const float4 *)h->spts.p, (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->glist.p,
                (const uint32_t *)h->ng.p, (const uint32_t *)h->vox_off.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p,
                h->gsC.p, h->vox_out.p, h->nvox.p, dc);
     LAUNCH(h, "layout", k_layout, 1, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->mcnt.p,
-           (const uint32_t *)h->ccnt.p, (const uint32_t *)h->moff.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->ng.p, h->out_off.p,
+           (const uint32_t *)Q(h).ccnt.p, (const uint32_t *)h->moff.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->ng.p, h->out_off.p,
            h->ground_off.p, h->rej_off.p, h->crej_off.p, ds);
 
     // ---- map write-back (OMU.cpp:281-290) ----
     float4 *Fnew = h->F[h->curF ^ 1].p;
     if (n_voi)
         LAUNCH(h, "assemble", k_assemble_map<true>, std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
-               sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p, (const uint32_t *)h->ccnt.p,
+               sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).ccnt.p,
                (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p,
                (const uint32_t *)h->rej_off.p, (const DevState *)ds, Fnew, h->rejected.p, h->rejected_src.p, h->lab_slots.p);
     LAUNCH(h, "assemble", k_assemble_bins<true>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
-           (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
+           (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
            (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, Fnew, h->curr_rejected.p, h->lab_slots.p);
     // (label counters of the new VoI-resident region are accumulated by the two assemble kernels)
-    LAUNCH(h, "step_end", k_step_end, 1, 1, ds, (const Counters *)dc, h->pin, (const unsigned long long *)h->lab_slots.p);
+    LAUNCH(h, "step_end", k_step_end, 1, 1, ds, dc, h->pin, (const unsigned long long *)h->lab_slots.p, (const Counters *)Q(h).d_qctr.p,
+           (const uint32_t *)Q(h).d_nvox.p);
+    {   // the NEXT scan's query chain goes into its queue now, behind this step's own launches; it runs while we wait
+        const int keep_side = h->qi;
+        const int rc_next = flush_announced(h);
+        h->qi = keep_side;
+        if (rc_next) {
+            (void)hipStreamSynchronize(h->stream);
+            return rc_next;
+        }
+    }
     const auto t_host1 = std::chrono::steady_clock::now();
     HIPC(h, hipStreamSynchronize(h->stream));
     h->st = h->pin->st;
@@ -975,6 +1129,36 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     return ERASOR_OK;
 }
 
+// Announce the NEXT scan: its query chain (voxelisation, label search, bucketing -- everything that does not depend on the
+// map) is enqueued now and runs beside the map-side stages of the step in flight.  The step call that follows must pass the
+// same (pointer, size, T_lidar2body); anything else simply drops the prefetch.
+int erasor_hip_prefetch_scan(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device, const float T_l2b[16]) {
+    if (!h || !T_l2b || (!scan_xyzi && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
+    HIPC(h, hipSetDevice(h->device));
+    int rc = flush_announced(h);  // an earlier announcement nobody stepped on yet: its chain starts now
+    if (rc) return rc;
+    if (h->npend >= 2) {
+        h->err = "erasor_hip_prefetch_scan: two scans are already announced";
+        return ERASOR_E_STATE;
+    }
+    const int side = h->npend ? (h->pend[0] ^ 1) : (h->qi ^ 1);
+    if (n && !src_is_device) {  // a host scan is taken over at once
+        SideGuard guard(h);
+        h->qi = side;
+        rc = alloc_scan(h, (uint32_t)n);
+        if (rc) return rc;
+        if (Q(h).used) HIPC(h, hipEventSynchronize(Q(h).ev_done));  // (a dropped chain may still be reading this side's scan)
+        HIPC(h, hipMemcpy(Q(h).scan.p, scan_xyzi, n * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    h->ann.valid = true;
+    h->ann.is_device = src_is_device != 0;
+    h->ann.src = scan_xyzi;
+    h->ann.n = n;
+    h->ann.side = side;
+    memcpy(h->ann.Tl, T_l2b, sizeof(h->ann.Tl));
+    return ERASOR_OK;
+}
+
 int erasor_hip_step(erasor_hip_handle *h, const float *scan_xyzi, size_t n_scan, const float T_lidar2body[16], const float T_body2origin[16],
                     const float T_origin2body[16], erasor_step_result *res) {
     return step_common(h, scan_xyzi, n_scan, false, T_lidar2body, T_body2origin, T_origin2body, res);
@@ -1038,7 +1222,7 @@ int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap
     HIPC(h, hipStreamSynchronize(h->stream));
     const DevState &s = h->st;
     switch (which) {
-        case ERASOR_CLOUD_QUERY_VOI: return out_cloud(h, h->query.p, h->last_nq, dst, cap, n);
+        case ERASOR_CLOUD_QUERY_VOI: return out_cloud(h, Q(h).query.p, h->last_nq, dst, cap, n);
         case ERASOR_CLOUD_MAP_VOI: return out_cloud(h, h->voi_ego.p, h->last_n_voi, dst, cap, n);
         case ERASOR_CLOUD_MAP_REJECTED: return out_cloud(h, h->rejected.p, s.n_rejected, dst, cap, n);
         case ERASOR_CLOUD_CURR_REJECTED: return out_cloud(h, h->curr_rejected.p, s.n_curr_rejected, dst, cap, n);
@@ -1057,11 +1241,11 @@ int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap
             if (n_voi)
                 LAUNCH(h, "get_cloud", k_assemble_map<false>, std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p,
                        (const uint32_t *)h->rev_idx.p, h->last_skeys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p,
-                       (const uint32_t *)h->moff.p, (const uint32_t *)h->ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p,
+                       (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p,
                        (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p, (const uint32_t *)h->rej_off.p,
                        (const DevState *)h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr);
             LAUNCH(h, "get_cloud", k_assemble_bins<false>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
-                   (const uint32_t *)h->qoff.p, (const float4 *)h->sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
+                   (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
                    (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, tmp, (float4 *)nullptr, (unsigned long long *)nullptr);
             HIPC(h, hipStreamSynchronize(h->stream));
             const size_t off = which == ERASOR_CLOUD_STATIC_ESTIMATE ? 0 : (which == ERASOR_CLOUD_COMPLEMENT ? s.n_static_est : s.total_bins);
@@ -1093,9 +1277,9 @@ int erasor_hip_get_bins(erasor_hip_handle *h, int which, uint32_t *count, double
     const uint32_t B = h->B, R = h->P.num_rings, S = h->P.num_sectors;
     std::vector<uint32_t> c(B);
     std::vector<float> mn(B), mx(B);
-    HIPC(h, hipMemcpy(c.data(), which ? h->ccnt.p : h->mcnt.p, B * 4, hipMemcpyDeviceToHost));
-    HIPC(h, hipMemcpy(mn.data(), which ? h->cmin.p : h->mmin.p, B * 4, hipMemcpyDeviceToHost));
-    HIPC(h, hipMemcpy(mx.data(), which ? h->cmax.p : h->mmax.p, B * 4, hipMemcpyDeviceToHost));
+    HIPC(h, hipMemcpy(c.data(), which ? Q(h).ccnt.p : h->mcnt.p, B * 4, hipMemcpyDeviceToHost));
+    HIPC(h, hipMemcpy(mn.data(), which ? Q(h).cmin.p : h->mmin.p, B * 4, hipMemcpyDeviceToHost));
+    HIPC(h, hipMemcpy(mx.data(), which ? Q(h).cmax.p : h->mmax.p, B * 4, hipMemcpyDeviceToHost));
     for (uint32_t key = 0; key < B; ++key) {  // device key = sector*R + ring -> API index = ring*S + sector
         const uint32_t ring = key % R, sector = key / R;
         const uint32_t o = ring * S + sector;
@@ -1139,38 +1323,39 @@ int erasor_hip_get_planes(erasor_hip_handle *h, uint32_t *bin_index, float *norm
     return ERASOR_OK;
 }
 
-// erasor_utils::voxelize_preserving_labels (utils.cpp:80-114) of a DEVICE cloud; the result is h->query[0..*nq_out).
+// erasor_utils::voxelize_preserving_labels (utils.cpp:80-114) of a DEVICE cloud; the result is Q(h).query[0..*nq_out).
 // d_src may be any device buffer except the scan-side scratch itself.
 static int voxelize_device(erasor_hip_handle *h, const float4 *d_src, uint32_t ns, double leaf_size, uint32_t *nq_out) {
+    q_drain(h);
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
-    h->scan_in = d_src;
-    LAUNCH(h, "step_begin", k_step_begin, 1, 256, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p, (uint32_t *)nullptr, 0u, (unsigned long long *)nullptr);
+    Q(h).scan_in = d_src;
+    LAUNCH(h, "q_begin", k_query_begin, 1, 256, Q(h).d_qctr.p, Q(h).bb.p, (uint32_t *)nullptr, 0u, Q(h).d_nvox.p, 0u);
     voxelize_query_part1(h, ns, (float)leaf_size, [] {});
-    DevState st;
+    uint32_t nvox_host = 0;
     VoxGrid g;
-    HIPC(h, hipMemcpyAsync(&st, h->d_st.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
-    HIPC(h, hipMemcpyAsync(&g, h->qgrid.p, sizeof(g), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipMemcpyAsync(&nvox_host, Q(h).d_nvox.p, sizeof(nvox_host), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipMemcpyAsync(&g, Q(h).qgrid.p, sizeof(g), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     if (ns && g.overflow) {
         h->err = "VoxelGrid index overflow (reference returns the input unvoxelised): not supported on device";
         return ERASOR_E_UNSUPPORTED;
     }
-    const uint32_t nq = st.q_nvox;
+    const uint32_t nq = nvox_host;
     *nq_out = nq;
     if (nq) {
         // identity lidar->body; the R-POD key output is ignored
         const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
         // x*1 + y*0 + z*0 + 0 reproduces x exactly (0*finite = 0, x+0 = x; -0.0 would become +0.0, irrelevant for a centroid)
-        LAUNCH(h, "q_centroids", k_centroids, cdiv((uint64_t)nq * 8, 256), 256, h->scan_in, (const uint32_t *)h->qk_b.p, (const uint32_t *)h->qv_b.p,
-               (const uint32_t *)h->run_begin.p, (const uint32_t *)&h->d_st.p->q_nvox, h->cent.p, h->ukeys.p, h->hkey.p, h->hval.p, h->hbits);
-        LAUNCH(h, "q_nn", k_query_nn, cdiv((uint64_t)nq * NN_SUB, 256), 256, h->scan_in, (const uint32_t *)h->qv_b.p, (const uint32_t *)h->run_begin.p,
-               (const uint32_t *)h->ukeys.p, (const float4 *)h->cent.p, (const uint32_t *)&h->d_st.p->q_nvox, (const VoxGrid *)h->qgrid.p, to_xf(I),
-               h->dp, h->d_ctr.p, h->query.p, h->qkey.p, (const uint32_t *)h->hkey.p, (const uint32_t *)h->hval.p, h->hbits);
+        LAUNCH(h, "q_centroids", k_centroids, cdiv((uint64_t)nq * 8, 256), 256, Q(h).scan_in, (const uint32_t *)Q(h).qk_b.p, (const uint32_t *)Q(h).qv_b.p,
+               (const uint32_t *)Q(h).run_begin.p, (const uint32_t *)Q(h).d_nvox.p, Q(h).cent.p, Q(h).ukeys.p, Q(h).hkey.p, Q(h).hval.p, Q(h).hbits);
+        LAUNCH(h, "q_nn", k_query_nn, cdiv((uint64_t)nq * NN_SUB, 256), 256, Q(h).scan_in, (const uint32_t *)Q(h).qv_b.p, (const uint32_t *)Q(h).run_begin.p,
+               (const uint32_t *)Q(h).ukeys.p, (const float4 *)Q(h).cent.p, (const uint32_t *)Q(h).d_nvox.p, (const VoxGrid *)Q(h).qgrid.p, to_xf(I),
+               h->dp, Q(h).d_qctr.p, Q(h).query.p, Q(h).qkey.p, (const uint32_t *)Q(h).hkey.p, (const uint32_t *)Q(h).hval.p, Q(h).hbits);
         HIPC(h, hipStreamSynchronize(h->stream));
     }
     Counters c;
-    HIPC(h, hipMemcpy(&c, h->d_ctr.p, sizeof(c), hipMemcpyDeviceToHost));
+    HIPC(h, hipMemcpy(&c, Q(h).d_qctr.p, sizeof(c), hipMemcpyDeviceToHost));
     if (c.sort_qoverflow) {
         h->err = "exact-sort segment queue overflow (site " + std::to_string(c.sort_qoverflow) + ")";
         return ERASOR_E_INTERNAL;
@@ -1184,16 +1369,17 @@ int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src
     HIPC(h, hipSetDevice(h->device));
     prof_collect(h);
     const uint32_t ns = (uint32_t)n;
+    q_drain(h);
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
-    if (ns) HIPC(h, hipMemcpyAsync(h->scan.p, src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    if (ns) HIPC(h, hipMemcpyAsync(Q(h).scan.p, src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     uint32_t nq = 0;
-    rc = voxelize_device(h, (const float4 *)h->scan.p, ns, leaf_size, &nq);
+    rc = voxelize_device(h, (const float4 *)Q(h).scan.p, ns, leaf_size, &nq);
     if (rc) return rc;
     if (n_out) *n_out = nq;
     if (!dst) return ERASOR_OK;
     if (nq > cap) return ERASOR_E_CAPACITY;
-    if (nq) HIPC(h, hipMemcpy(dst, h->query.p, (size_t)nq * sizeof(float4), hipMemcpyDeviceToHost));
+    if (nq) HIPC(h, hipMemcpy(dst, Q(h).query.p, (size_t)nq * sizeof(float4), hipMemcpyDeviceToHost));
     return ERASOR_OK;
 }
 
@@ -1240,18 +1426,19 @@ int erasor_hip_mapgen_accum(erasor_hip_handle *h, const float *scan_xyzi, size_t
     HIPC(h, hipSetDevice(h->device));
     prof_collect(h);
     const uint32_t ns = (uint32_t)n;
+    q_drain(h);
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
     if (ensure(h, h->mg_tmp, (size_t)ns + 8)) return ERASOR_E_NO_DEVICE;
     static const float L2O[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1.73f, 0, 0, 0, 1};  // mapgen.hpp:212-215
     uint32_t n_kept = 0;
     if (ns) {
-        HIPC(h, hipMemcpyAsync(h->scan.p, scan_xyzi, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+        HIPC(h, hipMemcpyAsync(Q(h).scan.p, scan_xyzi, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, h->stream));
         const float max_dist_square = (float)pow(2.7, 2);  // CAR_BODY_SIZE, mapgen.hpp:8,221
-        LAUNCH(h, "mapgen", k_mapgen_flag, cdiv(ns, 256), 256, (const float4 *)h->scan.p, ns, max_dist_square, h->qflag.p);
-        scan_u32(h, h->qflag.p, h->qpl.p, h->qtops.p, ns, ns, nullptr, h->dn.p, "mapgen");
-        LAUNCH(h, "mapgen", k_mapgen_scatter, cdiv(ns, 256), 256, (const float4 *)h->scan.p, ns, (const uint32_t *)h->qflag.p,
-               (const uint32_t *)h->qpl.p, (const uint32_t *)h->qtops.p, to_xf(T_lidar2origin ? T_lidar2origin : L2O), to_xf(T_pose), h->mg_tmp.p);
+        LAUNCH(h, "mapgen", k_mapgen_flag, cdiv(ns, 256), 256, (const float4 *)Q(h).scan.p, ns, max_dist_square, Q(h).qflag.p);
+        scan_u32(h, Q(h).qflag.p, Q(h).qpl.p, Q(h).qtops.p, ns, ns, nullptr, h->dn.p, "mapgen");
+        LAUNCH(h, "mapgen", k_mapgen_scatter, cdiv(ns, 256), 256, (const float4 *)Q(h).scan.p, ns, (const uint32_t *)Q(h).qflag.p,
+               (const uint32_t *)Q(h).qpl.p, (const uint32_t *)Q(h).qtops.p, to_xf(T_lidar2origin ? T_lidar2origin : L2O), to_xf(T_pose), h->mg_tmp.p);
         HIPC(h, hipMemcpyAsync(&n_kept, h->dn.p, 4, hipMemcpyDeviceToHost, h->stream));
         HIPC(h, hipStreamSynchronize(h->stream));
     }
@@ -1259,22 +1446,22 @@ int erasor_hip_mapgen_accum(erasor_hip_handle *h, const float *scan_xyzi, size_t
     rc = voxelize_device(h, (const float4 *)h->mg_tmp.p, n_kept, 0.2, &nq);  // cloud_curr (mapgen.hpp:239: fixed 0.2 m leaf)
     if (rc) return rc;
     h->mg_ncurr = 0;
-    rc = mg_append(h, h->mg_curr, h->mg_ncurr, (const float4 *)h->query.p, nq);
+    rc = mg_append(h, h->mg_curr, h->mg_ncurr, (const float4 *)Q(h).query.p, nq);
     if (rc) return rc;
     if (h->mg_initial) {  // :241-243
         h->mg_nmap = 0;
-        rc = mg_append(h, h->mg_map, h->mg_nmap, (const float4 *)h->query.p, nq);
+        rc = mg_append(h, h->mg_map, h->mg_nmap, (const float4 *)Q(h).query.p, nq);
         if (rc) return rc;
         h->mg_initial = false;
     } else {  // :244-256
-        rc = mg_append(h, h->mg_map, h->mg_nmap, (const float4 *)h->query.p, nq);
+        rc = mg_append(h, h->mg_map, h->mg_nmap, (const float4 *)Q(h).query.p, nq);
         if (rc) return rc;
         if (h->mg_large && (h->mg_cnt_voxel++ % 500 == 0)) {
             HIPC(h, hipStreamSynchronize(h->stream));
             uint32_t nv = 0;
             rc = voxelize_device(h, (const float4 *)h->mg_map.p, (uint32_t)h->mg_nmap, h->mg_leaf, &nv);
             if (rc) return rc;
-            rc = mg_append(h, h->mg_done, h->mg_ndone, (const float4 *)h->query.p, nv);  // cloud_maps.push_back
+            rc = mg_append(h, h->mg_done, h->mg_ndone, (const float4 *)Q(h).query.p, nv);  // cloud_maps.push_back
             if (rc) return rc;
             h->mg_nmap = 0;  // cloud_map.clear()
         }
@@ -1323,7 +1510,7 @@ int erasor_hip_mapgen_save(erasor_hip_handle *h, float *dst, size_t cap, size_t 
         if (n_out) *n_out = nq;
         if (dst) {
             if (nq > cap) rc = ERASOR_E_CAPACITY;
-            else if (nq && hipMemcpy(dst, h->query.p, (size_t)nq * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) rc = ERASOR_E_NO_DEVICE;
+            else if (nq && hipMemcpy(dst, Q(h).query.p, (size_t)nq * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) rc = ERASOR_E_NO_DEVICE;
         }
     }
     (void)hipStreamSynchronize(h->stream);
@@ -1398,14 +1585,15 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
     if (!h || (!keys && n) || (!vals && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
     const uint32_t ns = (uint32_t)n;
+    q_drain(h);
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
-    LAUNCH(h, "step_begin", k_step_begin, 1, 256, h->d_st.p, h->d_ctr.p, 0u, DevState{}, 0, h->bb.p, (uint32_t *)nullptr, 0u, (unsigned long long *)nullptr);
+    LAUNCH(h, "q_begin", k_query_begin, 1, 256, Q(h).d_qctr.p, Q(h).bb.p, (uint32_t *)nullptr, 0u, Q(h).d_nvox.p, 0u);
     if (ns) {
-        HIPC(h, hipMemcpyAsync(h->qk_a.p, keys, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
-        HIPC(h, hipMemcpyAsync(h->qv_a.p, vals, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
+        HIPC(h, hipMemcpyAsync(Q(h).qk_a.p, keys, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
+        HIPC(h, hipMemcpyAsync(Q(h).qv_a.p, vals, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
     }
-    Counters *dc = h->d_ctr.p;
+    Counters *dc = Q(h).d_qctr.p;
     run_exact_sort(h, ns);
     HIPC(h, hipStreamSynchronize(h->stream));
     Counters c;
@@ -1427,8 +1615,8 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
         (void)hipMemcpy(h->dbg_stamps.p, t, sizeof(t), hipMemcpyHostToDevice);
     }
     if (ns) {
-        HIPC(h, hipMemcpy(keys, h->qk_b.p, (size_t)ns * 4, hipMemcpyDeviceToHost));
-        HIPC(h, hipMemcpy(vals, h->qv_b.p, (size_t)ns * 4, hipMemcpyDeviceToHost));
+        HIPC(h, hipMemcpy(keys, Q(h).qk_b.p, (size_t)ns * 4, hipMemcpyDeviceToHost));
+        HIPC(h, hipMemcpy(vals, Q(h).qv_b.p, (size_t)ns * 4, hipMemcpyDeviceToHost));
     }
     return ERASOR_OK;
 }
@@ -1454,11 +1642,12 @@ int erasor_hip_radix_sort_u32(erasor_hip_handle *h, const uint32_t *keys, size_t
     if (!h || (!keys && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
     const uint32_t ns = (uint32_t)n;
+    q_drain(h);
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
-    if (ns) HIPC(h, hipMemcpyAsync(h->qkey.p, keys, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
+    if (ns) HIPC(h, hipMemcpyAsync(Q(h).qkey.p, keys, (size_t)ns * 4, hipMemcpyHostToDevice, h->stream));
     const uint32_t *sk = nullptr, *sp = nullptr;
-    rc = radix_sort(h, h->qkey.p, ns, nullptr, bits, h->qk_a.p, h->qposL.p, h->qv_a.p, h->qposR.p, &sk, &sp, "radix_test");
+    rc = radix_sort(h, Q(h).qkey.p, ns, nullptr, bits, Q(h).qk_a.p, Q(h).qposL.p, Q(h).qv_a.p, Q(h).qposR.p, &sk, &sp, "radix_test");
     if (rc) return rc;
     HIPC(h, hipStreamSynchronize(h->stream));
     if (ns) {

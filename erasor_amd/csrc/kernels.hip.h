@@ -294,9 +294,9 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
                                                      const uint32_t *__restrict__ cinfo, const uint32_t *__restrict__ pvl,
                                                      const uint32_t *__restrict__ phl, const uint32_t *__restrict__ topv,
                                                      const uint32_t *__restrict__ toph, Xf To2b, DP P, DevState *st,
-                                                     Counters *ctr, float4 *__restrict__ voi_ego, uint32_t *__restrict__ voi_key,
-                                                     uint32_t *__restrict__ voi_src) {
-    if (ctr->err) return;  // an earlier stage of this step failed: do not touch the map store
+                                                     Counters *ctr, const Counters *qctr, float4 *__restrict__ voi_ego,
+                                                     uint32_t *__restrict__ voi_key, uint32_t *__restrict__ voi_src) {
+    if (ctr->err || qctr->err) return;  // the voxelisation of this step's scan failed: do not touch the map store
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -2282,26 +2282,32 @@ struct HostOut {
     Counters ctr;
 };
 
-// `init` != nullptr semantics are by value: when use_init is set the whole device state is replaced by the host's mirror
-// (nF / o_begin may have been changed by host-side map maintenance); bb != nullptr also resets the query bounding box.
-__global__ void k_step_begin(DevState *st, Counters *ctr, uint32_t q_nvox_init, DevState init, int use_init, uint32_t *bb, uint32_t *qb_tot,
-                             uint32_t qb_n, unsigned long long *lab_slots) {
-    if (lab_slots && threadIdx.x < 128) lab_slots[threadIdx.x] = 0;
+// start of a scan's query chain (its own stream): counters, bounding box, bucket totals, voxel count of this query side
+__global__ void k_query_begin(Counters *qctr, uint32_t *bb, uint32_t *qb_tot, uint32_t qb_n, uint32_t *nvox, uint32_t nvox_init) {
     for (uint32_t b = threadIdx.x; b < qb_n; b += blockDim.x) qb_tot[b] = 0;  // bucket totals of the query counting sort
     if (threadIdx.x == 0) {
-        if (use_init) *st = init;
-        st->q_nvox = q_nvox_init;
+        qctr->n_neg_sector = qctr->n_ambiguous = qctr->n_degenerate = qctr->n_voxel_overflow = qctr->n_sort_fallback = 0;
+        qctr->sort_qoverflow = qctr->err = 0;
+        *nvox = nvox_init;  // (pre-voxelised input: the count is known; otherwise k_run_begin writes it)
+    }
+    if (threadIdx.x < 3) bb[threadIdx.x] = 0xFFFFFFFFu;
+    if (threadIdx.x >= 3 && threadIdx.x < 6) bb[threadIdx.x] = 0u;
+}
+// start of a step on the main stream: the host's mirror of the device state replaces it (nF / o_begin may have been
+// changed by host-side map maintenance); map-side counters and label tallies are cleared
+__global__ void k_step_begin(DevState *st, Counters *ctr, DevState init, unsigned long long *lab_slots) {
+    if (lab_slots && threadIdx.x < 128) lab_slots[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        *st = init;
         ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
         ctr->sort_qoverflow = ctr->err = 0;
         st->F_static = st->F_dynamic = 0;
         st->n_rev = 0;
     }
-    if (bb) {
-        if (threadIdx.x < 3) bb[threadIdx.x] = 0xFFFFFFFFu;
-        if (threadIdx.x >= 3 && threadIdx.x < 6) bb[threadIdx.x] = 0u;
-    }
 }
-__global__ void k_step_end(DevState *st, const Counters *ctr, HostOut *out, const unsigned long long *lab_slots) {
+// end of a step: fold in the query side's counters and voxel count, commit the map sizes, report to the pinned host block
+__global__ void k_step_end(DevState *st, Counters *ctr, HostOut *out, const unsigned long long *lab_slots, const Counters *qctr,
+                           const uint32_t *q_nvox) {
     if (lab_slots) {
         unsigned long long ns = 0, nd = 0;
         for (int i = 0; i < 16; ++i) {
@@ -2311,6 +2317,14 @@ __global__ void k_step_end(DevState *st, const Counters *ctr, HostOut *out, cons
         st->F_static = ns;
         st->F_dynamic = nd;
     }
+    ctr->n_neg_sector += qctr->n_neg_sector;
+    ctr->n_ambiguous += qctr->n_ambiguous;
+    ctr->n_degenerate += qctr->n_degenerate;
+    ctr->n_voxel_overflow += qctr->n_voxel_overflow;
+    ctr->n_sort_fallback += qctr->n_sort_fallback;
+    if (qctr->sort_qoverflow) ctr->sort_qoverflow = qctr->sort_qoverflow;
+    if (qctr->err) ctr->err = qctr->err;
+    st->q_nvox = *q_nvox;
     if (!(ctr->err || ctr->sort_qoverflow)) {
         st->nF = st->nF_new;
         st->o_begin = st->o_new_begin;

@@ -128,6 +128,19 @@ const char *erasor_hip_last_error(const erasor_hip_handle *h);
 int erasor_hip_set_map(erasor_hip_handle *h, const float *xyzi, size_t n);
 int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n);
 
+/* Look-ahead for offline sequences (the reference receives all nodes of a bag anyway, OMU.cpp:203): announce the scan
+ * of the NEXT callback_node.  Its voxelisation (OMU.cpp:238-241: voxelize_preserving_labels, lidar->body) and R-POD
+ * binning (erasor.cpp:100-115) do not depend on the map, so they run on their own stream beside the map-side stages
+ * of the step in flight.  Results are unchanged; only the throughput of a scan sequence rises.
+ *   erasor_hip_prefetch_scan(h, scan[0]);
+ *   for k: erasor_hip_prefetch_scan(h, scan[k+1]);  erasor_hip_step*(h, scan[k], ...);
+ * The following step must pass the same pointer, size and T_lidar2body (otherwise the prefetch is dropped).  A host
+ * scan is copied at once; a device scan (src_is_device != 0) is read in place and must stay valid until the step that
+ * consumes it has returned.  At most two scans can be announced ahead.  After a prefetch, the query-derived outputs
+ * of the step BEFORE the one in flight (erasor_hip_get_cloud / _get_bins of older steps) are no longer available. */
+int erasor_hip_prefetch_scan(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device,
+                             const float T_lidar2body[16]);
+
 /* replaces: the body of callback_node between OMU.cpp:237 and OMU.cpp:294:
  *   voxelize_preserving_labels(query) + transformPointCloud(tf_lidar2body_)   (OMU.cpp:238-241)
  *   fetch_VoI                                                                  (OMU.cpp:254, 381-438)

@@ -422,3 +422,37 @@ def test_mapgen_accumulation_matches_oracle(gpu_mod, large):
     same(g.mapgen_save(), o.save(), "saved (voxelised) map")
     if large:
         assert len(o.cloud_maps) == 1  # the first accumulated scan closes a submap (cnt_voxel == 0)
+
+
+@pytest.mark.parametrize("version", [3, 2])
+def test_prefetched_scans_give_the_same_results(gpu_mod, version):
+    """erasor_hip_prefetch_scan: the query chain of scan k+1 runs beside step k's map-side stages (second query side).
+    Every output of every step must be what the oracle's plain sequence gives; a prefetch that is not followed by
+    its scan is dropped; standalone calls in between do not disturb the sequence."""
+    sc = scenarios.small(version=version)
+    g, o = make_pair(gpu_mod, sc["params"])
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    n = 8
+    scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"][:n]]
+    held = g.prefetch(scans[0], sc["T_l2b"])
+    for k in range(n):
+        nxt = g.prefetch(scans[k + 1], sc["T_l2b"]) if k + 1 < n else None
+        rg = g.step(held, sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        ro = o.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        compare_step(g, o, rg, ro, full=True)
+        held = nxt
+    # a prefetch that is not honoured: the announced scan is dropped, the step's own scan is processed
+    g.prefetch(scans[0], sc["T_l2b"])
+    k = n
+    rg = g.step(np.ascontiguousarray(sc["scans"][k], np.float32), sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+    ro = o.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+    compare_step(g, o, rg, ro, full=True)
+    # a standalone voxelisation while a prefetch is pending: pending chain dropped, both calls still right
+    from oracle import orc
+    k = n + 1
+    held = g.prefetch(np.ascontiguousarray(sc["scans"][k], np.float32), sc["T_l2b"])
+    same(g.voxelize_preserving_labels(sc["scans"][0], 0.3), orc.voxelize_preserving_labels(sc["scans"][0], 0.3), "standalone voxelisation")
+    rg = g.step(held, sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+    ro = o.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+    compare_step(g, o, rg, ro, full=True)
