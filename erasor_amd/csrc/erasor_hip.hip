@@ -99,6 +99,7 @@ struct erasor_hip_handle {
     double mg_leaf = 0.05;
     bool mg_large = false, mg_initial = true, mg_active = false;
     uint64_t mg_cnt_voxel = 0, mg_accum = 0;
+    DBuf<uint32_t> mb_hist, mb_tot;   // the map's bucketing as a counting sort: [tiles][B + 1] table, [B + 1] totals
     DBuf<unsigned long long> lab_slots;  // [16][8] label tallies of the assemble kernels (one cache line per slot)
     HostOut *pin = nullptr;         // pinned host block k_step_end reports into
     bool forked = false;            // ev_join has been recorded at least once
@@ -347,7 +348,7 @@ int alloc_bins(erasor_hip_handle *h) {
     rc |= ensure(h, h->vox_off, B) | ensure(h, h->nvox, B) | ensure(h, h->ng, B) | ensure(h, h->out_off, B) | ensure(h, h->ground_off, B);
     rc |= ensure(h, h->rej_off, B) | ensure(h, h->crej_off, B);
     rc |= ensure(h, h->plane_n, B * (size_t)std::max(h->P.gf_iter, 1) * 3) | ensure(h, h->plane_d, B * (size_t)std::max(h->P.gf_iter, 1));
-    rc |= ensure(h, h->d_st, 1) | ensure(h, h->d_ctr, 1) | ensure(h, h->dn, 16) | ensure(h, h->lab_slots, 128);
+    rc |= ensure(h, h->d_st, 1) | ensure(h, h->d_ctr, 1) | ensure(h, h->dn, 16) | ensure(h, h->lab_slots, 128) | ensure(h, h->mb_tot, B + 2);
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
 
@@ -636,7 +637,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->vmask); release(h->hmask); release(h->cinfo); release(h->pvl); release(h->phl); release(h->topv); release(h->toph);
     release(h->voi_ego); release(h->spts); release(h->rejected); release(h->voi_key); release(h->voi_src); release(h->ssrc);
     release(h->rejected_src); release(h->grank); release(h->glist); release(h->gflag);
-    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->lab_slots); release(h->mg_curr); release(h->mg_map); release(h->mg_done); release(h->mg_tmp);
+    release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->lab_slots); release(h->mb_hist); release(h->mb_tot); release(h->mg_curr); release(h->mg_map); release(h->mg_done); release(h->mg_tmp);
     release(h->moff); release(h->mcnt); release(h->rev_idx); release(h->rev_list); release(h->vox_off);
     release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
     release(h->mmin); release(h->mmax); release(h->plane_n); release(h->plane_d);
@@ -944,7 +945,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_step_begin
     h->st.o_begin = h->o_begin;
     if (h->forked) (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);  // a previous step that bailed out between fork and join
-    LAUNCH(h, "step_begin", k_step_begin, 1, 256, ds, dc, h->st, h->lab_slots.p);
+    const bool mb_count = B + 1 <= QB_NB_MAX;  // the map's bucketing as a one-digit counting sort (else: LSD radix passes)
+    LAUNCH(h, "step_begin", k_step_begin, 1, 256, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u);
 
     MARK("prologue");
     // ---- sizes, scratch ----
@@ -964,7 +966,9 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     rc = alloc_step(h, n_voi, nq);
     if (rc) return rc;
     const int bits = key_bits(B + 1);
-    {   // the map chain's scratch bank of the bucket sort
+    if (B + 1 <= QB_NB_MAX) {  // [tiles][B + 1] table of the map's counting sort
+        if (ensure(h, h->mb_hist, (size_t)(B + 1) * std::max(1u, cdiv(n_voi, QB_TILE)) + 8)) return ERASOR_E_NO_DEVICE;
+    } else {  // the map chain's scratch bank of the radix bucket sort
         const uint32_t nb_m = 256u * std::max(1u, cdiv(n_voi, RTILE));
         if (ensure(h, h->hist2, nb_m) || ensure(h, h->hist2_l, nb_m) || ensure(h, h->hist2_t, cdiv(nb_m, 1024) + 2)) return ERASOR_E_NO_DEVICE;
     }
@@ -998,10 +1002,20 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
                    (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p, (const uint32_t *)h->topv.p, (const uint32_t *)h->toph.p, h->To2b, P, ds,
                    dc, (const Counters *)Q(h).d_qctr.p, h->voi_ego.p, h->voi_key.p, h->voi_src.p);
         }
-        radix_sort(h, h->voi_key.p, n_voi, nvoi_dev, bits, h->rk_a.p, h->rk_b.p, h->rv_a.p, h->rv_b.p, &sm_keys, &sm_perm, "voi_bucket");
-        if (n_voi) LAUNCH(h, "voi_bucket", k_gather, cdiv(n_voi, 256), 256, (const float4 *)h->voi_ego.p, (const uint32_t *)h->voi_src.p, sm_perm,
-                          n_voi, nvoi_dev, h->spts.p, h->ssrc.p);
-        LAUNCH(h, "voi_bucket", k_bin_offsets, cdiv((uint64_t)std::max(n_voi, B + 2) + 1, 256), 256, sm_keys, n_voi, nvoi_dev, B + 1, h->moff.p);
+        if (mb_count) {
+            const uint32_t ntile_ub = std::max(1u, cdiv(n_voi, QB_TILE));
+            LAUNCH(h, "voi_bucket", k_qb_hist, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, n_voi, nvoi_dev, B + 1, h->mb_hist.p, h->mb_tot.p);
+            LAUNCH(h, "voi_bucket", k_qb_scan, 1, 1024, (const uint32_t *)h->mb_tot.p, B + 1, h->moff.p);
+            LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv((uint64_t)(B + 1) * 64, 256), 256, h->mb_hist.p, n_voi, nvoi_dev, B + 1, (const uint32_t *)h->moff.p);
+            LAUNCH(h, "voi_bucket", k_mb_scatter, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
+                   (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, B + 1, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p);
+            sm_keys = h->rk_a.p;
+        } else {
+            radix_sort(h, h->voi_key.p, n_voi, nvoi_dev, bits, h->rk_a.p, h->rk_b.p, h->rv_a.p, h->rv_b.p, &sm_keys, &sm_perm, "voi_bucket");
+            if (n_voi) LAUNCH(h, "voi_bucket", k_gather, cdiv(n_voi, 256), 256, (const float4 *)h->voi_ego.p, (const uint32_t *)h->voi_src.p, sm_perm,
+                              n_voi, nvoi_dev, h->spts.p, h->ssrc.p);
+            LAUNCH(h, "voi_bucket", k_bin_offsets, cdiv((uint64_t)std::max(n_voi, B + 2) + 1, 256), 256, sm_keys, n_voi, nvoi_dev, B + 1, h->moff.p);
+        }
         LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->spts.p, (const uint32_t *)h->moff.p, B, h->mcnt.p,
                h->mmin.p, h->mmax.p);
         (void)hipEventRecord(h->ev_join, h->stream2);

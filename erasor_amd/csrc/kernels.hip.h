@@ -694,6 +694,67 @@ __global__ __launch_bounds__(1024) void k_qb_scatter(const uint32_t *__restrict_
     if (valid) dst[pre + r] = src[i];
 }
 
+// ---- the same one-digit counting sort for the (much longer) VoI list of the map: the per-tile prefix of a bucket
+// is made a table look-up by a column scan (one wavefront per bucket over the tiles), and the scatter carries the
+// point, its pre-step source index and the key along (k_gather folded in)
+__global__ __launch_bounds__(256) void k_mb_colscan(uint32_t *__restrict__ hist /* [tile][nb] -> start of (bucket, tile) */, uint32_t n_host,
+                                                     const uint32_t *n_dev, uint32_t nb, const uint32_t *__restrict__ off) {
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (b >= nb) return;
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t ntile = (n + QB_TILE - 1) / QB_TILE;
+    uint32_t run = off[b];
+    for (uint32_t t0 = 0; t0 < ntile; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        const uint32_t c = t < ntile ? hist[(size_t)t * nb + b] : 0u;
+        uint32_t inc = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += v;
+        }
+        if (t < ntile) hist[(size_t)t * nb + b] = run + inc - c;
+        run += __shfl(inc, 63, 64);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_mb_scatter(const uint32_t *__restrict__ keys, const float4 *__restrict__ src,
+                                                      const uint32_t *__restrict__ src_aux, uint32_t n_host, const uint32_t *n_dev, uint32_t nb,
+                                                      int bits, const uint32_t *__restrict__ base /* scanned hist */, float4 *__restrict__ dst,
+                                                      uint32_t *__restrict__ dst_aux, uint32_t *__restrict__ dst_keys) {
+    __shared__ uint32_t cnt[QB_NB_MAX];
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t ntile = (n + QB_TILE - 1) / QB_TILE;
+    if (blockIdx.x >= ntile) return;
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * QB_TILE + threadIdx.x;
+    const bool valid = i < n;
+    const uint32_t k = valid ? min(keys[i], nb - 1) : 0u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t pre = valid ? base[(size_t)blockIdx.x * nb + k] : 0u;
+    uint64_t peers = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+        const bool bit = (k >> b) & 1u;
+        const uint64_t m = __ballot(valid && bit);
+        peers &= bit ? m : ~m;
+    }
+    const uint64_t lt = lanemask_lt();
+    uint32_t r = 0;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {  // waves take their turn in index order
+        if (wave == w && valid) {
+            r = cnt[k] + (uint32_t)__popcll(peers & lt);
+            esort::wave_sync();
+            if ((peers >> (threadIdx.x & 63u)) >> 1 == 0) cnt[k] += (uint32_t)__popcll(peers);  // highest lane of the group
+        }
+        __syncthreads();
+    }
+    if (valid) {
+        dst[pre + r] = src[i];
+        dst_aux[pre + r] = src_aux[i];
+        dst_keys[pre + r] = k;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_bin_offsets(const uint32_t *__restrict__ skeys, uint32_t n_host, const uint32_t *n_dev,
                                                       uint32_t nbuckets, uint32_t *__restrict__ off) {
     const uint32_t n = n_dev ? *n_dev : n_host;
@@ -2295,8 +2356,9 @@ __global__ void k_query_begin(Counters *qctr, uint32_t *bb, uint32_t *qb_tot, ui
 }
 // start of a step on the main stream: the host's mirror of the device state replaces it (nF / o_begin may have been
 // changed by host-side map maintenance); map-side counters and label tallies are cleared
-__global__ void k_step_begin(DevState *st, Counters *ctr, DevState init, unsigned long long *lab_slots) {
+__global__ void k_step_begin(DevState *st, Counters *ctr, DevState init, unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n) {
     if (lab_slots && threadIdx.x < 128) lab_slots[threadIdx.x] = 0;
+    for (uint32_t b = threadIdx.x; b < mb_n; b += blockDim.x) mb_tot[b] = 0;  // bucket totals of the map's counting sort
     if (threadIdx.x == 0) {
         *st = init;
         ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
