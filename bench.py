@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--profile-all", action="store_true", help="second pass with per-kernel HIP events (breakdown on stderr)")
+    ap.add_argument("--lookahead", type=int, default=2, choices=[1, 2], help="scans announced ahead (erasor_hip_prefetch_scan)")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not announce the next scan (erasor_hip_prefetch_scan): every step runs its own query chain first")
     args = ap.parse_args()
@@ -74,7 +75,7 @@ def main():
     world, lidar = build_workload(args, rank)
     P = make_params(args)
     K, W = args.steps, args.warmup
-    n_frames = K + W + 1  # one scan beyond the timed ones: the last timed step announces it like every other step
+    n_frames = K + W + 2  # scans beyond the timed ones: the last timed steps announce them like every other step
 
     # ---- the global map: rank 0 samples it, RCCL broadcast over xGMI to every replica ----
     t0 = time.time()
@@ -107,16 +108,18 @@ def main():
     g.set_map_device(d_map.data_ptr(), N_map)
 
     lookahead = not args.no_lookahead
+    LA = args.lookahead  # scans announced ahead of the one being stepped
 
     def run(k):
         # offline sequence processing: scan k+1 is announced before step k, so that its voxelisation / binning (which do
         # not depend on the map) overlap step k's map-side stages; step k returns with ITS results on the host as before
-        if lookahead and k + 1 < n_frames:
-            g.prefetch_device(d_scans[k + 1].data_ptr(), len(scans[k + 1]), Tl)
+        if lookahead and k + LA < n_frames:
+            g.prefetch_device(d_scans[k + LA].data_ptr(), len(scans[k + LA]), Tl)
         return g.step_device(d_scans[k].data_ptr(), len(scans[k]), Tl, Tb[k], To[k])
 
     if lookahead:
-        g.prefetch_device(d_scans[0].data_ptr(), len(scans[0]), Tl)
+        for j in range(LA):
+            g.prefetch_device(d_scans[j].data_ptr(), len(scans[j]), Tl)
     for k in range(W):
         run(k)
     g.profile_reset()
@@ -231,7 +234,7 @@ def main():
         "config": {"workload": "KITTI-05-shaped synthetic street, %d-pt map resident in HBM, ~%d-pt HDL-64-like scans, R-POD 20 rings x 108 sectors @ 80 m, "
                                "seq_05.yaml thresholds, ERASOR v3; one scan per step, 1 m/frame" % (N_map, n_scan),
                    "map_points": N_map, "scan_points": n_scan, "rings": 20, "sectors": 108, "sharding": "scan-parallel replicas, RCCL broadcast of the map",
-                   "lookahead_scans": 1 if lookahead else 0},
+                   "lookahead_scans": LA if lookahead else 0},
         "map_points_x_scans_per_sec": round(value * N_map, 1),
         "ms_per_step_without_lookahead": None if sync_ms is None else round(sync_ms, 4),
         "roofline": roofline, "cpu_baseline": cpu,

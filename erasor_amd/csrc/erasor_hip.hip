@@ -44,6 +44,7 @@ struct DBuf {
 }  // namespace
 
 // The query side of a step (see erasor_hip_handle::q)
+static constexpr int NSIDE = 3;  // the scan being stepped + two announced ahead
 struct QSide {
     uint32_t capS = 0;
     DBuf<float4> scan, cent, query, sq;
@@ -79,8 +80,11 @@ struct erasor_hip_handle {
     DP dp;
     int device = 0;
     hipStream_t stream = nullptr;   // main stream: step begin, SRT .. write-back
+    // query chains alternate between two streams, so that two consecutive scans' chains overlap.  Four streams in all: the
+    // runtime multiplexes streams onto 4 hardware queues by default, a fifth would share one and serialise behind it
+    hipStream_t qstream[2] = {nullptr, nullptr};
+    unsigned n_chain = 0;
     hipStream_t stream2 = nullptr;  // map chain of a step (VoI split .. bin stats), concurrent with the query chain
-    hipStream_t streamQ = nullptr;  // query chains (voxelisation + bucketing of a scan), one after the other
     hipStream_t cur = nullptr;      // stream LAUNCH() currently targets
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int pend[2] = {0, 0};           // query sides with a prefetched chain in flight, oldest first
@@ -137,7 +141,7 @@ struct erasor_hip_handle {
     DBuf<uint8_t> st1, status, action;
     // ---- query side: everything the voxelisation / bucketing of ONE scan owns.  Two sets, so that the query chain of the
     // next scan (erasor_hip_prefetch_scan) can run while the current step is in its map-side stages ----
-    QSide q[2];
+    QSide q[NSIDE];
     int qi = 0;                      // the set the calls below work on
     DBuf<float4> curr_rejected;
     DBuf<unsigned long long> dbg_stamps;  // optional cycle stamps of the first finished segment (ERASOR_HIP_SORT_STAMPS)
@@ -336,7 +340,7 @@ int alloc_bins(erasor_hip_handle *h) {
     const size_t B = h->B;
     int rc = 0;
     const int keep = h->qi;
-    for (h->qi = 0; h->qi < 2; ++h->qi) {
+    for (h->qi = 0; h->qi < NSIDE; ++h->qi) {
         rc |= ensure(h, Q(h).qoff, B + 2) | ensure(h, Q(h).ccnt, B) | ensure(h, Q(h).cmin, B) | ensure(h, Q(h).cmax, B);
         rc |= ensure(h, Q(h).bb, 8) | ensure(h, Q(h).qgrid, 1) | ensure(h, Q(h).esqs, 1) | ensure(h, Q(h).qb_tot, B + 2);
         rc |= ensure(h, Q(h).d_nvox, 4) | ensure(h, Q(h).d_qctr, 1);
@@ -576,6 +580,16 @@ int erasor_hip_params_default(erasor_params *p) {
     return ERASOR_OK;
 }
 
+static bool create_sides(erasor_hip_handle *h, int prio) {
+    for (int k = 0; k < 2; ++k)
+        if (hipStreamCreateWithPriority(&h->qstream[k], hipStreamNonBlocking, prio) != hipSuccess) return false;
+    for (int k = 0; k < NSIDE; ++k)
+        if (hipEventCreateWithFlags(&h->q[k].ev_keys, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->q[k].ev_done, hipEventDisableTiming) != hipSuccess)
+            return false;
+    return true;
+}
+
 int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **out) {
     if (!p || !out) return ERASOR_E_INVALID;
     *out = nullptr;
@@ -599,13 +613,8 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&h->streamQ, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->q[0].ev_keys, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->q[1].ev_keys, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->q[0].ev_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->q[1].ev_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess || !create_sides(h, prio_hi) ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&h->pin, sizeof(HostOut), hipHostMallocDefault) != hipSuccess) {
         delete h;
@@ -623,12 +632,13 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
 void erasor_hip_destroy(erasor_hip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->streamQ) (void)hipStreamSynchronize(h->streamQ);
+    for (int k = 0; k < 2; ++k)
+        if (h->qstream[k]) (void)hipStreamSynchronize(h->qstream[k]);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     prof_collect(h);
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
-    for (h->qi = 0; h->qi < 2; ++h->qi) {  // both query sides
+    for (h->qi = 0; h->qi < NSIDE; ++h->qi) {  // every query side
         release(Q(h).d_nvox); release(Q(h).d_qctr); release(Q(h).qb_hist); release(Q(h).qb_tot); release(Q(h).hkey); release(Q(h).hval); release(Q(h).qoff); release(Q(h).ccnt); release(Q(h).cmin); release(Q(h).cmax); release(Q(h).scan); release(Q(h).cent); release(Q(h).query); release(Q(h).sq); release(Q(h).bb); release(Q(h).qk_a); release(Q(h).qk_b); release(Q(h).qv_a); release(Q(h).qv_b); release(Q(h).qposL); release(Q(h).qposR); release(Q(h).qflag); release(Q(h).qpl); release(Q(h).qtops); release(Q(h).run_begin); release(Q(h).ukeys); release(Q(h).qkey); release(Q(h).qhead); release(Q(h).wseg0); release(Q(h).wseg1); release(Q(h).wstate); release(Q(h).wtileL); release(Q(h).wtileR); release(Q(h).esq0); release(Q(h).esq1); release(Q(h).esq2); release(Q(h).essmall); release(Q(h).esqs); release(Q(h).qgrid);
     }
     h->qi = 0;
@@ -653,11 +663,12 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
         (void)hipStreamDestroy(h->stream2);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NSIDE; ++k) {
         if (h->q[k].ev_keys) (void)hipEventDestroy(h->q[k].ev_keys);
         if (h->q[k].ev_done) (void)hipEventDestroy(h->q[k].ev_done);
     }
-    if (h->streamQ) (void)hipStreamDestroy(h->streamQ);
+    for (int k = 0; k < 2; ++k)
+        if (h->qstream[k]) (void)hipStreamDestroy(h->qstream[k]);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -770,6 +781,20 @@ static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf, co
 
 enum { STEP_QUERY_PREVOXELIZED = 1, STEP_VOI_EVERYTHING = 2 };
 
+// a query side no announced / in-flight chain owns; the side of the last finished step only if nothing else is free
+// (its query-derived outputs are then gone)
+static int pick_side(const erasor_hip_handle *h) {
+    int fallback = -1;
+    for (int k = 0; k < NSIDE; ++k) {
+        bool busy = h->ann.valid && h->ann.side == k;
+        for (int j = 0; j < h->npend; ++j) busy = busy || h->pend[j] == k;
+        if (busy) continue;
+        if (k != h->qi) return k;
+        fallback = k;
+    }
+    return fallback;
+}
+
 // restores the handle's active query side / target stream when a helper that switched them returns (also on errors)
 struct SideGuard {
     erasor_hip_handle *h;
@@ -782,7 +807,7 @@ struct SideGuard {
     }
 };
 
-// The QUERY CHAIN of one scan, enqueued on streamQ into query side `side`: voxelize_preserving_labels (OMU.cpp:238),
+// The QUERY CHAIN of one scan, enqueued on the stream of query side `side`: voxelize_preserving_labels (OMU.cpp:238),
 // lidar->body + R-POD key (OMU.cpp:240; erasor.cpp:100-115), bucketing and per-bin statistics of the query.  It depends
 // on the scan and the lidar->body transform only -- not on the map -- which is what lets erasor_hip_prefetch_scan run
 // it for scan k+1 while step k is still in its map-side stages.
@@ -790,7 +815,9 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
                                bool prevox, bool staged = false) {
     SideGuard guard(h);
     h->qi = side;
-    h->cur = h->streamQ;
+    // (the radix fallback for very fine R-POD grids shares its scratch bank between the sides: one stream for all of them then)
+    hipStream_t qstream = h->B + 1 <= QB_NB_MAX ? h->qstream[h->n_chain++ & 1u] : h->qstream[0];
+    h->cur = qstream;
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
     const DP &P = h->dp;
@@ -812,13 +839,15 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
         HIPC(h, hipMemcpy(q.scan.p, scan_src, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice));
     }
     q.scan_in = src_is_device && ns ? (const float4 *)scan_src : (const float4 *)q.scan.p;
+    // the side's previous chain (possibly a dropped one, possibly on the other query stream) must be through with its buffers
+    if (q.used) (void)hipStreamWaitEvent(qstream, q.ev_done, 0);
     Counters *qc = q.d_qctr.p;
     const uint32_t *nq_dev = q.d_nvox.p;
     LAUNCH(h, "q_begin", k_query_begin, 1, 256, qc, q.bb.p, B + 1 <= QB_NB_MAX ? q.qb_tot.p : (uint32_t *)nullptr, B + 1 <= QB_NB_MAX ? B + 1 : 0u,
            q.d_nvox.p, prevox ? ns : 0u);
     // ---- part 1: bounding box, voxel keys, exact std::sort, runs ----
-    if (!prevox) voxelize_query_part1(h, ns, P.leaf_query, [&] { (void)hipEventRecord(q.ev_keys, h->streamQ); });
-    else (void)hipEventRecord(q.ev_keys, h->streamQ);
+    if (!prevox) voxelize_query_part1(h, ns, P.leaf_query, [&] { (void)hipEventRecord(q.ev_keys, qstream); });
+    else (void)hipEventRecord(q.ev_keys, qstream);
     // ---- part 2: centroids, label NN, lidar->body, R-POD key ----
     const uint32_t *sq_keys = nullptr, *sq_perm = nullptr;
     if (prevox) {
@@ -844,7 +873,7 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     }
     LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)q.sq.p, (const uint32_t *)q.qoff.p, B, q.ccnt.p, q.cmin.p,
            q.cmax.p);
-    (void)hipEventRecord(q.ev_done, h->streamQ);
+    (void)hipEventRecord(q.ev_done, qstream);
     q.used = true;
     q.src = scan_src;
     q.src_n = ns;
@@ -864,11 +893,11 @@ static int flush_announced(erasor_hip_handle *h) {
 }
 
 // standalone entry points (voxelize, mapgen, sort hooks, ERASOR-class runs) use the active query side as scratch:
-// forget prefetched chains and let streamQ run dry first
+// forget prefetched chains and let the query streams run dry first
 static void q_drain(erasor_hip_handle *h) {
     h->npend = 0;
     h->ann.valid = false;
-    (void)hipStreamSynchronize(h->streamQ);
+    for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(h->qstream[k]);
 }
 
 
@@ -912,7 +941,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         }
         if (side < 0) {
             // (an announcement that is not this scan is the NEXT scan: it keeps the side it was staged into)
-            side = h->npend ? (h->pend[0] ^ 1) : (h->ann.valid ? (h->ann.side ^ 1) : (h->qi ^ 1));
+            side = pick_side(h);
             rc = enqueue_query_chain(h, side, scan_src, ns, src_is_device, T_l2b, prevox);
             if (rc) return rc;
         }
@@ -975,7 +1004,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     const uint32_t *sm_keys = nullptr, *sm_perm = nullptr;
     HIPC(h, hipEventRecord(h->ev_fork, h->stream));  // state pushed, counters cleared
 
-    // ---- map chain, on stream2, concurrent with the query chain(s) on streamQ (they only meet at the Scan Ratio Test) ----
+    // ---- map chain, on stream2, concurrent with the query chains on the side streams (they only meet at the Scan Ratio Test) ----
     auto enqueue_map_chain = [&]() {
         MARK("  mapchain_begin");
         h->cur = h->stream2;
@@ -1149,13 +1178,13 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
 int erasor_hip_prefetch_scan(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device, const float T_l2b[16]) {
     if (!h || !T_l2b || (!scan_xyzi && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
-    int rc = flush_announced(h);  // an earlier announcement nobody stepped on yet: its chain starts now
-    if (rc) return rc;
-    if (h->npend >= 2) {
-        h->err = "erasor_hip_prefetch_scan: two scans are already announced";
+    if (h->ann.valid && h->npend >= 2) {
+        h->err = "erasor_hip_prefetch_scan: three scans are already announced";
         return ERASOR_E_STATE;
     }
-    const int side = h->npend ? (h->pend[0] ^ 1) : (h->qi ^ 1);
+    int rc = flush_announced(h);  // an earlier announcement nobody stepped on yet: its chain starts now
+    if (rc) return rc;
+    const int side = pick_side(h);
     if (n && !src_is_device) {  // a host scan is taken over at once
         SideGuard guard(h);
         h->qi = side;

@@ -132,12 +132,13 @@ int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n
  * of the NEXT callback_node.  Its voxelisation (OMU.cpp:238-241: voxelize_preserving_labels, lidar->body) and R-POD
  * binning (erasor.cpp:100-115) do not depend on the map, so they run on their own stream beside the map-side stages
  * of the step in flight.  Results are unchanged; only the throughput of a scan sequence rises.
- *   erasor_hip_prefetch_scan(h, scan[0]);
- *   for k: erasor_hip_prefetch_scan(h, scan[k+1]);  erasor_hip_step*(h, scan[k], ...);
+ *   erasor_hip_prefetch_scan(h, scan[0]);  erasor_hip_prefetch_scan(h, scan[1]);
+ *   for k: erasor_hip_prefetch_scan(h, scan[k+2]);  erasor_hip_step*(h, scan[k], ...);      (or one ahead: k+1)
  * The following step must pass the same pointer, size and T_lidar2body (otherwise the prefetch is dropped).  A host
  * scan is copied at once; a device scan (src_is_device != 0) is read in place and must stay valid until the step that
- * consumes it has returned.  At most two scans can be announced ahead.  After a prefetch, the query-derived outputs
- * of the step BEFORE the one in flight (erasor_hip_get_cloud / _get_bins of older steps) are no longer available. */
+ * consumes it has returned.  Up to three scans can be announced ahead of a step (three query sides); the chains of
+ * different scans run on their own streams.  When every side is taken, a new announcement re-uses the side of the last
+ * finished step: its query-derived outputs (erasor_hip_get_cloud / _get_bins) are gone from then on. */
 int erasor_hip_prefetch_scan(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device,
                              const float T_lidar2body[16]);
 

@@ -424,8 +424,8 @@ def test_mapgen_accumulation_matches_oracle(gpu_mod, large):
         assert len(o.cloud_maps) == 1  # the first accumulated scan closes a submap (cnt_voxel == 0)
 
 
-@pytest.mark.parametrize("version", [3, 2])
-def test_prefetched_scans_give_the_same_results(gpu_mod, version):
+@pytest.mark.parametrize("version,ahead", [(3, 1), (2, 1), (3, 2)])
+def test_prefetched_scans_give_the_same_results(gpu_mod, version, ahead):
     """erasor_hip_prefetch_scan: the query chain of scan k+1 runs beside step k's map-side stages (second query side).
     Every output of every step must be what the oracle's plain sequence gives; a prefetch that is not followed by
     its scan is dropped; standalone calls in between do not disturb the sequence."""
@@ -435,13 +435,18 @@ def test_prefetched_scans_give_the_same_results(gpu_mod, version):
     o.set_map(sc["map"])
     n = 8
     scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"][:n]]
-    held = g.prefetch(scans[0], sc["T_l2b"])
+    for j in range(ahead):
+        g.prefetch(scans[j], sc["T_l2b"])
     for k in range(n):
-        nxt = g.prefetch(scans[k + 1], sc["T_l2b"]) if k + 1 < n else None
-        rg = g.step(held, sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        if k + ahead < n:
+            g.prefetch(scans[k + ahead], sc["T_l2b"])
+        rg = g.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         ro = o.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         compare_step(g, o, rg, ro, full=True)
-        held = nxt
+    with pytest.raises(gpu_mod.ErasorError):  # nothing consumed in between: the fourth announcement has no side left
+        for j in range(4):
+            g.prefetch(scans[j], sc["T_l2b"])
+    g.voxelize_preserving_labels(sc["scans"][0][:100], 0.3)  # (standalone call: drops the three announcements)
     # a prefetch that is not honoured: the announced scan is dropped, the step's own scan is processed
     g.prefetch(scans[0], sc["T_l2b"])
     k = n
