@@ -996,7 +996,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     if (rc) return rc;
     const int bits = key_bits(B + 1);
     if (B + 1 <= QB_NB_MAX) {  // [tiles][B + 1] table of the map's counting sort
-        if (ensure(h, h->mb_hist, (size_t)(B + 1) * std::max(1u, cdiv(n_voi, QB_TILE)) + 8)) return ERASOR_E_NO_DEVICE;
+        if (ensure(h, h->mb_hist, (size_t)(B + 1) * std::max(1u, cdiv(n_voi, MB_TILE)) + 8)) return ERASOR_E_NO_DEVICE;
     } else {  // the map chain's scratch bank of the radix bucket sort
         const uint32_t nb_m = 256u * std::max(1u, cdiv(n_voi, RTILE));
         if (ensure(h, h->hist2, nb_m) || ensure(h, h->hist2_l, nb_m) || ensure(h, h->hist2_t, cdiv(nb_m, 1024) + 2)) return ERASOR_E_NO_DEVICE;
@@ -1032,8 +1032,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
                    dc, (const Counters *)Q(h).d_qctr.p, h->voi_ego.p, h->voi_key.p, h->voi_src.p);
         }
         if (mb_count) {
-            const uint32_t ntile_ub = std::max(1u, cdiv(n_voi, QB_TILE));
-            LAUNCH(h, "voi_bucket", k_qb_hist, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, n_voi, nvoi_dev, B + 1, h->mb_hist.p, h->mb_tot.p);
+            const uint32_t ntile_ub = std::max(1u, cdiv(n_voi, MB_TILE));
+            LAUNCH(h, "voi_bucket", k_mb_hist, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, n_voi, nvoi_dev, B + 1, h->mb_hist.p, h->mb_tot.p);
             LAUNCH(h, "voi_bucket", k_qb_scan, 1, 1024, (const uint32_t *)h->mb_tot.p, B + 1, h->moff.p);
             LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv((uint64_t)(B + 1) * 64, 256), 256, h->mb_hist.p, n_voi, nvoi_dev, B + 1, (const uint32_t *)h->moff.p);
             LAUNCH(h, "voi_bucket", k_mb_scatter, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,

@@ -694,15 +694,40 @@ __global__ __launch_bounds__(1024) void k_qb_scatter(const uint32_t *__restrict_
     if (valid) dst[pre + r] = src[i];
 }
 
-// ---- the same one-digit counting sort for the (much longer) VoI list of the map: the per-tile prefix of a bucket
-// is made a table look-up by a column scan (one wavefront per bucket over the tiles), and the scatter carries the
-// point, its pre-step source index and the key along (k_gather folded in)
+// ---- the same one-digit counting sort for the (much longer) VoI list of the map: tiles of 8192 keys keep the
+// [tile][bucket] table short (~100 rows for a 0.8 M-point VoI), the per-tile start of a bucket becomes a table look-up
+// through a column scan (one wavefront per bucket over the tiles), and the scatter carries the point, its pre-step
+// source index and the key along (k_gather folded in)
+static constexpr uint32_t MB_TILE = 8192;
+__global__ __launch_bounds__(1024) void k_mb_hist(const uint32_t *__restrict__ keys, uint32_t n_host, const uint32_t *n_dev, uint32_t nb,
+                                                   uint32_t *__restrict__ hist /* [tile][nb] */, uint32_t *__restrict__ tot /* [nb] */) {
+    __shared__ uint32_t cnt[QB_NB_MAX];
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
+    if (blockIdx.x >= ntile) return;
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t i0 = blockIdx.x * MB_TILE + threadIdx.x;
+    uint32_t k[MB_TILE / 1024];
+#pragma unroll
+    for (uint32_t r = 0; r < MB_TILE / 1024; ++r) k[r] = i0 + r * 1024 < n ? keys[i0 + r * 1024] : 0xFFFFFFFFu;
+#pragma unroll
+    for (uint32_t r = 0; r < MB_TILE / 1024; ++r)
+        if (k[r] != 0xFFFFFFFFu) atomicAdd(&cnt[min(k[r], nb - 1)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+        const uint32_t c = cnt[b];
+        hist[(size_t)blockIdx.x * nb + b] = c;
+        if (c) atomicAdd(&tot[b], c);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_mb_colscan(uint32_t *__restrict__ hist /* [tile][nb] -> start of (bucket, tile) */, uint32_t n_host,
                                                      const uint32_t *n_dev, uint32_t nb, const uint32_t *__restrict__ off) {
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (b >= nb) return;
     const uint32_t n = n_dev ? *n_dev : n_host;
-    const uint32_t ntile = (n + QB_TILE - 1) / QB_TILE;
+    const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
     uint32_t run = off[b];
     for (uint32_t t0 = 0; t0 < ntile; t0 += 64) {
         const uint32_t t = t0 + lane;
@@ -723,35 +748,43 @@ __global__ __launch_bounds__(1024) void k_mb_scatter(const uint32_t *__restrict_
                                                       uint32_t *__restrict__ dst_aux, uint32_t *__restrict__ dst_keys) {
     __shared__ uint32_t cnt[QB_NB_MAX];
     const uint32_t n = n_dev ? *n_dev : n_host;
-    const uint32_t ntile = (n + QB_TILE - 1) / QB_TILE;
+    const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
     if (blockIdx.x >= ntile) return;
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = 0;
+    // cnt[k] starts at the tile's first slot of bucket k and advances as the tile's keys are placed, in index order
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = base[(size_t)blockIdx.x * nb + b];
     __syncthreads();
-    const uint32_t i = blockIdx.x * QB_TILE + threadIdx.x;
-    const bool valid = i < n;
-    const uint32_t k = valid ? min(keys[i], nb - 1) : 0u;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t pre = valid ? base[(size_t)blockIdx.x * nb + k] : 0u;
-    uint64_t peers = __ballot(valid);
-    for (int b = 0; b < bits; ++b) {
-        const bool bit = (k >> b) & 1u;
-        const uint64_t m = __ballot(valid && bit);
-        peers &= bit ? m : ~m;
-    }
     const uint64_t lt = lanemask_lt();
-    uint32_t r = 0;
-    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {  // waves take their turn in index order
-        if (wave == w && valid) {
-            r = cnt[k] + (uint32_t)__popcll(peers & lt);
-            esort::wave_sync();
-            if ((peers >> (threadIdx.x & 63u)) >> 1 == 0) cnt[k] += (uint32_t)__popcll(peers);  // highest lane of the group
+    for (uint32_t r = 0; r < MB_TILE / 1024; ++r) {
+        const uint32_t i = blockIdx.x * MB_TILE + r * 1024 + threadIdx.x;
+        const bool valid = i < n;
+        const uint32_t k = valid ? min(keys[i], nb - 1) : 0u;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t aux = 0;
+        if (valid) {  // fetched before the ranking turns: the loads overlap them
+            p = src[i];
+            aux = src_aux[i];
         }
-        __syncthreads();
-    }
-    if (valid) {
-        dst[pre + r] = src[i];
-        dst_aux[pre + r] = src_aux[i];
-        dst_keys[pre + r] = k;
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < bits; ++b) {
+            const bool bit = (k >> b) & 1u;
+            const uint64_t m = __ballot(valid && bit);
+            peers &= bit ? m : ~m;
+        }
+        uint32_t d = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {  // waves take their turn in index order
+            if (wave == w && valid) {
+                d = cnt[k] + (uint32_t)__popcll(peers & lt);
+                esort::wave_sync();
+                if ((peers >> (threadIdx.x & 63u)) >> 1 == 0) cnt[k] += (uint32_t)__popcll(peers);  // highest lane of the group
+            }
+            __syncthreads();
+        }
+        if (valid) {
+            dst[d] = p;
+            dst_aux[d] = aux;
+            dst_keys[d] = k;
+        }
     }
 }
 
