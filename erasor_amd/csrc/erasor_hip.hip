@@ -80,13 +80,11 @@ struct erasor_hip_handle {
     DP dp;
     int device = 0;
     hipStream_t stream = nullptr;   // main stream: step begin, SRT .. write-back
-    // query chains alternate between two streams, so that two consecutive scans' chains overlap.  Four streams in all: the
-    // runtime multiplexes streams onto 4 hardware queues by default, a fifth would share one and serialise behind it
+    // query chains alternate between two streams, so that two consecutive scans' chains overlap (three streams in all; the
+    // runtime multiplexes streams onto 4 hardware queues by default -- a fifth stream shares one and serialises behind it)
     hipStream_t qstream[2] = {nullptr, nullptr};
     unsigned n_chain = 0;
-    hipStream_t stream2 = nullptr;  // map chain of a step (VoI split .. bin stats), concurrent with the query chain
     hipStream_t cur = nullptr;      // stream LAUNCH() currently targets
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int pend[2] = {0, 0};           // query sides with a prefetched chain in flight, oldest first
     int npend = 0;
     // a scan announced by erasor_hip_prefetch_scan whose chain is not enqueued yet (the step in flight goes first)
@@ -106,8 +104,7 @@ struct erasor_hip_handle {
     DBuf<uint32_t> mb_hist, mb_tot;   // the map's bucketing as a counting sort: [tiles][B + 1] table, [B + 1] totals
     DBuf<unsigned long long> lab_slots;  // [16][8] label tallies of the assemble kernels (one cache line per slot)
     HostOut *pin = nullptr;         // pinned host block k_step_end reports into
-    bool forked = false;            // ev_join has been recorded at least once
-    int bank = 0;                   // scratch bank of scan/radix helpers (0: main stream, 1: stream2)
+    int bank = 0;                   // scratch bank of scan/radix helpers (0: query chains, 1: map chain)
     std::string err;
     bool have_map = false, have_step = false;
 
@@ -609,13 +606,12 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
     memset(&h->st, 0, sizeof(h->st));
     memset(&h->ctr, 0, sizeof(h->ctr));
     memset(&h->last_res, 0, sizeof(h->last_res));
-    // the query chain is the critical path of a step: its stream gets the highest priority, the map chain's the lowest
+    // with look-ahead the main stream (map chain, SRT .. write-back) is the critical path of a sequence: highest priority;
+    // the query chains of the scans ahead get the lowest
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess || !create_sides(h, prio_hi) ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        !create_sides(h, prio_lo) ||
         hipHostMalloc((void **)&h->pin, sizeof(HostOut), hipHostMallocDefault) != hipSuccess) {
         delete h;
         return ERASOR_E_NO_DEVICE;
@@ -634,7 +630,6 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     (void)hipSetDevice(h->device);
     for (int k = 0; k < 2; ++k)
         if (h->qstream[k]) (void)hipStreamSynchronize(h->qstream[k]);
-    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     prof_collect(h);
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
@@ -658,18 +653,12 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
    
     release(h->gsK); release(h->gsV); release(h->gsL); release(h->gsR); release(h->gsK2); release(h->gsV2); release(h->gsH); release(h->gsC);
     release(h->vox_out); release(h->d_st); release(h->d_ctr);
-    if (h->stream2) {
-        (void)hipStreamSynchronize(h->stream2);
-        (void)hipStreamDestroy(h->stream2);
-    }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int k = 0; k < NSIDE; ++k) {
         if (h->q[k].ev_keys) (void)hipEventDestroy(h->q[k].ev_keys);
         if (h->q[k].ev_done) (void)hipEventDestroy(h->q[k].ev_done);
     }
     for (int k = 0; k < 2; ++k)
         if (h->qstream[k]) (void)hipStreamDestroy(h->qstream[k]);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -973,7 +962,6 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     }
     h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_step_begin
     h->st.o_begin = h->o_begin;
-    if (h->forked) (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);  // a previous step that bailed out between fork and join
     const bool mb_count = B + 1 <= QB_NB_MAX;  // the map's bucketing as a one-digit counting sort (else: LSD radix passes)
     LAUNCH(h, "step_begin", k_step_begin, 1, 256, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u);
 
@@ -1002,14 +990,14 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         if (ensure(h, h->hist2, nb_m) || ensure(h, h->hist2_l, nb_m) || ensure(h, h->hist2_t, cdiv(nb_m, 1024) + 2)) return ERASOR_E_NO_DEVICE;
     }
     const uint32_t *sm_keys = nullptr, *sm_perm = nullptr;
-    HIPC(h, hipEventRecord(h->ev_fork, h->stream));  // state pushed, counters cleared
 
-    // ---- map chain, on stream2, concurrent with the query chains on the side streams (they only meet at the Scan Ratio Test) ----
+    // ---- map chain (the query chains run on their own streams; the two only meet at the Scan Ratio Test) ----
     auto enqueue_map_chain = [&]() {
         MARK("  mapchain_begin");
-        h->cur = h->stream2;
+        // With the query chains on streams of their own, the map chain simply follows k_step_begin on the main stream
+        // (no fork / join events, one hardware queue less).
+        h->cur = h->stream;
         h->bank = 1;
-        (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
         {   // VoI split (OMU.cpp:254 fetch_VoI membership)
             // one chunk per wave while that needs <= 16 workgroups per CU: the hardware back-fills workgroups as they finish,
             // which balances better than a grid-stride tail (measured, tools/bw_probe.hip)
@@ -1023,7 +1011,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
             LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
                    nchunks, nFchunks, ds);
         }
-        (void)hipStreamWaitEvent(h->stream2, Q(h).ev_keys, 0);  // k_voi_gather must see the query side's error flag
+        (void)hipStreamWaitEvent(h->stream, Q(h).ev_keys, 0);  // k_voi_gather must see the query side's error flag
         {   // VoI gather + egocentric transform + R-POD key (OMU.cpp:435-437; erasor.cpp:124-139)
             const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nchunks, 4), 256 * 8));
             LAUNCH(h, "voi_gather", k_voi_gather, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, h->Oxy.p, h->Ozi.p, o_chunk0,
@@ -1047,9 +1035,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         }
         LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->spts.p, (const uint32_t *)h->moff.p, B, h->mcnt.p,
                h->mmin.p, h->mmax.p);
-        (void)hipEventRecord(h->ev_join, h->stream2);
         MARK("  mapchain_end");
-        h->forked = true;
         h->cur = h->stream;
         h->bank = 0;
     };
@@ -1057,7 +1043,6 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     enqueue_map_chain();
     MARK("map chain");
     HIPC(h, hipStreamWaitEvent(h->stream, Q(h).ev_done, 0));  // join: the query's bins are ready
-    HIPC(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));  // join: bins of the map are ready
 
     // ---- Scan Ratio Test, R-GPF, per-bin voxelisation (erasor.cpp:332-571) ----
     LAUNCH(h, "srt", k_srt, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
