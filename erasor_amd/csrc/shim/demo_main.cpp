@@ -81,13 +81,22 @@ static int config_mode(int argc, char **argv) {
     }
     printf("Total %zu poses are loaded\n", poses.size() + 1);  // main_in_your_env.cpp:58 counts the header line too
     int done = 0;
-    for (int i = drv.init_idx; i < (int)poses.size() && done < max_frames; ++i, ++done) {
+    auto load = [&](int i, pcl::PointCloud<pcl::PointXYZI> &c) {
         char name[64];
         snprintf(name, sizeof(name), "/pcds/%06d.pcd", i);
-        pcl::PointCloud<pcl::PointXYZI> scan;
-        if (erasor_utils::load_pcd(drv.data_dir + name, scan) == -1) return 3;
+        return erasor_utils::load_pcd(drv.data_dir + name, c) != -1;
+    };
+    pcl::PointCloud<pcl::PointXYZI> scan, next;
+    bool have = drv.init_idx < (int)poses.size() && load(drv.init_idx, scan);
+    for (int i = drv.init_idx; have && i < (int)poses.size() && done < max_frames; ++i, ++done) {
+        // offline: the next node's cloud is read (and announced) before this node is processed
+        const bool have_next = i + 1 < (int)poses.size() && done + 1 < max_frames && load(i + 1, next);
+        if (have_next) updater.announce_next(next);
         updater.callback_node(i, erasor_utils::eigen2geoPose(poses[i]), scan);
+        scan.points.swap(next.points);
+        have = have_next;
     }
+    if (done == 0 && !have) return 3;
     updater.save_static_map(0.2f);  // main_in_your_env.cpp:123
     printf("Static map building complete!\n");
     return 0;

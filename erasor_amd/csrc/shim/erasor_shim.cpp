@@ -260,8 +260,18 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
     mat16(tf_lidar2body_, Tl);
     mat16(tf_body2origin_, Tb);
     mat16(tf_origin2body, To);
-    const std::vector<float> s = to_xyzi(lidar);
-    check(h_, erasor_hip_step(h_, s.data(), lidar.size(), Tl, Tb, To, &last), "erasor_hip_step");
+    std::vector<float> own;
+    const float *scan = nullptr;
+    if (has_next_ && next_xyzi_.size() == 4 * lidar.size()) {
+        own = to_xyzi(lidar);
+        if (own.empty() || memcmp(own.data(), next_xyzi_.data(), own.size() * sizeof(float)) == 0) scan = next_xyzi_.data();  // as announced
+    }
+    if (!scan) {
+        if (own.empty()) own = to_xyzi(lidar);
+        scan = own.data();
+    }
+    has_next_ = false;
+    check(h_, erasor_hip_step(h_, scan, lidar.size(), Tl, Tb, To, &last), "erasor_hip_step");
     fetch_cloud(h_, ERASOR_CLOUD_MAP_REJECTED, map_rejected);
     fetch_cloud(h_, ERASOR_CLOUD_CURR_REJECTED, query_rejected);
     ++num_processed;
@@ -271,6 +281,15 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
         printf("[Debug] Total: %llu  dynamic %llu  static %llu\n", (unsigned long long)last.n_map_out, (unsigned long long)last.n_dynamic,
                (unsigned long long)last.n_static);
     }
+}
+void OfflineMapUpdater::announce_next(const Cloud &lidar) {
+    if ((stack_count_ + 1) % cfg_.params.removal_interval != 0) return;  // the next node will be gated out (OMU.cpp:206-209)
+    if (has_next_) return;                                                 // one cloud ahead is what callback_node can honour
+    next_xyzi_ = to_xyzi(lidar);
+    float Tl[16];
+    mat16(tf_lidar2body_, Tl);
+    check(h_, erasor_hip_prefetch_scan(h_, next_xyzi_.data(), lidar.size(), 0, Tl), "erasor_hip_prefetch_scan");
+    has_next_ = true;
 }
 void OfflineMapUpdater::get_map(Cloud &dst) {
     size_t n = 0;
