@@ -963,7 +963,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_step_begin
     h->st.o_begin = h->o_begin;
     const bool mb_count = B + 1 <= QB_NB_MAX;  // the map's bucketing as a one-digit counting sort (else: LSD radix passes)
-    LAUNCH(h, "step_begin", k_step_begin, 1, 256, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u);
+    // (k_step_begin's work -- state push, counters, tallies -- rides in k_chunk_scan_all, the first launch that needs it)
 
     MARK("prologue");
     // ---- sizes, scratch ----
@@ -1006,10 +1006,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
             if (h->prof == 2) LAUNCH(h, "voi_split_event_calib", k_null, 1, 64);
             LAUNCH(h, "voi_split", k_voi_split, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, (const float2 *)h->Oxy.p, h->o_begin,
                    o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p);
-            const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));
-            LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p);
-            LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
-                   nchunks, nFchunks, ds);
+            LAUNCH(h, "chunk_scan", k_chunk_scan_all, 1, 1024, (const uint32_t *)h->cinfo.p, nchunks, nFchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p,
+                   ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u);
         }
         (void)hipStreamWaitEvent(h->stream, Q(h).ev_keys, 0);  // k_voi_gather must see the query side's error flag
         {   // VoI gather + egocentric transform + R-POD key (OMU.cpp:435-437; erasor.cpp:124-139)
@@ -1022,10 +1020,14 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         if (mb_count) {
             const uint32_t ntile_ub = std::max(1u, cdiv(n_voi, MB_TILE));
             LAUNCH(h, "voi_bucket", k_mb_hist, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, n_voi, nvoi_dev, B + 1, h->mb_hist.p, h->mb_tot.p);
-            LAUNCH(h, "voi_bucket", k_qb_scan, 1, 1024, (const uint32_t *)h->mb_tot.p, B + 1, h->moff.p);
-            LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv((uint64_t)(B + 1) * 64, 256), 256, h->mb_hist.p, n_voi, nvoi_dev, B + 1, (const uint32_t *)h->moff.p);
-            LAUNCH(h, "voi_bucket", k_mb_scatter, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
-                   (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, B + 1, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p);
+            LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv((uint64_t)(B + 1) * 64, 256), 256, h->mb_hist.p, n_voi, nvoi_dev, B + 1, (const uint32_t *)h->mb_tot.p,
+                   h->moff.p);
+            if (B + 1 <= MBW_NB_MAX)
+                LAUNCH(h, "voi_bucket", k_mb_scatter_w, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
+                       (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, B + 1, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p);
+            else
+                LAUNCH(h, "voi_bucket", k_mb_scatter, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
+                       (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, B + 1, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p);
             sm_keys = h->rk_a.p;
         } else {
             radix_sort(h, h->voi_key.p, n_voi, nvoi_dev, bits, h->rk_a.p, h->rk_b.p, h->rv_a.p, h->rv_b.p, &sm_keys, &sm_perm, "voi_bucket");

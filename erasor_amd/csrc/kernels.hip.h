@@ -282,6 +282,76 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ 
     }
 }
 
+// Single-workgroup variant used by the step: k_step_begin's work, then the whole two-level scan in one launch (the main
+// stream is a chain of dependent launches -- every kernel boundary on it costs ~3 us).  pvl / phl receive FULL prefixes;
+// topv / toph are zeroed so that k_voi_gather's `pvl[c] + topv[c >> 10]` stays valid.
+__global__ __launch_bounds__(1024) void k_chunk_scan_all(const uint32_t *__restrict__ cinfo, uint32_t nchunks, uint32_t nFchunks,
+                                                          uint32_t *__restrict__ pvl, uint32_t *__restrict__ phl, uint32_t *__restrict__ topv,
+                                                          uint32_t *__restrict__ toph, DevState *st, Counters *ctr, DevState init,
+                                                          unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n) {
+    __shared__ uint32_t sm[40];
+    __shared__ uint32_t carry[2], atF[2];
+    // ---- start of the step: the host's mirror of the state replaces the device's, counters and tallies are cleared ----
+    if (lab_slots && threadIdx.x < 128) lab_slots[threadIdx.x] = 0;
+    for (uint32_t b = threadIdx.x; b < mb_n; b += blockDim.x) mb_tot[b] = 0;
+    for (uint32_t i = threadIdx.x; i < (nchunks + 1023) / 1024; i += blockDim.x) topv[i] = toph[i] = 0;
+    if (threadIdx.x == 0) {
+        ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
+        ctr->sort_qoverflow = ctr->err = 0;
+        carry[0] = carry[1] = 0;
+        atF[0] = atF[1] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (uint32_t base = 0; base < nchunks; base += blockDim.x * 4) {
+        const uint32_t i0 = base + threadIdx.x * 4;
+        uint32_t v[4], hh[4], sv = 0, sh = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t ci = (i0 + j < nchunks) ? cinfo[i0 + j] : 0u;
+            v[j] = ci & 0xFFFFu;
+            hh[j] = ci >> 16;
+            sv += v[j];
+            sh += hh[j];
+        }
+        uint32_t tv, th;
+        uint32_t pv = carry[0] + block_excl_scan(sv, sm, tv);
+        uint32_t ph = carry[1] + block_excl_scan(sh, sm, th);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + j < nchunks) {
+                pvl[i0 + j] = pv;
+                phl[i0 + j] = ph;
+                if (i0 + j == nFchunks) {
+                    atF[0] = pv;
+                    atF[1] = ph;
+                }
+            }
+            pv += v[j];
+            ph += hh[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            carry[0] += tv;
+            carry[1] += th;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        DevState s = init;
+        const uint32_t voi_total = carry[0], valid_total = carry[1];
+        const uint32_t voiF = nFchunks < nchunks ? atF[0] : voi_total, validF = nFchunks < nchunks ? atF[1] : valid_total;
+        s.F_static = s.F_dynamic = 0;
+        s.n_rev = 0;
+        s.voi_total = voi_total;
+        s.valid_total = valid_total;
+        s.voiF = voiF;
+        s.validF = validF;
+        s.n_leaving = validF - voiF;
+        s.o_new_begin = s.o_begin - (validF - voiF);
+        *st = s;
+    }
+}
+
 // ================================================================================================
 // (2) voi_gather — for every set VoI bit: fetch the point, egocentric transform (OMU.cpp:435-437),
 // R-POD key (erasor.cpp:124-139), write into VoI order; tombstone outskirts sources; move the
@@ -722,13 +792,34 @@ __global__ __launch_bounds__(1024) void k_mb_hist(const uint32_t *__restrict__ k
     }
 }
 
+// (the bucket offsets -- exclusive scan of the bucket totals -- are recomputed by every workgroup for its own four
+// buckets: cheaper than a launch of its own on the main stream's dependency chain; workgroup 0 publishes them)
 __global__ __launch_bounds__(256) void k_mb_colscan(uint32_t *__restrict__ hist /* [tile][nb] -> start of (bucket, tile) */, uint32_t n_host,
-                                                     const uint32_t *n_dev, uint32_t nb, const uint32_t *__restrict__ off) {
+                                                     const uint32_t *n_dev, uint32_t nb, const uint32_t *__restrict__ tot,
+                                                     uint32_t *__restrict__ off_out) {
+    __shared__ uint32_t sm[40];
+    __shared__ uint32_t s_off[4];
+    const uint32_t b0 = (blockIdx.x * blockDim.x) >> 6;  // first of this workgroup's four buckets
+    {
+        const uint32_t per = (nb + blockDim.x - 1) / blockDim.x;
+        const uint32_t lo = min(threadIdx.x * per, nb), hi = min(lo + per, nb);
+        uint32_t s = 0;
+        for (uint32_t i = lo; i < hi; ++i) s += tot[i];
+        uint32_t t;
+        uint32_t run = block_excl_scan(s, sm, t);
+        for (uint32_t i = lo; i < hi; ++i) {
+            if (blockIdx.x == 0) off_out[i] = run;
+            if (i >= b0 && i < b0 + 4) s_off[i - b0] = run;
+            run += tot[i];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) off_out[nb] = t;
+        __syncthreads();
+    }
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (b >= nb) return;
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
-    uint32_t run = off[b];
+    uint32_t run = s_off[b - b0];
     for (uint32_t t0 = 0; t0 < ntile; t0 += 64) {
         const uint32_t t = t0 + lane;
         const uint32_t c = t < ntile ? hist[(size_t)t * nb + b] : 0u;
@@ -785,6 +876,69 @@ __global__ __launch_bounds__(1024) void k_mb_scatter(const uint32_t *__restrict_
             dst_aux[d] = aux;
             dst_keys[d] = k;
         }
+    }
+}
+
+// Scatter for R-POD grids of up to 4096 buckets: every wavefront owns 512 CONSECUTIVE keys of the tile, so index order is
+// wavefront-major and the ranks need three block barriers instead of one per wavefront turn: (1) private per-wavefront
+// bucket counts, (2) their prefix over the wavefronts (tile-relative, 16 bit), (3) each wavefront ranks its own keys.
+static constexpr uint32_t MBW_NB_MAX = 4096;
+__global__ __launch_bounds__(1024) void k_mb_scatter_w(const uint32_t *__restrict__ keys, const float4 *__restrict__ src,
+                                                        const uint32_t *__restrict__ src_aux, uint32_t n_host, const uint32_t *n_dev, uint32_t nb,
+                                                        int bits, const uint32_t *__restrict__ base /* scanned hist */, float4 *__restrict__ dst,
+                                                        uint32_t *__restrict__ dst_aux, uint32_t *__restrict__ dst_keys) {
+    __shared__ uint16_t wcnt[16][MBW_NB_MAX];
+    __shared__ uint32_t sbase[MBW_NB_MAX];
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
+    if (blockIdx.x >= ntile) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t lt = lanemask_lt();
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) sbase[b] = base[(size_t)blockIdx.x * nb + b];
+    for (uint32_t i = threadIdx.x; i < 16 * MBW_NB_MAX / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(&wcnt[0][0])[i] = 0u;
+    __syncthreads();
+    constexpr uint32_t R = MB_TILE / 16 / 64;  // 64-key strips per wavefront
+    const uint32_t i0 = blockIdx.x * MB_TILE + wave * (MB_TILE / 16) + lane;
+    uint32_t k[R];
+    uint64_t peers[R];
+#pragma unroll
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t i = i0 + r * 64;
+        const bool valid = i < n;
+        k[r] = valid ? min(keys[i], nb - 1) : 0u;
+        uint64_t p = __ballot(valid);
+        for (int b = 0; b < bits; ++b) {
+            const bool bit = (k[r] >> b) & 1u;
+            const uint64_t m = __ballot(valid && bit);
+            p &= bit ? m : ~m;
+        }
+        peers[r] = valid ? p : 0ull;
+        if (valid && (p >> lane) >> 1 == 0) wcnt[wave][k[r]] += (uint16_t)__popcll(p);  // highest lane of the group
+        esort::wave_sync();
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {  // exclusive prefix over the wavefronts (<= 8192: 16 bit)
+        uint32_t run = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) {
+            const uint32_t c = wcnt[w][b];
+            wcnt[w][b] = (uint16_t)run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t i = i0 + r * 64;
+        if (i < n) {
+            const uint32_t d = sbase[k[r]] + wcnt[wave][k[r]] + (uint32_t)__popcll(peers[r] & lt);
+            dst[d] = src[i];
+            dst_aux[d] = src_aux[i];
+            dst_keys[d] = k[r];
+        }
+        esort::wave_sync();
+        if (i < n && (peers[r] >> lane) >> 1 == 0) wcnt[wave][k[r]] += (uint16_t)__popcll(peers[r]);
+        esort::wave_sync();
     }
 }
 

@@ -184,6 +184,23 @@ def test_step_parity_on_synthetic_sequences(gpu_mod, seq, version, steps):
         compare_step(g, o, rg, ro)
 
 
+@pytest.mark.parametrize("rings,sectors", [(40, 120), (100, 130)])
+def test_fine_rpod_grids_take_the_other_bucketing_paths(gpu_mod, rings, sectors):
+    """4800 bins: map scatter by wavefront turns (beyond the 4096-bucket LDS table of the wavefront-major scatter);
+    13000 bins: LSD radix passes on both sides (beyond the 12288-bucket counting-sort table)"""
+    import copy
+    sc = scenarios.small()
+    p = copy.copy(sc["params"])
+    p.num_rings, p.num_sectors = rings, sectors
+    g, o = make_pair(gpu_mod, p)
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    for f in range(3):
+        ro = o.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        rg = g.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        compare_step(g, o, rg, ro)
+
+
 def test_baseline_config_shapes(gpu_mod):
     """BASELINE.json configs 3-5 at test size: seq 02 thresholds; config/large_scale_05.yaml parameters with
     /large_scale/is_large_scale (submap 160 m, launch/run_erasor_in_large_scale.launch:4-5); an Ouster-128 stream
