@@ -637,7 +637,6 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
         release(Q(h).d_nvox); release(Q(h).d_qctr); release(Q(h).qb_hist); release(Q(h).qb_tot); release(Q(h).hkey); release(Q(h).hval); release(Q(h).qoff); release(Q(h).ccnt); release(Q(h).cmin); release(Q(h).cmax); release(Q(h).scan); release(Q(h).cent); release(Q(h).query); release(Q(h).sq); release(Q(h).bb); release(Q(h).qk_a); release(Q(h).qk_b); release(Q(h).qv_a); release(Q(h).qv_b); release(Q(h).qposL); release(Q(h).qposR); release(Q(h).qflag); release(Q(h).qpl); release(Q(h).qtops); release(Q(h).run_begin); release(Q(h).ukeys); release(Q(h).qkey); release(Q(h).qhead); release(Q(h).wseg0); release(Q(h).wseg1); release(Q(h).wstate); release(Q(h).wtileL); release(Q(h).wtileR); release(Q(h).esq0); release(Q(h).esq1); release(Q(h).esq2); release(Q(h).essmall); release(Q(h).esqs); release(Q(h).qgrid);
     }
     h->qi = 0;
-       
     release(h->Cbuf); release(h->F[0]); release(h->F[1]); release(h->Oxy); release(h->Ozi);
     release(h->vmask); release(h->hmask); release(h->cinfo); release(h->pvl); release(h->phl); release(h->topv); release(h->toph);
     release(h->voi_ego); release(h->spts); release(h->rejected); release(h->voi_key); release(h->voi_src); release(h->ssrc);
@@ -648,9 +647,6 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->mmin); release(h->mmax); release(h->plane_n); release(h->plane_d);
     release(h->st1); release(h->status); release(h->action);
     release(h->curr_rejected);
-   
-   
-   
     release(h->gsK); release(h->gsV); release(h->gsL); release(h->gsR); release(h->gsK2); release(h->gsV2); release(h->gsH); release(h->gsC);
     release(h->vox_out); release(h->d_st); release(h->d_ctr);
     for (int k = 0; k < NSIDE; ++k) {
@@ -960,10 +956,10 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         h->err = "map grew beyond the capacity reserved at set_map";
         return ERASOR_E_CAPACITY;
     }
-    h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_step_begin
+    h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_chunk_scan_all
     h->st.o_begin = h->o_begin;
     const bool mb_count = B + 1 <= QB_NB_MAX;  // the map's bucketing as a one-digit counting sort (else: LSD radix passes)
-    // (k_step_begin's work -- state push, counters, tallies -- rides in k_chunk_scan_all, the first launch that needs it)
+    // (state push, counters and tallies are reset by k_chunk_scan_all, the first launch of the step that needs them)
 
     MARK("prologue");
     // ---- sizes, scratch ----
@@ -994,7 +990,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     // ---- map chain (the query chains run on their own streams; the two only meet at the Scan Ratio Test) ----
     auto enqueue_map_chain = [&]() {
         MARK("  mapchain_begin");
-        // With the query chains on streams of their own, the map chain simply follows k_step_begin on the main stream
+        // With the query chains on streams of their own, the map chain simply opens the step on the main stream
         // (no fork / join events, one hardware queue less).
         h->cur = h->stream;
         h->bank = 1;

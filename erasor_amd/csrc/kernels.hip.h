@@ -207,82 +207,10 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
 
 // ---- chunk prefix sums (two-level) --------------------------------------------------------------
 // level 1: 1024 chunks per block; local exclusive prefixes of the voi and valid counts + block totals
-__global__ __launch_bounds__(256) void k_chunk_scan_local(const uint32_t *__restrict__ cinfo, uint32_t nchunks,
-                                                           uint32_t *__restrict__ pvl, uint32_t *__restrict__ phl,
-                                                           uint32_t *__restrict__ topv, uint32_t *__restrict__ toph) {
-    __shared__ uint32_t sm[40];
-    const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
-    uint32_t v[4], h[4];
-    uint32_t sv = 0, sh = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t ci = (base + j < nchunks) ? cinfo[base + j] : 0u;
-        v[j] = ci & 0xFFFFu;
-        h[j] = ci >> 16;
-        sv += v[j];
-        sh += h[j];
-    }
-    uint32_t tv, th;
-    uint32_t pv = block_excl_scan(sv, sm, tv);
-    uint32_t ph = block_excl_scan(sh, sm, th);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (base + j < nchunks) {
-            pvl[base + j] = pv;
-            phl[base + j] = ph;
-        }
-        pv += v[j];
-        ph += h[j];
-    }
-    if (threadIdx.x == 0) {
-        topv[blockIdx.x] = tv;
-        toph[blockIdx.x] = th;
-    }
-}
 
 // level 2 (single block): exclusive scan of the block totals in place; derive the step's VoI sizes.
-__global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ topv, uint32_t *__restrict__ toph, uint32_t ntop,
-                                                          const uint32_t *__restrict__ pvl, const uint32_t *__restrict__ phl,
-                                                          uint32_t nchunks, uint32_t nFchunks, DevState *st) {
-    __shared__ uint32_t sm[40];
-    __shared__ uint32_t carry[2];
-    if (threadIdx.x == 0) carry[0] = carry[1] = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < ntop; base += blockDim.x) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < ntop ? topv[i] : 0u, h = i < ntop ? toph[i] : 0u;
-        uint32_t tv, th;
-        const uint32_t pv = block_excl_scan(v, sm, tv);
-        const uint32_t ph = block_excl_scan(h, sm, th);
-        const uint32_t c0 = carry[0], c1 = carry[1];
-        if (i < ntop) {
-            topv[i] = c0 + pv;
-            toph[i] = c1 + ph;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            carry[0] = c0 + tv;
-            carry[1] = c1 + th;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const uint32_t voi_total = carry[0], valid_total = carry[1];
-        uint32_t voiF = voi_total, validF = valid_total;
-        if (nFchunks < nchunks) {
-            voiF = pvl[nFchunks] + topv[nFchunks >> 10];
-            validF = phl[nFchunks] + toph[nFchunks >> 10];
-        }
-        st->voi_total = voi_total;
-        st->valid_total = valid_total;
-        st->voiF = voiF;
-        st->validF = validF;
-        st->n_leaving = validF - voiF;
-        st->o_new_begin = st->o_begin - (validF - voiF);
-    }
-}
 
-// Single-workgroup variant used by the step: k_step_begin's work, then the whole two-level scan in one launch (the main
+// Opens a step on the main stream: state push / counter reset, then the whole scan of the chunk counts in one launch (the main
 // stream is a chain of dependent launches -- every kernel boundary on it costs ~3 us).  pvl / phl receive FULL prefixes;
 // topv / toph are zeroed so that k_voi_gather's `pvl[c] + topv[c >> 10]` stays valid.
 __global__ __launch_bounds__(1024) void k_chunk_scan_all(const uint32_t *__restrict__ cinfo, uint32_t nchunks, uint32_t nFchunks,
@@ -532,10 +460,6 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t *__restrict__
 }
 
 // writes *cnt_out = 256 * nblk (the number of histogram entries to scan)
-__global__ void k_radix_count(uint32_t n_host, const uint32_t *n_dev, uint32_t *cnt_out) {
-    const uint32_t n = n_dev ? *n_dev : n_host;
-    *cnt_out = 256u * ((n + RTILE - 1) / RTILE);
-}
 
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                         uint32_t n_host, const uint32_t *n_dev, int shift,
@@ -590,71 +514,6 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t *__restric
     }
 }
 
-// One-launch stable LSD radix sort for small inputs (the voxelised query, ~20 k keys): a single 1024-thread workgroup,
-// every wavefront owns a contiguous strip (stability), digit counters per wavefront in LDS, ping-pong through L2.
-__global__ __launch_bounds__(1024) void k_radix_small(const uint32_t *__restrict__ keys_in, uint32_t n_host, const uint32_t *n_dev, int bits,
-                                                       uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb) {
-    __shared__ uint32_t wcnt[16][256];
-    __shared__ uint32_t wbase[16][256];
-    __shared__ uint32_t sm[40];
-    const uint32_t n = n_dev ? *n_dev : n_host;
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint64_t lt = lanemask_lt();
-    const uint32_t per = ((n + 16 * 64 - 1) / (16 * 64)) * 64;  // strip length per wavefront, multiple of 64
-    const uint32_t s0 = wave * per, s1 = min(s0 + per, n);
-    const uint32_t *kin = keys_in;
-    const uint32_t *vin = nullptr;
-    uint32_t *kout = ka, *vout = va;
-    for (int shift = 0; shift < bits; shift += 8) {
-        for (uint32_t i = tid; i < 16 * 256; i += 1024) (&wcnt[0][0])[i] = 0;
-        __syncthreads();
-        for (uint32_t base = s0; base < s1; base += 64) {
-            const uint32_t i = base + lane;
-            const bool valid = i < s1;
-            const uint32_t d = valid ? ((kin[i] >> shift) & 0xFFu) : 0u;
-            const uint64_t peers = match_digit(d, valid);
-            if (valid && (peers & lt) == 0) wcnt[wave][d] += __popcll(peers);
-            esort::wave_sync();
-        }
-        __syncthreads();
-        // exclusive prefix in (digit-major, wavefront) order: thread d < 256 owns digit d
-        uint32_t tot = 0;
-        if (tid < 256)
-            for (int w = 0; w < 16; ++w) tot += wcnt[w][tid];
-        uint32_t all;
-        const uint32_t pre = block_excl_scan(tid < 256 ? tot : 0u, sm, all);
-        if (tid < 256) {
-            uint32_t b = pre;
-            for (int w = 0; w < 16; ++w) {
-                wbase[w][tid] = b;
-                b += wcnt[w][tid];
-            }
-        }
-        __syncthreads();
-        for (uint32_t base = s0; base < s1; base += 64) {
-            const uint32_t i = base + lane;
-            const bool valid = i < s1;
-            const uint32_t k = valid ? kin[i] : 0u;
-            const uint32_t v = valid ? (vin ? vin[i] : i) : 0u;
-            const uint32_t d = (k >> shift) & 0xFFu;
-            const uint64_t peers = match_digit(d, valid);
-            if (valid) {
-                const uint32_t pos = wbase[wave][d] + __popcll(peers & lt);
-                kout[pos] = k;
-                vout[pos] = v;
-            }
-            esort::wave_sync();
-            if (valid && (peers & lt) == 0) wbase[wave][d] += __popcll(peers);
-            esort::wave_sync();
-        }
-        __threadfence_block();
-        __syncthreads();
-        kin = kout;
-        vin = vout;
-        kout = (kout == ka) ? kb : ka;
-        vout = (vout == va) ? vb : va;
-    }
-}
 
 // gather points (and optionally a uint32 side array) into sorted order
 __global__ __launch_bounds__(256) void k_gather(const float4 *__restrict__ src, const uint32_t *__restrict__ src_aux,
@@ -690,7 +549,7 @@ __global__ __launch_bounds__(1024) void k_qb_hist(const uint32_t *__restrict__ k
     for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
         const uint32_t c = cnt[b];
         hist[(size_t)blockIdx.x * nb + b] = c;
-        if (c) atomicAdd(&tot[b], c);  // bucket totals (integer: order-independent); zeroed by k_step_begin
+        if (c) atomicAdd(&tot[b], c);  // bucket totals (integer: order-independent); zeroed by k_query_begin / k_chunk_scan_all
     }
 }
 
@@ -1001,10 +860,6 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
     return __uint_as_float(b);
 }
 
-__global__ void k_bbox_init(uint32_t *bb) {
-    if (threadIdx.x < 3) bb[threadIdx.x] = 0xFFFFFFFFu;
-    if (threadIdx.x >= 3 && threadIdx.x < 6) bb[threadIdx.x] = 0u;
-}
 // getMinMax3D (dense): plain min/max; -0.0/+0.0 order is irrelevant downstream (only products/floors of it)
 __global__ __launch_bounds__(256) void k_bbox(const float4 *__restrict__ pts, uint32_t n, uint32_t *bb) {
     __shared__ uint32_t sm[6];
@@ -2540,19 +2395,6 @@ __global__ void k_query_begin(Counters *qctr, uint32_t *bb, uint32_t *qb_tot, ui
     }
     if (threadIdx.x < 3) bb[threadIdx.x] = 0xFFFFFFFFu;
     if (threadIdx.x >= 3 && threadIdx.x < 6) bb[threadIdx.x] = 0u;
-}
-// start of a step on the main stream: the host's mirror of the device state replaces it (nF / o_begin may have been
-// changed by host-side map maintenance); map-side counters and label tallies are cleared
-__global__ void k_step_begin(DevState *st, Counters *ctr, DevState init, unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n) {
-    if (lab_slots && threadIdx.x < 128) lab_slots[threadIdx.x] = 0;
-    for (uint32_t b = threadIdx.x; b < mb_n; b += blockDim.x) mb_tot[b] = 0;  // bucket totals of the map's counting sort
-    if (threadIdx.x == 0) {
-        *st = init;
-        ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
-        ctr->sort_qoverflow = ctr->err = 0;
-        st->F_static = st->F_dynamic = 0;
-        st->n_rev = 0;
-    }
 }
 // end of a step: fold in the query side's counters and voxel count, commit the map sizes, report to the pinned host block
 __global__ void k_step_end(DevState *st, Counters *ctr, HostOut *out, const unsigned long long *lab_slots, const Counters *qctr,
