@@ -956,10 +956,10 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         h->err = "map grew beyond the capacity reserved at set_map";
         return ERASOR_E_CAPACITY;
     }
-    h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_chunk_scan_all
+    h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_chunk_scan_top
     h->st.o_begin = h->o_begin;
     const bool mb_count = B + 1 <= QB_NB_MAX;  // the map's bucketing as a one-digit counting sort (else: LSD radix passes)
-    // (state push, counters and tallies are reset by k_chunk_scan_all, the first launch of the step that needs them)
+    // (state push, counters and tallies are reset by k_chunk_scan_top, the first launch of the step that needs them)
 
     MARK("prologue");
     // ---- sizes, scratch ----
@@ -1002,8 +1002,10 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
             if (h->prof == 2) LAUNCH(h, "voi_split_event_calib", k_null, 1, 64);
             LAUNCH(h, "voi_split", k_voi_split, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, (const float2 *)h->Oxy.p, h->o_begin,
                    o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p);
-            LAUNCH(h, "chunk_scan", k_chunk_scan_all, 1, 1024, (const uint32_t *)h->cinfo.p, nchunks, nFchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p,
-                   ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u);
+            const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));
+            LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p);
+            LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
+                   nchunks, nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u);
         }
         (void)hipStreamWaitEvent(h->stream, Q(h).ev_keys, 0);  // k_voi_gather must see the query side's error flag
         {   // VoI gather + egocentric transform + R-POD key (OMU.cpp:435-437; erasor.cpp:124-139)

@@ -210,64 +210,83 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
 
 // level 2 (single block): exclusive scan of the block totals in place; derive the step's VoI sizes.
 
-// Opens a step on the main stream: state push / counter reset, then the whole scan of the chunk counts in one launch (the main
-// stream is a chain of dependent launches -- every kernel boundary on it costs ~3 us).  pvl / phl receive FULL prefixes;
-// topv / toph are zeroed so that k_voi_gather's `pvl[c] + topv[c >> 10]` stays valid.
-__global__ __launch_bounds__(1024) void k_chunk_scan_all(const uint32_t *__restrict__ cinfo, uint32_t nchunks, uint32_t nFchunks,
-                                                          uint32_t *__restrict__ pvl, uint32_t *__restrict__ phl, uint32_t *__restrict__ topv,
-                                                          uint32_t *__restrict__ toph, DevState *st, Counters *ctr, DevState init,
+// level 1 of the chunk-count scan: 1024 chunks per workgroup, local prefixes + workgroup totals
+__global__ __launch_bounds__(256) void k_chunk_scan_local(const uint32_t *__restrict__ cinfo, uint32_t nchunks,
+                                                           uint32_t *__restrict__ pvl, uint32_t *__restrict__ phl,
+                                                           uint32_t *__restrict__ topv, uint32_t *__restrict__ toph) {
+    __shared__ uint32_t sm[40];
+    const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t v[4], h[4];
+    uint32_t sv = 0, sh = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t ci = (base + j < nchunks) ? cinfo[base + j] : 0u;
+        v[j] = ci & 0xFFFFu;
+        h[j] = ci >> 16;
+        sv += v[j];
+        sh += h[j];
+    }
+    uint32_t tv, th;
+    uint32_t pv = block_excl_scan(sv, sm, tv);
+    uint32_t ph = block_excl_scan(sh, sm, th);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (base + j < nchunks) {
+            pvl[base + j] = pv;
+            phl[base + j] = ph;
+        }
+        pv += v[j];
+        ph += h[j];
+    }
+    if (threadIdx.x == 0) {
+        topv[blockIdx.x] = tv;
+        toph[blockIdx.x] = th;
+    }
+}
+
+// level 2 (single workgroup) -- and the opening of the step's state: the host's mirror of the device state replaces it,
+// counters and tallies are cleared (this is the first launch of a step that needs them); then the workgroup totals are
+// scanned in place and the step's VoI sizes derived.
+__global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ topv, uint32_t *__restrict__ toph, uint32_t ntop,
+                                                          const uint32_t *__restrict__ pvl, const uint32_t *__restrict__ phl,
+                                                          uint32_t nchunks, uint32_t nFchunks, DevState *st, Counters *ctr, DevState init,
                                                           unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n) {
     __shared__ uint32_t sm[40];
-    __shared__ uint32_t carry[2], atF[2];
-    // ---- start of the step: the host's mirror of the state replaces the device's, counters and tallies are cleared ----
+    __shared__ uint32_t carry[2];
     if (lab_slots && threadIdx.x < 128) lab_slots[threadIdx.x] = 0;
     for (uint32_t b = threadIdx.x; b < mb_n; b += blockDim.x) mb_tot[b] = 0;
-    for (uint32_t i = threadIdx.x; i < (nchunks + 1023) / 1024; i += blockDim.x) topv[i] = toph[i] = 0;
     if (threadIdx.x == 0) {
         ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
         ctr->sort_qoverflow = ctr->err = 0;
         carry[0] = carry[1] = 0;
-        atF[0] = atF[1] = 0xFFFFFFFFu;
     }
     __syncthreads();
-    for (uint32_t base = 0; base < nchunks; base += blockDim.x * 4) {
-        const uint32_t i0 = base + threadIdx.x * 4;
-        uint32_t v[4], hh[4], sv = 0, sh = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t ci = (i0 + j < nchunks) ? cinfo[i0 + j] : 0u;
-            v[j] = ci & 0xFFFFu;
-            hh[j] = ci >> 16;
-            sv += v[j];
-            sh += hh[j];
-        }
+    for (uint32_t base = 0; base < ntop; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < ntop ? topv[i] : 0u, h = i < ntop ? toph[i] : 0u;
         uint32_t tv, th;
-        uint32_t pv = carry[0] + block_excl_scan(sv, sm, tv);
-        uint32_t ph = carry[1] + block_excl_scan(sh, sm, th);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (i0 + j < nchunks) {
-                pvl[i0 + j] = pv;
-                phl[i0 + j] = ph;
-                if (i0 + j == nFchunks) {
-                    atF[0] = pv;
-                    atF[1] = ph;
-                }
-            }
-            pv += v[j];
-            ph += hh[j];
+        const uint32_t pv = block_excl_scan(v, sm, tv);
+        const uint32_t ph = block_excl_scan(h, sm, th);
+        const uint32_t c0 = carry[0], c1 = carry[1];
+        if (i < ntop) {
+            topv[i] = c0 + pv;
+            toph[i] = c1 + ph;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            carry[0] += tv;
-            carry[1] += th;
+            carry[0] = c0 + tv;
+            carry[1] = c1 + th;
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         DevState s = init;
         const uint32_t voi_total = carry[0], valid_total = carry[1];
-        const uint32_t voiF = nFchunks < nchunks ? atF[0] : voi_total, validF = nFchunks < nchunks ? atF[1] : valid_total;
+        uint32_t voiF = voi_total, validF = valid_total;
+        if (nFchunks < nchunks) {
+            voiF = pvl[nFchunks] + topv[nFchunks >> 10];
+            validF = phl[nFchunks] + toph[nFchunks >> 10];
+        }
         s.F_static = s.F_dynamic = 0;
         s.n_rev = 0;
         s.voi_total = voi_total;
@@ -549,7 +568,7 @@ __global__ __launch_bounds__(1024) void k_qb_hist(const uint32_t *__restrict__ k
     for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
         const uint32_t c = cnt[b];
         hist[(size_t)blockIdx.x * nb + b] = c;
-        if (c) atomicAdd(&tot[b], c);  // bucket totals (integer: order-independent); zeroed by k_query_begin / k_chunk_scan_all
+        if (c) atomicAdd(&tot[b], c);  // bucket totals (integer: order-independent); zeroed by k_query_begin / k_chunk_scan_top
     }
 }
 
