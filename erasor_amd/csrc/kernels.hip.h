@@ -642,11 +642,14 @@ __global__ __launch_bounds__(1024) void k_qb_scatter(const uint32_t *__restrict_
     if (valid) dst[pre + r] = src[i];
 }
 
-// ---- the same one-digit counting sort for the (much longer) VoI list of the map: tiles of 8192 keys keep the
-// [tile][bucket] table short (~100 rows for a 0.8 M-point VoI), the per-tile start of a bucket becomes a table look-up
+// ---- the same one-digit counting sort for the (much longer) VoI list of the map: tiles of 4096 keys keep the
+// [tile][bucket] table short (~200 rows for a 0.8 M-point VoI), the per-tile start of a bucket becomes a table look-up
 // through a column scan (one wavefront per bucket over the tiles), and the scatter carries the point, its pre-step
 // source index and the key along (k_gather folded in)
-static constexpr uint32_t MB_TILE = 8192;
+#ifndef ERASOR_MB_TILE
+#define ERASOR_MB_TILE 4096
+#endif
+static constexpr uint32_t MB_TILE = ERASOR_MB_TILE;
 __global__ __launch_bounds__(1024) void k_mb_hist(const uint32_t *__restrict__ keys, uint32_t n_host, const uint32_t *n_dev, uint32_t nb,
                                                    uint32_t *__restrict__ hist /* [tile][nb] */, uint32_t *__restrict__ tot /* [nb] */) {
     __shared__ uint32_t cnt[QB_NB_MAX];
