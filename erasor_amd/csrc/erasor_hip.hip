@@ -920,8 +920,9 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
                 h->pend[0] = h->pend[1];
                 --h->npend;
             } else {
-                h->npend = 0;  // not the scan that was announced: the prefetched chains are dropped (they still run, harmlessly)
-                h->ann.valid = false;
+                // not the scan that was announced: the prefetched chains are dropped.  Let them run out before going on, so
+                // that a device-resident scan they read in place may be released once this call has returned
+                q_drain(h);
             }
         }
         if (side < 0) {

@@ -134,7 +134,8 @@ int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n
  * of the step in flight.  Results are unchanged; only the throughput of a scan sequence rises.
  *   erasor_hip_prefetch_scan(h, scan[0]);  erasor_hip_prefetch_scan(h, scan[1]);
  *   for k: erasor_hip_prefetch_scan(h, scan[k+2]);  erasor_hip_step*(h, scan[k], ...);      (or one ahead: k+1)
- * The following step must pass the same pointer, size and T_lidar2body (otherwise the prefetch is dropped).  A host
+ * The following step must pass the same pointer, size and T_lidar2body (otherwise every announcement is dropped;
+ * their chains have run out when that step returns).  A host
  * scan is copied at once; a device scan (src_is_device != 0) is read in place and must stay valid until the step that
  * consumes it has returned.  Up to three scans can be announced ahead of a step (three query sides); the chains of
  * different scans run on their own streams.  When every side is taken, a new announcement re-uses the side of the last
