@@ -1597,6 +1597,101 @@ __global__ __launch_bounds__(256) void k_query_direct(const float4 *__restrict__
 // ================================================================================================
 __device__ __forceinline__ double std_min_d(double a, double b) { return (b < a) ? b : a; }
 
+// per-bin pieces of the Scan Ratio Test, shared by the two kernel variants below
+struct BinStat {
+    uint32_t mc, cc;
+    double mmaxh, mminh, cmaxh, cminh;
+};
+__device__ __forceinline__ BinStat srt_load(int key, const uint32_t *mcnt, const float *mmin, const float *mmax, const uint32_t *ccnt,
+                                            const float *cmin, const float *cmax) {
+    BinStat b;
+    b.mc = mcnt[key];
+    b.cc = ccnt[key];
+    b.mmaxh = b.mc ? (double)mmax[key] : -INF_H;
+    b.mminh = b.mc ? (double)mmin[key] : INF_H;
+    b.cmaxh = b.cc ? (double)cmax[key] : -INF_H;
+    b.cminh = b.cc ? (double)cmin[key] : INF_H;
+    return b;
+}
+// first pass of v3 (erasor.cpp:467-501): status from the pseudo-occupancy ratio
+__device__ __forceinline__ uint8_t srt_first(const DP &P, const BinStat &b) {
+    uint8_t s = ST_LITTLE;
+    if (P.version == 3) {
+        if (b.mc == 0) {
+            s = ST_LITTLE;
+        } else if ((long long)b.cc < (long long)P.min_pts) {
+            s = ST_LITTLE;
+        } else {
+            const double md = b.mmaxh - b.mminh, cd = b.cmaxh - b.cminh;
+            const double ratio = std_min_d(md / cd, cd / md);
+            if (b.cc > 0 && b.mc > 0) {
+                if (ratio < P.srt_thr) {
+                    if (md >= cd) s = ST_MAP;
+                    else if (md <= cd) s = ST_CURR;
+                } else {
+                    s = ST_MERGE;
+                }
+            }
+        }
+    }
+    return s;
+}
+// second pass (erasor.cpp:503-560 for v3, :332-434 for v2): final status and the action of the bin.  ST1: st1[] accessor
+template <class ST1>
+__device__ __forceinline__ void srt_second(const DP &P, int key, const BinStat &b, uint8_t s, ST1 st1, uint8_t &fs, uint8_t &act) {
+    fs = ST_LITTLE;
+    act = 0;
+    if (P.version == 3) {
+        if (s == ST_MAP) {
+            if ((b.mmaxh - b.mminh) > 0.5) {  // erasor.cpp:511
+                fs = ST_MAP;
+                act = 1;
+            } else {
+                fs = ST_NOT_ASSIGNED;
+            }
+        } else if (s == ST_CURR) {
+            fs = ST_CURR;
+        } else if (s == ST_MERGE) {
+            // is_dynamic_obj_close(r, theta, 1, 1): erasor.cpp:573-595 (theta wrap uses num_rings)
+            const int r_t = key % P.R, th_t = key / P.R;
+            bool close = false;
+            for (int j = th_t - 1; j <= th_t + 1; ++j) {
+                int th = j;
+                if (j < 0) th = j + P.R;
+                else if (j >= P.S) th = j - P.R;
+                if (th < 0 || th >= P.S) continue;  // reference: out-of-bounds read when num_rings > num_sectors
+                for (int r = max(0, r_t - 1); r <= min(r_t + 1, P.R - 1); ++r) {
+                    if (r == r_t && th == th_t) continue;
+                    if (st1[th * P.R + r] == ST_CURR) close = true;
+                }
+            }
+            fs = close ? ST_BLOCKED : ST_MERGE;
+        }
+    } else {  // version 2
+        if ((long long)b.cc < (long long)P.min_pts) {
+            act = 0;
+        } else if (b.cc > 0 && b.mc > 0) {
+            const double md = b.mmaxh - b.mminh, cd = b.cmaxh - b.cminh;
+            const double ratio = std_min_d(md / cd, cd / md);
+            if (ratio < P.srt_thr) {
+                if (md >= cd) {
+                    fs = ST_MAP;
+                    act = (b.mmaxh > P.th_bin_max_h) ? 1 : 0;
+                } else if (md <= cd) {
+                    fs = ST_CURR;
+                    act = (b.cmaxh > P.th_bin_max_h) ? 4 : 0;  // 4: keep map bin, curr points -> curr_rejected
+                }
+            } else {
+                fs = ST_MERGE;
+                act = 2;
+            }
+        } else if (b.cc > 0) {
+            act = 3;
+        }
+    }
+}
+
+// General variant: any number of bins, one key per thread and round.
 __global__ __launch_bounds__(1024) void k_srt(DP P, const uint32_t *__restrict__ mcnt, const float *__restrict__ mmin,
                                                const float *__restrict__ mmax, const uint32_t *__restrict__ ccnt,
                                                const float *__restrict__ cmin, const float *__restrict__ cmax, uint8_t *__restrict__ st1,
@@ -1606,86 +1701,11 @@ __global__ __launch_bounds__(1024) void k_srt(DP P, const uint32_t *__restrict__
     __shared__ uint32_t sm[40];
     __shared__ uint32_t carry[2];
     const int B = P.B;
-    for (int key = threadIdx.x; key < B; key += blockDim.x) {
-        const uint32_t mc = mcnt[key], cc = ccnt[key];
-        const double mmaxh = mc ? (double)mmax[key] : -INF_H, mminh = mc ? (double)mmin[key] : INF_H;
-        const double cmaxh = cc ? (double)cmax[key] : -INF_H, cminh = cc ? (double)cmin[key] : INF_H;
-        uint8_t s = ST_LITTLE;
-        if (P.version == 3) {
-            if (mc == 0) {
-                s = ST_LITTLE;
-            } else if ((long long)cc < (long long)P.min_pts) {
-                s = ST_LITTLE;
-            } else {
-                const double md = mmaxh - mminh, cd = cmaxh - cminh;
-                const double ratio = std_min_d(md / cd, cd / md);
-                if (cc > 0 && mc > 0) {
-                    if (ratio < P.srt_thr) {
-                        if (md >= cd) s = ST_MAP;
-                        else if (md <= cd) s = ST_CURR;
-                    } else {
-                        s = ST_MERGE;
-                    }
-                }
-            }
-        }
-        st1[key] = s;
-    }
+    for (int key = threadIdx.x; key < B; key += blockDim.x) st1[key] = srt_first(P, srt_load(key, mcnt, mmin, mmax, ccnt, cmin, cmax));
     __syncthreads();
     for (int key = threadIdx.x; key < B; key += blockDim.x) {
-        const uint32_t mc = mcnt[key], cc = ccnt[key];
-        const double mmaxh = mc ? (double)mmax[key] : -INF_H, mminh = mc ? (double)mmin[key] : INF_H;
-        const double cmaxh = cc ? (double)cmax[key] : -INF_H, cminh = cc ? (double)cmin[key] : INF_H;
-        uint8_t fs = ST_LITTLE, act = 0;
-        if (P.version == 3) {
-            const uint8_t s = st1[key];
-            if (s == ST_MAP) {
-                if ((mmaxh - mminh) > 0.5) {  // erasor.cpp:511
-                    fs = ST_MAP;
-                    act = 1;
-                } else {
-                    fs = ST_NOT_ASSIGNED;
-                }
-            } else if (s == ST_CURR) {
-                fs = ST_CURR;
-            } else if (s == ST_MERGE) {
-                // is_dynamic_obj_close(r, theta, 1, 1): erasor.cpp:573-595 (theta wrap uses num_rings)
-                const int r_t = key % P.R, th_t = key / P.R;
-                bool close = false;
-                for (int j = th_t - 1; j <= th_t + 1; ++j) {
-                    int th = j;
-                    if (j < 0) th = j + P.R;
-                    else if (j >= P.S) th = j - P.R;
-                    if (th < 0 || th >= P.S) continue;  // reference: out-of-bounds read when num_rings > num_sectors
-                    for (int r = max(0, r_t - 1); r <= min(r_t + 1, P.R - 1); ++r) {
-                        if (r == r_t && th == th_t) continue;
-                        if (st1[th * P.R + r] == ST_CURR) close = true;
-                    }
-                }
-                fs = close ? ST_BLOCKED : ST_MERGE;
-            }
-        } else {  // version 2
-            if ((long long)cc < (long long)P.min_pts) {
-                act = 0;
-            } else if (cc > 0 && mc > 0) {
-                const double md = mmaxh - mminh, cd = cmaxh - cminh;
-                const double ratio = std_min_d(md / cd, cd / md);
-                if (ratio < P.srt_thr) {
-                    if (md >= cd) {
-                        fs = ST_MAP;
-                        act = (mmaxh > P.th_bin_max_h) ? 1 : 0;
-                    } else if (md <= cd) {
-                        fs = ST_CURR;
-                        act = (cmaxh > P.th_bin_max_h) ? 4 : 0;  // 4: keep map bin, curr points -> curr_rejected
-                    }
-                } else {
-                    fs = ST_MERGE;
-                    act = 2;
-                }
-            } else if (cc > 0) {
-                act = 3;
-            }
-        }
+        uint8_t fs, act;
+        srt_second(P, key, srt_load(key, mcnt, mmin, mmax, ccnt, cmin, cmax), st1[key], (const uint8_t *)st1, fs, act);
         status[key] = fs;
         action[key] = act;
     }
@@ -1716,6 +1736,68 @@ __global__ __launch_bounds__(1024) void k_srt(DP P, const uint32_t *__restrict__
     if (threadIdx.x == 0) {
         st->n_rev = carry[0];
         st->vox_scratch_total = carry[1];
+    }
+}
+
+// Up to 4096 bins: every thread owns FOUR CONSECUTIVE bins.  The statistics are loaded once (all loads in flight
+// together), the first-pass status lives in LDS, and the reverted list needs two block scans in all.  This kernel sits on
+// the main stream's dependency chain, where the general variant's nine dependent rounds of global accesses cost 20 us.
+static constexpr int SRT_KPT = 4;
+__global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict__ mcnt, const float *__restrict__ mmin,
+                                                const float *__restrict__ mmax, const uint32_t *__restrict__ ccnt,
+                                                const float *__restrict__ cmin, const float *__restrict__ cmax, uint8_t *__restrict__ st1,
+                                                uint8_t *__restrict__ status, uint8_t *__restrict__ action, uint32_t *__restrict__ rev_idx,
+                                                uint32_t *__restrict__ rev_list, uint32_t *__restrict__ vox_off, DevState *st) {
+    __shared__ uint32_t sm[40];
+    __shared__ uint8_t s_st1[1024 * SRT_KPT];
+    const int B = P.B;
+    const int k0 = threadIdx.x * SRT_KPT;
+    BinStat bs[SRT_KPT];
+#pragma unroll
+    for (int j = 0; j < SRT_KPT; ++j)
+        if (k0 + j < B) bs[j] = srt_load(k0 + j, mcnt, mmin, mmax, ccnt, cmin, cmax);
+#pragma unroll
+    for (int j = 0; j < SRT_KPT; ++j)
+        if (k0 + j < B) {
+            const uint8_t s = srt_first(P, bs[j]);
+            s_st1[k0 + j] = s;
+            st1[k0 + j] = s;
+        }
+    __syncthreads();
+    uint8_t act[SRT_KPT];
+    uint32_t nrv = 0, ncap = 0;
+#pragma unroll
+    for (int j = 0; j < SRT_KPT; ++j) {
+        act[j] = 0;
+        if (k0 + j < B) {
+            uint8_t fs;
+            srt_second(P, k0 + j, bs[j], s_st1[k0 + j], (const uint8_t *)s_st1, fs, act[j]);
+            status[k0 + j] = fs;
+            action[k0 + j] = act[j];
+            if (act[j] == 1) {
+                ++nrv;
+                ncap += bs[j].mc + bs[j].cc;
+            }
+        }
+    }
+    uint32_t t0, t1;
+    uint32_t p0 = block_excl_scan(nrv, sm, t0);
+    uint32_t p1 = block_excl_scan(ncap, sm, t1);
+#pragma unroll
+    for (int j = 0; j < SRT_KPT; ++j)
+        if (k0 + j < B) {
+            const bool rv = act[j] == 1;
+            rev_idx[k0 + j] = rv ? p0 : 0xFFFFFFFFu;
+            if (rv) {
+                rev_list[p0] = (uint32_t)(k0 + j);
+                vox_off[p0] = p1;
+                ++p0;
+                p1 += bs[j].mc + bs[j].cc;
+            }
+        }
+    if (threadIdx.x == 0) {
+        st->n_rev = t0;
+        st->vox_scratch_total = t1;
     }
 }
 
@@ -2253,6 +2335,79 @@ __global__ __launch_bounds__(1024) void k_layout(DP P, const uint8_t *__restrict
         st->n_static_est = carry[0] + carry[1];
         st->n_compl = ncompl;
         st->nF_new = carry[0] + carry[1] + ncompl;
+    }
+}
+
+// Up to 4096 bins: four consecutive bins per thread, four block scans in all (see k_srt4)
+__global__ __launch_bounds__(1024) void k_layout4(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
+                                                   const uint32_t *__restrict__ mcnt, const uint32_t *__restrict__ ccnt,
+                                                   const uint32_t *__restrict__ moff, const uint32_t *__restrict__ nvox,
+                                                   const uint32_t *__restrict__ ng_arr, uint32_t *__restrict__ out_off,
+                                                   uint32_t *__restrict__ ground_off, uint32_t *__restrict__ rej_off,
+                                                   uint32_t *__restrict__ crej_off, DevState *st) {
+    __shared__ uint32_t sm[40];
+    const int B = P.B;
+    const int k0 = threadIdx.x * SRT_KPT;
+    uint8_t act[SRT_KPT];
+    uint32_t rk[SRT_KPT], sz[SRT_KPT], g[SRT_KPT], rj[SRT_KPT], cr[SRT_KPT];
+    uint32_t ssz = 0, sg = 0, srj = 0, scr = 0;
+#pragma unroll
+    for (int j = 0; j < SRT_KPT; ++j) {
+        act[j] = 0;
+        rk[j] = 0;
+        sz[j] = g[j] = rj[j] = cr[j] = 0;
+        if (k0 + j < B) {
+            const int key = k0 + j;
+            act[j] = action[key];
+            const uint32_t mc = mcnt[key], cc = ccnt[key];
+            if (act[j] == 1) {
+                rk[j] = rev_idx[key];
+                g[j] = ng_arr[rk[j]];
+                rj[j] = mc - g[j];
+                if (P.version == 3) sz[j] = cc > 0 ? nvox[rk[j]] : 0u;
+                else sz[j] = cc > 0 ? (cc + g[j]) : 0u;  // v2: curr points then ground, no voxelisation (erasor.cpp:384-392)
+            } else if (act[j] == 2) {
+                sz[j] = cc + mc;  // merge_bins: curr then map (erasor.cpp:296-307)
+            } else if (act[j] == 3) {
+                sz[j] = cc;
+            } else {
+                sz[j] = mc;
+                if (act[j] == 4) cr[j] = cc;
+            }
+            ssz += sz[j];
+            sg += g[j];
+            srj += rj[j];
+            scr += cr[j];
+        }
+    }
+    uint32_t t0, t1, t2, t3;
+    uint32_t p0 = block_excl_scan(ssz, sm, t0);
+    uint32_t p1 = block_excl_scan(sg, sm, t1);
+    uint32_t p2 = block_excl_scan(srj, sm, t2);
+    uint32_t p3 = block_excl_scan(scr, sm, t3);
+#pragma unroll
+    for (int j = 0; j < SRT_KPT; ++j)
+        if (k0 + j < B) {
+            out_off[k0 + j] = p0;
+            crej_off[k0 + j] = p3;
+            if (act[j] == 1) {
+                ground_off[rk[j]] = p1;  // relative to total_bins
+                rej_off[rk[j]] = p2;
+            }
+            p0 += sz[j];
+            p1 += g[j];
+            p2 += rj[j];
+            p3 += cr[j];
+        }
+    if (threadIdx.x == 0) {
+        const uint32_t ncompl = moff[B + 1] - moff[B];
+        st->total_bins = t0;
+        st->n_ground = t1;
+        st->n_rejected = t2;
+        st->n_curr_rejected = t3;
+        st->n_static_est = t0 + t1;
+        st->n_compl = ncompl;
+        st->nF_new = t0 + t1 + ncompl;
     }
 }
 
