@@ -1126,6 +1126,10 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
             h->err = "exact-sort segment queue overflow (site " + std::to_string(h->ctr.sort_qoverflow) + ")";
             return ERASOR_E_INTERNAL;
         }
+        if (h->ctr.err == 3) {
+            h->err = "non-finite coordinate (NaN / Inf) in the scan";
+            return ERASOR_E_INVALID;
+        }
         h->err = h->ctr.err == 2 ? "VoxelGrid index overflow on the query scan (reference returns the input unvoxelised): not supported on device"
                                  : "per-bin VoxelGrid index overflow (unsupported on device)";
         return ERASOR_E_UNSUPPORTED;
@@ -1376,6 +1380,10 @@ static int voxelize_device(erasor_hip_handle *h, const float4 *d_src, uint32_t n
     HIPC(h, hipMemcpyAsync(&g, Q(h).qgrid.p, sizeof(g), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     if (ns && g.overflow) {
+        if (g.overflow == 2) {
+            h->err = "non-finite coordinate (NaN / Inf) in the cloud";
+            return ERASOR_E_INVALID;
+        }
         h->err = "VoxelGrid index overflow (reference returns the input unvoxelised): not supported on device";
         return ERASOR_E_UNSUPPORTED;
     }

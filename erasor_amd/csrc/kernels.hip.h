@@ -950,13 +950,20 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4 *__restrict__ p
     for (uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x; sl < hsize; sl += gridDim.x * blockDim.x) hkey[sl] = 0xFFFFFFFFu;
     const float mn[3] = {fkey_inv(bb[0]), fkey_inv(bb[1]), fkey_inv(bb[2])};
     const float mx[3] = {fkey_inv(bb[3]), fkey_inv(bb[4]), fkey_inv(bb[5])};
-    const VoxGrid g = vox_grid_from_bbox(mn, mx, leaf);
+    VoxGrid g = vox_grid_from_bbox(mn, mx, leaf);
+    // A NaN / Inf coordinate anywhere in the cloud shows up in its bounding box (NaN keys order beyond +-Inf).  PCL would
+    // drop such points only for clouds flagged !is_dense; here the cloud is refused -- with garbage voxel indices the
+    // neighbour search below has no bound on its shells.
+    bool finite = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) finite = finite && isfinite(mn[a]) && isfinite(mx[a]);
+    if (n && !finite) g.overflow = 2;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         *gout = g;
         if (g.overflow && n) {
             atomicAdd(&ctr->n_voxel_overflow, 1u);
-            ctr->err = 2;  // VoxelGrid pass-through (reference returns the input unvoxelised): unsupported on device
+            ctr->err = g.overflow == 2 ? 3 : 2;  // 2: VoxelGrid pass-through (reference returns the input unvoxelised); 3: non-finite input
         }
     }
     if (i >= n) return;
@@ -1492,6 +1499,7 @@ __global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts
     const uint32_t nv = *nv_dev;
     if (v >= nv) return;  // the eight lanes of a voxel leave together
     const VoxGrid g = *gp;
+    if (g.overflow) return;  // the cloud was refused (k_voxel_keys): the step fails, nothing downstream is used
     const float4 c = cent[v];
     const uint32_t key = ukeys[v];
     const int dx = g.div_b[0], dy = g.div_b[1], dz = g.div_b[2];

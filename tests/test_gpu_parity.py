@@ -368,6 +368,31 @@ def test_api_error_behaviour(gpu_mod):
         gpu_mod.Erasor(p)
 
 
+def test_non_finite_scan_is_refused_and_leaves_the_map_alone(gpu_mod):
+    """A NaN / Inf coordinate makes the VoxelGrid geometry meaningless: the step (and the standalone voxelisation) fail
+    with ERASOR_E_INVALID, the map is untouched, and the sequence carries on bit-exactly afterwards."""
+    sc = scenarios.small()
+    g, o = make_pair(gpu_mod, sc["params"])
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    ro = o.step(sc["scans"][0], sc["T_l2b"], sc["T_b2o"][0], sc["T_o2b"][0])
+    rg = g.step(sc["scans"][0], sc["T_l2b"], sc["T_b2o"][0], sc["T_o2b"][0])
+    compare_step(g, o, rg, ro, full=False)
+    for bad_value, col in ((np.nan, 1), (np.inf, 0), (-np.inf, 2)):
+        bad = np.array(sc["scans"][1], np.float32)
+        bad[len(bad) // 3, col] = bad_value
+        with pytest.raises(gpu_mod.ErasorError) as e:
+            g.step(bad, sc["T_l2b"], sc["T_b2o"][1], sc["T_o2b"][1])
+        assert e.value.rc == -1
+        with pytest.raises(gpu_mod.ErasorError) as e:
+            g.voxelize_preserving_labels(bad, 0.2)
+        assert e.value.rc == -1
+        same(g.get_map(), o.get_map(), "map after a refused scan")
+    ro = o.step(sc["scans"][1], sc["T_l2b"], sc["T_b2o"][1], sc["T_o2b"][1])
+    rg = g.step(sc["scans"][1], sc["T_l2b"], sc["T_b2o"][1], sc["T_o2b"][1])
+    compare_step(g, o, rg, ro, full=True)
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json sizes: ~10 M-pt map, 120 k-pt scans, 20 x 108 bins
 # ---------------------------------------------------------------------------------------------
