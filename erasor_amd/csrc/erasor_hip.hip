@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <functional>
 #include <cmath>
@@ -103,6 +104,7 @@ struct erasor_hip_handle {
     uint64_t mg_cnt_voxel = 0, mg_accum = 0;
     DBuf<uint32_t> mb_hist, mb_tot;   // the map's bucketing as a counting sort: [tiles][B + 1] table, [B + 1] totals
     DBuf<unsigned long long> lab_slots;  // [16][8] label tallies of the assemble kernels (one cache line per slot)
+    unsigned long long step_seq = 0;  // steps issued so far (k_step_end echoes it into the pinned block)
     HostOut *pin = nullptr;         // pinned host block k_step_end reports into
     int bank = 0;                   // scratch bank of scan/radix helpers (0: query chains, 1: map chain)
     std::string err;
@@ -616,6 +618,7 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
         delete h;
         return ERASOR_E_NO_DEVICE;
     }
+    memset(h->pin, 0, sizeof(HostOut));
     h->cur = h->stream;
     if (alloc_bins(h)) {
         erasor_hip_destroy(h);
@@ -1080,8 +1083,9 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
            (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
            (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, Fnew, h->curr_rejected.p, h->lab_slots.p);
     // (label counters of the new VoI-resident region are accumulated by the two assemble kernels)
+    const unsigned long long step_seq = ++h->step_seq;
     LAUNCH(h, "step_end", k_step_end, 1, 1, ds, dc, h->pin, (const unsigned long long *)h->lab_slots.p, (const Counters *)Q(h).d_qctr.p,
-           (const uint32_t *)Q(h).d_nvox.p);
+           (const uint32_t *)Q(h).d_nvox.p, step_seq);
     {   // the NEXT scan's query chain goes into its queue now, behind this step's own launches; it runs while we wait
         const int keep_side = h->qi;
         const int rc_next = flush_announced(h);
@@ -1092,7 +1096,21 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         }
     }
     const auto t_host1 = std::chrono::steady_clock::now();
-    HIPC(h, hipStreamSynchronize(h->stream));
+    {   // k_step_end's last store into the pinned block is the step's number: poll it (a blocking stream wait wakes up tens
+        // of microseconds late, a visible share of a 0.35 ms step), then fall back to the stream wait
+        static const bool no_spin = getenv("ERASOR_HIP_NO_SPIN") != nullptr;
+        volatile unsigned long long *seq = &h->pin->seq;
+        if (!no_spin && !g_debug_sync) {
+            const auto t_spin = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (*seq != step_seq) {
+                __builtin_ia32_pause();
+                if ((++spins & 0x3FFu) == 0 && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(20)) break;
+            }
+        }
+        if (*seq != step_seq) HIPC(h, hipStreamSynchronize(h->stream));
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     h->st = h->pin->st;
     h->ctr = h->pin->ctr;
     if (host_timing) {

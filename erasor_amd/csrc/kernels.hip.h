@@ -2571,6 +2571,7 @@ __global__ void k_null() {}
 struct HostOut {
     DevState st;
     Counters ctr;
+    unsigned long long seq;  // number of the step these results belong to: written last, the host polls it
 };
 
 // start of a scan's query chain (its own stream): counters, bounding box, bucket totals, voxel count of this query side
@@ -2586,7 +2587,7 @@ __global__ void k_query_begin(Counters *qctr, uint32_t *bb, uint32_t *qb_tot, ui
 }
 // end of a step: fold in the query side's counters and voxel count, commit the map sizes, report to the pinned host block
 __global__ void k_step_end(DevState *st, Counters *ctr, HostOut *out, const unsigned long long *lab_slots, const Counters *qctr,
-                           const uint32_t *q_nvox) {
+                           const uint32_t *q_nvox, unsigned long long seq) {
     if (lab_slots) {
         unsigned long long ns = 0, nd = 0;
         for (int i = 0; i < 16; ++i) {
@@ -2611,6 +2612,8 @@ __global__ void k_step_end(DevState *st, Counters *ctr, HostOut *out, const unsi
     if (out) {
         out->st = *st;
         out->ctr = *ctr;
+        __threadfence_system();
+        *(volatile unsigned long long *)&out->seq = seq;
     }
 }
 
