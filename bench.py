@@ -150,14 +150,10 @@ def main():
     value = world_size * K / elapsed
     ms_per_step = elapsed / K * 1e3
     # ---- roofline of the dominant kernel (voi_split): bytes its layout must stream per launch / measured launch time ----
+    # k_voi_split is launched with its own start / stop HIP events (hipExtLaunchKernelGGL) on the handle's stream during the
+    # timed region: they stamp the kernel's execution window, which is also what rocprofv3 reports (profiles/).
     vs_ms, vs_n = prof.get("voi_split", (0.0, 0))
-    cal_ms, cal_n = prof.get("voi_split_event_calib", (0.0, 0))
-    raw_ms = vs_ms / max(vs_n, 1)
-    # The HIP-event bracket also times its own record/dispatch overhead: an EMPTY kernel bracketed the same way right
-    # before k_voi_split reads `empty_bracket_us`.  Subtracting it over-corrects (it contains the empty kernel's own
-    # dispatch), so the roofline uses the RAW bracket (conservative); rocprofv3's kernel-only average is in profiles/.
-    ovh_ms = cal_ms / max(cal_n, 1)
-    avg_ms = raw_ms
+    avg_ms = vs_ms / max(vs_n, 1)
     alg_bytes = float(np.mean([b for b, _ in split_bytes]))
     entries = float(np.mean([e for _, e in split_bytes]))
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -179,7 +175,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_voi_split", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "bytes_per_launch": int(alg_bytes),
                 "entries_per_launch": int(entries), "avg_launch_us": round(avg_ms * 1e3, 2),
-                "empty_bracket_us": round(ovh_ms * 1e3, 2), "rocprofv3_kernel_avg_us": rocprof_avg,
+                "rocprofv3_kernel_avg_us": rocprof_avg,
                 "launches": int(vs_n),
                 "aos16_equiv_GBps": round(16.0 * entries / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0}
 
