@@ -221,7 +221,8 @@ int erasor_hip_count_static_dynamic(erasor_hip_handle *h, uint64_t *n_static, ui
 /* ---- measurement hooks (no reference counterpart) ------------------------ */
 /* When enabled, every kernel launch of a step is bracketed by HIP events on the
  * handle's stream; totals are accumulated per kernel name. */
-/* enable: 0 off, 1 every kernel, 2 only the HBM-roofline kernel (voi_split) */
+/* enable: 0 off, 1 every kernel, 2 only the HBM-roofline kernel (voi_split), timed by start / stop events attached
+ * to its launch (hipExtLaunchKernelGGL): the kernel's own execution window, without perturbing the step */
 int erasor_hip_profiling(erasor_hip_handle *h, int enable);
 int erasor_hip_profile_reset(erasor_hip_handle *h);
 /* returns number of distinct kernels; fills up to cap entries */
