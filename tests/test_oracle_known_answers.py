@@ -397,3 +397,55 @@ def test_large_scale_submap_semantics():
             break
     assert moved > 12.5, "scenario does not travel far enough to re-centre the submap"
     assert r.n_static + r.n_dynamic == r.n_map_out                   # counters are over the submap only
+
+
+# ---------------------------------------------------------------------------------------------
+# mapgen restatement (oracle/orc.py:Mapgen, src/mapgen/mapgen.hpp:198-305)
+# ---------------------------------------------------------------------------------------------
+def test_mapgen_self_filter_boundary_and_transform_order():
+    """mapgen.hpp:219-228: a point is dropped iff pow(x,2)+pow(y,2) (double) < (float)pow(2.7,2); z is ignored.
+    :231-237: lidar->origin-of-body (z + 1.73) THEN the pose."""
+    thr = float(np.float32(2.7 ** 2))  # 7.28999996185302734375
+    inside = np.float32(np.sqrt(thr) * (1 - 1e-6))
+    outside = np.float32(np.sqrt(thr) * (1 + 1e-6))
+    scan = np.array([[inside, 0, 50, 1], [0, inside, -50, 2], [outside, 0, 0, 3], [0, -outside, 0, 4], [2.0, 2.0, 0, 5],  # 8 >= thr: kept
+                     [1.9, 1.9, 0, 6]], np.float32)                                                                      # 7.22 < thr: dropped
+    assert float(inside) ** 2 < thr <= float(outside) ** 2
+    T = orc.geopose2eigen([10.0, -5.0, 0.5, 0, 0, 0.7071068, 0.7071068])  # yaw +90 deg
+    g = orc.Mapgen(0.2)
+    n = g.accum(scan, np.asarray(T, np.float32).reshape(4, 4))
+    kept = g.cloud_curr[np.argsort(g.cloud_curr[:, 3])]
+    assert n == 3 and kept[:, 3].tolist() == [3.0, 4.0, 5.0]
+    # label 3: (outside, 0, 0) -> z + 1.73 -> rotate +90 deg about z (x -> y), then translate
+    assert np.allclose(kept[0, :3], [10.0, -5.0 + float(outside), 0.5 + 1.73], atol=1e-5)
+    assert np.allclose(kept[2, :3], [10.0 - 2.0, -5.0 + 2.0, 0.5 + 1.73], atol=1e-5)
+
+
+def test_mapgen_large_scale_submap_counter():
+    """mapgen.hpp:241-256: the first scan initialises the map; from the second on `cnt_voxel++ % 500 == 0` closes a submap,
+    i.e. right at the second scan and then every 500 accumulated scans; saveNaiveMap concatenates submaps + remainder."""
+    rng = np.random.default_rng(0)
+    I = np.eye(4, dtype=np.float32)
+    g = orc.Mapgen(0.5, is_large_scale=True)
+    scans = []
+    for k in range(4):
+        s = np.zeros((200, 4), np.float32)
+        s[:, :2] = rng.uniform(5, 30, (200, 2))
+        s[:, 2] = rng.uniform(-1, 1, 200)
+        s[:, 3] = 40 + k
+        scans.append(s)
+        g.accum(s, I)
+        if k == 0:
+            assert len(g.cloud_maps) == 0 and len(g.cloud_map) == len(g.cloud_curr)
+        elif k == 1:
+            assert len(g.cloud_maps) == 1 and len(g.cloud_map) == 0   # cnt_voxel == 0: re-voxelised at leafsize, pushed, cleared
+        else:
+            assert len(g.cloud_maps) == 1 and len(g.cloud_map) > 0
+    first_two = np.concatenate([orc.voxelize_preserving_labels(orc.transform(orc.transform(s, np.array(
+        [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 1.73], [0, 0, 0, 1]], np.float32)), I), 0.2) for s in scans[:2]])
+    assert np.array_equal(g.cloud_maps[0], orc.voxelize_preserving_labels(first_two, 0.5))
+    assert len(g.naive_map()) == len(g.cloud_maps[0]) + len(g.cloud_map)
+    small = orc.Mapgen(0.5, is_large_scale=False)
+    for s in scans:
+        small.accum(s, I)
+    assert len(small.cloud_maps) == 0 and small.accum_count == 3 and len(small.save()) <= len(small.cloud_map)
