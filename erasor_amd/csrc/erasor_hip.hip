@@ -1068,12 +1068,12 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
            (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
     LAUNCH(h, "rgpf", k_rgpf, B, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->moff.p,
            (const float4 *)h->spts.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p, h->gflag.p, h->grank.p, h->glist.p,
-           h->ng.p, h->plane_n.p, h->plane_d.p, dc);
+           h->ng.p, h->plane_n.p, h->plane_d.p, dc, h->dbg_stamps.p);
     if (P.version == 3)
         LAUNCH(h, "bin_voxelize", k_binvox, B, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->moff.p,
                (const float4 *)h->spts.p, (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->glist.p,
                (const uint32_t *)h->ng.p, (const uint32_t *)h->vox_off.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p,
-               h->gsC.p, h->vox_out.p, h->nvox.p, dc);
+               h->gsC.p, h->vox_out.p, h->nvox.p, dc, h->dbg_stamps.p);
     if (B <= 1024 * SRT_KPT)
         LAUNCH(h, "layout", k_layout4, 1, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->mcnt.p,
            (const uint32_t *)Q(h).ccnt.p, (const uint32_t *)h->moff.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->ng.p, h->out_off.p,
@@ -1138,6 +1138,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         for (int i = 4; i < 15; ++i) fprintf(stderr, " %llu", t[i + 1] > t[i] ? t[i + 1] - t[i] : 0ull);
         fprintf(stderr, "; kernel span: first start -> last working end %.1f us, -> last end %.1f us; long segments left for the global path: %llu (longest %llu)\n",
                 (double)(t[26] - t[28]) / 100.0, (double)(t[27] - t[28]) / 100.0, t[25], t[24]);
+        fprintf(stderr, "[slowest reverted bin] R-GPF: %llu points, z-sort %.1f us + rest %.1f us; per-bin voxelisation: %llu points -> %llu voxels, %.1f us\n",
+                t[19], (double)t[17] / 100.0, (double)t[18] / 100.0, t[21], t[22], (double)t[20] / 100.0);
         memset(t, 0, sizeof(t));
         t[28] = ~0ull;
         (void)hipMemcpy(h->dbg_stamps.p, t, sizeof(t), hipMemcpyHostToDevice);

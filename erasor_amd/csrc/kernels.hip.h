@@ -2087,7 +2087,7 @@ __global__ __launch_bounds__(1024) void k_rgpf(DP P, const uint8_t *__restrict__
                                                uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
                                                uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
                                                uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
-                                               Counters *ctr) {
+                                               Counters *ctr, unsigned long long *dbg) {
     __shared__ uint32_t sK[RG_LMAX], sV[RG_LMAX], sL[RG_LMAX], sR[RG_LMAX];
     __shared__ uint32_t sH[RG_LMAX / 32 + 2];
     __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
@@ -2110,9 +2110,19 @@ __global__ __launch_bounds__(1024) void k_rgpf(DP P, const uint8_t *__restrict__
             sV[i] = i;
         }
         __syncthreads();
+        const unsigned long long t_a = dbg ? wall_clock64() : 0ull;
         esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
                            &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+        const unsigned long long t_b = dbg ? wall_clock64() : 0ull;
         rgpf_after_sort(P, pts, M, o0, rk, sR, sK, sm, sProd, s_n, &s_th, &s_lpr, &s_carry, gflag, grank, glist_out, ng_out, plane_n, plane_d, ctr);
+        if (dbg && tid == 0) {  // diagnostics (ERASOR_HIP_SORT_STAMPS): the slowest bin's split between the z-sort and the rest, 10 ns ticks
+            const unsigned long long t_c = wall_clock64();
+            if (atomicMax(&dbg[16], t_c - t_a) < t_c - t_a) {
+                dbg[17] = t_b - t_a;
+                dbg[18] = t_c - t_b;
+                dbg[19] = M;
+            }
+        }
     } else {
         uint32_t *K = gsK + o0, *V = gsV + o0;
         for (uint32_t i = tid; i < M; i += bs) {
@@ -2160,10 +2170,18 @@ __device__ __forceinline__ void binvox_core(const DP &P, uint32_t m, uint32_t nc
                 mx[a] = k3[a] > mx[a] ? k3[a] : mx[a];
             }
         }
+        // wavefront reduction first: one LDS atomic per wavefront and extreme (1024 threads hitting six LDS words serialise)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&sbb[a], mn[a]);
-            atomicMax(&sbb[3 + a], mx[a]);
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t t0 = __shfl_down(mn[a], o, 64), t1 = __shfl_down(mx[a], o, 64);
+                mn[a] = t0 < mn[a] ? t0 : mn[a];
+                mx[a] = t1 > mx[a] ? t1 : mx[a];
+            }
+            if ((tid & 63u) == 0) {
+                atomicMin(&sbb[a], mn[a]);
+                atomicMax(&sbb[3 + a], mx[a]);
+            }
         }
     }
     __syncthreads();
@@ -2225,11 +2243,16 @@ __device__ __forceinline__ void binvox_core(const DP &P, uint32_t m, uint32_t nc
     __threadfence_block();
     __syncthreads();
     // phase B: exact 1-NN of every centroid over all inputs of this call (lowest index on float ties)
-    for (uint32_t v = tid; v < nv; v += bs) {
+    // (a few hundred voxels against ~1000 points: up to eight lanes share a voxel's candidate list, merged by (distance, index))
+    uint32_t S = 1;
+    while (S < 8 && (uint64_t)nv * S * 2 <= bs) S <<= 1;
+    for (uint32_t v0 = 0; v0 < nv; v0 += bs / S) {
+        const uint32_t v = v0 + tid / S, part = tid % S;
+        if (v >= nv) continue;  // (all S lanes of a voxel take the same branch)
         const float cx = __uint_as_float(K[v]), cy = __uint_as_float(V[v]), cz = vout[v].z;
         float best = __int_as_float(0x7F800000);
-        uint32_t best_j = 0;
-        for (uint32_t j = 0; j < m; ++j) {
+        uint32_t best_j = 0xFFFFFFFFu;
+        for (uint32_t j = part; j < m; j += S) {
             const float4 p = C[j];
             const float dd = l2_simple(cx, cy, cz, p.x, p.y, p.z);
             if (dd < best) {
@@ -2237,8 +2260,18 @@ __device__ __forceinline__ void binvox_core(const DP &P, uint32_t m, uint32_t nc
                 best_j = j;
             }
         }
-        const float4 pb = C[best_j];
-        vout[v] = make_float4(cx, cy, cz, pb.w);
+        for (uint32_t o = S >> 1; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, (int)o, 64);
+            const uint32_t oj = __shfl_xor(best_j, (int)o, 64);
+            if (ob < best || (ob == best && oj < best_j)) {
+                best = ob;
+                best_j = oj;
+            }
+        }
+        if (part == 0) {
+            const float4 pb = C[best_j < m ? best_j : 0u];
+            vout[v] = make_float4(cx, cy, cz, pb.w);
+        }
     }
     if (tid == 0) *nvox_slot = nv;
 }
@@ -2249,7 +2282,8 @@ __global__ __launch_bounds__(1024) void k_binvox(DP P, const uint8_t *__restrict
                                                  const uint32_t *__restrict__ glist, const uint32_t *__restrict__ ng_arr,
                                                  const uint32_t *__restrict__ vox_off, uint32_t *gsK, uint32_t *gsV, uint32_t *gsL,
                                                  uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
-                                                 float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr) {
+                                                 float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr,
+                                                 unsigned long long *dbg) {
     __shared__ uint32_t sK[BV_LMAX], sV[BV_LMAX], sL[BV_LMAX], sR[BV_LMAX];
     __shared__ uint32_t sH[BV_LMAX / 32 + 2];
     __shared__ float4 sC[BV_LMAX];
@@ -2269,12 +2303,20 @@ __global__ __launch_bounds__(1024) void k_binvox(DP P, const uint8_t *__restrict
         return;
     }
     const uint32_t vo = vox_off[rk];
+    const unsigned long long t_a = dbg ? wall_clock64() : 0ull;
     if (m <= BV_LMAX)
         binvox_core(P, m, nc, sq + qo, spts + mo, glist + mo, sK, sV, sL, sR, sC, sL, sR, sH, qa, qb, qcnt, sm, sbb, &s_carry, vox_out + vo,
                     nvox_out + rk, ctr);
     else
         binvox_core(P, m, nc, sq + qo, spts + mo, glist + mo, gsK + vo, gsV + vo, gsK2 + vo, gsV2 + vo, gsC + vo, gsL + vo, gsR + vo, gsH + (vo >> 5) + 2 * rk, qa, qb,
                     qcnt, sm, sbb, &s_carry, vox_out + vo, nvox_out + rk, ctr);
+    if (dbg && threadIdx.x == 0) {
+        const unsigned long long t_c = wall_clock64();
+        if (atomicMax(&dbg[20], t_c - t_a) < t_c - t_a) {
+            dbg[21] = m;
+            dbg[22] = nvox_out[rk];
+        }
+    }
 }
 
 // ================================================================================================
