@@ -223,8 +223,16 @@ int prof_id(erasor_hip_handle *h, const char *name) {
     h->prof_ids[name] = id;
     return id;
 }
-void prof_collect(erasor_hip_handle *h) {
+// fold finished event pairs into the per-name totals.  Pairs of launches that are still in flight (query chains of scans
+// announced ahead) stay pending; `force` waits for them (profile_get / reset, after the streams were synchronised).
+void prof_collect(erasor_hip_handle *h, bool force = false) {
+    if (!force && h->pending.size() < 256) return;  // (not on every step: an elapsed-time query costs microseconds)
+    std::vector<PendingEvt> keep;
     for (auto &p : h->pending) {
+        if (!force && hipEventQuery(p.b) == hipErrorNotReady) {
+            keep.push_back(p);
+            continue;
+        }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             h->prof_tab[p.name_id].ms += ms;
@@ -233,7 +241,7 @@ void prof_collect(erasor_hip_handle *h) {
         h->evt_pool.push_back(p.a);
         h->evt_pool.push_back(p.b);
     }
-    h->pending.clear();
+    h->pending.swap(keep);
 }
 
 // kernel launch with optional event bracketing on the handle's stream
@@ -635,7 +643,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     for (int k = 0; k < 2; ++k)
         if (h->qstream[k]) (void)hipStreamSynchronize(h->qstream[k]);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    prof_collect(h);
+    prof_collect(h, true);
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
     for (h->qi = 0; h->qi < NSIDE; ++h->qi) {  // every query side
         release(Q(h).d_nvox); release(Q(h).d_qctr); release(Q(h).qb_hist); release(Q(h).qb_tot); release(Q(h).hkey); release(Q(h).hval); release(Q(h).qoff); release(Q(h).ccnt); release(Q(h).cmin); release(Q(h).cmax); release(Q(h).scan); release(Q(h).cent); release(Q(h).query); release(Q(h).sq); release(Q(h).bb); release(Q(h).qk_a); release(Q(h).qk_b); release(Q(h).qv_a); release(Q(h).qv_b); release(Q(h).qposL); release(Q(h).qposR); release(Q(h).qflag); release(Q(h).qpl); release(Q(h).qtops); release(Q(h).run_begin); release(Q(h).ukeys); release(Q(h).qkey); release(Q(h).qhead); release(Q(h).wseg0); release(Q(h).wseg1); release(Q(h).wstate); release(Q(h).wtileL); release(Q(h).wtileR); release(Q(h).esq0); release(Q(h).esq1); release(Q(h).esq2); release(Q(h).essmall); release(Q(h).esqs); release(Q(h).qgrid);
@@ -1611,14 +1619,16 @@ int erasor_hip_profiling(erasor_hip_handle *h, int enable) {
 int erasor_hip_profile_reset(erasor_hip_handle *h) {
     if (!h) return ERASOR_E_INVALID;
     (void)hipStreamSynchronize(h->stream);
-    prof_collect(h);
+    for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(h->qstream[k]);
+    prof_collect(h, true);
     for (auto &e : h->prof_tab) e = ProfEntry();
     return ERASOR_OK;
 }
 int erasor_hip_profile_get(erasor_hip_handle *h, const char **names, double *total_ms, uint64_t *launches, size_t cap, size_t *n) {
     if (!h) return ERASOR_E_INVALID;
     (void)hipStreamSynchronize(h->stream);
-    prof_collect(h);
+    for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(h->qstream[k]);
+    prof_collect(h, true);
     const size_t cnt = h->prof_names.size();
     if (n) *n = cnt;
     for (size_t k = 0; k < cnt && k < cap; ++k) {
