@@ -1,0 +1,32 @@
+# oracle/ref.mk — builds oracle/_ref/liberasor_ref.so: the reference's OWN hot-path sources, compiled
+# UNMODIFIED from where they lie under /root/reference, against the stand-in headers in oracle/stubs/
+# (ros / pcl / Eigen / tf are not installed; their arithmetic delegates to oracle/third_party_restated.h).
+# TEST INFRASTRUCTURE ONLY: tests/test_oracle_vs_ref.py pins oracle/erasor_oracle.cpp to this library,
+# bench.py's cpu_baseline may time it (kind "reference").  Outputs go to oracle/_ref/ only (git-ignored,
+# travels to the GPU box as a prebuilt file; /root/reference does not exist there).
+# Flags follow the reference's build: no -march (CMakeLists.txt:4), so no FMA contraction.
+REF      ?= /root/reference
+CXX      ?= g++
+CXXFLAGS ?= -O2 -std=c++17 -ffp-contract=off -fPIC -w
+INC       = -I$(REF)/include -I$(REF)/src/mapgen -Istubs
+OUT       = _ref
+REFSRC    = $(REF)/src/offline_map_updater/src
+OBJS      = $(OUT)/erasor.o $(OUT)/erasor_utils.o $(OUT)/OfflineMapUpdater.o $(OUT)/ref_driver.o
+STUBS     = stubs/ref_stubs.h third_party_restated.h
+
+all: $(OUT)/liberasor_ref.so
+
+$(OUT)/%.o: $(REFSRC)/%.cpp $(STUBS)
+	@mkdir -p $(OUT)
+	$(CXX) $(CXXFLAGS) $(INC) -c $< -o $@
+
+# the driver reads private members the reference only exposes through RViz topics
+$(OUT)/ref_driver.o: ref_driver.cpp $(STUBS) ../include/erasor_hip.h
+	@mkdir -p $(OUT)
+	$(CXX) $(CXXFLAGS) -fno-access-control $(INC) -c ref_driver.cpp -o $@
+
+$(OUT)/liberasor_ref.so: $(OBJS)
+	$(CXX) -shared -o $@ $(OBJS)
+
+clean:
+	rm -rf $(OUT)

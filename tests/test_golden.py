@@ -65,4 +65,76 @@ def test_hip_reproduces_golden(path):
 
 
 def test_fixtures_exist():
-    assert len(FIXTURES) >= 3
+    assert len(FIXTURES) >= 3 and len(REF_FIXTURES) >= 4
+
+
+# ---------------------------------------------------------------------------------------------
+# vectors produced by the reference itself (tests/golden/make_ref_golden.py -> oracle/_ref = the reference's
+# unmodified sources): every product of OfflineMapUpdater::callback_node, per step
+# ---------------------------------------------------------------------------------------------
+REF_FIXTURES = sorted(glob.glob(os.path.join(HERE, "golden", "ref_*.npz")))
+
+
+def replay_ref(engine, z, voxelize):
+    names = [str(s) for s in z["param_names"]]
+    R, S = int(z["params"][names.index("num_rings")]), int(z["params"][names.index("num_sectors")])
+    min_pts = int(z["params"][names.index("minimum_num_pts")])
+    engine.set_map(z["map0"])
+    for k in range(int(z["n_steps"])):
+        r = engine.step(z["scan%d" % k], z["T_l2b"], z["T_b2o%d" % k], z["T_o2b%d" % k])
+        for which, key in ((0, "query"), (2, "static_estimate"), (4, "map_rejected"), (5, "curr_rejected"), (6, "ground")):
+            got, want = engine.get_cloud(which), z["%s%d" % (key, k)]
+            assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, key)
+        st = engine.get_status()
+        order = np.arange(R * S).reshape(R, S).T.reshape(-1)  # the reference pushes polygons theta-major
+        cnt = {}
+        for which in (0, 1):
+            c, mn, mx = engine.get_bins(which)
+            cnt[which] = c
+            assert np.array_equal(c, z["bins%d_cnt%d" % (which, k)])
+            occ = c > 0
+            assert np.array_equal(mn[occ], z["bins%d_min%d" % (which, k)][occ]) and np.array_equal(mx[occ], z["bins%d_max%d" % (which, k)][occ])
+        if int(z["version"]) == 3:
+            assert np.array_equal(st, z["status%d" % k])
+            assert np.array_equal(z["likelihood%d" % k], st[order].astype(np.float32))
+        else:  # v2 only publishes the SRT outcome as polygon likelihoods (erasor.cpp:345-425)
+            pushed = (cnt[1] < min_pts) | ((cnt[1] > 0) & (cnt[0] > 0))
+            assert np.array_equal(z["likelihood%d" % k], st[order][pushed[order]].astype(np.float32))
+        _, n, d = engine.get_planes()
+        want_n = z["plane_n%d" % k]
+        # north_star: plane coefficients within 1e-5 — they are in fact bit-identical
+        assert n.reshape(-1, 3).shape == want_n.shape and np.allclose(n.reshape(-1, 3), want_n, atol=1e-5, rtol=0)
+        assert np.array_equal(bits(n.reshape(-1, 3)), bits(want_n))
+        if d.size:
+            assert abs(d.reshape(-1)[-1] - z["plane_last_d%d" % k][0]) <= 1e-5 and d.reshape(-1)[-1] == z["plane_last_d%d" % k][0]
+        assert (r.n_static, r.n_dynamic) == tuple(z["labels%d" % k].tolist())
+        assert r.n_map_rejected == len(z["map_rejected%d" % k]) and r.n_reverted_bins * 3 == len(want_n)
+    m = engine.get_map()
+    assert m.shape == z["map_final"].shape and np.array_equal(bits(m), bits(z["map_final"]))
+    saved = voxelize(m, 0.2)
+    assert saved.shape == z["saved_0_2"].shape and np.array_equal(bits(saved), bits(z["saved_0_2"]))
+
+
+def params_from(z, P):
+    p = P
+    for f, v in zip([str(s) for s in z["param_names"]], z["params"]):
+        cur = getattr(p, f)
+        setattr(p, f, int(v) if isinstance(cur, int) else float(v))
+    return p
+
+
+@pytest.mark.parametrize("path", REF_FIXTURES, ids=[os.path.basename(p) for p in REF_FIXTURES])
+def test_oracle_reproduces_reference_vectors(path):
+    from oracle import orc
+    z = np.load(path)
+    replay_ref(orc.Oracle(params_from(z, orc.params_default())), z, orc.voxelize_preserving_labels)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", REF_FIXTURES, ids=[os.path.basename(p) for p in REF_FIXTURES])
+def test_hip_reproduces_reference_vectors(path):
+    """data-only: nothing but the committed vectors and the C ABI"""
+    import erasor_amd
+    z = np.load(path)
+    e = erasor_amd.Erasor(params_from(z, erasor_amd.params_default()))
+    replay_ref(e, z, e.voxelize_preserving_labels)
