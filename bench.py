@@ -2,18 +2,33 @@
 """bench.py — ERASOR per-scan hot path on MI355X.
 
 A "step" is one pass of the hot path (query voxelise -> fetch_VoI -> R-POD -> Scan Ratio Test -> R-GPF ->
-map write-back; reference OfflineMapUpdater.cpp:237-294) over one synthetic 120 k-point scan against a
-~10 M-point map that is resident in HBM.  Inputs (map and scans) are in HBM before the timed region.
+map write-back; reference OfflineMapUpdater.cpp:237-294) over one synthetic scan against a map that is
+resident in HBM.  Inputs (map and scans) are in HBM before the timed region.
 
-  python bench.py --gpus N --steps K --warmup W
-N > 1: launched by torch.distributed.run, one rank per GPU.  Rank 0 builds the map and RCCL-broadcasts it
-(xGMI); every rank then processes its own scans against its own replica — no data-path collective, weak scaling.
+  python bench.py --gpus N --steps K --warmup W [--workload W] [--mode M]
 
-Prints ONE JSON line on rank 0 (see README/DESIGN.md for the roofline and cpu_baseline definitions).
+--gpus N > 1 without a torchrun environment re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU
+(backend "nccl" = RCCL).  It refuses to run with fewer than N devices.
+
+workloads (BASELINE.json configs):
+  seq05           config[1]: ~10 M-pt map, ~120 k-pt HDL-64 scans, R-POD 20 x 108 @ 80 m, seq_05.yaml thresholds  (default)
+  seq05_yaml      config[1] with config/seq_05.yaml's own geometry: 15 x 60 @ 60 m
+  large_scale_05  config[3]: config/large_scale_05.yaml, ~40 M-pt un-voxelised map (> the 256 MiB L3: fetch_VoI is truly HBM-bound)
+  ouster128       config[4]: config/your_own_env_ouster.yaml, 256 k-pt Ouster-128 scans, 20 x 60 @ 20 m
+modes:
+  replicas        rank 0 builds the map, ONE RCCL broadcast over xGMI, every rank processes its own shard of the scan
+                  stream against its replica, no data-path collective (weak scaling)                                 (default)
+  seq-per-gpu     config[2]: the five KITTI-shaped sequences 00/01/02/05/07 (config/seq_0X.yaml parameters), dealt
+                  round-robin over the ranks; every rank builds its own worlds, no map exchange
+Both modes end with one RCCL all_gather of per-rank result counters.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §6 for the roofline and cpu_baseline definitions).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -22,124 +37,295 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_HBM_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
 
-def build_workload(args, rank):
-    """KITTI-05-shaped synthetic world; ~10 M-pt map, 120 k-pt scans, 20 rings x 108 sectors."""
-    from erasor_amd import synth
-    w = synth.World(seed=20210305 + 5, length=args.street_length, n_streets=args.streets, street_gap=50.0, n_moving=10, n_peds=6)
-    lidar = synth.Lidar.hdl64(args.az_steps)
-    return w, lidar
-
-
-def make_params(args):
-    import erasor_amd
-    from erasor_amd import synth
-    p = erasor_amd.params_default()
-    synth.apply_params(p, "05")           # config/seq_05.yaml thresholds ...
-    p.max_range, p.num_rings, p.num_sectors = 80.0, 20, 108  # ... on BASELINE.json config[1]'s 20 x 108 R-POD (80 m, as in seq_00/07/large_scale YAMLs)
-    return p
+WORKLOADS = {
+    # name: (params preset, R-POD override, lidar, map spacing, streets, description)
+    "seq05": dict(seq="05", rpod=(80.0, 20, 108), lidar="hdl64", spacing=0.2, l2b_z=True,
+                  desc="KITTI-05-shaped synthetic street, R-POD 20 rings x 108 sectors @ 80 m, seq_05.yaml thresholds"),
+    "seq05_yaml": dict(seq="05", rpod=None, lidar="hdl64", spacing=0.2, l2b_z=True,
+                       desc="KITTI-05-shaped synthetic street, config/seq_05.yaml verbatim (15 x 60 @ 60 m)"),
+    "large_scale_05": dict(seq="large_scale_05", rpod=None, lidar="hdl64", spacing=0.1, l2b_z=True,
+                           desc="config/large_scale_05.yaml (20 x 108 @ 80 m), dense un-voxelised map"),
+    "ouster128": dict(seq="ouster", rpod=None, lidar="ouster128", spacing=0.2, l2b_z=False,
+                      desc="config/your_own_env_ouster.yaml (20 x 60 @ 20 m, lidar2body = identity), Ouster-128 256 k-pt scans"),
+}
+SEQS = ["00", "01", "02", "05", "07"]  # BASELINE config[2]
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="seq05")
+    ap.add_argument("--mode", choices=["replicas", "seq-per-gpu"], default="replicas")
+    ap.add_argument("--large-scale-mode", choices=["off", "on"], default="off",
+                    help="large_scale_05 only: is_large_scale with submap_size 160 (launch/run_erasor_in_large_scale.launch)")
     ap.add_argument("--streets", type=int, default=5)
     ap.add_argument("--street-length", type=float, default=1000.0)
-    ap.add_argument("--az-steps", type=int, default=2000)
+    ap.add_argument("--az-steps", type=int, default=0, help="0 = the sensor's own (2000 HDL-64, 2048 Ouster-128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="stop the CPU leg after this much CPU work")
     ap.add_argument("--profile-all", action="store_true", help="second pass with per-kernel HIP events (breakdown on stderr)")
     ap.add_argument("--lookahead", type=int, default=2, choices=[1, 2], help="scans announced ahead (erasor_hip_prefetch_scan)")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not announce the next scan (erasor_hip_prefetch_scan): every step runs its own query chain first")
-    args = ap.parse_args()
+    ap.add_argument("--eval", action="store_true", help="seq-per-gpu: PR/RR of every sequence's final map (erasor_amd.evalmap)")
+    return ap.parse_args()
 
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` must be an N-rank RCCL run by itself"""
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not os.environ.get("ERASOR_BENCH_ONE_DEVICE"):
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible — refusing to measure fewer ranks than asked" % (args.gpus, n_dev))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def host_identity():
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count()}
+
+
+def make_params(wl, args, seq=None):
+    import erasor_amd
+    from erasor_amd import synth
+    p = erasor_amd.params_default()
+    synth.apply_params(p, seq or wl["seq"])
+    if seq is None and wl["rpod"]:
+        p.max_range, p.num_rings, p.num_sectors = wl["rpod"]
+    if seq is None and wl["seq"] == "large_scale_05" and args.large_scale_mode == "on":
+        p.is_large_scale, p.submap_size = 1, 160.0
+    return p
+
+
+def make_lidar(wl, args):
+    from erasor_amd import synth
+    if wl["lidar"] == "ouster128":
+        return synth.Lidar.ouster128(args.az_steps or 2048)
+    return synth.Lidar.hdl64(args.az_steps or 2000)
+
+
+class Sequence:
+    """one map + its scan stream, resident on the device, with the look-ahead driver loop"""
+
+    def __init__(self, args, P, world, lidar, d_map, n_map, x0, n_frames, dev, device_index, l2b_z, seed):
+        import torch
+        import erasor_amd
+        from erasor_amd import synth
+        self.args, self.P, self.n_frames = args, P, n_frames
+        jr = np.random.default_rng(seed)
+        self.scans, self.Tb, self.To, self.poses = [], [], [], []
+        for k in range(n_frames):
+            p7 = world.pose(k, 1.0, x0=x0, jitter_rng=jr)
+            s = world.cast(p7, lidar, k)
+            if not l2b_z:  # sensors whose lidar2body is the identity: express the scan in the body frame (z up from the ground)
+                s = s.copy()
+                s[:, 2] += synth.LIDAR_HEIGHT
+            self.poses.append(p7)
+            self.scans.append(s)
+            tb = erasor_amd.geopose2eigen(p7)
+            self.Tb.append(tb)
+            self.To.append(erasor_amd.invert_rigid(tb))
+        self.Tl = erasor_amd.geopose2eigen([0, 0, synth.LIDAR_HEIGHT if l2b_z else 0.0, 0, 0, 0, 1])
+        self.d_scans = [torch.from_numpy(s).to(dev) for s in self.scans]
+        self.n_scan = int(np.mean([len(s) for s in self.scans]))
+        self.g = erasor_amd.Erasor(P, device=device_index)
+        self.g.set_map_device(d_map.data_ptr(), n_map)
+        self.lookahead = not args.no_lookahead
+        self.LA = args.lookahead
+        self.primed = False
+
+    def prime(self):
+        if self.lookahead and not self.primed:
+            for j in range(min(self.LA, self.n_frames)):
+                self.g.prefetch_device(self.d_scans[j].data_ptr(), len(self.scans[j]), self.Tl)
+        self.primed = True
+
+    def run(self, k):
+        # offline sequence processing: scan k+LA is announced before step k, so that its voxelisation / binning (which do
+        # not depend on the map) overlap step k's map-side stages; step k returns with ITS results on the host as before
+        g = self.g
+        if self.lookahead and k + self.LA < self.n_frames:
+            g.prefetch_device(self.d_scans[k + self.LA].data_ptr(), len(self.scans[k + self.LA]), self.Tl)
+        return g.step_device(self.d_scans[k].data_ptr(), len(self.scans[k]), self.Tl, self.Tb[k], self.To[k])
+
+
+def cpu_baseline(args, P, m, seq, l2b7):
+    """the CPU path on this box's host cores, same workload, bounded sample.  Preferred: oracle/_ref = the reference's own
+    sources (kind "reference", with its own two wall-clock spans); the oracle port is timed beside it."""
+    import ctypes as C
+    from oracle import orc, ref  # checker / baseline only — never on the product path
+    po = orc.Params()
+    C.memmove(C.byref(po), C.byref(P), C.sizeof(po))
+    out = {}
+    o = orc.Oracle(po)
+    o.set_map(m)
+    ns, tcpu = 0, 0.0
+    for k in range(min(args.cpu_steps, seq.n_frames)):
+        tc = time.perf_counter()
+        o.step(seq.scans[k], seq.Tl, seq.Tb[k], seq.To[k])
+        tcpu += time.perf_counter() - tc
+        ns += 1
+        if tcpu > args.cpu_seconds / 2:
+            break
+    o.close()
+    port = {"value": round(ns / tcpu, 3), "unit": "scans/s", "cores": 1, "kind": "port",
+            "sample": "%d steps of the same workload (same %d-pt map, same scans), oracle/erasor_oracle.cpp -O2 (copy-free restatement), 1 thread" % (ns, len(m))}
+    if not ref.available():
+        return port, None
+    r = ref.RefUpdater(po, m, l2b7)
+    ns, tcpu, sv, se = 0, 0.0, 0.0, 0.0
+    for k in range(min(args.cpu_steps, seq.n_frames)):
+        tc = time.perf_counter()
+        r.step(seq.scans[k], seq.poses[k])
+        tcpu += time.perf_counter() - tc
+        a, b = r.spans()
+        sv, se, ns = sv + a, se + b, ns + 1
+        if tcpu > args.cpu_seconds / 2:
+            break
+    r.close()
+    refd = {"value": round(ns / tcpu, 3), "unit": "scans/s", "cores": 1, "kind": "reference",
+            "sample": "%d callback_node steps of the same workload (same %d-pt map, same scans) through oracle/_ref = the reference's "
+                      "unmodified erasor.cpp / erasor_utils.cpp / OfflineMapUpdater.cpp (-O2, 1 thread, like the single-threaded node); "
+                      "PCL/Eigen/ROS underneath are the stand-ins of oracle/stubs (publishing is a no-op)" % (ns, len(m)),
+            "ms_per_scan": round(tcpu / ns * 1e3, 1),
+            "reference_spans_ms": {"Extracting VoI": round(sv / ns * 1e3, 1), "ERASOR": round(se / ns * 1e3, 1)}}
+    return refd, port
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)  # does not return
     import torch
     import erasor_amd
     from erasor_amd import synth
-
     from erasor_amd import dist as ed
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # "nccl" is RCCL on ROCm.  ERASOR_BENCH_BACKEND / ERASOR_BENCH_ONE_DEVICE exist only to smoke-test the multi-rank
     # control flow on a single-GPU box (RCCL refuses two ranks on one device).
-    dist, world_size, rank, local_rank = ed.init(os.environ.get("ERASOR_BENCH_BACKEND", "nccl"))
+    backend = os.environ.get("ERASOR_BENCH_BACKEND", "nccl")
+    dist, world_size, rank, local_rank = ed.init(backend)
+    if world_size != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_size))
     if os.environ.get("ERASOR_BENCH_ONE_DEVICE"):
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     erasor_amd.build()
-    world, lidar = build_workload(args, rank)
-    P = make_params(args)
+    wl = WORKLOADS[args.workload]
     K, W = args.steps, args.warmup
-    n_frames = K + W + 2  # scans beyond the timed ones: the last timed steps announce them like every other step
+    n_frames = K + W + args.lookahead  # scans beyond the timed ones: the last timed steps announce them like every other step
+    lidar = make_lidar(wl, args)
+    l2b7 = [0, 0, synth.LIDAR_HEIGHT if wl["l2b_z"] else 0.0, 0, 0, 0, 1]
 
-    # ---- the global map: rank 0 samples it, RCCL broadcast over xGMI to every replica ----
     t0 = time.time()
-    m = world.sample_map(spacing=0.2, frames=range(0, 320, 2), step=1.0) if rank == 0 else None
-    if dist is not None:
-        dist.barrier()
-    tb = time.time()
-    d_map = ed.broadcast_map(dist, rank, dev, m)
+    t_bcast = None
+    m = None
+    seqs = []  # the Sequence objects this rank owns (replicas: one; seq-per-gpu: its share of the five)
+    if args.mode == "replicas":
+        world = synth.World(seed=20210305 + 5, length=args.street_length, n_streets=args.streets, street_gap=50.0, n_moving=10, n_peds=6)
+        P = make_params(wl, args)
+        # ---- the global map: rank 0 samples it, ONE RCCL broadcast over xGMI to every replica ----
+        m = world.sample_map(spacing=wl["spacing"], frames=range(0, 320, 2), step=1.0) if rank == 0 else None
+        if dist is not None:
+            dist.barrier()
+        tb = time.time()
+        d_map = ed.broadcast_map(dist, rank, dev, m)
+        torch.cuda.synchronize()
+        t_bcast = (time.time() - tb) if dist is not None else None
+        x0, _ = ed.shard_frames(rank, world_size, n_frames)
+        seqs.append(("replica%d" % rank, Sequence(args, P, world, lidar, d_map, int(d_map.shape[0]), x0, n_frames, dev, local_rank,
+                                                  wl["l2b_z"], 1234 + rank)))
+        maps = {"replica%d" % rank: m}
+    else:
+        maps = {}
+        for i in ed.deal_round_robin(len(SEQS), rank, world_size):
+            sid = SEQS[i]
+            world = synth.World(seed=20210305 + int(sid), length=args.street_length, n_streets=args.streets, street_gap=50.0,
+                                n_moving=10, n_peds=6)
+            P = make_params(wl, args, seq=sid)
+            mm = world.sample_map(spacing=wl["spacing"], frames=range(0, 320, 2), step=1.0)
+            d_map = torch.from_numpy(mm).to(dev)
+            seqs.append((sid, Sequence(args, P, world, lidar, d_map, len(mm), 300.0, n_frames, dev, local_rank, True, 4321 + int(sid))))
+            maps[sid] = mm
     torch.cuda.synchronize()
-    t_bcast = (time.time() - tb) if dist is not None else None
-    N_map = int(d_map.shape[0])
     t_map = time.time() - t0
 
-    # ---- this rank's scans (its shard of the scan stream) and poses; uploaded before the timed region ----
-    jr = np.random.default_rng(1234 + rank)
-    x0, frame_ids = ed.shard_frames(rank, world_size, n_frames)
-    scans, Tb, To = [], [], []
-    for k in frame_ids:
-        p7 = world.pose(k, 1.0, x0=x0, jitter_rng=jr)
-        scans.append(world.cast(p7, lidar, k))
-        tb_ = erasor_amd.geopose2eigen(p7)
-        Tb.append(tb_)
-        To.append(erasor_amd.invert_rigid(tb_))
-    Tl = erasor_amd.geopose2eigen([0, 0, synth.LIDAR_HEIGHT, 0, 0, 0, 1])
-    d_scans = [torch.from_numpy(s).to(dev) for s in scans]
-    n_scan = int(np.mean([len(s) for s in scans]))
-    torch.cuda.synchronize()
-
-    g = erasor_amd.Erasor(P, device=local_rank)
-    g.set_map_device(d_map.data_ptr(), N_map)
-
-    lookahead = not args.no_lookahead
-    LA = args.lookahead  # scans announced ahead of the one being stepped
-
-    def run(k):
-        # offline sequence processing: scan k+1 is announced before step k, so that its voxelisation / binning (which do
-        # not depend on the map) overlap step k's map-side stages; step k returns with ITS results on the host as before
-        if lookahead and k + LA < n_frames:
-            g.prefetch_device(d_scans[k + LA].data_ptr(), len(scans[k + LA]), Tl)
-        return g.step_device(d_scans[k].data_ptr(), len(scans[k]), Tl, Tb[k], To[k])
-
-    if lookahead:
-        for j in range(LA):
-            g.prefetch_device(d_scans[j].data_ptr(), len(scans[j]), Tl)
-    for k in range(W):
-        run(k)
-    g.profile_reset()
-    g.profiling(2)  # HIP events around voi_split only, on the handle's stream, during the timed region
+    for _, s in seqs:
+        s.prime()
+        for k in range(W):
+            s.run(k)
+    first = seqs[0][1] if seqs else None
+    if first is not None:
+        first.g.profile_reset()
+        first.g.profiling(2)  # HIP events around voi_split only, on the handle's stream, during the timed region
     split_bytes = []
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t_start = time.perf_counter()
     last = None
-    for k in range(W, W + K):
-        split_bytes.append(g.voi_split_bytes())
-        last = run(k)  # synchronous: returns after the step's results are on the host
+    totals = np.zeros(6, np.int64)  # steps, map_rejected, reverted_bins, final map size, static, dynamic
+    for si, (_, s) in enumerate(seqs):
+        for k in range(W, W + K):
+            if si == 0:
+                split_bytes.append(s.g.voi_split_bytes())
+            last = s.run(k)  # synchronous: returns after the step's results are on the host
+            totals[0] += 1
+            totals[1] += last.n_map_rejected
+            totals[2] += last.n_reverted_bins
+        totals[3] += last.n_map_out
+        totals[4] += last.n_static
+        totals[5] += last.n_dynamic
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    prof = g.profile_get()
-    g.profiling(0)
-    elapsed = ed.max_over_ranks(dist, elapsed, dev)
+    elapsed_local = time.perf_counter() - t_start
+    prof = first.g.profile_get() if first is not None else {}
+    if first is not None:
+        first.g.profiling(0)
+    elapsed = ed.max_over_ranks(dist, elapsed_local, dev)
+    # ---- result exchange (SURVEY C2): one RCCL all_gather of the per-rank counters ----
+    gathered = ed.gather_counts(dist, world_size, list(totals) + [int(elapsed_local * 1e6)], dev)
+    rccl_ranks = len(gathered)
+
+    evals = None
+    if args.eval and args.mode == "seq-per-gpu":
+        from erasor_amd import evalmap
+        mine = []
+        for sid, s in seqs:
+            est = s.g.voxelize_preserving_labels(s.g.get_map(), 0.2)
+            gt = s.g.voxelize_preserving_labels(maps[sid], 0.2)
+            ev = evalmap.evaluate_clouds(gt, est, 0.2)
+            mine.append([int(sid), int(round(ev["PR"] * 1e2)), int(round(ev["RR"] * 1e2))])
+        while len(mine) < (len(SEQS) + world_size - 1) // world_size:
+            mine.append([-1, 0, 0])
+        evals = [e for per in ed.gather_counts(dist, world_size, [v for row in mine for v in row], dev)
+                 for e in np.array(per).reshape(-1, 3).tolist() if e[0] >= 0]
 
     if rank != 0:
         if dist is not None:
@@ -147,45 +333,61 @@ def main():
             dist.destroy_process_group()
         return
 
-    value = world_size * K / elapsed
-    ms_per_step = elapsed / K * 1e3
+    total_steps = int(sum(g_[0] for g_ in gathered))
+    value = total_steps / elapsed
+    ms_per_step = elapsed / max(K * len(seqs), 1) * 1e3  # this rank's wall per step
+    g = first.g
+    P = first.P
+    N_map = int(first.g.map_size())
+    n_scan = first.n_scan
     # ---- roofline of the dominant kernel (voi_split): bytes its layout must stream per launch / measured launch time ----
     # k_voi_split is launched with its own start / stop HIP events (hipExtLaunchKernelGGL) on the handle's stream during the
     # timed region: they stamp the kernel's execution window, which is also what rocprofv3 reports (profiles/).
     vs_ms, vs_n = prof.get("voi_split", (0.0, 0))
     avg_ms = vs_ms / max(vs_n, 1)
-    alg_bytes = float(np.mean([b for b, _ in split_bytes]))
-    entries = float(np.mean([e for _, e in split_bytes]))
+    alg_bytes = float(np.mean([b for b, _ in split_bytes])) if split_bytes else 0.0
+    entries = float(np.mean([e for _, e in split_bytes])) if split_bytes else 0.0
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None  # HBM bytes per launch from the PMC counters: measured in a separate rocprofv3 --pmc pass (profiles/)
+    # traffic / rocprofv3 average: NOT measured in this run — read from the committed separate rocprofv3 passes (profiles/)
+    traffic = rocprof_avg = None
+    prof_tag = "" if args.workload == "seq05" else "_" + args.workload
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest%s.json" % prof_tag)) as f:
             traffic = int(json.load(f)["traffic_bytes_per_launch"])
     except Exception:
         pass
-    rocprof_avg = None  # kernel-only average of the committed rocprofv3 --kernel-trace --stats run of this command
     try:
         import csv
-        with open(os.path.join(ROOT, "profiles", "kernel_stats_latest.csv")) as f:
+        with open(os.path.join(ROOT, "profiles", "kernel_stats_latest%s.csv" % prof_tag)) as f:
             for row in csv.DictReader(f):
                 if "k_voi_split" in row["Name"]:
                     rocprof_avg = round(float(row["AverageNs"]) / 1e3, 2)
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": "k_voi_split", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "bytes_per_launch": int(alg_bytes),
+    # SURVEY §8(d) step-level figure: ALG_BYTES = 16*N_map + 16*n_scan + 16*N_voi_out (write-back of the updated VoI region)
+    n_voi_out = int(last.n_static_estimate + last.n_complement)
+    step_alg = 16.0 * N_map + 16.0 * n_scan + 16.0 * n_voi_out
+    step_gbps = step_alg / (ms_per_step * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_voi_split", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": traffic,
+                "traffic_source": "from_profiles (separate rocprofv3 --pmc pass, profiles/pmc_latest%s.json)" % prof_tag,
+                "bytes_per_launch": int(alg_bytes),
+                "bytes_note": "this layout streams {x,y} pairs (8 B) of the outskirts + float4 of the VoI-resident part + masks; "
+                              "SURVEY §8(d)'s 16 B/pt assumed an AoS map (aos16_equiv_GBps is the rate in that currency)",
                 "entries_per_launch": int(entries), "avg_launch_us": round(avg_ms * 1e3, 2),
-                "rocprofv3_kernel_avg_us": rocprof_avg,
+                "rocprofv3_kernel_avg_us": rocprof_avg, "rocprofv3_source": "from_profiles (profiles/kernel_stats_latest%s.csv)" % prof_tag,
                 "launches": int(vs_n),
-                "aos16_equiv_GBps": round(16.0 * entries / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0}
+                "aos16_equiv_GBps": round(16.0 * entries / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
+                "working_set_vs_L3": "%.0f MB streamed per launch vs 256 MiB Infinity Cache" % (alg_bytes / 1e6),
+                "step_alg_bytes": int(step_alg), "step_achieved": round(step_gbps, 1), "step_frac": round(step_gbps / PEAK_HBM_GBPS, 4),
+                "step_note": "SURVEY §8(d): (16*N_map + 16*n_scan + 16*N_voi_out) / ms_per_step — the whole step against the HBM peak"}
 
     # ---- optional per-kernel breakdown (extra K steps, all kernels bracketed) ----
     if args.profile_all:
         g.profile_reset()
         g.profiling(1)
         for k in range(W, W + K):
-            # re-running the same scans against the already-updated map is fine for a time breakdown
-            run(k)
+            first.run(k)  # re-running the same scans against the already-updated map is fine for a time breakdown
         pa = g.profile_get()
         g.profiling(0)
         tot = sum(v[0] for v in pa.values())
@@ -193,50 +395,46 @@ def main():
             print("  %-14s %8.3f ms/step  (%5.1f%%, %d launches)" % (name, ms / K, 100 * ms / max(tot, 1e-9), cnt // K), file=sys.stderr)
         print("  sum of kernels %.3f ms/step vs wall %.3f ms/step" % (tot / K, ms_per_step), file=sys.stderr)
 
-    # ---- the same K scans again without look-ahead (every step runs its own query chain first): latency-style figure ----
+    # ---- the same K scans again without look-ahead (every step runs its own query chain first): what a ROS callback sees ----
     sync_ms = None
-    if lookahead and world_size == 1:
-        lookahead = False
+    if first.lookahead and world_size == 1:
+        first.lookahead = False
         torch.cuda.synchronize()
         ts = time.perf_counter()
         for k in range(W, W + K):
-            run(k)  # against the already-updated map: same work per step, results not used
+            first.run(k)  # against the already-updated map: same work per step, results not used
         torch.cuda.synchronize()
         sync_ms = (time.perf_counter() - ts) * 1e3 / K
-        lookahead = True
+        first.lookahead = True
 
-    # ---- CPU baseline: the oracle (single-threaded port, like the single-threaded reference) on a bounded sample ----
-    cpu = None
-    if world_size == 1 and not args.no_cpu_baseline:
-        import ctypes as C
-        from oracle import orc  # the CPU oracle: cpu_baseline leg only
-        po = orc.Params()
-        C.memmove(C.byref(po), C.byref(P), C.sizeof(po))
-        o = orc.Oracle(po)
-        o.set_map(m)
-        ns = min(args.cpu_steps, n_frames)
-        tc = time.perf_counter()
-        for k in range(ns):
-            o.step(scans[k], Tl, Tb[k], To[k])
-        tcpu = time.perf_counter() - tc
-        cpu = {"value": round(ns / tcpu, 3), "unit": "scans/s", "cores": 1, "kind": "port",
-               "sample": "%d steps of the same workload (same %d-pt map, same scans), oracle/erasor_oracle.cpp -O2, 1 thread" % (ns, N_map)}
-        o.close()
+    # ---- CPU baseline: the reference's own sources (oracle/_ref) and the oracle port, one thread, bounded sample ----
+    cpu = cpu_port = None
+    if world_size == 1 and not args.no_cpu_baseline and args.mode == "replicas":
+        cpu, cpu_port = cpu_baseline(args, P, m, first, l2b7)
 
     out = {
         "metric": "scans_per_sec", "value": round(value, 2), "unit": "scans/s", "n_gpus": world_size, "steps": K, "warmup": W,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (transforms, R-GPF) + f64 (VoI test, polar binning, scan ratio)", "data": "synthetic",
-        "config": {"workload": "KITTI-05-shaped synthetic street, %d-pt map resident in HBM, ~%d-pt HDL-64-like scans, R-POD 20 rings x 108 sectors @ 80 m, "
-                               "seq_05.yaml thresholds, ERASOR v3; one scan per step, 1 m/frame" % (N_map, n_scan),
-                   "map_points": N_map, "scan_points": n_scan, "rings": 20, "sectors": 108, "sharding": "scan-parallel replicas, RCCL broadcast of the map",
-                   "lookahead_scans": LA if lookahead else 0},
+        "config": {"workload": "%s: %s; %d-pt map resident in HBM, ~%d-pt scans, ERASOR v%d; one scan per step, 1 m/frame"
+                               % (args.workload, wl["desc"], N_map, n_scan, P.version),
+                   "map_points": N_map, "scan_points": n_scan, "rings": int(P.num_rings), "sectors": int(P.num_sectors),
+                   "max_range": float(P.max_range), "is_large_scale": int(P.is_large_scale), "mode": args.mode,
+                   "sharding": ("scan-parallel replicas, one RCCL broadcast of the map, no data-path collective" if args.mode == "replicas"
+                                else "one KITTI-shaped sequence per GPU (00/01/02/05/07 dealt round-robin), no map exchange"),
+                   "lookahead_scans": first.LA if first.lookahead else 0},
         "map_points_x_scans_per_sec": round(value * N_map, 1),
         "ms_per_step_without_lookahead": None if sync_ms is None else round(sync_ms, 4),
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "cpu_port": cpu_port, "host": host_identity(),
+        "rccl_ranks": rccl_ranks, "backend": backend if dist is not None else None,
+        "per_rank": [{"rank": i, "steps": int(v[0]), "map_rejected": int(v[1]), "reverted_bins": int(v[2]), "final_map_points": int(v[3]),
+                      "static": int(v[4]), "dynamic": int(v[5]), "wall_ms": round(v[6] / 1e3, 2)} for i, v in enumerate(gathered)],
         "last_step": last.as_dict() if last is not None else None,
-        "setup_s": {"map_build_and_upload": round(t_map, 2), "rccl_broadcast": None if t_bcast is None else round(t_bcast, 4)},
+        "setup_s": {"map_build_and_upload": round(t_map, 2), "rccl_broadcast": None if t_bcast is None else round(t_bcast, 4),
+                    "rccl_broadcast_bytes": None if t_bcast is None else 16 * N_map},
     }
+    if evals is not None:
+        out["pr_rr"] = [{"seq": "%02d" % e[0], "PR": e[1] / 1e2, "RR": e[2] / 1e2} for e in sorted(evals)]
     print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -49,6 +49,11 @@ def shard_frames(rank, world, frames_per_rank, stride=37):
     return 300.0 + float(stride) * rank, list(range(frames_per_rank))
 
 
+def deal_round_robin(n_items, rank, world):
+    """indices of the items rank `rank` owns when n_items independent jobs (sequences) are dealt over `world` ranks"""
+    return list(range(rank, n_items, world))
+
+
 def max_over_ranks(dist, value, device):
     import torch
     if dist is None:

@@ -25,6 +25,9 @@ WORKER = textwrap.dedent('''
     x0, frames = ed.shard_frames(rank, world, 7)
     shards = ed.gather_counts(dist, world, [int(x0)] + frames, dev)
     assert shards[0] != shards[1] and shards[0][1:] == shards[1][1:] == list(range(7))   # disjoint streams, equal work
+    mine = ed.deal_round_robin(5, rank, world)   # seq-per-gpu mode: five sequences dealt over the ranks
+    dealt = ed.gather_counts(dist, world, mine + [-1] * (3 - len(mine)), dev)
+    assert sorted(v for per in dealt for v in per if v >= 0) == [0, 1, 2, 3, 4]
     tmax = ed.max_over_ranks(dist, 1.0 + rank, dev)
     assert tmax == 2.0
     dist.barrier()

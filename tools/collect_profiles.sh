@@ -1,16 +1,18 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): collects the evidence committed under profiles/.
-#   tools/collect_profiles.sh <tag>      -> gpurun_out/profiles_<tag>/...
+#   tools/collect_profiles.sh <tag> [bench.py args]     -> gpurun_out/profiles_<tag>/...
 # Passes (each its own process; counters never share a run with tracing, as the pool requires):
 #   1. plain bench.py (+ per-kernel HIP-event breakdown)
 #   2. rocprofv3 --kernel-trace --stats
 #   3. rocprofv3 --pmc FETCH_SIZE        4. rocprofv3 --pmc WRITE_SIZE
 TAG=${1:-run}
+shift
+EXTRA="$@"   # e.g. --workload large_scale_05
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 20 --warmup 3"
+BENCH="python $ROOT/bench.py --steps 20 --warmup 3 $EXTRA"
 $BENCH > $OUT/bench.json 2> $OUT/bench.stderr
 $BENCH --no-cpu-baseline --profile-all > /dev/null 2> $OUT/bench_kernel_breakdown.txt
 rm -rf /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write
