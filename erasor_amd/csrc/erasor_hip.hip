@@ -396,7 +396,7 @@ int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
     Q(h).hbits = 10;  // voxel hash table: >= 2 slots per possible voxel
     while ((1ull << Q(h).hbits) < 2ull * S) ++Q(h).hbits;
     rc |= ensure(h, Q(h).hkey, (size_t)1 << Q(h).hbits) | ensure(h, Q(h).hval, (size_t)1 << Q(h).hbits);
-    if (getenv("ERASOR_HIP_SORT_STAMPS")) rc |= ensure(h, h->dbg_stamps, 32);
+    if (getenv("ERASOR_HIP_SORT_STAMPS")) rc |= ensure(h, h->dbg_stamps, 64);
     rc |= ensure(h, Q(h).wseg0, WSEG_MAX) | ensure(h, Q(h).wseg1, WSEG_MAX) | ensure(h, Q(h).wstate, 1) | ensure(h, Q(h).wtileL, WTILES_MAX) | ensure(h, Q(h).wtileR, WTILES_MAX);
     rc |= ensure(h, Q(h).esq0, 65536) | ensure(h, Q(h).esq1, 65536) | ensure(h, Q(h).esq2, 65536) | ensure(h, Q(h).essmall, 65536);
     return rc ? ERASOR_E_NO_DEVICE : 0;
@@ -1026,9 +1026,14 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
                 LAUNCH(h, "voi_split", k_voi_split, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, (const float2 *)h->Oxy.p, h->o_begin,
                        o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p);
             const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));
-            LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p);
-            LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
-                   nchunks, nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u);
+            if (nchunks <= 16384) {
+                LAUNCH(h, "chunk_scan", k_chunk_scan_one, 1, 1024, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, ntop,
+                       nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u);
+            } else {
+                LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p);
+                LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
+                       nchunks, nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u);
+            }
         }
         (void)hipStreamWaitEvent(h->stream, Q(h).ev_keys, 0);  // k_voi_gather must see the query side's error flag
         {   // VoI gather + egocentric transform + R-POD key (OMU.cpp:435-437; erasor.cpp:124-139)
@@ -1074,14 +1079,16 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     else
         LAUNCH(h, "srt", k_srt, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
            (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
-    LAUNCH(h, "rgpf", k_rgpf, B, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->moff.p,
+    // R-GPF and the per-bin voxelisation walk the reverted-bin LIST on a small fixed grid (n_rev is on the device)
+    static const uint32_t rev_grid = getenv("ERASOR_HIP_REV_GRID") ? (uint32_t)atoi(getenv("ERASOR_HIP_REV_GRID")) : 128u;
+    LAUNCH(h, "rgpf", k_rgpf2, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds, (const uint32_t *)h->moff.p,
            (const float4 *)h->spts.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p, h->gflag.p, h->grank.p, h->glist.p,
            h->ng.p, h->plane_n.p, h->plane_d.p, dc, h->dbg_stamps.p);
     if (P.version == 3)
-        LAUNCH(h, "bin_voxelize", k_binvox, B, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->moff.p,
-               (const float4 *)h->spts.p, (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->glist.p,
-               (const uint32_t *)h->ng.p, (const uint32_t *)h->vox_off.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p,
-               h->gsC.p, h->vox_out.p, h->nvox.p, dc, h->dbg_stamps.p);
+        LAUNCH(h, "bin_voxelize", k_binvox2, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds,
+               (const uint32_t *)h->moff.p, (const float4 *)h->spts.p, (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p,
+               (const uint32_t *)h->glist.p, (const uint32_t *)h->ng.p, (const uint32_t *)h->vox_off.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p,
+               h->gsH.p, h->gsK2.p, h->gsV2.p, h->gsC.p, h->vox_out.p, h->nvox.p, dc, h->dbg_stamps.p);
     if (B <= 1024 * SRT_KPT)
         LAUNCH(h, "layout", k_layout4, 1, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->mcnt.p,
            (const uint32_t *)Q(h).ccnt.p, (const uint32_t *)h->moff.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->ng.p, h->out_off.p,
@@ -1093,14 +1100,21 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
 
     // ---- map write-back (OMU.cpp:281-290) ----
     float4 *Fnew = h->F[h->curF ^ 1].p;
-    if (n_voi)
-        LAUNCH(h, "assemble", k_assemble_map<true>, std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
-               sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).ccnt.p,
-               (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p,
-               (const uint32_t *)h->rej_off.p, (const DevState *)ds, Fnew, h->rejected.p, h->rejected_src.p, h->lab_slots.p);
-    LAUNCH(h, "assemble", k_assemble_bins<true>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
-           (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
-           (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, Fnew, h->curr_rejected.p, h->lab_slots.p);
+    {
+        // v3: the voxelised reverted bins are written by `tail` extra workgroups of the same launch (from the reverted list)
+        const uint32_t tail = (P.version == 3 && n_voi) ? 32u : 0u;
+        if (n_voi)
+            LAUNCH(h, "assemble", k_assemble_map<true>, std::min<uint32_t>(cdiv(n_voi, 256), 2048) + tail, 256, P, h->Tb2o, (const uint8_t *)h->action.p,
+                   (const uint32_t *)h->rev_idx.p, sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p,
+                   (const uint32_t *)Q(h).ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p, (const uint32_t *)h->out_off.p,
+                   (const uint32_t *)h->ground_off.p, (const uint32_t *)h->rej_off.p, (const DevState *)ds, Fnew, h->rejected.p, h->rejected_src.p,
+                   h->lab_slots.p, tail, (const uint32_t *)h->rev_list.p, (const uint32_t *)Q(h).qoff.p, (const uint32_t *)h->nvox.p,
+                   (const uint32_t *)h->vox_off.p, (const float4 *)h->vox_out.p);
+        if (!tail)
+            LAUNCH(h, "assemble", k_assemble_bins<true>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
+                   (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
+                   (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, Fnew, h->curr_rejected.p, h->lab_slots.p);
+    }
     // (label counters of the new VoI-resident region are accumulated by the two assemble kernels)
     const unsigned long long step_seq = ++h->step_seq;
     LAUNCH(h, "step_end", k_step_end, 1, 1, ds, dc, h->pin, (const unsigned long long *)h->lab_slots.p, (const Counters *)Q(h).d_qctr.p,
@@ -1139,8 +1153,10 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
                 std::chrono::duration<double, std::micro>(t_host2 - t_host1).count());
     }
     if (h->dbg_stamps.p) {
-        unsigned long long t[32];
+        unsigned long long t[64];
         (void)hipMemcpy(t, h->dbg_stamps.p, sizeof(t), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[slowest R-GPF bin, 10 ns ticks] key load %llu, exact sort %llu, seeds %llu, staging %llu, it0: cov %llu svd %llu classify %llu (final ground %llu)\n",
+                t[32], t[33], t[34], t[35], t[36], t[37], t[38], t[39]);
         fprintf(stderr, "[esort slowest segment: len %llu depth %llu of %llu segments] phase1 %llu, queue %llu, finalize %llu cycles; levels:", t[30] >> 32,
                 t[30] & 0xFFFFFFFFull, t[29], t[1] - t[0], t[2] - t[1], t[3] - t[2]);
         for (int i = 4; i < 15; ++i) fprintf(stderr, " %llu", t[i + 1] > t[i] ? t[i + 1] - t[i] : 0ull);
@@ -1324,7 +1340,7 @@ int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap
                        (const uint32_t *)h->rev_idx.p, h->last_skeys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p,
                        (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p,
                        (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p, (const uint32_t *)h->rej_off.p,
-                       (const DevState *)h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+                       (const DevState *)h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const float4 *)nullptr);
             LAUNCH(h, "get_cloud", k_assemble_bins<false>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
                    (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
                    (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, tmp, (float4 *)nullptr, (unsigned long long *)nullptr);

@@ -299,6 +299,88 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ 
     }
 }
 
+// Both levels in ONE launch (maps of up to ~16 M entries: <= 16384 chunks): a single workgroup, 16 consecutive chunk counts
+// per thread, writes ABSOLUTE prefixes (the per-group tops are all zero) and opens the step's state exactly like
+// k_chunk_scan_top.  One kernel boundary less on the main stream's dependency chain.
+__global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restrict__ cinfo, uint32_t nchunks, uint32_t *__restrict__ pvl,
+                                                          uint32_t *__restrict__ phl, uint32_t *__restrict__ topv, uint32_t *__restrict__ toph,
+                                                          uint32_t ntop, uint32_t nFchunks, DevState *st, Counters *ctr, DevState init,
+                                                          unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n) {
+    __shared__ uint32_t sm[40];
+    __shared__ uint32_t s_voiF, s_validF;
+    if (lab_slots && threadIdx.x < 128) lab_slots[threadIdx.x] = 0;
+    for (uint32_t b = threadIdx.x; b < mb_n; b += blockDim.x) mb_tot[b] = 0;
+    for (uint32_t t = threadIdx.x; t < ntop; t += blockDim.x) {
+        topv[t] = 0;
+        toph[t] = 0;
+    }
+    if (threadIdx.x == 0) {
+        ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
+        ctr->sort_qoverflow = ctr->err = 0;
+    }
+    // every thread owns 16 CONSECUTIVE chunks (four 16-byte loads in flight, issued before anything else is waited for): ONE
+    // pair of block scans for the whole table
+    uint32_t cv = 0, ch = 0;
+    {
+        const uint32_t base = threadIdx.x * 16;
+        uint32_t ci[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 t = make_uint4(0u, 0u, 0u, 0u);
+            if (base + q * 4 + 3 < nchunks) t = *reinterpret_cast<const uint4 *>(cinfo + base + q * 4);
+            else {
+                if (base + q * 4 + 0 < nchunks) t.x = cinfo[base + q * 4 + 0];
+                if (base + q * 4 + 1 < nchunks) t.y = cinfo[base + q * 4 + 1];
+                if (base + q * 4 + 2 < nchunks) t.z = cinfo[base + q * 4 + 2];
+            }
+            ci[q * 4 + 0] = t.x;
+            ci[q * 4 + 1] = t.y;
+            ci[q * 4 + 2] = t.z;
+            ci[q * 4 + 3] = t.w;
+        }
+        uint32_t sv = 0, sh = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sv += ci[j] & 0xFFFFu;
+            sh += ci[j] >> 16;
+        }
+        uint32_t pv = block_excl_scan(sv, sm, cv);
+        uint32_t ph = block_excl_scan(sh, sm, ch);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (base + j < nchunks) {
+                pvl[base + j] = pv;
+                phl[base + j] = ph;
+                if (base + j == nFchunks) {  // the F region's share of the totals
+                    s_voiF = pv;
+                    s_validF = ph;
+                }
+            }
+            pv += ci[j] & 0xFFFFu;
+            ph += ci[j] >> 16;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        DevState s = init;
+        const uint32_t voi_total = cv, valid_total = ch;
+        uint32_t voiF = voi_total, validF = valid_total;
+        if (nFchunks < nchunks) {
+            voiF = s_voiF;
+            validF = s_validF;
+        }
+        s.F_static = s.F_dynamic = 0;
+        s.n_rev = 0;
+        s.voi_total = voi_total;
+        s.valid_total = valid_total;
+        s.voiF = voiF;
+        s.validF = validF;
+        s.n_leaving = validF - voiF;
+        s.o_new_begin = s.o_begin - (validF - voiF);
+        *st = s;
+    }
+}
+
 // ================================================================================================
 // (2) voi_gather — for every set VoI bit: fetch the point, egocentric transform (OMU.cpp:435-437),
 // R-POD key (erasor.cpp:124-139), write into VoI order; tombstone outskirts sources; move the
@@ -2139,6 +2221,263 @@ __global__ __launch_bounds__(1024) void k_rgpf(DP P, const uint8_t *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_rgpf2: R-GPF over the reverted-bin LIST (a small fixed grid; bin r of the list is handled by workgroup r mod grid),
+// bins of <= RG_LMAX points entirely in LDS:
+//   * z-sort: the reference's std::sort (erasor.cpp:240) is unstable and float32 z values of a bin DO collide (a few
+//     ties per thousand points), so the tie order matters for the float32 covariance sums: the exact introsort
+//     emulation (esort::block_esort) cannot be replaced by a plain parallel sort;
+//   * the bin's x / y / z are staged in LDS once; plane-fit products go to LDS rows padded to 1028 floats (nine lanes read
+//     nine different banks with 128-bit loads) and are added strictly in list order by lane a of wave 0;
+//   * classification: every thread owns strided points, ONE table scan per iteration instead of one block scan per 1024.
+// Larger bins take the global-memory path of k_rgpf (same arithmetic).
+// ------------------------------------------------------------------------------------------------
+static constexpr uint32_t RG_RS = RG_CH + 4;  // padded row stride of the product rows (floats)
+
+__device__ __forceinline__ float key_to_float(uint32_t k) {  // inverse of esort::float_key (-0 comes back as +0)
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+__global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict__ rev_list, const DevState *__restrict__ st,
+                                                const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *gsK,
+                                                uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
+                                                uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
+                                                uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
+                                                Counters *ctr, unsigned long long *dbg) {
+    __shared__ uint32_t pool[4 * RG_LMAX];  // sort phase: K | V | posL | posR ; fit phase: glist | X | Y | Z
+    __shared__ uint32_t sH[RG_LMAX / 32 + 2];
+    __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
+    __shared__ uint32_t qcnt[2];
+    __shared__ uint32_t sm[40];
+    __shared__ __attribute__((aligned(16))) float sProd[9 * RG_RS];
+    __shared__ float s_n[3];
+    __shared__ double s_th, s_lpr;
+    __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_tab[64];
+    __shared__ unsigned long long s_t[12];
+#define RG_STAMP(i) do { if (dbg && tid == 0) s_t[i] = wall_clock64(); } while (0)
+    uint32_t *sK = pool, *sV = pool + RG_LMAX, *sL = pool + 2 * RG_LMAX, *sR = pool + 3 * RG_LMAX;
+    const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = bs >> 6;
+    const uint32_t n_rev = st->n_rev;
+    for (uint32_t rk = blockIdx.x; rk < n_rev; rk += gridDim.x) {
+        const uint32_t key = rev_list[rk];
+        const uint32_t o0 = moff[key], M = moff[key + 1] - o0;
+        const float4 *pts = spts + o0;
+        __syncthreads();  // LDS of the previous bin is dead
+        if (M > RG_LMAX) {  // rare: the bin does not fit LDS -> global scratch, same arithmetic (see k_rgpf)
+            uint32_t *K = gsK + o0, *V = gsV + o0;
+            for (uint32_t i = tid; i < M; i += bs) {
+                K[i] = esort::float_key(__float_as_uint(pts[i].z));
+                V[i] = i;
+            }
+            __threadfence_block();
+            __syncthreads();
+            esort::block_esort(K, V, gsL + o0, gsR + o0, gsH + (o0 >> 5) + 2 * key, gsK2 + o0, gsV2 + o0, 0u, M, 2 * esort::lg2_floor(M), qa, qb,
+                               qcnt, (uint32_t)(RG_LMAX / 16 + 2), &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+            __threadfence_block();
+            __syncthreads();
+            rgpf_after_sort(P, pts, M, o0, rk, gsV2 + o0, K, sm, sProd, s_n, &s_th, &s_lpr, &s_carry, gflag, grank, glist_out, ng_out, plane_n,
+                            plane_d, ctr);
+            continue;
+        }
+        const unsigned long long t_a = dbg ? wall_clock64() : 0ull;
+        // ---- (1) std::sort(src_copy, point_cmp), erasor.cpp:239-240: exact introsort emulation, level-synchronous in LDS ----
+        for (uint32_t i = tid; i < M; i += bs) {
+            sK[i] = esort::float_key(__float_as_uint(pts[i].z));
+            sV[i] = i;
+        }
+        __syncthreads();
+        RG_STAMP(0);
+        esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
+                           &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+        RG_STAMP(1);
+        // sorted keys in sL, sorted bin-local indices in sR
+        uint32_t drop = 0, ng = 0;
+        {
+            // --- drop leading z < min_h (erasor.cpp:242-251); monotone in sorted order ---
+            uint32_t cnt = 0;
+            for (uint32_t k = tid; k < M; k += bs) cnt += ((double)key_to_float(sL[k]) < P.min_h) ? 1u : 0u;
+            uint32_t tot;
+            block_excl_scan(cnt, sm, tot);
+            drop = tot;
+            const uint32_t Ms = M - drop;
+            // --- extract_initial_seeds_ (erasor.cpp:204-231) ---
+            if (tid == 0) {
+                uint32_t cl = 0;
+                if (P.num_lowest >= 0 && Ms > (uint32_t)P.num_lowest && P.gf_lpr > 0) cl = min((uint32_t)P.gf_lpr, Ms - (uint32_t)P.num_lowest);
+                double sum = 0;
+                for (uint32_t t = 0; t < cl; ++t) sum += (double)key_to_float(sL[drop + (uint32_t)P.num_lowest + t]);
+                s_lpr = cl != 0 ? sum / (int)cl : 0;
+            }
+            __syncthreads();
+            const double seed_thr = s_lpr + P.gf_seeds_h;
+            cnt = 0;
+            for (uint32_t k = tid; k < Ms; k += bs) cnt += ((double)key_to_float(sL[drop + k]) < seed_thr) ? 1u : 0u;
+            block_excl_scan(cnt, sm, tot);
+            ng = tot;  // seeds = the first ng of the sorted points (the predicate is monotone in z)
+        }
+        const unsigned long long t_b = dbg ? wall_clock64() : 0ull;
+        // ---- (2) ground list <- seeds; stage the bin's coordinates in LDS ----
+        uint32_t *glist = sK;
+        for (uint32_t k = tid; k < ng; k += bs) glist[k] = sR[drop + k];
+        __syncthreads();  // sV / sL / sR are dead from here on
+        float *X = reinterpret_cast<float *>(sV), *Y = reinterpret_cast<float *>(sL), *Z = reinterpret_cast<float *>(sR);
+        for (uint32_t i = tid; i < M; i += bs) {
+            const float4 q = pts[i];
+            X[i] = q.x;
+            Y[i] = q.y;
+            Z[i] = q.z;
+        }
+        __syncthreads();
+        RG_STAMP(2);
+        const uint32_t E = (M + bs - 1) / bs;  // points per thread in the classification (<= 4)
+        for (int it = 0; it < P.gf_iter; ++it) {
+            // --- estimate_plane_: pcl::computeMeanAndCovarianceMatrix, nine float32 accumulators in list order ---
+            float acc = 0.f;
+            for (uint32_t cb = 0; cb < ng; cb += RG_CH) {
+                const uint32_t cn = min(RG_CH, ng - cb);
+                for (uint32_t t = tid; t < cn; t += bs) {
+                    const uint32_t gi = glist[cb + t];
+                    const float x = X[gi], y = Y[gi], z = Z[gi];
+                    sProd[0 * RG_RS + t] = x * x;
+                    sProd[1 * RG_RS + t] = x * y;
+                    sProd[2 * RG_RS + t] = x * z;
+                    sProd[3 * RG_RS + t] = y * y;
+                    sProd[4 * RG_RS + t] = y * z;
+                    sProd[5 * RG_RS + t] = z * z;
+                    sProd[6 * RG_RS + t] = x;
+                    sProd[7 * RG_RS + t] = y;
+                    sProd[8 * RG_RS + t] = z;
+                }
+                __syncthreads();
+                if (wave == 0 && lane < 9) {
+                    const float4 *row4 = reinterpret_cast<const float4 *>(sProd + lane * RG_RS);
+                    const uint32_t c4 = cn >> 2;
+#pragma unroll 4
+                    for (uint32_t k = 0; k < c4; ++k) {
+                        const float4 v = row4[k];
+                        acc += v.x;
+                        acc += v.y;
+                        acc += v.z;
+                        acc += v.w;
+                    }
+                    const float *row = sProd + lane * RG_RS;
+                    for (uint32_t k = c4 << 2; k < cn; ++k) acc += row[k];
+                }
+                __syncthreads();
+            }
+            if (it == 0) RG_STAMP(3);
+            if (wave == 0) {
+                float a[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) a[k] = __shfl(acc, k, 64);
+                if (lane == 0) {
+                    float cov[9], mean[3], U[9], sv[3];
+                    if (ng == 0) {
+                        for (int k = 0; k < 9; ++k) cov[k] = 0.f;
+                        mean[0] = mean[1] = mean[2] = 0.f;
+                        atomicAdd(&ctr->n_degenerate, 1u);
+                    } else {
+                        const float fn = (float)ng;
+                        for (int k = 0; k < 9; ++k) a[k] /= fn;
+                        mean[0] = a[6];
+                        mean[1] = a[7];
+                        mean[2] = a[8];
+                        cov[0] = a[0] - a[6] * a[6];
+                        cov[1] = a[1] - a[6] * a[7];
+                        cov[2] = a[2] - a[6] * a[8];
+                        cov[4] = a[3] - a[7] * a[7];
+                        cov[5] = a[4] - a[7] * a[8];
+                        cov[8] = a[5] - a[8] * a[8];
+                        cov[3] = cov[1];
+                        cov[6] = cov[2];
+                        cov[7] = cov[5];
+                    }
+                    jacobi_svd3(cov, U, sv);
+                    const float n0 = U[2], n1 = U[5], n2_ = U[8];
+                    const float dot = (n0 * mean[0] + n1 * mean[1]) + n2_ * mean[2];
+                    const double d = -dot;
+                    s_n[0] = n0;
+                    s_n[1] = n1;
+                    s_n[2] = n2_;
+                    s_th = P.gf_dist - d;
+                    plane_n[((size_t)rk * P.gf_iter + it) * 3 + 0] = n0;
+                    plane_n[((size_t)rk * P.gf_iter + it) * 3 + 1] = n1;
+                    plane_n[((size_t)rk * P.gf_iter + it) * 3 + 2] = n2_;
+                    plane_d[(size_t)rk * P.gf_iter + it] = d;
+                }
+            }
+            __syncthreads();
+            if (it == 0) RG_STAMP(4);
+            // --- points * normal_ < th_dist_d_ in source order (erasor.cpp:265-281) ---
+            const float n0 = s_n[0], n1 = s_n[1], n2_ = s_n[2];
+            const double th = s_th;
+            const bool last = it == P.gf_iter - 1;
+            // point i = e * bs + tid; per (e, wave) ground counts -> one 64-entry table scan gives every wave its offset
+            uint64_t bal[4];
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                bool g = false;
+                const uint32_t i = e * bs + tid;
+                if (e < E && i < M) {
+                    const float res = (X[i] * n0 + Y[i] * n1) + Z[i] * n2_;
+                    g = (double)res < th;
+                }
+                bal[e] = __ballot(g);
+                if (lane == 0) s_tab[e * 16 + wave] = (e < E && wave < nw) ? (uint32_t)__popcll(bal[e]) : 0u;
+            }
+            __syncthreads();
+            if (wave == 0) {  // exclusive scan of the 64 (e-major, wave-minor) counts
+                const uint32_t v = s_tab[lane];
+                uint32_t inc = v;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = __shfl_up(inc, off, 64);
+                    if ((int)lane >= off) inc += t;
+                }
+                s_tab[lane] = inc - v;
+                if (lane == 63) s_carry = inc;
+            }
+            __syncthreads();
+            const uint64_t lt = lanemask_lt();
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                const uint32_t i = e * bs + tid;
+                if (e < E && i < M) {
+                    const bool g = (bal[e] >> lane) & 1ull;
+                    const uint32_t gr = s_tab[e * 16 + wave] + (uint32_t)__popcll(bal[e] & lt);  // rank among the ground points
+                    if (g) glist[gr] = i;
+                    if (last) {
+                        gflag[o0 + i] = g ? 1 : 0;
+                        grank[o0 + i] = g ? gr : (i - gr);  // rank among ground / among rejected
+                    }
+                }
+            }
+            ng = s_carry;
+            __syncthreads();
+            if (it == 0) RG_STAMP(5);
+        }
+        for (uint32_t k = tid; k < ng; k += bs) glist_out[o0 + k] = glist[k];
+        if (tid == 0) ng_out[rk] = ng;
+        if (dbg && tid == 0) {  // diagnostics (ERASOR_HIP_SORT_STAMPS): the slowest bin's split between the z-sort and the rest, 10 ns ticks
+            const unsigned long long t_c = wall_clock64();
+            if (atomicMax(&dbg[16], t_c - t_a) < t_c - t_a) {
+                dbg[17] = t_b - t_a;
+                dbg[18] = t_c - t_b;
+                dbg[19] = M;
+                dbg[32] = s_t[0] - t_a;   // key load
+                dbg[33] = s_t[1] - s_t[0];  // exact sort
+                dbg[34] = t_b - s_t[1];   // seeds
+                dbg[35] = s_t[2] - t_b;   // staging
+                dbg[36] = s_t[3] - s_t[2];  // covariance sums (iteration 0)
+                dbg[37] = s_t[4] - s_t[3];  // SVD
+                dbg[38] = s_t[5] - s_t[4];  // classification
+                dbg[39] = ng;
+            }
+        }
+    }
+#undef RG_STAMP
+}
+
 // ================================================================================================
 // per-bin voxelize_preserving_labels(curr points + reverted ground, /erasor/map_voxel_size) —
 // erasor.cpp:523-528.  One workgroup per reverted bin.
@@ -2315,6 +2654,250 @@ __global__ __launch_bounds__(1024) void k_binvox(DP P, const uint8_t *__restrict
         if (atomicMax(&dbg[20], t_c - t_a) < t_c - t_a) {
             dbg[21] = m;
             dbg[22] = nvox_out[rk];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_binvox2: per-bin voxelisation over the reverted-bin LIST, clouds of <= BV2_LMAX points entirely in LDS.
+// VoxelGrid's std::sort has equal keys by construction (the points of a voxel), so the exact introsort emulation stays;
+// what changed against k_binvox: (i) twice the LDS-resident size, (ii) run heads through one table scan, (iii) the exact
+// 1-NN label search walks the voxel grid (own cell, then shells of neighbour cells found by binary search in the sorted
+// unique keys, pruned by conservative cell bounds) instead of testing every centroid against every input point —
+// the result is the same minimum over (distance, index) pairs.
+// ------------------------------------------------------------------------------------------------
+static constexpr uint32_t BV2_LMAX = 4096;
+
+__global__ __launch_bounds__(1024) void k_binvox2(DP P, const uint32_t *__restrict__ rev_list, const DevState *__restrict__ st,
+                                                  const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
+                                                  const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq,
+                                                  const uint32_t *__restrict__ glist, const uint32_t *__restrict__ ng_arr,
+                                                  const uint32_t *__restrict__ vox_off, uint32_t *gsK, uint32_t *gsV, uint32_t *gsL,
+                                                  uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
+                                                  float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr,
+                                                  unsigned long long *dbg) {
+    __shared__ uint32_t pool[4 * BV2_LMAX];  // K | V | posL (-> sorted keys) | posR (-> sorted indices); after the sort K -> unique keys, V -> run begins
+    __shared__ uint32_t sH[BV2_LMAX / 32 + 2];
+    __shared__ float4 sC[BV2_LMAX];
+    __shared__ esort::Seg qa2[BV2_LMAX / 16 + 2], qb2[BV2_LMAX / 16 + 2];
+    __shared__ uint32_t qcnt[2];
+    __shared__ uint32_t sm[40];
+    __shared__ uint32_t sbb[6];
+    __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_tab[64];
+    uint32_t *sK = pool, *sV = pool + BV2_LMAX, *sL = pool + 2 * BV2_LMAX, *sR = pool + 3 * BV2_LMAX;
+    const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = bs >> 6;
+    const uint32_t n_rev = st->n_rev;
+    for (uint32_t rk = blockIdx.x; rk < n_rev; rk += gridDim.x) {
+        const uint32_t key = rev_list[rk];
+        const uint32_t mo = moff[key], qo = qoff[key];
+        const uint32_t nc = qoff[key + 1] - qo, ngr = ng_arr[rk];
+        const uint32_t m = nc + ngr;
+        __syncthreads();  // LDS of the previous bin is dead
+        if (nc == 0) {  // selected = bin_curr with is_occupied == false: r_pod2pc skips the bin
+            if (tid == 0) nvox_out[rk] = 0;
+            continue;
+        }
+        const uint32_t vo = vox_off[rk];
+        const unsigned long long t_a = dbg ? wall_clock64() : 0ull;
+        if (m > BV2_LMAX) {  // rare: global scratch, brute-force search (k_binvox's path)
+            esort::Seg *qa = qa2, *qb = qb2;
+            binvox_core(P, m, nc, sq + qo, spts + mo, glist + mo, gsK + vo, gsV + vo, gsK2 + vo, gsV2 + vo, gsC + vo, gsL + vo, gsR + vo,
+                        gsH + (vo >> 5) + 2 * rk, qa, qb, qcnt, sm, sbb, &s_carry, vox_out + vo, nvox_out + rk, ctr);
+            continue;
+        }
+        const float4 *sqb = sq + qo, *sptb = spts + mo;
+        const uint32_t *glb = glist + mo;
+        float4 *vout = vox_out + vo;
+        // input cloud of this call: curr bin points (scan order) then the reverted ground (source order)
+        for (uint32_t j = tid; j < m; j += bs) sC[j] = j < nc ? sqb[j] : sptb[glb[j - nc]];
+        if (tid < 3) sbb[tid] = 0xFFFFFFFFu;
+        if (tid >= 3 && tid < 6) sbb[tid] = 0u;
+        __syncthreads();
+        {
+            uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+            for (uint32_t j = tid; j < m; j += bs) {
+                const float4 p = sC[j];
+                const uint32_t k3[3] = {fkey_ord(p.x), fkey_ord(p.y), fkey_ord(p.z)};
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    mn[a] = k3[a] < mn[a] ? k3[a] : mn[a];
+                    mx[a] = k3[a] > mx[a] ? k3[a] : mx[a];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                for (int o = 32; o > 0; o >>= 1) {
+                    const uint32_t t0 = __shfl_down(mn[a], o, 64), t1 = __shfl_down(mx[a], o, 64);
+                    mn[a] = t0 < mn[a] ? t0 : mn[a];
+                    mx[a] = t1 > mx[a] ? t1 : mx[a];
+                }
+                if (lane == 0) {
+                    atomicMin(&sbb[a], mn[a]);
+                    atomicMax(&sbb[3 + a], mx[a]);
+                }
+            }
+        }
+        __syncthreads();
+        const float mnf[3] = {fkey_inv(sbb[0]), fkey_inv(sbb[1]), fkey_inv(sbb[2])};
+        const float mxf[3] = {fkey_inv(sbb[3]), fkey_inv(sbb[4]), fkey_inv(sbb[5])};
+        const VoxGrid g = vox_grid_from_bbox(mnf, mxf, P.leaf_map);
+        if (g.overflow) {  // VoxelGrid returns the input unchanged; not supported on device -> flagged, host fails the step
+            if (tid == 0) {
+                atomicAdd(&ctr->n_voxel_overflow, 1u);
+                ctr->err = 1;
+                nvox_out[rk] = 0;
+            }
+            continue;
+        }
+        for (uint32_t j = tid; j < m; j += bs) {
+            const float4 p = sC[j];
+            sK[j] = vox_index(g, p.x, p.y, p.z);
+            sV[j] = j;
+        }
+        __syncthreads();
+        esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, m, 2 * esort::lg2_floor(m), qa2, qb2, qcnt, (uint32_t)(BV2_LMAX / 16 + 2),
+                           &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+        __syncthreads();
+        // ---- run heads: unique keys (ascending) -> sK, run begins -> sV ----
+        const uint32_t E = (m + bs - 1) / bs;
+        uint64_t bal[4];
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t i = e * bs + tid;
+            const bool hd = e < E && i < m && (i == 0 || sL[i] != sL[i - 1]);
+            bal[e] = __ballot(hd);
+            if (lane == 0) s_tab[e * 16 + wave] = (wave < nw) ? (uint32_t)__popcll(bal[e]) : 0u;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t v = s_tab[lane];
+            uint32_t inc = v;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(inc, off, 64);
+                if ((int)lane >= off) inc += t;
+            }
+            s_tab[lane] = inc - v;
+            if (lane == 63) s_carry = inc;
+        }
+        __syncthreads();
+        {
+            const uint64_t lt = lanemask_lt();
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                const uint32_t i = e * bs + tid;
+                if ((bal[e] >> lane) & 1ull) {
+                    const uint32_t v = s_tab[e * 16 + wave] + (uint32_t)__popcll(bal[e] & lt);
+                    sK[v] = sL[i];
+                    sV[v] = i;
+                }
+            }
+        }
+        const uint32_t nv = s_carry;
+        __syncthreads();
+        // ---- per voxel: CentroidPoint float sums in sorted order, then the exact 1-NN label (utils.cpp:94-112) ----
+        const int dx = g.div_b[0], dy = g.div_b[1], dz = g.div_b[2];
+        const double L = 1.0 / (double)g.inv_leaf;
+        const int maxrho = max(dx, max(dy, dz));
+        for (uint32_t v0 = 0; v0 < nv; v0 += bs / NN_SUB) {
+            const uint32_t v = v0 + tid / NN_SUB, sub = tid & (NN_SUB - 1);
+            if (v >= nv) continue;  // (the eight lanes of a voxel take the same branch; no barrier inside this loop)
+            const uint32_t rs = sV[v], re = (v + 1 < nv) ? sV[v + 1] : m;
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (uint32_t li = rs; li < re; ++li) {  // (the averaged intensity is overwritten by the nearest input point's label)
+                const float4 p = sC[sR[li]];
+                sx += p.x;
+                sy += p.y;
+                sz += p.z;
+            }
+            const float fc = (float)(re - rs);
+            const float cx = sx / fc, cy = sy / fc, cz = sz / fc;
+            const uint32_t vkey = sK[v];
+            const int ci = (int)(vkey % (uint32_t)dx), cj = (int)((vkey / (uint32_t)dx) % (uint32_t)dy), ck = (int)(vkey / ((uint32_t)dx * (uint32_t)dy));
+            const double cc[3] = {(double)cx, (double)cy, (double)cz};
+            const int cidx[3] = {ci, cj, ck};
+            float best = __int_as_float(0x7F800000);
+            uint32_t best_i = 0xFFFFFFFFu;
+            for (uint32_t li = rs + sub; li < re; li += NN_SUB) {  // stage 0: the voxel's own points
+                const uint32_t pi = sR[li];
+                const float4 p = sC[pi];
+                nn_take(l2_simple(cx, cy, cz, p.x, p.y, p.z), pi, best, best_i);
+            }
+            nn_merge(best, best_i);
+            bool done = false;
+            {
+                double gmin = 1e300;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double lo = (double)(g.min_b[a] + cidx[a]) * L;
+                    const double hi = (double)(g.min_b[a] + cidx[a] + 1) * L;
+                    const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
+                    gmin = fmin(gmin, fmin(cc[a] - lo, hi - cc[a]) - margin);
+                }
+                done = (gmin > 0.0 && (double)best <= gmin * gmin);
+            }
+            for (int rho = 1; !done; ++rho) {
+                const float shell_best = best;
+                uint32_t turn = 0;
+                for (int kk = ck - rho; kk <= ck + rho; ++kk) {
+                    if (kk < 0 || kk >= dz) continue;
+                    for (int jj = cj - rho; jj <= cj + rho; ++jj) {
+                        if (jj < 0 || jj >= dy) continue;
+                        const bool shell_jk = (abs(jj - cj) == rho) || (abs(kk - ck) == rho);
+                        for (int ii = ci - rho; ii <= ci + rho; ++ii) {
+                            if (ii < 0 || ii >= dx) continue;
+                            if (!shell_jk && abs(ii - ci) < rho) continue;
+                            if ((turn++ & (NN_SUB - 1)) != sub) continue;
+                            {
+                                const int cell[3] = {ii, jj, kk};
+                                double d2c = 0.0;
+#pragma unroll
+                                for (int a = 0; a < 3; ++a) {
+                                    const double lo_a = (double)(g.min_b[a] + cell[a]) * L, hi_a = (double)(g.min_b[a] + cell[a] + 1) * L;
+                                    const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
+                                    const double da = fmax(0.0, fmax(lo_a - cc[a], cc[a] - hi_a) - margin);
+                                    d2c += da * da;
+                                }
+                                if (d2c > (double)shell_best) continue;
+                            }
+                            const uint32_t q = (uint32_t)ii + (uint32_t)jj * (uint32_t)dx + (uint32_t)kk * (uint32_t)dx * (uint32_t)dy;
+                            uint32_t lo = 0, hi = nv;  // binary search in the ascending unique keys
+                            while (lo < hi) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (sK[mid] < q) lo = mid + 1;
+                                else hi = mid;
+                            }
+                            if (lo >= nv || sK[lo] != q) continue;  // empty cell
+                            const uint32_t ws = sV[lo], we = (lo + 1 < nv) ? sV[lo + 1] : m;
+                            for (uint32_t li = ws; li < we; ++li) {
+                                const uint32_t pi = sR[li];
+                                const float4 p = sC[pi];
+                                nn_take(l2_simple(cx, cy, cz, p.x, p.y, p.z), pi, best, best_i);
+                            }
+                        }
+                    }
+                }
+                nn_merge(best, best_i);
+                if (rho >= maxrho) break;
+                double gmin = 1e300;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double lo = (double)(g.min_b[a] + cidx[a] - rho) * L;
+                    const double hi = (double)(g.min_b[a] + cidx[a] + rho + 1) * L;
+                    const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
+                    gmin = fmin(gmin, fmin(cc[a] - lo, hi - cc[a]) - margin);
+                }
+                if (best_i != 0xFFFFFFFFu && gmin > 0.0 && (double)best <= gmin * gmin) break;
+            }
+            if (sub == 0) vout[v] = make_float4(cx, cy, cz, sC[best_i < m ? best_i : 0u].w);
+        }
+        if (tid == 0) nvox_out[rk] = nv;
+        if (dbg && tid == 0) {
+            const unsigned long long t_c = wall_clock64();
+            if (atomicMax(&dbg[20], t_c - t_a) < t_c - t_a) {
+                dbg[21] = m;
+                dbg[22] = nv;
+            }
         }
     }
 }
@@ -2502,10 +3085,31 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
                                                        const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ ground_off,
                                                        const uint32_t *__restrict__ rej_off, const DevState *st,
                                                        float4 *__restrict__ Fnew, float4 *__restrict__ rejected,
-                                                       uint32_t *__restrict__ rejected_src, unsigned long long *cnt) {
+                                                       uint32_t *__restrict__ rejected_src, unsigned long long *cnt,
+                                                       // v3 only: the last `tail` workgroups write the voxelised reverted bins (k_assemble_bins' v3
+                                                       // branch) from the reverted-bin list -- one launch less on the dependency chain
+                                                       uint32_t tail, const uint32_t *__restrict__ rev_list, const uint32_t *__restrict__ qoff,
+                                                       const uint32_t *__restrict__ nvox, const uint32_t *__restrict__ vox_off,
+                                                       const float4 *__restrict__ vox_out) {
     uint32_t nd = 0, nst = 0;  // label tallies of the copies this thread wrote to Fnew
+    const uint32_t gmap = gridDim.x - tail;
+    if (blockIdx.x >= gmap) {
+        const uint32_t n_rev = st->n_rev;
+        for (uint32_t rk = blockIdx.x - gmap; rk < n_rev; rk += tail) {
+            const uint32_t key = rev_list[rk];
+            if (qoff[key + 1] == qoff[key]) continue;  // selected = an unoccupied bin_curr: r_pod2pc skips it
+            const uint32_t nv = nvox[rk], vo = vox_off[rk], oo = out_off[key];
+            for (uint32_t v = threadIdx.x; v < nv; v += blockDim.x) {
+                const float4 p = vox_out[vo + v];
+                Fnew[oo + v] = XFORM ? xform(Tb2o, p) : p;
+                if (is_dynamic_label(p.w)) ++nd; else ++nst;
+            }
+        }
+        block_commit_labels(nd, nst, cnt);
+        return;
+    }
     const uint32_t n_act = st->voi_total;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_act; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_act; i += gmap * blockDim.x) {
         uint32_t nwr = 0;
         const uint32_t key = skeys[i];
         const float4 p = spts[i];

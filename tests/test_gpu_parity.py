@@ -425,6 +425,36 @@ def test_full_size_parity_and_properties(gpu_mod):
         compare_step(g, o, rg, ro, full=(k == 0))
 
 
+@pytest.mark.parametrize("large_scale", [0, 1])
+def test_config4_dense_40M_map_parity(gpu_mod, large_scale):
+    """BASELINE config 4: config/large_scale_05.yaml on a ~40 M-point un-voxelised map (640 MB > the 256 MiB L3), with
+    is_large_scale off and on (submap 160, launch/run_erasor_in_large_scale.launch:4-5): ~3 M-point VoI, reverted bins
+    beyond the LDS-resident sizes of k_rgpf / k_binvox"""
+    from oracle import orc
+    w = synth.World(seed=20210305 + 5, length=1000.0, n_streets=5, street_gap=50.0, n_moving=10, n_peds=6)
+    lid = synth.Lidar.hdl64(2000)
+    m = w.sample_map(spacing=0.1, frames=range(0, 320, 2))
+    assert len(m) > 38_000_000
+    p = orc.params_default()
+    synth.apply_params(p, "large_scale_05")
+    if large_scale:
+        p.is_large_scale, p.submap_size = 1, 160.0
+    g, o = make_pair(gpu_mod, p)
+    g.set_map(m)
+    o.set_map(m)
+    jr = np.random.default_rng(11)
+    Tl = gpu_mod.geopose2eigen([0, 0, synth.LIDAR_HEIGHT, 0, 0, 0, 1])
+    for k in range(2):
+        p7 = w.pose(k * 2, 1.0, x0=300.0, jitter_rng=jr)
+        s = w.cast(p7, lid, k * 2)
+        Tb = gpu_mod.geopose2eigen(p7)
+        To = gpu_mod.invert_rigid(Tb)
+        rg = g.step(s, Tl, Tb, To)
+        ro = o.step(s, Tl, Tb, To)
+        assert rg.n_voi > 2_500_000 and rg.n_reverted_bins > 0
+        compare_step(g, o, rg, ro, full=False)
+
+
 def test_whole_map_save_voxelisation(gpu_mod):
     """save_static_map's voxelize_preserving_labels over a multi-million-point map (OMU.cpp:186): the exact sort's
     multi-workgroup levels, thousands of wide segments, label NN at scale"""
