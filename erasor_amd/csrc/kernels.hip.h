@@ -318,26 +318,22 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restr
         ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
         ctr->sort_qoverflow = ctr->err = 0;
     }
-    // every thread owns 16 CONSECUTIVE chunks (four 16-byte loads in flight, issued before anything else is waited for): ONE
-    // pair of block scans for the whole table
+    // Every thread owns 16 CONSECUTIVE chunks for the scan (ONE pair of block scans for the whole table), but global memory
+    // is touched in coalesced strips only (element k * 1024 + tid): both directions go through a padded LDS stage
+    // (16 consecutive words per thread would put a wavefront's 64 lanes on 64 different cache lines per access).
+    __shared__ uint32_t stage[16384 + 1024];
     uint32_t cv = 0, ch = 0;
     {
         const uint32_t base = threadIdx.x * 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t e = k * 1024 + threadIdx.x;
+            stage[e + (e >> 4)] = e < nchunks ? cinfo[e] : 0u;
+        }
+        __syncthreads();
         uint32_t ci[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint4 t = make_uint4(0u, 0u, 0u, 0u);
-            if (base + q * 4 + 3 < nchunks) t = *reinterpret_cast<const uint4 *>(cinfo + base + q * 4);
-            else {
-                if (base + q * 4 + 0 < nchunks) t.x = cinfo[base + q * 4 + 0];
-                if (base + q * 4 + 1 < nchunks) t.y = cinfo[base + q * 4 + 1];
-                if (base + q * 4 + 2 < nchunks) t.z = cinfo[base + q * 4 + 2];
-            }
-            ci[q * 4 + 0] = t.x;
-            ci[q * 4 + 1] = t.y;
-            ci[q * 4 + 2] = t.z;
-            ci[q * 4 + 3] = t.w;
-        }
+        for (int j = 0; j < 16; ++j) ci[j] = stage[threadIdx.x * 17 + j];
         uint32_t sv = 0, sh = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -346,18 +342,38 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restr
         }
         uint32_t pv = block_excl_scan(sv, sm, cv);
         uint32_t ph = block_excl_scan(sh, sm, ch);
+        if (nFchunks >= base && nFchunks < base + 16) {  // the F region's share of the totals
+            uint32_t a = pv, b2 = ph;
+            for (uint32_t j = 0; base + j < nFchunks; ++j) {
+                a += ci[j] & 0xFFFFu;
+                b2 += ci[j] >> 16;
+            }
+            s_voiF = a;
+            s_validF = b2;
+        }
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            if (base + j < nchunks) {
-                pvl[base + j] = pv;
-                phl[base + j] = ph;
-                if (base + j == nFchunks) {  // the F region's share of the totals
-                    s_voiF = pv;
-                    s_validF = ph;
-                }
-            }
+            stage[threadIdx.x * 17 + j] = pv;
             pv += ci[j] & 0xFFFFu;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t e = k * 1024 + threadIdx.x;
+            if (e < nchunks) pvl[e] = stage[e + (e >> 4)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            stage[threadIdx.x * 17 + j] = ph;
             ph += ci[j] >> 16;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t e = k * 1024 + threadIdx.x;
+            if (e < nchunks) phl[e] = stage[e + (e >> 4)];
         }
     }
     __syncthreads();

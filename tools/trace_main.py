@@ -4,11 +4,12 @@ path = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ends = [r for r in rows if "k_step_end" in r["Kernel_Name"]]
-q = ends[-3]["Queue_Id"]
+step = int(sys.argv[2]) if len(sys.argv) > 2 else -3  # which k_step_end closes the step to print
+q = ends[step]["Queue_Id"]
 main = [r for r in rows if r["Queue_Id"] == q]
 # last complete step on that queue: from the kernel after the previous k_step_end to the next k_step_end
 idx = [i for i, r in enumerate(main) if "k_step_end" in r["Kernel_Name"]]
-a, b = idx[-3] + 1, idx[-2]
+a, b = idx[step - 1] + 1, idx[step]
 t0 = int(main[a]["Start_Timestamp"])
 prev_end = int(main[a - 1]["End_Timestamp"])
 print("gap since the previous step's k_step_end: %.1f us" % ((t0 - prev_end) / 1e3))
