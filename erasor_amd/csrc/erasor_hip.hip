@@ -110,9 +110,12 @@ struct erasor_hip_handle {
     int bank = 0;                   // scratch bank of scan/radix helpers (0: query chains, 1: map chain)
     std::string err;
     bool have_map = false, have_step = false;
+    bool poisoned = false;        // a step failed after the map store had been touched: only set_map makes the handle usable again
+    bool q_passthrough = false;   // the last scan overflowed PCL's VoxelGrid indices (utils.cpp:88-91): start the next chains in pass-through mode
 
     // ---- map store ----
     uint32_t capMap = 0, capF = 0, capO = 0, capV = 0, capG = 0;
+    uint32_t n_grow = 0;  // times the map-sized scratch was enlarged (grow_map_scratch)
     uint32_t B = 0;
     DBuf<float4> F[2];
     int curF = 0;
@@ -366,7 +369,9 @@ int alloc_bins(erasor_hip_handle *h) {
 
 // capacity-sized buffers that depend on the map size
 int alloc_map(erasor_hip_handle *h, uint32_t n) {
-    const uint64_t slack = std::max<uint64_t>(n / 4, 1u << 20);
+    // ERASOR_HIP_MAP_SLACK (test hook): head-room in points, so that a small test map outgrows it and exercises grow_map_scratch
+    static const long slack_env = getenv("ERASOR_HIP_MAP_SLACK") ? atol(getenv("ERASOR_HIP_MAP_SLACK")) : -1;
+    const uint64_t slack = slack_env >= 0 ? (uint64_t)slack_env : std::max<uint64_t>(n / 4, 1u << 20);
     const uint64_t capMap = (uint64_t)n + slack;
     if (2 * capMap + (1u << 22) >= 0xFFFFFFF0ull) {
         h->err = "map too large for 32-bit indexing";
@@ -381,6 +386,27 @@ int alloc_map(erasor_hip_handle *h, uint32_t n) {
     rc |= ensure(h, h->voi_ego, V) | ensure(h, h->spts, V) | ensure(h, h->voi_key, V) | ensure(h, h->voi_src, V) | ensure(h, h->ssrc, V);
     rc |= ensure(h, h->rejected, V) | ensure(h, h->rejected_src, V) | ensure(h, h->grank, V) | ensure(h, h->glist, V) | ensure(h, h->gflag, V);
     rc |= ensure(h, h->rk_a, V) | ensure(h, h->rk_b, V) | ensure(h, h->rv_a, V) | ensure(h, h->rv_b, V);
+    return rc ? ERASOR_E_NO_DEVICE : 0;
+}
+
+// the map outgrew the capacity chosen at set_map: re-allocate every map-sized scratch array (none of them carries state from
+// one step to the next; the outskirts region grows on its own in rebuild_outskirts, the F buffers in alloc_step)
+int grow_map_scratch(erasor_hip_handle *h, uint64_t need) {
+    static const long slack_env = getenv("ERASOR_HIP_MAP_SLACK") ? atol(getenv("ERASOR_HIP_MAP_SLACK")) : -1;
+    const uint64_t capMap = need + (slack_env >= 0 ? (uint64_t)slack_env : std::max<uint64_t>(need / 2, 1u << 20));
+    if (2 * capMap + (1u << 22) >= 0xFFFFFFF0ull) {
+        h->err = "map too large for 32-bit indexing";
+        return ERASOR_E_CAPACITY;
+    }
+    ++h->n_grow;
+    h->capMap = (uint32_t)capMap;
+    h->capV = h->capMap;
+    const uint32_t V = h->capV;
+    int rc = 0;
+    rc |= ensure(h, h->voi_ego, V) | ensure(h, h->spts, V) | ensure(h, h->voi_key, V) | ensure(h, h->voi_src, V) | ensure(h, h->ssrc, V);
+    rc |= ensure(h, h->rejected, V) | ensure(h, h->rejected_src, V) | ensure(h, h->grank, V) | ensure(h, h->glist, V) | ensure(h, h->gflag, V);
+    rc |= ensure(h, h->rk_a, V) | ensure(h, h->rk_b, V) | ensure(h, h->rv_a, V) | ensure(h, h->rv_b, V);
+    h->have_step = false;  // the previous step's read-back clouds lived in these arrays
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
 
@@ -704,6 +730,7 @@ static int set_map_common(erasor_hip_handle *h, const void *src, size_t n, bool 
     HIPC(h, hipMemcpyAsync(&h->st, h->d_st.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     h->have_map = true;
+    h->poisoned = false;
     h->have_step = false;
     return ERASOR_OK;
 }
@@ -776,7 +803,7 @@ static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf, co
     return 0;
 }
 
-enum { STEP_QUERY_PREVOXELIZED = 1, STEP_VOI_EVERYTHING = 2 };
+enum { STEP_QUERY_PREVOXELIZED = 1, STEP_VOI_EVERYTHING = 2, STEP_RETRIED = 4 };
 
 // a query side no announced / in-flight chain owns; the side of the last finished step only if nothing else is free
 // (its query-derived outputs are then gone)
@@ -808,12 +835,30 @@ struct SideGuard {
 // lidar->body + R-POD key (OMU.cpp:240; erasor.cpp:100-115), bucketing and per-bin statistics of the query.  It depends
 // on the scan and the lidar->body transform only -- not on the map -- which is what lets erasor_hip_prefetch_scan run
 // it for scan k+1 while step k is still in its map-side stages.
+// VoxelGrid pass-through (see k_dup_label_passthrough): out[0..ns) = T * (point with the label of its first exact duplicate),
+// on the current stream.  Scratch: the current query side's sort buffers.
+static int enqueue_passthrough(erasor_hip_handle *h, const float4 *d_src, uint32_t ns, const float T[16], float4 *out, uint32_t *qkey) {
+    if (!ns) return ERASOR_OK;
+    int bits = 8;
+    while ((1u << bits) < 2u * ns && bits < 24) ++bits;
+    QSide &q = Q(h);
+    LAUNCH(h, "q_passthrough", k_xyz_hash_keys, cdiv(ns, 256), 256, d_src, ns, bits, q.ukeys.p);
+    const uint32_t *sk = nullptr, *sp = nullptr;
+    const int rc = radix_sort(h, q.ukeys.p, ns, nullptr, bits, q.qk_a.p, q.qposL.p, q.qv_a.p, q.qposR.p, &sk, &sp, "q_passthrough");
+    if (rc) return rc;
+    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    LAUNCH(h, "q_passthrough", k_dup_label_passthrough, cdiv(ns, 256), 256, d_src, ns, sk, sp, bits, to_xf(T ? T : I), T ? 1 : 0, h->dp, q.d_qctr.p, out,
+           qkey);
+    return ERASOR_OK;
+}
+
 static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_src, uint32_t ns, bool src_is_device, const float T_l2b[16],
-                               bool prevox, bool staged = false) {
+                               bool prevox, bool staged = false, bool passthrough = false) {
     SideGuard guard(h);
     h->qi = side;
-    // (the radix fallback for very fine R-POD grids shares its scratch bank between the sides: one stream for all of them then)
-    hipStream_t qstream = h->B + 1 <= QB_NB_MAX ? h->qstream[h->n_chain++ & 1u] : h->qstream[0];
+    // (the radix fallback for very fine R-POD grids -- and the pass-through chain's radix sort -- share their scratch bank
+    // between the sides: one stream for all of them then)
+    hipStream_t qstream = (h->B + 1 <= QB_NB_MAX && !passthrough) ? h->qstream[h->n_chain++ & 1u] : h->qstream[0];
     h->cur = qstream;
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
@@ -841,14 +886,24 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     Counters *qc = q.d_qctr.p;
     const uint32_t *nq_dev = q.d_nvox.p;
     LAUNCH(h, "q_begin", k_query_begin, 1, 256, qc, q.bb.p, B + 1 <= QB_NB_MAX ? q.qb_tot.p : (uint32_t *)nullptr, B + 1 <= QB_NB_MAX ? B + 1 : 0u,
-           q.d_nvox.p, prevox ? ns : 0u);
+           q.d_nvox.p, (prevox || passthrough) ? ns : 0u);
     // ---- part 1: bounding box, voxel keys, exact std::sort, runs ----
-    if (!prevox) voxelize_query_part1(h, ns, P.leaf_query, [&] { (void)hipEventRecord(q.ev_keys, qstream); });
+    if (passthrough && !prevox) {
+        // PCL's VoxelGrid refuses this cloud (index overflow) and hands it back unchanged (utils.cpp:88-91): the chain verifies
+        // that on the device (err 4 if not) and produces the un-voxelised query with the label search's answers
+        if (ns) LAUNCH(h, "q_bbox", k_bbox, std::min<uint32_t>(cdiv(ns, 256), 1024), 256, q.scan_in, ns, q.bb.p);
+        LAUNCH(h, "q_passthrough", k_passthrough_check, 1, 64, (const uint32_t *)q.bb.p, ns, P.leaf_query, q.qgrid.p, qc);
+        (void)hipEventRecord(q.ev_keys, qstream);
+        rc = enqueue_passthrough(h, q.scan_in, ns, T_l2b, q.query.p, q.qkey.p);
+        if (rc) return rc;
+    } else if (!prevox) voxelize_query_part1(h, ns, P.leaf_query, [&] { (void)hipEventRecord(q.ev_keys, qstream); });
     else (void)hipEventRecord(q.ev_keys, qstream);
     // ---- part 2: centroids, label NN, lidar->body, R-POD key ----
     const uint32_t *sq_keys = nullptr, *sq_perm = nullptr;
     if (prevox) {
         if (nq) LAUNCH(h, "q_direct", k_query_direct, cdiv(nq, 256), 256, q.scan_in, nq, P, qc, q.query.p, q.qkey.p);
+    } else if (passthrough) {
+        // (query and keys are already there)
     } else if (nq) {
         LAUNCH(h, "q_centroids", k_centroids, cdiv((uint64_t)nq * 8, 256), 256, q.scan_in, (const uint32_t *)q.qk_b.p, (const uint32_t *)q.qv_b.p,
                (const uint32_t *)q.run_begin.p, nq_dev, q.cent.p, q.ukeys.p, q.hkey.p, q.hval.p, q.hbits);
@@ -883,7 +938,8 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
 static int flush_announced(erasor_hip_handle *h) {
     if (!h->ann.valid) return ERASOR_OK;
     h->ann.valid = false;
-    const int rc = enqueue_query_chain(h, h->ann.side, h->ann.src, (uint32_t)h->ann.n, h->ann.is_device, h->ann.Tl, false, /*staged=*/true);
+    const int rc = enqueue_query_chain(h, h->ann.side, h->ann.src, (uint32_t)h->ann.n, h->ann.is_device, h->ann.Tl, false, /*staged=*/true,
+                                       h->q_passthrough);
     if (rc) return rc;
     h->pend[h->npend++] = h->ann.side;
     return ERASOR_OK;
@@ -902,7 +958,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
                        const float T_b2o[16], const float T_o2b[16], erasor_step_result *res, int flags = 0) {
     if (!h) return ERASOR_E_INVALID;
     if (!h->have_map) {
-        h->err = "erasor_hip_step before erasor_hip_set_map";
+        h->err = h->poisoned ? "an earlier step failed after it had modified the map store: call erasor_hip_set_map again"
+                             : "erasor_hip_step before erasor_hip_set_map";
         return ERASOR_E_STATE;
     }
     if (!T_l2b || !T_b2o || !T_o2b || (!scan_src && n_scan) || n_scan > 0x3FFFFFFFull) return ERASOR_E_INVALID;
@@ -940,7 +997,7 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         if (side < 0) {
             // (an announcement that is not this scan is the NEXT scan: it keeps the side it was staged into)
             side = pick_side(h);
-            rc = enqueue_query_chain(h, side, scan_src, ns, src_is_device, T_l2b, prevox);
+            rc = enqueue_query_chain(h, side, scan_src, ns, src_is_device, T_l2b, prevox, false, h->q_passthrough && !prevox);
             if (rc) return rc;
         }
         h->qi = side;
@@ -966,8 +1023,10 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     }
     const uint64_t n_map_in = (uint64_t)h->nF + h->o_valid;
     if (n_map_in + ns + 64 > h->capV) {
-        h->err = "map grew beyond the capacity reserved at set_map";
-        return ERASOR_E_CAPACITY;
+        // the reference's map_arranged_ simply grows (scan points enter every reverted bin, erasor.cpp:512; v2 merges whole
+        // query bins, erasor.cpp:296-307): enlarge the map-sized scratch between steps (it carries no state across steps)
+        rc = grow_map_scratch(h, n_map_in + ns + 64);
+        if (rc) return rc;
     }
     h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_chunk_scan_top
     h->st.o_begin = h->o_begin;
@@ -1174,19 +1233,37 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         return ERASOR_E_NO_DEVICE;
     }
     if (h->ctr.err || h->ctr.sort_qoverflow) {
-        // nothing was committed on the device (k_voi_gather / k_step_end bail out); restore the host mirror of the state
+        // errors raised by the query chain (2, 3, 4) are seen by k_voi_gather before it touches the map store: the step left
+        // no trace and the host mirror of the state is simply restored.
         h->st.nF = h->nF;
         h->st.o_begin = h->o_begin;
-        if (h->ctr.sort_qoverflow) {
-            h->err = "exact-sort segment queue overflow (site " + std::to_string(h->ctr.sort_qoverflow) + ")";
+        if (!h->ctr.sort_qoverflow && (h->ctr.err == 2 || h->ctr.err == 4)) {
+            // 2: PCL's VoxelGrid would overflow its int32 voxel indices on this scan and pass it through unchanged
+            //    (utils.cpp:88-91) -> run the step again with the pass-through chain, and start the next scans that way;
+            // 4: the pass-through chain found that VoxelGrid would NOT overflow -> back to the voxelising chain.
+            h->q_passthrough = h->ctr.err == 2;
+            if (!(flags & STEP_RETRIED)) {
+                q_drain(h);  // chains announced ahead were enqueued in the other mode: dropped, their steps enqueue their own
+                return step_common(h, scan_src, n_scan, src_is_device, T_l2b, T_b2o, T_o2b, res, flags | STEP_RETRIED);
+            }
+            h->err = "VoxelGrid pass-through decision did not settle";
             return ERASOR_E_INTERNAL;
         }
-        if (h->ctr.err == 3) {
+        if (!h->ctr.sort_qoverflow && h->ctr.err == 3) {
             h->err = "non-finite coordinate (NaN / Inf) in the scan";
             return ERASOR_E_INVALID;
         }
-        h->err = h->ctr.err == 2 ? "VoxelGrid index overflow on the query scan (reference returns the input unvoxelised): not supported on device"
-                                 : "per-bin VoxelGrid index overflow (unsupported on device)";
+        // everything else was raised AFTER k_voi_gather had tombstoned / moved map entries (a per-bin VoxelGrid overflow in a
+        // bin too large for LDS, an exact-sort queue overflow): the map store is no longer the map.  The handle refuses
+        // further work until erasor_hip_set_map replaces it.
+        h->poisoned = true;
+        h->have_map = false;
+        h->have_step = false;
+        if (h->ctr.sort_qoverflow) {
+            h->err = "exact-sort segment queue overflow (site " + std::to_string(h->ctr.sort_qoverflow) + "); the map store is invalid: call erasor_hip_set_map again";
+            return ERASOR_E_INTERNAL;
+        }
+        h->err = "VoxelGrid index overflow in a reverted bin of more than 4096 points (unsupported on device); the map store is invalid: call erasor_hip_set_map again";
         return ERASOR_E_UNSUPPORTED;
     }
     // commit (from here on n_voi / nq are the actual sizes)
@@ -1311,6 +1388,29 @@ int erasor_hip_get_map(erasor_hip_handle *h, float *dst, size_t cap, size_t *n) 
     return ERASOR_OK;
 }
 
+// the last step's [selected bins theta-major | ground_viz | complement] WITHOUT tf_body2origin_ (the egocentric clouds
+// ERASOR::get_static_estimate hands out, erasor.cpp:612-626), assembled into the retired F buffer (free until the next step)
+static int assemble_egocentric(erasor_hip_handle *h, float4 **out) {
+    const DevState &s = h->st;
+    if (ensure(h, h->F[h->curF ^ 1], (size_t)s.nF_new + 8)) return ERASOR_E_NO_DEVICE;
+    float4 *tmp = h->F[h->curF ^ 1].p;
+    const DP &P = h->dp;
+    const uint32_t B = h->B, n_voi = h->last_n_voi;
+    if (n_voi)
+        LAUNCH(h, "get_cloud", k_assemble_map<false>, std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p,
+               (const uint32_t *)h->rev_idx.p, h->last_skeys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p,
+               (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p,
+               (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p, (const uint32_t *)h->rej_off.p,
+               (const DevState *)h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr, 0u, (const uint32_t *)nullptr,
+               (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const float4 *)nullptr);
+    LAUNCH(h, "get_cloud", k_assemble_bins<false>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
+           (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
+           (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, tmp, (float4 *)nullptr, (unsigned long long *)nullptr);
+    HIPC(h, hipStreamSynchronize(h->stream));
+    *out = tmp;
+    return ERASOR_OK;
+}
+
 int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap, size_t *n) {
     if (!h) return ERASOR_E_INVALID;
     if (which == ERASOR_CLOUD_MAP) return erasor_hip_get_map(h, dst, cap, n);
@@ -1331,20 +1431,9 @@ int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap
             if (n) *n = cnt;
             if (!dst) return ERASOR_OK;
             if (cnt > cap) return ERASOR_E_CAPACITY;
-            if (ensure(h, h->F[h->curF ^ 1], (size_t)s.nF_new + 8)) return ERASOR_E_NO_DEVICE;
-            float4 *tmp = h->F[h->curF ^ 1].p;
-            const DP &P = h->dp;
-            const uint32_t B = h->B, n_voi = h->last_n_voi;
-            if (n_voi)
-                LAUNCH(h, "get_cloud", k_assemble_map<false>, std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p,
-                       (const uint32_t *)h->rev_idx.p, h->last_skeys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p,
-                       (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p,
-                       (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p, (const uint32_t *)h->rej_off.p,
-                       (const DevState *)h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const float4 *)nullptr);
-            LAUNCH(h, "get_cloud", k_assemble_bins<false>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
-                   (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
-                   (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, tmp, (float4 *)nullptr, (unsigned long long *)nullptr);
-            HIPC(h, hipStreamSynchronize(h->stream));
+            float4 *tmp = nullptr;
+            const int rc_a = assemble_egocentric(h, &tmp);
+            if (rc_a) return rc_a;
             const size_t off = which == ERASOR_CLOUD_STATIC_ESTIMATE ? 0 : (which == ERASOR_CLOUD_COMPLEMENT ? s.n_static_est : s.total_bins);
             if (cnt) HIPC(h, hipMemcpy(dst, tmp + off, cnt * sizeof(float4), hipMemcpyDeviceToHost));
             return ERASOR_OK;
@@ -1400,6 +1489,49 @@ int erasor_hip_get_status(erasor_hip_handle *h, double *status) {
     return ERASOR_OK;
 }
 
+// The point lists of an R-POD of the last step (erasor.h:143-145), egocentric, theta-major (the order r_pod2pc walks,
+// erasor.cpp:309-320): which 0 = r_pod_map, 1 = r_pod_curr, 2 = r_pod_selected.  begin / count: per bin, index ring*S+sector.
+int erasor_hip_get_rpod(erasor_hip_handle *h, int which, float *xyzi, size_t cap, size_t *n, uint32_t *begin, uint32_t *count) {
+    if (!h || which < 0 || which > 2) return ERASOR_E_INVALID;
+    if (!h->have_step) return ERASOR_E_STATE;
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    const uint32_t B = h->B, R = h->P.num_rings, S = h->P.num_sectors;
+    std::vector<uint32_t> off(B + 2, 0u);
+    const float4 *src = nullptr;
+    size_t total = 0;
+    if (which == 0) {
+        HIPC(h, hipMemcpy(off.data(), h->moff.p, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost));
+        src = h->spts.p;
+        total = off[B];
+    } else if (which == 1) {
+        HIPC(h, hipMemcpy(off.data(), Q(h).qoff.p, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost));
+        src = Q(h).sq.p;
+        total = off[B];
+    } else {
+        HIPC(h, hipMemcpy(off.data(), h->out_off.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+        off[B] = h->st.total_bins;
+        total = h->st.total_bins;
+    }
+    if (n) *n = total;
+    if (begin && count)
+        for (uint32_t key = 0; key < B; ++key) {  // device key = sector*R + ring -> API index = ring*S + sector
+            const uint32_t o = (key % R) * S + key / R;
+            begin[o] = off[key];
+            count[o] = off[key + 1] - off[key];
+        }
+    if (!xyzi) return ERASOR_OK;
+    if (total > cap) return ERASOR_E_CAPACITY;
+    if (which == 2) {
+        float4 *tmp = nullptr;
+        const int rc = assemble_egocentric(h, &tmp);
+        if (rc) return rc;
+        src = tmp;
+    }
+    if (total) HIPC(h, hipMemcpy(xyzi, src, total * sizeof(float4), hipMemcpyDeviceToHost));
+    return ERASOR_OK;
+}
+
 int erasor_hip_get_planes(erasor_hip_handle *h, uint32_t *bin_index, float *normal, double *d, size_t cap_bins, size_t *n_bins) {
     if (!h) return ERASOR_E_INVALID;
     if (!h->have_step) return ERASOR_E_STATE;
@@ -1439,8 +1571,12 @@ static int voxelize_device(erasor_hip_handle *h, const float4 *d_src, uint32_t n
             h->err = "non-finite coordinate (NaN / Inf) in the cloud";
             return ERASOR_E_INVALID;
         }
-        h->err = "VoxelGrid index overflow (reference returns the input unvoxelised): not supported on device";
-        return ERASOR_E_UNSUPPORTED;
+        // PCL returns the input unchanged (utils.cpp:88-91); the label search then answers with the point itself or its first duplicate
+        rc = enqueue_passthrough(h, d_src, ns, nullptr, Q(h).query.p, nullptr);
+        if (rc) return rc;
+        HIPC(h, hipStreamSynchronize(h->stream));
+        *nq_out = ns;
+        return ERASOR_OK;
     }
     const uint32_t nq = nvox_host;
     *nq_out = nq;

@@ -1025,7 +1025,19 @@ __device__ __forceinline__ VoxGrid vox_grid_from_bbox(const float mn[3], const f
     long long d[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) d[a] = (long long)((mx[a] - mn[a]) * inv) + 1;
-    g.overflow = (d[0] * d[1] * d[2]) > 2147483647LL ? 1 : 0;
+    // PCL: (dx*dy*dz) > INT_MAX in int64 -- with saturation, so that extents whose int64 product itself would wrap (undefined
+    // behaviour in the reference) report the overflow they stand for instead of a garbage grid
+    bool too_many = false;
+    long long prod = 1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (d[a] <= 0 || d[a] > 2147483647LL) too_many = true;
+        if (!too_many) {
+            prod *= d[a];
+            if (prod > 2147483647LL) too_many = true;
+        }
+    }
+    g.overflow = too_many ? 1 : 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         g.min_b[a] = (int)floorf(mn[a] * inv);
@@ -1068,6 +1080,73 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4 *__restrict__ p
     const float4 p = pts[i];
     keys[i] = g.overflow ? 0u : vox_index(g, p.x, p.y, p.z);
     vals[i] = i;
+}
+
+// ---- VoxelGrid index overflow: PCL warns and returns the input cloud unchanged (utils.cpp:88-91), after which the label
+// search of voxelize_preserving_labels gives every point the label of its nearest input point: itself, or -- distance 0,
+// "lowest index wins" -- the first exact duplicate.  Duplicates are found through a stable radix sort of a hash of the
+// coordinates: within a bucket the points come in index order, the first one with equal coordinates is the answer.
+__device__ __forceinline__ uint32_t xyz_hash(float x, float y, float z) {
+    // -0.0 == +0.0 under the float comparison that defines "duplicate": one canonical zero
+    const uint32_t a = x == 0.f ? 0u : __float_as_uint(x), b = y == 0.f ? 0u : __float_as_uint(y), c = z == 0.f ? 0u : __float_as_uint(z);
+    uint32_t h = a * 0x9E3779B1u;
+    h = (h ^ (h >> 15)) + b * 0x85EBCA77u;
+    h = (h ^ (h >> 13)) + c * 0xC2B2AE3Du;
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    return h;
+}
+__global__ __launch_bounds__(256) void k_xyz_hash_keys(const float4 *__restrict__ pts, uint32_t n, int bits, uint32_t *__restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    keys[i] = xyz_hash(p.x, p.y, p.z) >> (32 - bits);
+}
+// the pass-through chain's own check that VoxelGrid WOULD overflow for this cloud and leaf (the host only guesses it from
+// the previous scan): err 4 = "it would not", the caller falls back to the voxelising chain; err 3 = non-finite input
+__global__ void k_passthrough_check(const uint32_t *__restrict__ bb, uint32_t n, float leaf, VoxGrid *gout, Counters *ctr) {
+    if (threadIdx.x || blockIdx.x) return;
+    const float mn[3] = {fkey_inv(bb[0]), fkey_inv(bb[1]), fkey_inv(bb[2])};
+    const float mx[3] = {fkey_inv(bb[3]), fkey_inv(bb[4]), fkey_inv(bb[5])};
+    VoxGrid g = vox_grid_from_bbox(mn, mx, leaf);
+    bool finite = true;
+    for (int a = 0; a < 3; ++a) finite = finite && isfinite(mn[a]) && isfinite(mx[a]);
+    if (n && !finite) g.overflow = 2;
+    *gout = g;
+    if (!n) return;
+    if (g.overflow == 2) ctr->err = 3;
+    else if (!g.overflow) ctr->err = 4;
+    else atomicAdd(&ctr->n_voxel_overflow, 1u);
+}
+// out[i] = T * (x, y, z, label of the first point with the same coordinates); optionally the R-POD key of the result
+__global__ __launch_bounds__(256) void k_dup_label_passthrough(const float4 *__restrict__ pts, uint32_t n, const uint32_t *__restrict__ skeys,
+                                                                const uint32_t *__restrict__ sperm, int bits, Xf T, int apply_T, DP P,
+                                                                Counters *ctr, float4 *__restrict__ out, uint32_t *__restrict__ qkey) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const uint32_t key = xyz_hash(p.x, p.y, p.z) >> (32 - bits);
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {  // first entry of the bucket
+        const uint32_t mid = (lo + hi) >> 1;
+        if (skeys[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    float label = p.w;
+    for (uint32_t j = lo; j < n && skeys[j] == key; ++j) {
+        const uint32_t c = sperm[j];
+        if (c >= i) break;  // stable: index order inside the bucket; nothing below i matched
+        const float4 q = pts[c];
+        if (q.x == p.x && q.y == p.y && q.z == p.z) {
+            label = q.w;
+            break;
+        }
+    }
+    float4 o = make_float4(p.x, p.y, p.z, label);
+    if (apply_T) o = xform(T, o);
+    out[i] = o;
+    if (qkey) qkey[i] = bin_key(P, o.x, o.y, o.z, ctr);
 }
 
 // ---- exact std::sort of the (idx, point) pairs, global memory -----------------------------------
@@ -2758,11 +2837,23 @@ __global__ __launch_bounds__(1024) void k_binvox2(DP P, const uint32_t *__restri
         const float mnf[3] = {fkey_inv(sbb[0]), fkey_inv(sbb[1]), fkey_inv(sbb[2])};
         const float mxf[3] = {fkey_inv(sbb[3]), fkey_inv(sbb[4]), fkey_inv(sbb[5])};
         const VoxGrid g = vox_grid_from_bbox(mnf, mxf, P.leaf_map);
-        if (g.overflow) {  // VoxelGrid returns the input unchanged; not supported on device -> flagged, host fails the step
+        if (g.overflow) {  // VoxelGrid returns the input unchanged (utils.cpp:88-91); the label search then finds the point itself or
+            // its first exact duplicate (distance 0, lowest index)
+            for (uint32_t j = tid; j < m; j += bs) {
+                const float4 p = sC[j];
+                float label = p.w;
+                for (uint32_t i = 0; i < j; ++i) {
+                    const float4 q = sC[i];
+                    if (q.x == p.x && q.y == p.y && q.z == p.z) {
+                        label = q.w;
+                        break;
+                    }
+                }
+                vout[j] = make_float4(p.x, p.y, p.z, label);
+            }
             if (tid == 0) {
                 atomicAdd(&ctr->n_voxel_overflow, 1u);
-                ctr->err = 1;
-                nvox_out[rk] = 0;
+                nvox_out[rk] = m;
             }
             continue;
         }

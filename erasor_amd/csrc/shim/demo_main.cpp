@@ -49,6 +49,26 @@ static int erasor_class_mode(int argc, char **argv) {
     write_bin(out + "_complement.bin", complement);
     write_bin(out + "_map_rejected.bin", map_rejected);
     write_bin(out + "_ground_viz.bin", erasor.ground_viz);
+    {   // the public R-PODs (erasor.h:143-145): per bin count / min_h / max_h / status, theta-major point dumps, and
+        // is_dynamic_obj_close for every bin (erasor.cpp:573-595)
+        std::ofstream f(out + "_rpod.txt");
+        pcl::PointCloud<pcl::PointXYZI> flat[3];
+        R_POD *pods[3] = {&erasor.r_pod_map, &erasor.r_pod_curr, &erasor.r_pod_selected};
+        for (int t = 0; t < p.num_sectors; ++t)
+            for (int r = 0; r < p.num_rings; ++r) {
+                for (int w = 0; w < 3; ++w)
+                    if ((*pods[w])[r][t].is_occupied) flat[w] += (*pods[w])[r][t].points;  // r_pod2pc, erasor.cpp:309-320
+                const Bin &m = erasor.r_pod_map[r][t], &c = erasor.r_pod_curr[r][t], &s = erasor.r_pod_selected[r][t];
+                char line[256];
+                snprintf(line, sizeof(line), "%d %d %zu %.17g %.17g %zu %.17g %.17g %zu %.17g %d\n", r, t, m.points.size(), m.min_h, m.max_h,
+                         c.points.size(), c.min_h, c.max_h, s.points.size(), s.status,
+                         erasor.is_dynamic_obj_close(erasor.r_pod_selected, r, t, 1, 1) ? 1 : 0);
+                f << line;
+            }
+        write_bin(out + "_rpod_map.bin", flat[0]);
+        write_bin(out + "_rpod_curr.bin", flat[1]);
+        write_bin(out + "_rpod_selected.bin", flat[2]);
+    }
     printf("ERASOR class: arranged %zu complement %zu rejected %zu max_range %.1f\n", arranged.size(), complement.size(), map_rejected.size(),
            erasor.get_max_range());
     return 0;
@@ -128,7 +148,28 @@ static int mapgen_mode(int argc, char **argv) {
     return 0;
 }
 
+// --voxelize <in.bin> <leaf> <out.bin>: the free function erasor_utils::voxelize_preserving_labels(Ptr, Cloud&, double)
+// (utils.hpp:103), as OMU.cpp:186,238 / erasor.cpp:528 / mapgen.hpp:239 call it
+static int voxelize_mode(int argc, char **argv) {
+    if (argc < 5) return 2;
+    pcl::PointCloud<pcl::PointXYZI>::Ptr src(new pcl::PointCloud<pcl::PointXYZI>());
+    pcl::PointCloud<pcl::PointXYZI> dst;
+    if (!read_bin(argv[2], *src)) return 3;
+    erasor_utils::voxelize_preserving_labels(src, dst, atof(argv[3]));
+    write_bin(argv[4], dst);
+    printf("voxelize_preserving_labels: %zu -> %zu\n", src->size(), dst.size());
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 2 && std::string(argv[1]) == "--voxelize") {
+        try {
+            return voxelize_mode(argc, argv);
+        } catch (const std::exception &e) {
+            fprintf(stderr, "error: %s\n", e.what());
+            return 1;
+        }
+    }
     if (argc >= 2 && std::string(argv[1]) == "--mapgen") {
         try {
             return mapgen_mode(argc, argv);

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <algorithm>
 #include <sstream>
 
 namespace {
@@ -116,10 +117,58 @@ void count_stat_dyn(const Cloud &cloudIn, int &num_static, int &num_dynamic) {
     num_dynamic = d;
 }
 
+int &voxelize_device() {
+    static int dev = 0;
+    return dev;
+}
+void voxelize_preserving_labels(Cloud::Ptr src, Cloud &dst, double leaf_size) {
+    static erasor_hip_handle *h = nullptr;  // process-wide, created on first use (like the reference's function-static VoxelGrid, utils.cpp:88)
+    static int h_dev = -1;
+    if (!h || h_dev != voxelize_device()) {
+        if (h) erasor_hip_destroy(h);
+        h = nullptr;
+        erasor_params p;
+        erasor_hip_params_default(&p);
+        check(nullptr, erasor_hip_create(&p, voxelize_device(), &h), "erasor_hip_create");
+        h_dev = voxelize_device();
+    }
+    if (!src) throw std::invalid_argument("voxelize_preserving_labels: null input cloud");
+    const std::vector<float> v = to_xyzi(*src);
+    std::vector<float> out(v.size() + 4);
+    size_t n = 0;
+    check(h, erasor_hip_voxelize_preserving_labels(h, v.data(), src->size(), leaf_size, out.data(), src->size(), &n), "voxelize_preserving_labels");
+    from_xyzi(out, n, dst);
+}
+
 }  // namespace erasor_utils
 
 // ------------------------------------------------------------------------------------------------
 ERASOR::ERASOR(const erasor_params &p, int device) : P_(p), device_(device) {}
+#ifdef ERASOR_SHIM_WITH_ROS
+static erasor_params params_from_rosparam(ros::NodeHandle &nh) {  // erasor.h:47-61, OMU.cpp:66-83
+    erasor_params p;
+    erasor_hip_params_default(&p);
+    int i;
+    nh.param("/erasor/max_range", p.max_range, 10.0);
+    nh.param("/erasor/num_rings", i, 20); p.num_rings = i;
+    nh.param("/erasor/num_sectors", i, 60); p.num_sectors = i;
+    nh.param("/erasor/max_h", p.max_h, 3.0);
+    nh.param("/erasor/min_h", p.min_h, 0.0);
+    nh.param("/erasor/th_bin_max_h", p.th_bin_max_h, 0.39);
+    nh.param("/erasor/scan_ratio_threshold", p.scan_ratio_threshold, 0.22);
+    nh.param("/erasor/num_lowest_pts", i, 5); p.num_lowest_pts = i;
+    nh.param("/erasor/minimum_num_pts", i, 4); p.minimum_num_pts = i;
+    nh.param("/erasor/rejection_ratio", p.rejection_ratio, 0.33);
+    nh.param("/erasor/gf_dist_thr", p.gf_dist_thr, 0.05);
+    nh.param("/erasor/gf_iter", i, 3); p.gf_iter = i;
+    nh.param("/erasor/gf_num_lpr", i, 10); p.gf_num_lpr = i;
+    nh.param("/erasor/gf_th_seeds_height", p.gf_th_seeds_height, 0.5);
+    nh.param("/erasor/map_voxel_size", p.map_voxel_size, 0.2);
+    nh.param("/erasor/version", i, 3); p.version = i;
+    return p;
+}
+ERASOR::ERASOR(ros::NodeHandle *nodehandler) : P_(params_from_rosparam(*nodehandler)), device_(0) {}
+#endif
 ERASOR::~ERASOR() {
     for (auto *h : h_)
         if (h) erasor_hip_destroy(h);
@@ -148,6 +197,54 @@ void ERASOR::run(int version) {
     fetch_cloud(h, ERASOR_CLOUD_STATIC_ESTIMATE, arranged_);
     status.assign((size_t)P_.num_rings * P_.num_sectors, 0.0);
     check(h, erasor_hip_get_status(h, status.data()), "erasor_hip_get_status");
+    // the public R-PODs (erasor.h:143-145)
+    const size_t B = (size_t)P_.num_rings * P_.num_sectors;
+    std::vector<uint32_t> begin(B), count(B);
+    R_POD *pods[3] = {&r_pod_map, &r_pod_curr, &r_pod_selected};
+    for (int which = 0; which < 3; ++which) {
+        size_t n = 0;
+        check(h, erasor_hip_get_rpod(h, which, nullptr, 0, &n, begin.data(), count.data()), "erasor_hip_get_rpod");
+        std::vector<float> v(n * 4 + 4);
+        check(h, erasor_hip_get_rpod(h, which, v.data(), n, &n, begin.data(), count.data()), "erasor_hip_get_rpod");
+        R_POD &pod = *pods[which];
+        pod.assign((size_t)P_.num_rings, Ring((size_t)P_.num_sectors));
+        for (int r = 0; r < P_.num_rings; ++r)
+            for (int t = 0; t < P_.num_sectors; ++t) {
+                Bin &b = pod[r][t];
+                const size_t i = (size_t)r * P_.num_sectors + t;
+                b.max_h = -10000000000000.0;  // clear_bin, erasor.cpp:44-52 (INF = 1e13, erasor.h:3)
+                b.min_h = 10000000000000.0;
+                b.x = b.y = 0;
+                b.status = which == 2 ? status[i] : 0.0;
+                b.is_occupied = count[i] > 0;
+                b.points.points.resize(count[i]);
+                for (uint32_t k = 0; k < count[i]; ++k) {  // pt2r_pod, erasor.cpp:87-98
+                    pcl::PointXYZI &pt = b.points.points[k];
+                    const float *q = &v[4 * ((size_t)begin[i] + k)];
+                    pt.x = q[0]; pt.y = q[1]; pt.z = q[2]; pt.intensity = q[3];
+                    if (pt.z >= b.max_h) { b.max_h = pt.z; b.x = pt.x; b.y = pt.y; }
+                    if (pt.z <= b.min_h) b.min_h = pt.z;
+                }
+                b.points.width = count[i];
+                b.points.height = 1;
+            }
+    }
+}
+bool ERASOR::is_dynamic_obj_close(R_POD &r_pod, int r_target, int theta_target, int r_range, int theta_range) {
+    const int num_rings = P_.num_rings, num_sectors = P_.num_sectors;
+    std::vector<int> theta_candidates;
+    for (int j = theta_target - theta_range; j <= theta_target + theta_range; j++) {
+        if (j < 0) theta_candidates.push_back(j + num_rings);            // (sic: the reference wraps by num_rings, erasor.cpp:578)
+        else if (j >= num_sectors) theta_candidates.push_back(j - num_rings);
+        else theta_candidates.push_back(j);
+    }
+    for (int r = std::max(0, r_target - r_range); r <= std::min(r_target + r_range, num_rings - 1); r++)
+        for (int theta : theta_candidates) {
+            if ((r == r_target) && (theta == theta_target)) continue;
+            if (theta < 0 || theta >= num_sectors) continue;  // the reference reads out of bounds here (num_rings > num_sectors only)
+            if (r_pod[r][theta].status == ERASOR_ST_CURR_IS_HIGHER) return true;
+        }
+    return false;
 }
 void ERASOR::compare_vois_and_revert_ground(int) { run(2); }
 void ERASOR::compare_vois_and_revert_ground_w_block(int) { run(3); }

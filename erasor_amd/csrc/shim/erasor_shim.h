@@ -16,6 +16,9 @@
 
 #include "../../../include/erasor_hip.h"
 #include "erasor_shim_types.h"
+#ifdef ERASOR_SHIM_WITH_ROS
+#include <ros/ros.h>
+#endif
 
 namespace erasor_utils {
 typedef pcl::PointCloud<pcl::PointXYZI> Cloud;
@@ -35,12 +38,34 @@ int load_pcd(const std::string &pcd_name, Cloud &dst);
 // pcl::io::savePCDFileASCII as used at OMU.cpp:193 (PCL's default: 8 significant digits), and the lossless binary form
 int save_pcd_ascii(const std::string &pcd_name, const Cloud &src);
 int save_pcd_binary(const std::string &pcd_name, const Cloud &src);
+// utils.cpp:80-114, same signature as utils.hpp:103 (called at OMU.cpp:186,238, erasor.cpp:528, mapgen.hpp:239,252,295):
+// PCL VoxelGrid + exact 1-NN label, on the GPU (erasor_hip_voxelize_preserving_labels).  The free function has no
+// object to hang a device handle on: it uses one process-wide handle on device `voxelize_device()` (default 0).
+void voxelize_preserving_labels(Cloud::Ptr src, Cloud &dst, double leaf_size);
+int &voxelize_device();
 }  // namespace erasor_utils
+
+// struct Bin / R_POD / Ring of the reference (erasor.h:24-41), same member names
+struct Bin {
+    double max_h;
+    double min_h;
+    double x;
+    double y;
+    double status;
+    bool is_occupied;
+    pcl::PointCloud<pcl::PointXYZI> points;
+};
+typedef std::vector<std::vector<Bin>> R_POD;
+typedef std::vector<Bin> Ring;
 
 // class ERASOR (erasor.h:43-228).  Inputs of set_inputs are egocentric clouds, as in the reference.
 class ERASOR {
 public:
     explicit ERASOR(const erasor_params &p, int device = 0);
+#ifdef ERASOR_SHIM_WITH_ROS
+    // the reference's constructor (erasor.h:46-61): parameters from the rosparam server under their reference names
+    explicit ERASOR(ros::NodeHandle *nodehandler);
+#endif
     ~ERASOR();
     void set_inputs(const pcl::PointCloud<pcl::PointXYZI> &map_voi, const pcl::PointCloud<pcl::PointXYZI> &query_voi);  // erasor.cpp:57-85
     void compare_vois_and_revert_ground(int frame);           // v2, erasor.cpp:332-434
@@ -48,6 +73,12 @@ public:
     void get_static_estimate(pcl::PointCloud<pcl::PointXYZI> &arranged, pcl::PointCloud<pcl::PointXYZI> &complement);  // :612-626
     void get_outliers(pcl::PointCloud<pcl::PointXYZI> &map_rejected, pcl::PointCloud<pcl::PointXYZI> &curr_rejected);   // :322-327
     double get_max_range();  // :628
+    // erasor.cpp:573-595: is a CURR_IS_HIGHER bin within (r_range, theta_range) of the target?  Works on the R-POD it is
+    // given (the reference passes r_pod_selected) and keeps the reference's theta wrap by num_rings.
+    bool is_dynamic_obj_close(R_POD &r_pod_selected, int r_target, int theta_target, int r_range, int theta_range);
+    // erasor.h:143-145, filled by compare_*: r_pod[ring][sector]; Bin::points are the device's bin lists (egocentric),
+    // max_h / min_h / is_occupied / status as the reference leaves them (x, y: the bin's highest point, erasor.cpp:91-94)
+    R_POD r_pod_map, r_pod_curr, r_pod_selected;
     // public members of the reference (erasor.h:127,139-141)
     pcl::PointCloud<pcl::PointXYZI> ground_viz, debug_curr_rejected, debug_map_rejected, map_complement;
     // r_pod_selected[r][theta].status after compare_* (erasor.h:145), index = ring*num_sectors + sector
@@ -108,6 +139,7 @@ public:
     void announce_next(const pcl::PointCloud<pcl::PointXYZI> &lidar);
     void save_static_map(float voxel_size);                    // OMU.cpp:174-196
     void get_map(pcl::PointCloud<pcl::PointXYZI> &dst);        // *map_arranged_
+    erasor_hip_handle *handle() { return h_; }                 // for adapters that read more of the last step (ros1_adapter.cpp)
     // last step's products (the clouds the reference publishes, OMU.cpp:316-320)
     pcl::PointCloud<pcl::PointXYZI> map_rejected, query_rejected;
     erasor_step_result last;

@@ -11,6 +11,7 @@
 #include <geometry_msgs/Pose.h>
 #else
 #include <cstddef>
+#include <memory>
 #include <vector>
 
 namespace pcl {
@@ -19,6 +20,8 @@ struct PointXYZI {  // same field names as pcl::PointXYZI; 16 B here (PCL pads t
 };
 template <class T>
 struct PointCloud {
+    typedef std::shared_ptr<PointCloud<T>> Ptr;             // boost::shared_ptr in PCL 1.8
+    typedef std::shared_ptr<const PointCloud<T>> ConstPtr;
     std::vector<T> points;
     unsigned width = 0, height = 1;
     bool is_dense = true;

@@ -186,6 +186,13 @@ int erasor_hip_get_bins(erasor_hip_handle *h, int which, uint32_t *count, double
 /* r_pod_selected[r][theta].status after the step (erasor.cpp:503-560), index = ring*num_sectors + sector */
 int erasor_hip_get_status(erasor_hip_handle *h, double *status);
 
+/* replaces: the public R-PODs themselves, `R_POD r_pod_map, r_pod_curr, r_pod_selected` (erasor.h:143-145): the
+ * point list of every bin (Bin::points, erasor.h:32), egocentric.  which: 0 = map, 1 = curr, 2 = selected.
+ * The points come theta-major (the order ERASOR::r_pod2pc walks the bins, erasor.cpp:309-320), each bin's points in
+ * the reference's order; begin[i] / count[i] locate bin i = ring*num_sectors + sector inside xyzi. */
+int erasor_hip_get_rpod(erasor_hip_handle *h, int which, float *xyzi, size_t cap_points, size_t *n,
+                        uint32_t *begin, uint32_t *count);
+
 /* R-GPF plane per reverted bin, in the (theta, ring) order the reference visits them
  * (erasor.cpp:493-494): for reverted bin k and iteration it < gf_iter:
  *   normal[(k*gf_iter+it)*3 .. +3], d[k*gf_iter+it]  (erasor.cpp:183-198);

@@ -274,6 +274,7 @@ public:
         if (!stub::capture_topics().empty() && stub::capture_topics().count(topic_)) stub::published()[topic_] = msg;
     }
     const std::string &getTopic() const { return topic_; }
+    uint32_t getNumSubscribers() const { return stub::capture_topics().count(topic_) ? 1u : 0u; }
 
 private:
     std::string topic_;
@@ -319,6 +320,8 @@ public:
     }
 };
 
+inline void init(int &, char **, const std::string &) {}
+inline void spin() {}
 inline void spinOnce() {}
 inline bool ok() { return true; }
 

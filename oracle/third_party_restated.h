@@ -123,7 +123,20 @@ static void voxel_grid(const Cloud &in, double leaf_d, VoxelGridOut &vo) {
     }
     int64_t d[3];
     for (int a = 0; a < 3; ++a) d[a] = static_cast<int64_t>((mx[a] - mn[a]) * inv) + 1;
-    if ((d[0] * d[1] * d[2]) > static_cast<int64_t>(std::numeric_limits<int32_t>::max())) {
+    // PCL: (dx*dy*dz) > INT_MAX in int64.  Evaluated with saturation here: where PCL's own int64 product would wrap
+    // (extents beyond ~2e6 voxels per axis: undefined behaviour in the reference) this reports the overflow it stands for.
+    bool too_many = false;
+    {
+        int64_t prod = 1;
+        for (int a = 0; a < 3; ++a) {
+            if (d[a] <= 0 || d[a] > static_cast<int64_t>(std::numeric_limits<int32_t>::max())) too_many = true;
+            if (!too_many) {
+                prod *= d[a];
+                if (prod > static_cast<int64_t>(std::numeric_limits<int32_t>::max())) too_many = true;
+            }
+        }
+    }
+    if (too_many) {
         vo.overflow = true;  // "Leaf size is too small ... Integer indices would overflow." -> output = *input_
         return;
     }

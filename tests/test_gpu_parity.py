@@ -352,6 +352,93 @@ def test_one_bin_known_answers_on_the_gpu(gpu_mod):
         compare_step(g, o, g.step(s, I4, I4, I4), o.step(s, I4, I4, I4))
 
 
+def test_voxelgrid_index_overflow_passes_the_cloud_through(gpu_mod):
+    """PCL's VoxelGrid refuses a cloud whose voxel indices would overflow int32 and returns it unchanged (utils.cpp:88-91);
+    the label search then finds every point itself or its first exact duplicate.  /MapUpdater/query_voxel_size defaults to
+    0.05 (OMU.cpp:66), which overflows on any outdoor scan (4800 x 4800 x 600 voxels): the step must keep working, with
+    the un-voxelised scan, and go back to voxelising when a later scan does not overflow."""
+    from oracle import orc
+    sc = scenarios.small()
+    g0 = gpu_mod.Erasor(gpu_mod.params_default())
+    # standalone (save_static_map(0.05) on a street-sized map): input back, duplicate labels fixed
+    rng = np.random.default_rng(4)
+    wide = np.concatenate([rng.uniform(-4000, 4000, (5000, 3)), rng.integers(1, 99, (5000, 1))], 1).astype(np.float32)
+    wide = np.concatenate([wide, wide[:300]])
+    wide[-300:, 3] = 7
+    wide[17, 0], wide[5017, 0] = 0.0, -0.0  # -0.0 == +0.0 is still a duplicate
+    wide[5017, 1:3] = wide[17, 1:3]
+    got, want = g0.voxelize_preserving_labels(wide, 0.001), orc.voxelize_preserving_labels(wide, 0.001)
+    assert len(got) == len(wide)
+    same(got, want, "standalone pass-through")
+    same(g0.voxelize_preserving_labels(sc["map"][:50000], 0.01), orc.voxelize_preserving_labels(sc["map"][:50000], 0.01), "map at 1 cm")
+    # steps: 2 cm query leaf -> overflow on every scan of this (narrow) street; then a scan cropped to a small box -> voxelised again
+    p = orc.params_default()
+    synth.apply_params(p, "05", query_voxel_size=0.02)
+    g, o = make_pair(gpu_mod, p)
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    for k in range(3):
+        rg = g.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        ro = o.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        assert ro.n_voxel_overflow >= 1 and rg.n_query == len(sc["scans"][k])
+        compare_step(g, o, rg, ro)
+    s3 = sc["scans"][3]
+    crop = s3[(np.abs(s3[:, 0]) < 5) & (np.abs(s3[:, 1]) < 5)]
+    rg = g.step(crop, sc["T_l2b"], sc["T_b2o"][3], sc["T_o2b"][3])
+    ro = o.step(crop, sc["T_l2b"], sc["T_b2o"][3], sc["T_o2b"][3])
+    assert ro.n_voxel_overflow == 0 and rg.n_voxel_overflow == 0
+    compare_step(g, o, rg, ro)
+    # with look-ahead: chains announced in the wrong mode are dropped and redone
+    rg = None
+    g.prefetch(sc["scans"][4], sc["T_l2b"])
+    rg = g.step(sc["scans"][4], sc["T_l2b"], sc["T_b2o"][4], sc["T_o2b"][4])
+    ro = o.step(sc["scans"][4], sc["T_l2b"], sc["T_b2o"][4], sc["T_o2b"][4])
+    compare_step(g, o, rg, ro)
+    # per-bin VoxelGrid overflow (/erasor/map_voxel_size absurdly small): the reverted bin keeps curr + ground un-voxelised
+    p2 = orc.params_default()
+    synth.apply_params(p2, "05", map_voxel_size=1e-4)
+    g2, o2 = make_pair(gpu_mod, p2)
+    g2.set_map(sc["map"])
+    o2.set_map(sc["map"])
+    tot = 0
+    for k in range(3):
+        rg = g2.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        ro = o2.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        tot += ro.n_voxel_overflow
+        compare_step(g2, o2, rg, ro)
+    assert tot > 0
+
+
+def test_map_grows_without_bound():
+    """the reference's map_arranged_ just grows (v2 appends every merged query bin, erasor.cpp:296-307): the map-sized
+    scratch is enlarged between steps instead of failing with ERASOR_E_CAPACITY.  ERASOR_HIP_MAP_SLACK shrinks the
+    head-room chosen at set_map so that a small test map outgrows it several times."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, 'tests')\n"
+        "import scenarios, erasor_amd\n"
+        "from oracle import orc\n"
+        "sc = scenarios.small(version=2)\n"
+        "g = erasor_amd.Erasor(scenarios.to_product_params(sc['params'])); o = orc.Oracle(sc['params'])\n"
+        "g.set_map(sc['map']); o.set_map(sc['map'])\n"
+        "n0 = len(sc['map'])\n"
+        "for k in range(8):\n"
+        "    rg = g.step(sc['scans'][k], sc['T_l2b'], sc['T_b2o'][k], sc['T_o2b'][k])\n"
+        "    ro = o.step(sc['scans'][k], sc['T_l2b'], sc['T_b2o'][k], sc['T_o2b'][k])\n"
+        "    a, b = g.get_map(), o.get_map()\n"
+        "    assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), k\n"
+        "    assert np.array_equal(g.get_rejected_indices(), o.get_rejected_indices())\n"
+        "assert len(a) > n0 + 20000, (len(a), n0)\n"
+        "print('GROWTH-OK', n0, len(a))\n"
+    )
+    env = dict(os.environ, ERASOR_HIP_MAP_SLACK="3000")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert "GROWTH-OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_api_error_behaviour(gpu_mod):
     p = gpu_mod.params_default()
     g = gpu_mod.Erasor(p)

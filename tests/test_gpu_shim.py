@@ -100,9 +100,122 @@ def test_erasor_class_on_egocentric_clouds(tmp_path, version):
         assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), nm
     # debug_map_rejected is egocentric inside ERASOR (the oracle hands it out in the map frame): same count here
     assert len(rd("map_rejected")) == len(o.get_cloud(4))
+    # public R-PODs (erasor.h:143-145) and is_dynamic_obj_close (erasor.h:132, erasor.cpp:573-595)
+    p = sc["params"]
+    R, S = p.num_rings, p.num_sectors
+    rows = np.loadtxt(os.path.join(d, "out_rpod.txt")).reshape(-1, 11)
+    idx = (rows[:, 0] * S + rows[:, 1]).astype(int)
+    (mc, mmin, mmax), (cc, cmin, cmax) = o.get_bins(0), o.get_bins(1)
+    assert np.array_equal(rows[:, 2], mc[idx]) and np.array_equal(rows[:, 5], cc[idx])
+    assert np.array_equal(rows[:, 3], mmin[idx]) and np.array_equal(rows[:, 4], mmax[idx])
+    assert np.array_equal(rows[:, 6], cmin[idx]) and np.array_equal(rows[:, 7], cmax[idx])
+    st = o.get_status()
+    assert np.array_equal(rows[:, 9], st[idx])
+    # flattening the R-PODs the way r_pod2pc does gives back: the binned part of map_voi / query_voi, and the bins part of the estimate
+    code, _ = o.get_voi_codes()
+    theta_major = lambda cl, cd: cl[np.argsort((cd % S) * R + cd // S, kind="stable")]  # noqa: E731
+    want_map = theta_major(map_voi[code >= 0], code[code >= 0])
+    got_map = rd("rpod_map")
+    assert got_map.shape == want_map.shape and np.array_equal(got_map.view(np.uint32), want_map.view(np.uint32))
+    n_ground = len(o.get_cloud(6))
+    want_sel = o.get_cloud(2)[: len(o.get_cloud(2)) - n_ground]
+    got_sel = rd("rpod_selected")
+    assert got_sel.shape == want_sel.shape and np.array_equal(got_sel.view(np.uint32), want_sel.view(np.uint32))
+    assert len(rd("rpod_curr")) == int(cc.sum())
+    if version == 3:  # BLOCKED bins are exactly the MERGE-candidates with a CURR_IS_HIGHER neighbour
+        st2 = st.reshape(R, S)
+        close = rows[:, 10].astype(bool)
+        for r, t, c in zip(rows[:, 0].astype(int), rows[:, 1].astype(int), close):
+            if st2[r, t] == 0.8:
+                assert c
+            if st2[r, t] == 0.25:
+                assert not c
     bad = subprocess.run([DEMO, "--erasor-class", os.path.join(d, "map_voi.bin"), os.path.join(d, "query_voi.bin"), os.path.join(d, "o2"), "4"],
                          capture_output=True, text=True, timeout=600)
     assert bad.returncode == 1 and "not implemented" in bad.stderr   # std::invalid_argument, as OMU.cpp:274
+
+
+def test_free_function_voxelize_preserving_labels(tmp_path):
+    """erasor_utils::voxelize_preserving_labels(Ptr, Cloud&, double) (utils.hpp:103) through the shim"""
+    from oracle import orc
+    ensure_demo()
+    sc = scenarios.small()
+    d = str(tmp_path)
+    for k, (cloud, leaf) in enumerate(((sc["scans"][0], 0.2), (sc["map"][:40000], 0.5))):
+        src, dst = os.path.join(d, "in%d.bin" % k), os.path.join(d, "out%d.bin" % k)
+        np.ascontiguousarray(cloud, np.float32).tofile(src)
+        out = subprocess.run([DEMO, "--voxelize", src, repr(leaf), dst], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        got = np.fromfile(dst, np.float32).reshape(-1, 4)
+        want = orc.voxelize_preserving_labels(cloud, leaf)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+ADAPTER = os.path.join(ROOT, "tests", "cpp", "ros1_adapter_check")
+
+
+def build_adapter_check():
+    """ros1_adapter.cpp + the shim, compiled with -DERASOR_SHIM_WITH_PCL -DERASOR_SHIM_WITH_ROS against the stand-in ROS / PCL
+    headers of oracle/stubs (this image has neither)"""
+    shim = os.path.join(ROOT, "erasor_amd", "csrc", "shim")
+    cmd = ["g++", "-O1", "-std=c++17", "-DERASOR_SHIM_WITH_PCL", "-DERASOR_SHIM_WITH_ROS", "-I" + os.path.join(ROOT, "oracle", "stubs"), "-I" + shim,
+           "-o", ADAPTER, os.path.join(ROOT, "tests", "cpp", "ros1_adapter_check.cpp"), os.path.join(shim, "erasor_shim.cpp"),
+           os.path.join(shim, "erasor_io.cpp"), "-L" + os.path.join(ROOT, "erasor_amd"), "-lerasor_hip",
+           "-Wl,-rpath," + os.path.join(ROOT, "erasor_amd")]
+    subprocess.check_call(cmd)
+
+
+@pytest.mark.parametrize("version,interval", [(3, 1), (3, 2), (2, 1)])
+def test_ros1_adapter_node(tmp_path, version, interval):
+    """The thin ROS1 node (erasor_amd/csrc/shim/ros1_adapter.cpp): erasor::node messages in through the subscribed callback,
+    the reference's topics out (OMU.cpp:5-23, 316-326; SRT polygons erasor.cpp:496-570, 630-670) — against the oracle."""
+    from oracle import orc
+    build_adapter_check()
+    sc = scenarios.small(version=version)
+    d = str(tmp_path)
+    write_pcd_binary(os.path.join(d, "map.pcd"), sc["map"])
+    n = 4
+    with open(os.path.join(d, "poses.txt"), "w") as f:
+        for k in range(n):
+            np.ascontiguousarray(sc["scans"][k], np.float32).tofile(os.path.join(d, "scan%d.bin" % k))
+            f.write(" ".join("%.17g" % v for v in sc["poses"][k]) + "\n")
+    out = subprocess.run([ADAPTER, d, str(n), str(version), str(interval)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    o = orc.Oracle(sc["params"])
+    o.set_map(sc["map"])
+    p = sc["params"]
+    R, S = p.num_rings, p.num_sectors
+    rd = lambda nm, j: np.fromfile(os.path.join(d, "out_%s_%d.bin" % (nm, j)), np.float32)  # noqa: E731
+    same = lambda a, b: a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))  # noqa: E731
+    j = 0
+    for k in range(n):
+        if (k + 1) % interval != 0:
+            continue  # "PASS!" (OMU.cpp:206-209)
+        ro = o.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        assert same(rd("map_rejected", j).reshape(-1, 4), o.get_cloud(4))
+        assert same(rd("curr_rejected", j).reshape(-1, 4), o.get_cloud(5))
+        assert same(rd("map_body", j).reshape(-1, 4), o.get_cloud(1))
+        assert same(rd("pc_curr_body", j).reshape(-1, 4), o.get_cloud(0))
+        assert same(rd("pc2_curr", j).reshape(-1, 4), orc.transform(o.get_cloud(0), sc["T_b2o"][k]))
+        m = o.get_map()
+        from erasor_amd import synth
+        dyn = synth.is_dynamic(m[:, 3])
+        assert same(rd("static", j).reshape(-1, 4), m[~dyn]) and same(rd("dynamic", j).reshape(-1, 4), m[dyn])
+        assert (len(m[~dyn]), len(m[dyn])) == (ro.n_static, ro.n_dynamic)
+        like = rd("likelihood", j)
+        assert np.array_equal(like, o.get_status().reshape(R, S).T.reshape(-1).astype(np.float32))
+        poly = rd("polygon0", j).reshape(-1, 3)  # bin ring 1, sector 2: set_polygons(1, 2, 3), erasor.cpp:630-670
+        rs, ss = p.max_range / R, 2 * 3.1415926535 / S
+        ang = [2 * ss, 2 * ss, 2 * ss + ss / 3, 2 * ss + 2 * ss / 3, 3 * ss, 3 * ss, 3 * ss - ss / 3, 3 * ss - 2 * ss / 3]
+        rad = [rs, 2 * rs, 2 * rs, 2 * rs, 2 * rs, rs, rs, rs]
+        want = np.array([[r_ * np.cos(a), r_ * np.sin(a), p.max_h + 0.5] for r_, a in zip(rad, ang)], np.float32)
+        assert poly.shape == want.shape and np.allclose(poly, want, atol=1e-5)
+        j += 1
+    assert ("processed %d" % j) in out.stdout
+    # /saveflag -> save_static_map(0.2) -> <save_path>/<data_name>_result.pcd (OMU.cpp:169-196)
+    saved = np.loadtxt(os.path.join(d, "05_result.pcd"), skiprows=11, dtype=np.float64).reshape(-1, 4)
+    ref_saved = orc.voxelize_preserving_labels(o.get_map(), 0.2)
+    assert saved.shape == ref_saved.shape and np.array_equal(saved[:, 3], ref_saved[:, 3].astype(np.float64))
 
 
 def test_config_driver_like_main_in_your_env(tmp_path):

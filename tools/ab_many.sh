@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B several builds of liberasor_hip.so on the same box: tools/ab_many.sh "<bench args>" a.so b.so ...
+ARGS=$1; shift
+cp erasor_amd/liberasor_hip.so /tmp/lib_keep.so
+for r in 1 2; do
+  for v in "$@"; do
+    cp $v erasor_amd/liberasor_hip.so
+    echo -n "$v: "
+    python bench.py --steps 30 --warmup 5 --no-cpu-baseline $ARGS 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms/step; no look-ahead', d['ms_per_step_without_lookahead'])"
+  done
+done
+cp /tmp/lib_keep.so erasor_amd/liberasor_hip.so
