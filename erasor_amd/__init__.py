@@ -174,7 +174,9 @@ class Erasor:
     def prefetch(self, scan, T_l2b):
         """announce the next scan (host array): its query chain starts now, beside the step in flight"""
         scan = _f32(scan).reshape(-1, 4)
-        self._keep = scan  # the step that follows must pass this very buffer
+        # every announced buffer stays alive until a step has consumed it (up to three scans can be announced ahead; a freed
+        # buffer's address could be handed to the next np.ascontiguousarray)
+        self._keep = (getattr(self, "_keep", []) + [scan])[-4:]
         self._check(lib().erasor_hip_prefetch_scan(self._h, _p(scan), C.c_size_t(len(scan)), C.c_int(0), _p(_f32(T_l2b).reshape(16))))
         return scan
 

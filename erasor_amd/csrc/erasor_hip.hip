@@ -74,6 +74,8 @@ struct QSide {
     size_t src_n = 0;
     float Tl[16] = {0};
     uint32_t ns = 0;
+    bool src_dev = false;             // src is a device pointer (read in place; not fingerprinted)
+    uint64_t fp = 0;                  // host scans are copied when they are announced: fingerprint of that copy
     bool used = false;                // ev_done has been recorded at least once
 };
 
@@ -96,6 +98,7 @@ struct erasor_hip_handle {
         size_t n = 0;
         float Tl[16] = {0};
         int side = 0;
+        uint64_t fp = 0;
     } ann;
     // mapgen state (mapgen.hpp:27-46): cloud_curr, cloud_map, the finished submaps (cloud_maps, concatenated)
     DBuf<float4> mg_curr, mg_map, mg_done, mg_tmp;
@@ -415,7 +418,7 @@ int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
     const uint32_t S = ns + ns / 4 + 1024;
     Q(h).capS = S;
     int rc = 0;
-    rc |= ensure(h, Q(h).scan, S) | ensure(h, Q(h).cent, S) | ensure(h, Q(h).query, S) | ensure(h, Q(h).sq, S) | ensure(h, h->curr_rejected, S);
+    rc |= ensure(h, Q(h).scan, S) | ensure(h, Q(h).cent, S) | ensure(h, Q(h).query, S) | ensure(h, Q(h).sq, S) | ensure(h, h->curr_rejected, S, /*keep: the last step's CURR_REJECTED*/ true);
     rc |= ensure(h, Q(h).qk_a, S) | ensure(h, Q(h).qk_b, S) | ensure(h, Q(h).qv_a, S) | ensure(h, Q(h).qv_b, S) | ensure(h, Q(h).qposL, S) | ensure(h, Q(h).qposR, S);
     rc |= ensure(h, Q(h).qflag, S) | ensure(h, Q(h).qpl, S) | ensure(h, Q(h).qtops, S / 1024 + 4) | ensure(h, Q(h).run_begin, S + 1) | ensure(h, Q(h).ukeys, S);
     rc |= ensure(h, Q(h).qkey, S) | ensure(h, Q(h).qhead, S / 32 + 8);
@@ -835,6 +838,26 @@ struct SideGuard {
 // lidar->body + R-POD key (OMU.cpp:240; erasor.cpp:100-115), bucketing and per-bin statistics of the query.  It depends
 // on the scan and the lidar->body transform only -- not on the map -- which is what lets erasor_hip_prefetch_scan run
 // it for scan k+1 while step k is still in its map-side stages.
+// A host scan is copied to the device when it is announced (erasor_hip_prefetch_scan).  The step that claims the prefetched
+// chain recognises "the same scan" by (pointer, size, T_lidar2body) -- and by this fingerprint of the contents, so that a
+// buffer that was refilled (or freed and re-used at the same address) in between is not mistaken for the announced one.
+// FNV-1a over at most 256 evenly spaced points plus the first and the last: microseconds, not a checksum of 2 MB.
+static uint64_t scan_fingerprint(const void *host_xyzi, size_t n) {
+    uint64_t hsh = 1469598103934665603ull ^ (uint64_t)n;
+    if (!host_xyzi || !n) return hsh;
+    const uint32_t *w = static_cast<const uint32_t *>(host_xyzi);
+    const size_t step = n > 256 ? n / 256 : 1;
+    auto mix = [&](size_t i) {
+        for (int k = 0; k < 4; ++k) {
+            hsh ^= w[4 * i + k];
+            hsh *= 1099511628211ull;
+        }
+    };
+    for (size_t i = 0; i < n; i += step) mix(i);
+    mix(n - 1);
+    return hsh;
+}
+
 // VoxelGrid pass-through (see k_dup_label_passthrough): out[0..ns) = T * (point with the label of its first exact duplicate),
 // on the current stream.  Scratch: the current query side's sort buffers.
 static int enqueue_passthrough(erasor_hip_handle *h, const float4 *d_src, uint32_t ns, const float T[16], float4 *out, uint32_t *qkey) {
@@ -930,6 +953,8 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     q.src = scan_src;
     q.src_n = ns;
     q.ns = ns;
+    q.src_dev = src_is_device;
+    if (!src_is_device) q.fp = staged ? h->ann.fp : scan_fingerprint(scan_src, ns);
     memcpy(q.Tl, T_l2b, sizeof(q.Tl));
     return ERASOR_OK;
 }
@@ -977,14 +1002,16 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     // ---- this scan's query chain: already in flight (erasor_hip_prefetch_scan), or enqueued now -- first, it is the long one ----
     {
         int side = -1;
-        if (h->npend == 0 && h->ann.valid && !prevox && h->ann.src == scan_src && h->ann.n == n_scan &&
-            memcmp(h->ann.Tl, T_l2b, sizeof(h->ann.Tl)) == 0) {
+        const uint64_t fp_now = src_is_device ? 0ull : scan_fingerprint(scan_src, n_scan);
+        if (h->npend == 0 && h->ann.valid && !prevox && h->ann.src == scan_src && h->ann.n == n_scan && h->ann.is_device == src_is_device &&
+            (src_is_device || h->ann.fp == fp_now) && memcmp(h->ann.Tl, T_l2b, sizeof(h->ann.Tl)) == 0) {
             rc = flush_announced(h);  // announced, not yet started (first scan of a sequence): start it now, it is ours
             if (rc) return rc;
         }
         if (h->npend > 0) {
             const QSide &c = h->q[h->pend[0]];
-            if (!prevox && c.src == scan_src && c.src_n == n_scan && memcmp(c.Tl, T_l2b, sizeof(c.Tl)) == 0) {
+            if (!prevox && c.src == scan_src && c.src_n == n_scan && c.src_dev == src_is_device && (src_is_device || c.fp == fp_now) &&
+                memcmp(c.Tl, T_l2b, sizeof(c.Tl)) == 0) {
                 side = h->pend[0];
                 h->pend[0] = h->pend[1];
                 --h->npend;
@@ -1328,6 +1355,7 @@ int erasor_hip_prefetch_scan(erasor_hip_handle *h, const void *scan_xyzi, size_t
     h->ann.is_device = src_is_device != 0;
     h->ann.src = scan_xyzi;
     h->ann.n = n;
+    h->ann.fp = src_is_device ? 0ull : scan_fingerprint(scan_xyzi, n);
     h->ann.side = side;
     memcpy(h->ann.Tl, T_l2b, sizeof(h->ann.Tl));
     return ERASOR_OK;
@@ -1556,6 +1584,9 @@ int erasor_hip_get_planes(erasor_hip_handle *h, uint32_t *bin_index, float *norm
 // d_src may be any device buffer except the scan-side scratch itself.
 static int voxelize_device(erasor_hip_handle *h, const float4 *d_src, uint32_t ns, double leaf_size, uint32_t *nq_out) {
     q_drain(h);
+    // this borrows the query side of the last finished step: its QUERY_VOI / STATIC_ESTIMATE / ... read-backs are gone
+    // (erasor_hip_get_cloud answers ERASOR_E_STATE until the next step instead of handing out clobbered buffers)
+    h->have_step = false;
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
     Q(h).scan_in = d_src;
@@ -1823,6 +1854,7 @@ int erasor_hip_probe_math(erasor_hip_handle *h, const double *x, const double *y
 int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *vals, size_t n, uint32_t *n_fallback) {
     if (!h || (!keys && n) || (!vals && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
+    h->have_step = false;  // borrows the last step's query side
     const uint32_t ns = (uint32_t)n;
     q_drain(h);
     int rc = alloc_scan(h, std::max(ns, 1u));
@@ -1880,6 +1912,7 @@ int erasor_hip_debug_rebuild_outskirts(erasor_hip_handle *h) {
 int erasor_hip_radix_sort_u32(erasor_hip_handle *h, const uint32_t *keys, size_t n, int bits, uint32_t *keys_out, uint32_t *perm_out) {
     if (!h || (!keys && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
+    h->have_step = false;  // borrows the last step's query side
     const uint32_t ns = (uint32_t)n;
     q_drain(h);
     int rc = alloc_scan(h, std::max(ns, 1u));

@@ -238,7 +238,25 @@ int load_pcd(const std::string &pcd_name, Cloud &dst) {
         if (fields[k].name == "intensity") ii = (int)k;
     }
     if (ix < 0 || iy < 0 || iz < 0) return -1;
-    dst.points.resize(npts);
+    // the header is untrusted input: check POINTS / SIZE / COUNT against what the file can hold before allocating
+    {
+        const std::streampos data_pos = f.tellg();
+        f.seekg(0, std::ios::end);
+        const std::streampos end_pos = f.tellg();
+        f.seekg(data_pos);
+        if (data_pos < 0 || end_pos < data_pos) return -1;
+        const size_t remaining = (size_t)(end_pos - data_pos);
+        if (stride == 0 || npts > SIZE_MAX / stride) return -1;
+        if (mode == "binary" && stride * npts > remaining) return -1;
+        if (mode == "ascii" && npts > remaining) return -1;  // at least one byte per point
+        if (mode == "binary_compressed" && remaining < 8) return -1;
+        if (npts > (size_t)0x3FFFFFFF) return -1;
+    }
+    try {
+        dst.points.resize(npts);
+    } catch (const std::exception &) {
+        return -1;
+    }
     if (mode == "ascii") {
         size_t ncol = 0;
         for (const auto &pf : fields) ncol += (size_t)pf.count;
@@ -246,9 +264,15 @@ int load_pcd(const std::string &pcd_name, Cloud &dst) {
         std::vector<size_t> col0(fields.size());
         size_t c = 0;
         for (size_t k = 0; k < fields.size(); ++k) { col0[k] = c; c += (size_t)fields[k].count; }
+        std::string tok;
         for (size_t i = 0; i < npts; ++i) {
-            for (size_t k = 0; k < ncol; ++k)
-                if (!(f >> row[k])) return -1;
+            for (size_t k = 0; k < ncol; ++k) {
+                // strtod, not operator>>: PCL's ASCII writer emits "nan" for invalid points, which stream extraction rejects
+                if (!(f >> tok)) return -1;
+                char *endp = nullptr;
+                row[k] = strtod(tok.c_str(), &endp);
+                if (endp == tok.c_str()) return -1;
+            }
             dst.points[i].x = (float)row[col0[ix]];
             dst.points[i].y = (float)row[col0[iy]];
             dst.points[i].z = (float)row[col0[iz]];
@@ -268,7 +292,20 @@ int load_pcd(const std::string &pcd_name, Cloud &dst) {
         uint32_t csize = 0, usize = 0;
         if (!f.read(reinterpret_cast<char *>(&csize), 4) || !f.read(reinterpret_cast<char *>(&usize), 4)) return -1;
         if ((size_t)usize != stride * npts) return -1;
-        std::vector<uint8_t> cbuf(csize), ubuf(usize);
+        {
+            const std::streampos here = f.tellg();
+            f.seekg(0, std::ios::end);
+            const std::streampos endp2 = f.tellg();
+            f.seekg(here);
+            if (here < 0 || endp2 < here || (size_t)(endp2 - here) < (size_t)csize) return -1;
+        }
+        std::vector<uint8_t> cbuf, ubuf;
+        try {
+            cbuf.resize(csize);
+            ubuf.resize(usize);
+        } catch (const std::exception &) {
+            return -1;
+        }
         if (csize && !f.read(reinterpret_cast<char *>(cbuf.data()), csize)) return -1;
         if (!lzf_decompress(cbuf.data(), csize, ubuf.data(), usize)) return -1;
         // structure of arrays: all values of field 0, then field 1, ...
@@ -339,6 +376,13 @@ bool load_config_yaml(const std::string &path, OfflineMapUpdater::Config &cfg, D
     get_d(kv, "/erasor/gf_th_seeds_height", p.gf_th_seeds_height);
     get_d(kv, "/erasor/map_voxel_size", p.map_voxel_size);
     get_i(kv, "/erasor/version", p.version);
+    // fetch_VoI's radius is the same key read a second time with ITS OWN default of 60 m (OMU.cpp:78; ERASOR's is 10 m,
+    // erasor.h:47): a YAML without /erasor/max_range must not shrink the VoI to the R-POD's default
+    {
+        double voi = 60.0;
+        get_d(kv, "/erasor/max_range", voi);
+        p.voi_max_range = voi;
+    }
     // set_params (OMU.cpp:63-105)
     get_d(kv, "/MapUpdater/query_voxel_size", p.query_voxel_size);
     get_i(kv, "/MapUpdater/removal_interval", p.removal_interval);

@@ -439,6 +439,32 @@ def test_map_grows_without_bound():
     assert "GROWTH-OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_refilled_prefetch_buffer_is_not_mistaken_for_the_announced_scan(gpu_mod):
+    """host scans are copied when they are announced; a buffer refilled in place (same address, same size) before the step
+    must be processed with its NEW contents (the prefetched chain is dropped), and standalone operations that borrow the
+    last step's query side make its read-backs unavailable instead of handing out clobbered buffers"""
+    from oracle import orc
+    sc = scenarios.small()
+    g, o = make_pair(gpu_mod, sc["params"])
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    n = min(len(sc["scans"][0]), len(sc["scans"][1]))
+    buf = np.ascontiguousarray(sc["scans"][0][:n]).copy()
+    g.prefetch(buf, sc["T_l2b"])
+    buf[:] = sc["scans"][1][:n]            # same address, same size, other scan
+    rg = g.step(buf, sc["T_l2b"], sc["T_b2o"][1], sc["T_o2b"][1])
+    ro = o.step(sc["scans"][1][:n], sc["T_l2b"], sc["T_b2o"][1], sc["T_o2b"][1])
+    compare_step(g, o, rg, ro)
+    g.voxelize_preserving_labels(sc["scans"][2], 0.2)
+    with pytest.raises(gpu_mod.ErasorError) as e:
+        g.get_cloud(0)
+    assert e.value.rc == -4
+    same(g.get_map(), o.get_map(), "the map itself is untouched by the standalone call")
+    rg = g.step(sc["scans"][2], sc["T_l2b"], sc["T_b2o"][2], sc["T_o2b"][2])
+    ro = o.step(sc["scans"][2], sc["T_l2b"], sc["T_b2o"][2], sc["T_o2b"][2])
+    compare_step(g, o, rg, ro)
+
+
 def test_api_error_behaviour(gpu_mod):
     p = gpu_mod.params_default()
     g = gpu_mod.Erasor(p)
