@@ -734,6 +734,7 @@ static int set_map_common(erasor_hip_handle *h, const void *src, size_t n, bool 
     HIPC(h, hipStreamSynchronize(h->stream));
     h->have_map = true;
     h->poisoned = false;
+    h->last_n_voi = 0;  // (also the grid hint of the map bucketing: unknown for a new map)
     h->have_step = false;
     return ERASOR_OK;
 }
@@ -1130,7 +1131,10 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
                    dc, (const Counters *)Q(h).d_qctr.p, h->voi_ego.p, h->voi_key.p, h->voi_src.p);
         }
         if (mb_count) {
-            const uint32_t ntile_ub = std::max(1u, cdiv(n_voi, MB_TILE));
+            // the table is sized for the whole map (n_voi is an upper bound), the GRIDS for 1.5 x the previous step's VoI: the
+            // kernels walk the tiles with a grid stride, so an under-estimate only costs a second round
+            const uint32_t ntile_tab = std::max(1u, cdiv(n_voi, MB_TILE));
+            const uint32_t ntile_ub = h->last_n_voi ? std::min(ntile_tab, std::max(64u, cdiv((uint64_t)h->last_n_voi * 3 / 2, MB_TILE))) : ntile_tab;
             LAUNCH(h, "voi_bucket", k_mb_hist, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, n_voi, nvoi_dev, B + 1, h->mb_hist.p, h->mb_tot.p);
             LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv((uint64_t)(B + 1) * 64, 256), 256, h->mb_hist.p, n_voi, nvoi_dev, B + 1, (const uint32_t *)h->mb_tot.p,
                    h->moff.p);

@@ -128,7 +128,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *sm, ui
 
 // ================================================================================================
 // (1) voi_split — THE HBM-bound kernel.  fetch_VoI's membership test (OMU.cpp:391-395) over every
-// physical entry of the map store.  One wavefront per 512-point chunk, 8 loads in flight per lane.
+// physical entry of the map store.  One wavefront per 1024-entry chunk (CHUNK), 16 loads in flight per lane.
 //   F region: dense float4 (the previous step's VoI-resident part of the map, nF entries)
 //   O region: outskirts, split SoA-of-pairs layout {x,y} | {z,intensity}; only {x,y} is streamed.
 // Outputs: per 64-point tile an in-VoI mask and a valid mask, per chunk (voi | valid<<16).
@@ -753,21 +753,24 @@ __global__ __launch_bounds__(1024) void k_mb_hist(const uint32_t *__restrict__ k
     __shared__ uint32_t cnt[QB_NB_MAX];
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
-    if (blockIdx.x >= ntile) return;
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = 0;
-    __syncthreads();
-    const uint32_t i0 = blockIdx.x * MB_TILE + threadIdx.x;
-    uint32_t k[MB_TILE / 1024];
+    // (the grid is sized from the previous step's VoI, not from the whole map: tiles are walked with a grid stride)
+    for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = 0;
+        __syncthreads();
+        const uint32_t i0 = tile * MB_TILE + threadIdx.x;
+        uint32_t k[MB_TILE / 1024];
 #pragma unroll
-    for (uint32_t r = 0; r < MB_TILE / 1024; ++r) k[r] = i0 + r * 1024 < n ? keys[i0 + r * 1024] : 0xFFFFFFFFu;
+        for (uint32_t r = 0; r < MB_TILE / 1024; ++r) k[r] = i0 + r * 1024 < n ? keys[i0 + r * 1024] : 0xFFFFFFFFu;
 #pragma unroll
-    for (uint32_t r = 0; r < MB_TILE / 1024; ++r)
-        if (k[r] != 0xFFFFFFFFu) atomicAdd(&cnt[min(k[r], nb - 1)], 1u);
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
-        const uint32_t c = cnt[b];
-        hist[(size_t)blockIdx.x * nb + b] = c;
-        if (c) atomicAdd(&tot[b], c);
+        for (uint32_t r = 0; r < MB_TILE / 1024; ++r)
+            if (k[r] != 0xFFFFFFFFu) atomicAdd(&cnt[min(k[r], nb - 1)], 1u);
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+            const uint32_t c = cnt[b];
+            hist[(size_t)tile * nb + b] = c;
+            if (c) atomicAdd(&tot[b], c);
+        }
+        __syncthreads();
     }
 }
 
@@ -819,14 +822,15 @@ __global__ __launch_bounds__(1024) void k_mb_scatter(const uint32_t *__restrict_
     __shared__ uint32_t cnt[QB_NB_MAX];
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
-    if (blockIdx.x >= ntile) return;
-    // cnt[k] starts at the tile's first slot of bucket k and advances as the tile's keys are placed, in index order
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = base[(size_t)blockIdx.x * nb + b];
-    __syncthreads();
     const uint32_t wave = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
+    for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    __syncthreads();
+    // cnt[k] starts at the tile's first slot of bucket k and advances as the tile's keys are placed, in index order
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = base[(size_t)tile * nb + b];
+    __syncthreads();
     for (uint32_t r = 0; r < MB_TILE / 1024; ++r) {
-        const uint32_t i = blockIdx.x * MB_TILE + r * 1024 + threadIdx.x;
+        const uint32_t i = tile * MB_TILE + r * 1024 + threadIdx.x;
         const bool valid = i < n;
         const uint32_t k = valid ? min(keys[i], nb - 1) : 0u;
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -856,6 +860,7 @@ __global__ __launch_bounds__(1024) void k_mb_scatter(const uint32_t *__restrict_
             dst_keys[d] = k;
         }
     }
+    }
 }
 
 // Scatter for R-POD grids of up to 4096 buckets: every wavefront owns 512 CONSECUTIVE keys of the tile, so index order is
@@ -870,14 +875,15 @@ __global__ __launch_bounds__(1024) void k_mb_scatter_w(const uint32_t *__restric
     __shared__ uint32_t sbase[MBW_NB_MAX];
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
-    if (blockIdx.x >= ntile) return;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint64_t lt = lanemask_lt();
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) sbase[b] = base[(size_t)blockIdx.x * nb + b];
+    constexpr uint32_t R = MB_TILE / 16 / 64;  // 64-key strips per wavefront
+    for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) sbase[b] = base[(size_t)tile * nb + b];
     for (uint32_t i = threadIdx.x; i < 16 * MBW_NB_MAX / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(&wcnt[0][0])[i] = 0u;
     __syncthreads();
-    constexpr uint32_t R = MB_TILE / 16 / 64;  // 64-key strips per wavefront
-    const uint32_t i0 = blockIdx.x * MB_TILE + wave * (MB_TILE / 16) + lane;
+    const uint32_t i0 = tile * MB_TILE + wave * (MB_TILE / 16) + lane;
     uint32_t k[R];
     uint64_t peers[R];
 #pragma unroll
@@ -918,6 +924,7 @@ __global__ __launch_bounds__(1024) void k_mb_scatter_w(const uint32_t *__restric
         esort::wave_sync();
         if (i < n && (peers[r] >> lane) >> 1 == 0) wcnt[wave][k[r]] += (uint16_t)__popcll(peers[r]);
         esort::wave_sync();
+    }
     }
 }
 
