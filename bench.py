@@ -211,6 +211,48 @@ def cpu_baseline(args, P, m, seq, l2b7):
     return refd, port
 
 
+def _ref_sequence_worker(job):
+    """one reference updater (oracle/_ref) on one sequence, in its own process: (steps, seconds)"""
+    import ctypes as C
+    from oracle import orc, ref  # baseline only
+    pbytes, m, scans, poses, l2b7, n_steps = job
+    po = orc.Params()
+    C.memmove(C.byref(po), pbytes, C.sizeof(po))
+    r = ref.RefUpdater(po, m, l2b7)
+    t0 = time.perf_counter()
+    for k in range(n_steps):
+        r.step(scans[k], poses[k])
+    dt = time.perf_counter() - t0
+    r.close()
+    return n_steps, dt
+
+
+def cpu_sequence_parallel(args, seqs, maps, l2b7):
+    """config 3's fair multi-core comparison: one single-threaded reference updater per sequence, min(5, nproc)
+    of them side by side on the host cores; aggregate scans/s over the slowest worker's wall time"""
+    import ctypes as C
+    import multiprocessing as mp
+    from oracle import ref
+    if not ref.available():
+        return None
+    jobs = []
+    n_steps = max(1, min(args.cpu_steps, 3))
+    for sid, s in seqs:
+        pb = bytes(C.string_at(C.addressof(s.P), C.sizeof(s.P)))
+        jobs.append((pb, maps[sid], s.scans[:n_steps], s.poses[:n_steps], l2b7, n_steps))
+    cores = min(len(jobs), os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_ref_sequence_worker, jobs)
+    wall = time.perf_counter() - t0
+    steps = sum(r[0] for r in res)
+    slowest = max(r[1] for r in res)
+    return {"value": round(steps / slowest, 3), "unit": "scans/s", "cores": cores, "kind": "reference",
+            "sample": "%d sequences x %d callback_node steps, one single-threaded reference updater (oracle/_ref) per sequence on %d host "
+                      "cores side by side; aggregate steps / slowest worker's stepping time (wall incl. start-up %.1f s)"
+                      % (len(jobs), n_steps, cores, wall)}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -411,6 +453,8 @@ def main():
     cpu = cpu_port = None
     if world_size == 1 and not args.no_cpu_baseline and args.mode == "replicas":
         cpu, cpu_port = cpu_baseline(args, P, m, first, l2b7)
+    elif world_size == 1 and not args.no_cpu_baseline:
+        cpu = cpu_sequence_parallel(args, seqs, maps, l2b7)
 
     out = {
         "metric": "scans_per_sec", "value": round(value, 2), "unit": "scans/s", "n_gpus": world_size, "steps": K, "warmup": W,
