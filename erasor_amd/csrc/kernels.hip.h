@@ -2265,64 +2265,6 @@ __device__ __forceinline__ void rgpf_after_sort(const DP &P, const float4 *__res
     if (tid == 0) ng_out[rk] = ng;
 }
 
-// gsK..gsH: global scratch arrays (capV [+1]) used when a bin has more than RG_LMAX points.
-__global__ __launch_bounds__(1024) void k_rgpf(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
-                                               const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *gsK,
-                                               uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
-                                               uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
-                                               uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
-                                               Counters *ctr, unsigned long long *dbg) {
-    __shared__ uint32_t sK[RG_LMAX], sV[RG_LMAX], sL[RG_LMAX], sR[RG_LMAX];
-    __shared__ uint32_t sH[RG_LMAX / 32 + 2];
-    __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
-    __shared__ uint32_t qcnt[2];
-    __shared__ uint32_t sm[40];
-    __shared__ float sProd[9 * RG_CH];
-    __shared__ float s_n[3];
-    __shared__ double s_th, s_lpr;
-    __shared__ uint32_t s_carry;
-    const int key = blockIdx.x;
-    if (action[key] != 1) return;
-    const uint32_t rk = rev_idx[key];
-    const uint32_t o0 = moff[key], M = moff[key + 1] - o0;
-    const float4 *pts = spts + o0;
-    const uint32_t tid = threadIdx.x, bs = blockDim.x;
-    // --- std::sort(src_copy, point_cmp) : erasor.cpp:239-240 ---
-    if (M <= RG_LMAX) {
-        for (uint32_t i = tid; i < M; i += bs) {
-            sK[i] = esort::float_key(__float_as_uint(pts[i].z));
-            sV[i] = i;
-        }
-        __syncthreads();
-        const unsigned long long t_a = dbg ? wall_clock64() : 0ull;
-        esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
-                           &ctr->n_sort_fallback, &ctr->sort_qoverflow);
-        const unsigned long long t_b = dbg ? wall_clock64() : 0ull;
-        rgpf_after_sort(P, pts, M, o0, rk, sR, sK, sm, sProd, s_n, &s_th, &s_lpr, &s_carry, gflag, grank, glist_out, ng_out, plane_n, plane_d, ctr);
-        if (dbg && tid == 0) {  // diagnostics (ERASOR_HIP_SORT_STAMPS): the slowest bin's split between the z-sort and the rest, 10 ns ticks
-            const unsigned long long t_c = wall_clock64();
-            if (atomicMax(&dbg[16], t_c - t_a) < t_c - t_a) {
-                dbg[17] = t_b - t_a;
-                dbg[18] = t_c - t_b;
-                dbg[19] = M;
-            }
-        }
-    } else {
-        uint32_t *K = gsK + o0, *V = gsV + o0;
-        for (uint32_t i = tid; i < M; i += bs) {
-            K[i] = esort::float_key(__float_as_uint(pts[i].z));
-            V[i] = i;
-        }
-        __threadfence_block();
-        __syncthreads();
-        esort::block_esort(K, V, gsL + o0, gsR + o0, gsH + (o0 >> 5) + 2 * key, gsK2 + o0, gsV2 + o0, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt,
-                           (uint32_t)(RG_LMAX / 16 + 2), &ctr->n_sort_fallback, &ctr->sort_qoverflow);
-        __threadfence_block();
-        __syncthreads();
-        rgpf_after_sort(P, pts, M, o0, rk, gsV2 + o0, K, sm, sProd, s_n, &s_th, &s_lpr, &s_carry, gflag, grank, glist_out, ng_out, plane_n, plane_d, ctr);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_rgpf2: R-GPF over the reverted-bin LIST (a small fixed grid; bin r of the list is handled by workgroup r mod grid),
 // bins of <= RG_LMAX points entirely in LDS:
@@ -2332,7 +2274,7 @@ __global__ __launch_bounds__(1024) void k_rgpf(DP P, const uint8_t *__restrict__
 //   * the bin's x / y / z are staged in LDS once; plane-fit products go to LDS rows padded to 1028 floats (nine lanes read
 //     nine different banks with 128-bit loads) and are added strictly in list order by lane a of wave 0;
 //   * classification: every thread owns strided points, ONE table scan per iteration instead of one block scan per 1024.
-// Larger bins take the global-memory path of k_rgpf (same arithmetic).
+// Larger bins take the global-memory path (rgpf_after_sort on global scratch, same arithmetic).
 // ------------------------------------------------------------------------------------------------
 static constexpr uint32_t RG_RS = RG_CH + 4;  // padded row stride of the product rows (floats)
 
@@ -2366,7 +2308,7 @@ __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict
         const uint32_t o0 = moff[key], M = moff[key + 1] - o0;
         const float4 *pts = spts + o0;
         __syncthreads();  // LDS of the previous bin is dead
-        if (M > RG_LMAX) {  // rare: the bin does not fit LDS -> global scratch, same arithmetic (see k_rgpf)
+        if (M > RG_LMAX) {  // rare: the bin does not fit LDS -> global scratch, same arithmetic (rgpf_after_sort)
             uint32_t *K = gsK + o0, *V = gsV + o0;
             for (uint32_t i = tid; i < M; i += bs) {
                 K[i] = esort::float_key(__float_as_uint(pts[i].z));
@@ -2586,7 +2528,7 @@ __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict
 // ================================================================================================
 static constexpr uint32_t BV_LMAX = 2048;
 
-// body of k_binvox, templated on the scratch pointers so that the LDS instantiation compiles to ds_* instructions
+// per-bin voxelisation for clouds beyond the LDS-resident size (global scratch), templated on the scratch pointers so that the LDS instantiation compiles to ds_* instructions
 template <class KP, class VP, class K2P, class V2P, class CP, class PP, class HP>
 __device__ __forceinline__ void binvox_core(const DP &P, uint32_t m, uint32_t nc, const float4 *__restrict__ sqb, const float4 *__restrict__ sptb,
                                             const uint32_t *__restrict__ glb, KP K, VP V, K2P K2, V2P V2, CP C, PP posL, PP posR, HP head,
@@ -2717,53 +2659,10 @@ __device__ __forceinline__ void binvox_core(const DP &P, uint32_t m, uint32_t nc
     if (tid == 0) *nvox_slot = nv;
 }
 
-__global__ __launch_bounds__(1024) void k_binvox(DP P, const uint8_t *__restrict__ action, const uint32_t *__restrict__ rev_idx,
-                                                 const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
-                                                 const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq,
-                                                 const uint32_t *__restrict__ glist, const uint32_t *__restrict__ ng_arr,
-                                                 const uint32_t *__restrict__ vox_off, uint32_t *gsK, uint32_t *gsV, uint32_t *gsL,
-                                                 uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
-                                                 float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr,
-                                                 unsigned long long *dbg) {
-    __shared__ uint32_t sK[BV_LMAX], sV[BV_LMAX], sL[BV_LMAX], sR[BV_LMAX];
-    __shared__ uint32_t sH[BV_LMAX / 32 + 2];
-    __shared__ float4 sC[BV_LMAX];
-    __shared__ esort::Seg qa[BV_LMAX / 16 + 2], qb[BV_LMAX / 16 + 2];
-    __shared__ uint32_t qcnt[2];
-    __shared__ uint32_t sm[40];
-    __shared__ uint32_t sbb[6];
-    __shared__ uint32_t s_carry;
-    const int key = blockIdx.x;
-    if (action[key] != 1) return;
-    const uint32_t rk = rev_idx[key];
-    const uint32_t mo = moff[key], qo = qoff[key];
-    const uint32_t nc = qoff[key + 1] - qo, ngr = ng_arr[rk];
-    const uint32_t m = nc + ngr;
-    if (nc == 0) {  // selected = bin_curr with is_occupied == false: r_pod2pc skips the bin
-        if (threadIdx.x == 0) nvox_out[rk] = 0;
-        return;
-    }
-    const uint32_t vo = vox_off[rk];
-    const unsigned long long t_a = dbg ? wall_clock64() : 0ull;
-    if (m <= BV_LMAX)
-        binvox_core(P, m, nc, sq + qo, spts + mo, glist + mo, sK, sV, sL, sR, sC, sL, sR, sH, qa, qb, qcnt, sm, sbb, &s_carry, vox_out + vo,
-                    nvox_out + rk, ctr);
-    else
-        binvox_core(P, m, nc, sq + qo, spts + mo, glist + mo, gsK + vo, gsV + vo, gsK2 + vo, gsV2 + vo, gsC + vo, gsL + vo, gsR + vo, gsH + (vo >> 5) + 2 * rk, qa, qb,
-                    qcnt, sm, sbb, &s_carry, vox_out + vo, nvox_out + rk, ctr);
-    if (dbg && threadIdx.x == 0) {
-        const unsigned long long t_c = wall_clock64();
-        if (atomicMax(&dbg[20], t_c - t_a) < t_c - t_a) {
-            dbg[21] = m;
-            dbg[22] = nvox_out[rk];
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_binvox2: per-bin voxelisation over the reverted-bin LIST, clouds of <= BV2_LMAX points entirely in LDS.
 // VoxelGrid's std::sort has equal keys by construction (the points of a voxel), so the exact introsort emulation stays;
-// what changed against k_binvox: (i) twice the LDS-resident size, (ii) run heads through one table scan, (iii) the exact
+// what changed against round 1 (one workgroup of a num_bins-sized grid per bin, 2048 points in LDS, every centroid x every point): (i) twice the LDS-resident size, (ii) run heads through one table scan, (iii) the exact
 // 1-NN label search walks the voxel grid (own cell, then shells of neighbour cells found by binary search in the sorted
 // unique keys, pruned by conservative cell bounds) instead of testing every centroid against every input point —
 // the result is the same minimum over (distance, index) pairs.
@@ -2802,7 +2701,7 @@ __global__ __launch_bounds__(1024) void k_binvox2(DP P, const uint32_t *__restri
         }
         const uint32_t vo = vox_off[rk];
         const unsigned long long t_a = dbg ? wall_clock64() : 0ull;
-        if (m > BV2_LMAX) {  // rare: global scratch, brute-force search (k_binvox's path)
+        if (m > BV2_LMAX) {  // rare: global scratch, brute-force search (binvox_core)
             esort::Seg *qa = qa2, *qb = qb2;
             binvox_core(P, m, nc, sq + qo, spts + mo, glist + mo, gsK + vo, gsV + vo, gsK2 + vo, gsV2 + vo, gsC + vo, gsL + vo, gsR + vo,
                         gsH + (vo >> 5) + 2 * rk, qa, qb, qcnt, sm, sbb, &s_carry, vox_out + vo, nvox_out + rk, ctr);
