@@ -474,13 +474,26 @@ int erasor_shim_dump_config(const char *path, char *out, int cap) {
       << "\nquery_voxel_size=" << p.query_voxel_size << "\nremoval_interval=" << p.removal_interval << "\ndata_name=" << cfg.data_name
       << "\nenv=" << cfg.environment << "\ninitial_map_path=" << cfg.initial_map_path << "\nsave_path=" << cfg.save_path
       << "\nis_large_scale=" << (cfg.is_large_scale ? 1 : 0) << "\nsubmap_size=" << cfg.submap_size << "\nverbose=" << (cfg.verbose ? 1 : 0)
-      << "\nlidar2body=";
+      << "\nvoi_max_range=" << p.voi_max_range << "\nlidar2body=";
     for (int i = 0; i < 7; ++i) o << (i ? "," : "") << cfg.lidar2body[i];
     o << "\ndata_dir=" << drv.data_dir << "\nvoxel_size=" << drv.voxel_size << "\ninit_idx=" << drv.init_idx << "\ninterval=" << drv.interval << "\n";
     const std::string s = o.str();
     if ((int)s.size() + 1 > cap) return -1;
     memcpy(out, s.c_str(), s.size() + 1);
     return (int)s.size();
+}
+// ERASOR::is_dynamic_obj_close (erasor.h:132) on an R-POD that carries only statuses (status[ring*S+sector]); no device needed
+int erasor_shim_is_dynamic_obj_close(const erasor_params *p, const double *status, int r_target, int theta_target, int r_range, int theta_range) {
+    ERASOR e(*p);
+    R_POD pod((size_t)p->num_rings, Ring((size_t)p->num_sectors));
+    for (int r = 0; r < p->num_rings; ++r)
+        for (int t = 0; t < p->num_sectors; ++t) {
+            Bin &b = pod[r][t];
+            b.max_h = b.min_h = b.x = b.y = 0;
+            b.is_occupied = false;
+            b.status = status[(size_t)r * p->num_sectors + t];
+        }
+    return e.is_dynamic_obj_close(pod, r_target, theta_target, r_range, theta_range) ? 1 : 0;
 }
 // loads a .pcd; copies up to cap points (x y z intensity rows); returns the point count or -1
 long erasor_shim_load_pcd(const char *path, float *xyzi, long cap) {

@@ -5,9 +5,11 @@
 # bench.py's cpu_baseline may time it (kind "reference").  Outputs go to oracle/_ref/ only (git-ignored,
 # travels to the GPU box as a prebuilt file; /root/reference does not exist there).
 # Flags follow the reference's build: no -march (CMakeLists.txt:4), so no FMA contraction.
+# -fno-gnu-unique: oracle/ref.py loads one private copy of the library per object; GNU_UNIQUE symbols (statics of
+# inline functions, e.g. the stub's topic registry) would otherwise be shared between live copies.
 REF      ?= /root/reference
 CXX      ?= g++
-CXXFLAGS ?= -O2 -std=c++17 -ffp-contract=off -fPIC -w
+CXXFLAGS ?= -O2 -std=c++17 -ffp-contract=off -fno-gnu-unique -fPIC -w
 INC       = -I$(REF)/include -I$(REF)/src/mapgen -Istubs
 OUT       = _ref
 REFSRC    = $(REF)/src/offline_map_updater/src

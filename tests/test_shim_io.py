@@ -117,7 +117,42 @@ def test_rosparam_defaults_are_the_references(shim, tmp_path):
     assert d["is_large_scale"] == "0" and float(d["submap_size"]) == 200.0
     assert d["data_dir"] == "/data/bongeunsa" and float(d["voxel_size"]) == 0.075 and int(d["init_idx"]) == 130 and int(d["interval"]) == 2
     assert [float(x) for x in d["lidar2body"].split(",")] == [0.1, -0.2, 0.3, 0.0, 0.0, 0.7071, 0.7071]
+    assert float(d["voi_max_range"]) == 9.5  # fetch_VoI reads the same /erasor/max_range key (OMU.cpp:78)
+    q = tmp_path / "no_range.yaml"
+    q.write_text("erasor:\n    num_rings: 8\n")
+    d2 = dump_config(shim, q)
+    # absent key: ERASOR's own default is 10 m (erasor.h:47), fetch_VoI's default is 60 m (OMU.cpp:78)
+    assert float(d2["max_range"]) == 10.0 and float(d2["voi_max_range"]) == 60.0
 
+
+def test_is_dynamic_obj_close_matches_the_reference_source(shim):
+    """the shim's ERASOR::is_dynamic_obj_close (erasor.h:132, erasor.cpp:573-595, incl. the wrap by num_rings) against the
+    reference's own function (oracle/_ref) on the statuses of a real step"""
+    import scenarios
+    from erasor_amd import synth
+    from oracle import ref
+    if not (ref.available() or ref.build()):
+        pytest.skip("oracle/_ref not available")
+    rng = np.random.default_rng(12)
+    shim.erasor_shim_is_dynamic_obj_close.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    shim.erasor_shim_is_dynamic_obj_close.restype = C.c_int
+    for seq in ("05", "00"):
+        sc = scenarios.small(seq=seq)
+        p = sc["params"]
+        R, S = p.num_rings, p.num_sectors
+        r = ref.RefUpdater(p, sc["map"], [0, 0, synth.LIDAR_HEIGHT, 0, 0, 0, 1])
+        for k in range(5):
+            r.step(sc["scans"][k], sc["poses"][k])
+        st = np.ascontiguousarray(r.get_status(), np.float64)
+        assert (st == 1.0).any()  # some bin is CURR_IS_HIGHER, else the test is vacuous
+        n_true = 0
+        for _ in range(400):
+            rt, tt = int(rng.integers(0, R)), int(rng.integers(0, S))
+            rr, tr = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+            got = bool(shim.erasor_shim_is_dynamic_obj_close(C.byref(p), st.ctypes.data, rt, tt, rr, tr))
+            assert got == r.is_dynamic_obj_close(rt, tt, rr, tr), (seq, rt, tt, rr, tr)
+            n_true += got
+        assert 0 < n_true < 400
 
 def load_pcd(shim, path, cap=1 << 20):
     buf = np.zeros((cap, 4), np.float32)
