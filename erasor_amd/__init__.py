@@ -102,6 +102,19 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+Mat16 = C.c_float * 16
+
+
+def c_mat(T):
+    """a 4x4 row-major transform as a ctypes float[16], converted once: the step / prefetch wrappers take it as it is
+    (the numpy -> ctypes conversion of three matrices costs ~10 us per call, a visible share of a 0.3 ms step)"""
+    return T if isinstance(T, Mat16) else Mat16(*[float(v) for v in _f32(T).reshape(16)])
+
+
+def _m(T):
+    return T if isinstance(T, Mat16) else _p(_f32(T).reshape(16))
+
+
 def geopose2eigen(pose7):
     """erasor_utils::geoPose2eigen (erasor_utils.cpp:35-55): tf::Matrix3x3(tf::Quaternion) evaluated in double with
     tf's association, each entry narrowed to float32.  pose7 = x y z qx qy qz qw.  Returns 16 floats, row-major."""
@@ -181,7 +194,7 @@ class Erasor:
         return scan
 
     def prefetch_device(self, d_ptr, n, T_l2b):
-        self._check(lib().erasor_hip_prefetch_scan(self._h, C.c_void_p(d_ptr), C.c_size_t(n), C.c_int(1), _p(_f32(T_l2b).reshape(16))))
+        self._check(lib().erasor_hip_prefetch_scan(self._h, C.c_void_p(d_ptr), C.c_size_t(n), C.c_int(1), _m(T_l2b)))
 
     def step(self, scan, T_l2b, T_b2o, T_o2b):
         scan = _f32(scan).reshape(-1, 4)
@@ -192,8 +205,7 @@ class Erasor:
 
     def step_device(self, dptr, n, T_l2b, T_b2o, T_o2b):
         res = StepResult()
-        self._check(lib().erasor_hip_step_device(self._h, C.c_void_p(dptr), C.c_size_t(n), _p(_f32(T_l2b).reshape(16)),
-                                                 _p(_f32(T_b2o).reshape(16)), _p(_f32(T_o2b).reshape(16)), C.byref(res)))
+        self._check(lib().erasor_hip_step_device(self._h, C.c_void_p(dptr), C.c_size_t(n), _m(T_l2b), _m(T_b2o), _m(T_o2b), C.byref(res)))
         return res
 
     # -- read-back --

@@ -1124,7 +1124,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         }
         (void)hipStreamWaitEvent(h->stream, Q(h).ev_keys, 0);  // k_voi_gather must see the query side's error flag
         {   // VoI gather + egocentric transform + R-POD key (OMU.cpp:435-437; erasor.cpp:124-139)
-            const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nchunks, 4), 256 * 8));
+            // one wavefront per work item: GATHER_SUB pieces per chunk of the VoI-resident region, one per outskirts chunk
+            const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nFchunks * GATHER_SUB + nOchunks, 4), 256 * 16));
             LAUNCH(h, "voi_gather", k_voi_gather, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, h->Oxy.p, h->Ozi.p, o_chunk0,
                    nOchunks, (const unsigned long long *)h->vmask.p, (const unsigned long long *)h->hmask.p, (const uint32_t *)h->cinfo.p,
                    (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p, (const uint32_t *)h->topv.p, (const uint32_t *)h->toph.p, h->To2b, P, ds,

@@ -21,6 +21,10 @@ namespace ek {
 static constexpr uint32_t HOLE_BITS = 0xFFC0DEADu;  // x of a tombstoned outskirts slot (a quiet NaN payload)
 static constexpr int TILE = 64;
 static constexpr int CHUNK_TILES = 16;
+#ifndef ERASOR_GATHER_SUB
+#define ERASOR_GATHER_SUB 4
+#endif
+static constexpr uint32_t GATHER_SUB = ERASOR_GATHER_SUB;  // pieces per VoI-resident chunk in k_voi_gather (1, 2, 4, 8 or 16)
 static constexpr int CHUNK = TILE * CHUNK_TILES;  // 1024 points handled by one wavefront iteration (16 loads in flight per lane)
 static constexpr double INF_H = 10000000000000.0;  // erasor.h:3
 static constexpr double PI_REF = 3.1415926535;     // erasor.h:4
@@ -415,20 +419,36 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t nchunks = nFchunks + nOchunks;
     const uint64_t lt = lanemask_lt();
     const uint32_t validF = st->validF, voiF = st->voiF, o_new_begin = st->o_new_begin;
     uint32_t dyn_leave = 0, stat_leave = 0, dyn_enter = 0, stat_enter = 0;
-    for (uint32_t c = wid; c < nchunks; c += nwaves) {
+    // Work items: a chunk of the VoI-resident region is nearly all VoI (every tile fetches, transforms and runs the f64
+    // sqrt / atan2 of the R-POD key), and there are only ~800 of them for a 0.8 M-point VoI -- fewer wavefronts than SIMDs,
+    // each with 16 dependent rounds.  They are cut into GATHER_SUB pieces of CHUNK_TILES / GATHER_SUB tiles (a piece finds
+    // its offsets from the popcounts of the chunk's earlier masks).  Outskirts chunks stay whole: almost all are skipped.
+    const uint32_t nitems = nFchunks * GATHER_SUB + nOchunks;
+    for (uint32_t w = wid; w < nitems; w += nwaves) {
+        const bool isF = w < nFchunks * GATHER_SUB;
+        const uint32_t c = isF ? w / GATHER_SUB : w - nFchunks * (GATHER_SUB - 1);
+        const int t_lo = isF ? (int)(w % GATHER_SUB) * (CHUNK_TILES / (int)GATHER_SUB) : 0;
+        const int t_hi = isF ? t_lo + CHUNK_TILES / (int)GATHER_SUB : CHUNK_TILES;
         const uint32_t ci = cinfo[c];
         const uint32_t cv = ci & 0xFFFFu, ch = ci >> 16;
-        const bool isF = c < nFchunks;
         if (cv == 0 && !(isF && ch > cv)) continue;
         uint32_t pv = pvl[c] + topv[c >> 10];
         uint32_t ph = phl[c] + toph[c >> 10];
         const unsigned long long mv = lane < CHUNK_TILES ? vmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
         const unsigned long long mh = lane < CHUNK_TILES ? hmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
-        for (int t = 0; t < CHUNK_TILES; ++t) {
+        if (t_lo > 0) {  // entries of the chunk's tiles before this piece
+            uint32_t av = (int)lane < t_lo ? (uint32_t)__popcll(mv) : 0u, ah = (int)lane < t_lo ? (uint32_t)__popcll(mh) : 0u;
+            for (int o = 32; o > 0; o >>= 1) {  // (lanes >= CHUNK_TILES hold empty masks; every lane ends with the total)
+                av += __shfl_xor(av, o, 64);
+                ah += __shfl_xor(ah, o, 64);
+            }
+            pv += av;
+            ph += ah;
+        }
+        for (int t = t_lo; t < t_hi; ++t) {
             const unsigned long long vm = __shfl(mv, t, 64), hm = __shfl(mh, t, 64);
             if (isF) {
                 const unsigned long long lm = hm & ~vm;
@@ -802,16 +822,25 @@ __global__ __launch_bounds__(256) void k_mb_colscan(uint32_t *__restrict__ hist 
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
     uint32_t run = s_off[b - b0];
-    for (uint32_t t0 = 0; t0 < ntile; t0 += 64) {
-        const uint32_t t = t0 + lane;
-        const uint32_t c = t < ntile ? hist[(size_t)t * nb + b] : 0u;
-        uint32_t inc = c;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = __shfl_up(inc, o, 64);
-            if ((int)lane >= o) inc += v;
+    // (a column is walked with a stride of nb words -- one cache line per lane: four rounds of loads are issued together)
+    for (uint32_t t0 = 0; t0 < ntile; t0 += 256) {
+        uint32_t c[4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t t = t0 + r * 64 + lane;
+            c[r] = t < ntile ? hist[(size_t)t * nb + b] : 0u;
         }
-        if (t < ntile) hist[(size_t)t * nb + b] = run + inc - c;
-        run += __shfl(inc, 63, 64);
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t t = t0 + r * 64 + lane;
+            uint32_t inc = c[r];
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(inc, o, 64);
+                if ((int)lane >= o) inc += v;
+            }
+            if (t < ntile) hist[(size_t)t * nb + b] = run + inc - c[r];
+            run += __shfl(inc, 63, 64);
+        }
     }
 }
 
@@ -958,7 +987,21 @@ __global__ __launch_bounds__(256) void k_bin_stats(const float4 *__restrict__ sp
     if (b >= B) return;
     const uint32_t s = off[b], e = off[b + 1];
     float mn = __int_as_float(0x7F800000), mx = __int_as_float(0xFF800000);
-    for (uint32_t i = s + lane; i < e; i += 64) {
+    // bins hold up to a few thousand points: four loads in flight per lane (one load per round made the largest bin's
+    // ~50 dependent rounds the kernel's length); the lane's compare order is unchanged
+    uint32_t i = s + lane;
+    for (; i + 192 < e; i += 256) {
+        const float z0 = spts[i].z, z1 = spts[i + 64].z, z2 = spts[i + 128].z, z3 = spts[i + 192].z;
+        mn = z0 < mn ? z0 : mn;
+        mx = z0 > mx ? z0 : mx;
+        mn = z1 < mn ? z1 : mn;
+        mx = z1 > mx ? z1 : mx;
+        mn = z2 < mn ? z2 : mn;
+        mx = z2 > mx ? z2 : mx;
+        mn = z3 < mn ? z3 : mn;
+        mx = z3 > mx ? z3 : mx;
+    }
+    for (; i < e; i += 64) {
         const float z = spts[i].z;
         mn = z < mn ? z : mn;
         mx = z > mx ? z : mx;
