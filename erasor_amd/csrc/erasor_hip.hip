@@ -1248,6 +1248,11 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         (void)hipMemcpy(t, h->dbg_stamps.p, sizeof(t), hipMemcpyDeviceToHost);
         fprintf(stderr, "[slowest R-GPF bin, 10 ns ticks] key load %llu, exact sort %llu, seeds %llu, staging %llu, it0: cov %llu svd %llu classify %llu (final ground %llu)\n",
                 t[32], t[33], t[34], t[35], t[36], t[37], t[38], t[39]);
+        fprintf(stderr, "[slowest R-GPF bin, exact sort, shader cycles] start->levels %llu, levels+small %llu, leaf ranking %llu; level starts:", t[41] - t[40],
+                t[42] - t[41], t[43] - t[42]);
+        for (int i = 44; i < 56; ++i) fprintf(stderr, " %llu", t[i] > t[40] ? t[i] - t[40] : 0ull);
+        fprintf(stderr, "\n[slowest R-GPF bin, level-0 partition, cycles] median+first loads %llu, stop lists %llu, search %llu, swaps %llu (m = %llu), queueing %llu; level 0 began %llu before\n",
+                t[57] - t[56], t[58] - t[57], t[59] - t[58], t[60] - t[59], t[61], t[62] - t[60], t[56] - t[44]);
         fprintf(stderr, "[esort slowest segment: len %llu depth %llu of %llu segments] phase1 %llu, queue %llu, finalize %llu cycles; levels:", t[30] >> 32,
                 t[30] & 0xFFFFFFFFull, t[29], t[1] - t[0], t[2] - t[1], t[3] - t[2]);
         for (int i = 4; i < 15; ++i) fprintf(stderr, " %llu", t[i + 1] > t[i] ? t[i + 1] - t[i] : 0ull);

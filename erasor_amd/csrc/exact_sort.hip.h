@@ -29,45 +29,147 @@ __device__ __forceinline__ void wave_sync() { __threadfence_block(); }
 
 // One wavefront partitions [first,last) (size > kThreshold).  posL/posR: scratch, same index space
 // as K (entries [first+1,last) are used).  Returns the cut (wave-uniform).
+//
+// A partition is a chain of dependent memory round trips (~130 cycles each in LDS), not arithmetic: a short segment
+// used to take ~16 of them (the sequential median move alone five).  This version needs five or six:
+//   1. the old head, the three median candidates and the first 256 keys are fetched TOGETHER; the median swap is
+//      applied to the registers (the key that moves to the median's place is patched in) while lane 0 stores it;
+//   2. stop lists: four strips of loads in flight at a time;
+//   3. m (a monotone predicate over the paired stop lists) by 64-ary search: two rounds for any m <= 4096;
+//   4. the cut's two table entries ride along with the first swap indices; swaps run two strips at a time.
+// The swaps performed and the cut are those of the sequential algorithm (exact_sort_core.h).
 template <class KP, class VP, class PP>
-__device__ __forceinline__ uint32_t wave_partition(KP K, VP V, PP posL, PP posR, uint32_t first, uint32_t last) {
+__device__ __forceinline__ uint32_t wave_partition(KP K, VP V, PP posL, PP posR, uint32_t first, uint32_t last,
+                                                   unsigned long long *ts = nullptr) {
+#define WP_STAMP(i) do { if (ts && (threadIdx.x & 63u) == 0) ts[i] = clock64(); } while (0)
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lt = lanemask_lt();
-    if (lane == 0) move_median_to_first(K, V, first, last);
-    wave_sync();
-    const uint32_t p = K[first];
     const uint32_t lo = first + 1, hi = last;
+    WP_STAMP(0);
+    // ---- median of (first+1, mid, last-1) to first: std::__move_median_to_first ----
+    const uint32_t a = first + 1, b = first + (last - first) / 2, c = last - 1;
+    const uint32_t cand = K[lane == 0 ? first : (lane == 1 ? a : (lane == 2 ? b : c))];
+    uint32_t kq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t i = lo + (uint32_t)r * 64u + lane;
+        kq[r] = i < hi ? (uint32_t)K[i] : 0u;
+    }
+    const uint32_t kf = __builtin_amdgcn_readlane(cand, 0), ka = __builtin_amdgcn_readlane(cand, 1), kb = __builtin_amdgcn_readlane(cand, 2),
+                   kc = __builtin_amdgcn_readlane(cand, 3);
+    uint32_t mpos, p;
+    if (ka < kb) {
+        if (kb < kc) { mpos = b; p = kb; }
+        else if (ka < kc) { mpos = c; p = kc; }
+        else { mpos = a; p = ka; }
+    } else if (ka < kc) { mpos = a; p = ka; }
+    else if (kb < kc) { mpos = c; p = kc; }
+    else { mpos = b; p = kb; }
+    if (lane == 0) {  // iter_swap(first, median), unconditional like the library's
+        const uint32_t v0 = V[first], v1 = V[mpos];
+        K[first] = p;
+        K[mpos] = kf;
+        V[first] = v1;
+        V[mpos] = v0;
+    }
+    // ---- stop lists: L = positions (ascending) with !(k < p), R = positions with !(p < k) ----
+    WP_STAMP(1);
     uint32_t nL = 0, nR = 0;
-    for (uint32_t base = lo; base < hi; base += 64) {
-        const uint32_t i = base + lane;
-        const bool valid = i < hi;
-        const uint32_t k = valid ? (uint32_t)K[i] : 0u;
-        const bool isL = valid && !(k < p);
-        const bool isR = valid && !(p < k);
-        const uint64_t mL = __ballot(isL), mR = __ballot(isR);
-        if (isL) posL[lo + nL + __popcll(mL & lt)] = i;
-        if (isR) posR[lo + nR + __popcll(mR & lt)] = i;
-        nL += __popcll(mL);
-        nR += __popcll(mR);
+    for (uint32_t base = lo; base < hi; base += 256) {
+        if (base != lo) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t i = base + (uint32_t)r * 64u + lane;
+                kq[r] = i < hi ? (uint32_t)K[i] : 0u;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t i = base + (uint32_t)r * 64u + lane;
+            const bool valid = i < hi;
+            const uint32_t k = i == mpos ? kf : kq[r];  // (the median's place holds the old head now, whatever the load saw)
+            const bool isL = valid && !(k < p);
+            const bool isR = valid && !(p < k);
+            const uint64_t mL = __ballot(isL), mR = __ballot(isR);
+            if (isL) posL[lo + nL + __popcll(mL & lt)] = i;
+            if (isR) posR[lo + nR + __popcll(mR & lt)] = i;
+            nL += __popcll(mL);
+            nR += __popcll(mR);
+        }
     }
     wave_sync();
+    WP_STAMP(2);
+    // ---- m = #{k < min(nL, nR) : L[k] < R[k]}, R[k] = posR[lo + nR - 1 - k]; the predicate is monotone ----
     const uint32_t lim = nL < nR ? nL : nR;
-    uint32_t m = 0;
-    for (uint32_t base = 0; base < lim; base += 64) {
-        const uint32_t k = base + lane;
-        const bool ok = (k < lim) && ((uint32_t)posL[lo + k] < (uint32_t)posR[lo + nR - 1 - k]);
-        const uint32_t c = __popcll(__ballot(ok));
-        m += c;
-        if (c < 64) break;  // monotone predicate
+    uint32_t mlo = 0, cnt = lim;  // invariant: the predicate holds below mlo and m <= mlo + cnt
+    while (cnt > 64) {
+        const uint32_t step = (cnt + 63u) / 64u;
+        const uint32_t k = mlo + lane * step;
+        const bool ok = (k < mlo + cnt) && ((uint32_t)posL[lo + k] < (uint32_t)posR[lo + nR - 1 - k]);
+        const uint32_t t = (uint32_t)__popcll(__ballot(ok));
+        if (t == 0) {
+            cnt = 0;
+            break;
+        }
+        const uint32_t nlo = mlo + (t - 1u) * step + 1u;
+        uint32_t nhi = mlo + t * step;
+        if (t == 64u || nhi > mlo + cnt) nhi = mlo + cnt;
+        cnt = nhi - nlo;
+        mlo = nlo;
     }
-    uint32_t cut = 0xFFFFFFFFu;
-    if (m < nL) cut = posL[lo + m];
-    if (m > 0) {
-        const uint32_t r = posR[lo + nR - m];
-        if (r < cut) cut = r;
+    uint32_t m;
+    {
+        const uint32_t k = mlo + lane;
+        const bool ok = (lane < cnt) && ((uint32_t)posL[lo + k] < (uint32_t)posR[lo + nR - 1 - k]);
+        m = mlo + (uint32_t)__popcll(__ballot(ok));
     }
-    for (uint32_t k = lane; k < m; k += 64) swap_kv(K, V, (uint32_t)posL[lo + k], (uint32_t)posR[lo + nR - 1 - k]);
+    WP_STAMP(3);
+    // ---- cut = min(L[m] if it exists, R[m-1] if m > 0); swaps (L[k], R[k]) for k < m (pairwise disjoint positions) ----
+    const uint32_t cl = posL[lo + (m < nL ? m : 0u)], cr = posR[lo + (m > 0 ? nR - m : 0u)];  // (both lists are non-empty)
+    for (uint32_t k0 = 0; k0 < m; k0 += 128) {
+        const uint32_t k1 = k0 + lane, k2 = k0 + 64u + lane;
+        const bool v1 = k1 < m, v2 = k2 < m;
+        uint32_t i1 = 0, j1 = 0, i2 = 0, j2 = 0;
+        if (v1) {
+            i1 = posL[lo + k1];
+            j1 = posR[lo + nR - 1 - k1];
+        }
+        if (v2) {
+            i2 = posL[lo + k2];
+            j2 = posR[lo + nR - 1 - k2];
+        }
+        uint32_t a1 = 0, b1 = 0, c1 = 0, d1 = 0, a2 = 0, b2 = 0, c2 = 0, d2 = 0;
+        if (v1) {
+            a1 = K[i1];
+            b1 = K[j1];
+            c1 = V[i1];
+            d1 = V[j1];
+        }
+        if (v2) {
+            a2 = K[i2];
+            b2 = K[j2];
+            c2 = V[i2];
+            d2 = V[j2];
+        }
+        if (v1) {
+            K[i1] = b1;
+            K[j1] = a1;
+            V[i1] = d1;
+            V[j1] = c1;
+        }
+        if (v2) {
+            K[i2] = b2;
+            K[j2] = a2;
+            V[i2] = d2;
+            V[j2] = c2;
+        }
+    }
+    uint32_t cut = m < nL ? cl : 0xFFFFFFFFu;
+    if (m > 0 && cr < cut) cut = cr;
     wave_sync();
+    WP_STAMP(4);
+    if (ts && lane == 0) ts[5] = m;
+#undef WP_STAMP
     return cut;
 }
 
@@ -299,7 +401,7 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
         __syncthreads();
         int cur = 0;
     for (;;) {
-        const uint32_t nseg = qcnt[cur];
+        const uint32_t nseg = __builtin_amdgcn_readfirstlane(qcnt[cur]);
         if (nseg == 0) break;
         if (lvl_ < 12) ESORT_STAMP(4 + lvl_);
         ++lvl_;
@@ -323,19 +425,22 @@ __device__ __forceinline__ void block_esort(KP K, VP V, PP posL, PP posR, HP hea
                 }
                 continue;
             }
-            const uint32_t cut = wave_partition(K, V, posL, posR, sg.first, sg.last);
-            if (lane == 0) {
-                atomicOr(&head[cut >> 5], 1u << (cut & 31u));
-                const Seg ch[2] = {{sg.first, cut, sg.depth - 1}, {cut, sg.last, sg.depth - 1}};
-                for (int t = 0; t < 2; ++t) {
-                    const uint32_t len = ch[t].last - ch[t].first;
-                    if (len <= (uint32_t)kThreshold) continue;
-                    if (len <= 64u && ch[t].depth > 0) {
+            const uint32_t cut = wave_partition(K, V, posL, posR, sg.first, sg.last, (tstamp && lvl_ == 1) ? tstamp + 16 : nullptr);
+            if (tstamp && lvl_ == 1 && lane == 0) tstamp[22] = clock64();
+            if (lane == 0) atomicOr(&head[cut >> 5], 1u << (cut & 31u));
+            if (lane < 2) {  // the two children are queued side by side (their order in a queue is irrelevant)
+                Seg ch;
+                ch.first = lane == 0 ? sg.first : cut;
+                ch.last = lane == 0 ? cut : sg.last;
+                ch.depth = sg.depth - 1;
+                const uint32_t len = ch.last - ch.first;
+                if (len > (uint32_t)kThreshold) {
+                    if (len <= 64u && ch.depth > 0) {
                         const uint32_t at = atomicAdd(&s_nsmall, 1u);
-                        if (at < small_cap) s_small[at] = ch[t]; else *overflow_flag = 3;
+                        if (at < small_cap) s_small[at] = ch; else *overflow_flag = 3;
                     } else {
                         const uint32_t at = atomicAdd(&qcnt[cur ^ 1], 1u);
-                        if (at < qcap) qn[at] = ch[t]; else *overflow_flag = 3;
+                        if (at < qcap) qn[at] = ch; else *overflow_flag = 3;
                     }
                 }
             }

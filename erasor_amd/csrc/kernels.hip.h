@@ -348,10 +348,12 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restr
         uint32_t ph = block_excl_scan(sh, sm, ch);
         if (nFchunks >= base && nFchunks < base + 16) {  // the F region's share of the totals
             uint32_t a = pv, b2 = ph;
-            for (uint32_t j = 0; base + j < nFchunks; ++j) {
-                a += ci[j] & 0xFFFFu;
-                b2 += ci[j] >> 16;
-            }
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j)  // (static indices: a run-time index would put ci[] into scratch memory for every thread)
+                if (base + j < nFchunks) {
+                    a += ci[j] & 0xFFFFu;
+                    b2 += ci[j] >> 16;
+                }
             s_voiF = a;
             s_validF = b2;
         }
@@ -1588,7 +1590,7 @@ __global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, 
                 sV[i] = V[sg.first + i];
             }
             __syncthreads();
-            __shared__ unsigned long long s_stamps[20];
+            __shared__ unsigned long long s_stamps[24];
             const unsigned long long t_a = clock64();
             esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, len, sg.depth, qa, qb, qcnt, (uint32_t)(ES_LMAX / 16 + 2),
                                &ctr->n_sort_fallback, &ctr->sort_qoverflow, dbg ? s_stamps : nullptr);
@@ -2342,6 +2344,7 @@ __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict
     __shared__ uint32_t s_carry;
     __shared__ uint32_t s_tab[64];
     __shared__ unsigned long long s_t[12];
+    __shared__ unsigned long long s_es[24];  // diagnostics: block_esort's own stamps (shader clock)
 #define RG_STAMP(i) do { if (dbg && tid == 0) s_t[i] = wall_clock64(); } while (0)
     uint32_t *sK = pool, *sV = pool + RG_LMAX, *sL = pool + 2 * RG_LMAX, *sR = pool + 3 * RG_LMAX;
     const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = bs >> 6;
@@ -2375,8 +2378,9 @@ __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict
         }
         __syncthreads();
         RG_STAMP(0);
+        if (dbg && tid < 24) s_es[tid] = 0;
         esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
-                           &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+                           &ctr->n_sort_fallback, &ctr->sort_qoverflow, dbg ? s_es : nullptr);
         RG_STAMP(1);
         // sorted keys in sL, sorted bin-local indices in sR
         uint32_t drop = 0, ng = 0;
@@ -2559,6 +2563,7 @@ __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict
                 dbg[37] = s_t[4] - s_t[3];  // SVD
                 dbg[38] = s_t[5] - s_t[4];  // classification
                 dbg[39] = ng;
+                for (int i = 0; i < 24; ++i) dbg[40 + i] = s_es[i];
             }
         }
     }

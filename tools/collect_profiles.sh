@@ -3,8 +3,8 @@
 #   tools/collect_profiles.sh <tag> [bench.py args]     -> gpurun_out/profiles_<tag>/...
 # Passes (each its own process; counters never share a run with tracing, as the pool requires):
 #   1. plain bench.py (+ per-kernel HIP-event breakdown)
-#   2. rocprofv3 --kernel-trace --stats
-#   3. rocprofv3 --pmc FETCH_SIZE        4. rocprofv3 --pmc WRITE_SIZE
+#   2. timeout 240 rocprofv3 --kernel-trace --stats
+#   3. timeout 240 rocprofv3 --pmc FETCH_SIZE        4. timeout 240 rocprofv3 --pmc WRITE_SIZE
 TAG=${1:-run}
 shift
 EXTRA="$@"   # e.g. --workload large_scale_05
@@ -12,12 +12,12 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 20 --warmup 3 $EXTRA"
+BENCH="timeout 200 python $ROOT/bench.py --steps 20 --warmup 3 $EXTRA"
 $BENCH > $OUT/bench.json 2> $OUT/bench.stderr
 $BENCH --no-cpu-baseline --profile-all > /dev/null 2> $OUT/bench_kernel_breakdown.txt
 rm -rf /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -- $BENCH --no-cpu-baseline > $OUT/bench_under_rocprofv3.json 2> /dev/null
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/rp_fetch -- $BENCH --steps 6 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -- $BENCH --steps 6 --no-cpu-baseline > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -- $BENCH --no-cpu-baseline > $OUT/bench_under_rocprofv3.json 2> /dev/null
+timeout 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/rp_fetch -- $BENCH --steps 6 --no-cpu-baseline > /dev/null 2>&1
+timeout 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -- $BENCH --steps 6 --no-cpu-baseline > /dev/null 2>&1
 cd $ROOT && python tools/summarize_profiles.py /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write $OUT
 ls -la $OUT
