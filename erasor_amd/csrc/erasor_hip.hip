@@ -309,6 +309,10 @@ void fill_dp(erasor_hip_handle *h) {
 }
 
 // two-level exclusive scan helper (n on host or device)
+// k_bbox ends with six same-line atomics per workgroup (~6 ns each, serialised): 475 workgroups for a 121 k-point scan
+// were 17 us of atomics around 2 MB of loads.  Eight points per thread, at most 512 workgroups.
+static inline uint32_t bbox_grid(uint32_t n) { return std::max(1u, std::min<uint32_t>(cdiv(n, 2048), 512)); }
+
 int scan_u32(erasor_hip_handle *h, const uint32_t *in, uint32_t *out_local, uint32_t *tops, uint32_t n_host_max, uint32_t n_host,
              const uint32_t *n_dev, uint32_t *total_out, const char *tag) {
     const uint32_t nb = std::max(1u, cdiv(n_host_max, 1024));
@@ -793,13 +797,20 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
 static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf, const std::function<void()> &after_keys) {
     Counters *dc = Q(h).d_qctr.p;
     // (the bounding box was reset by k_query_begin)
-    if (n) LAUNCH(h, "q_bbox", k_bbox, std::min<uint32_t>(cdiv(n, 256), 1024), 256, Q(h).scan_in, n, Q(h).bb.p);
+    if (n) LAUNCH(h, "q_bbox", k_bbox, bbox_grid(n), 256, Q(h).scan_in, n, Q(h).bb.p);
     LAUNCH(h, "q_keys", k_voxel_keys, std::max(1u, cdiv(n, 256)), 256, Q(h).scan_in, n, (const uint32_t *)Q(h).bb.p, leaf, Q(h).qk_a.p,
            Q(h).qv_a.p, Q(h).qgrid.p, dc, Q(h).hkey.p, 1u << Q(h).hbits);
     after_keys();  // ctr->err (VoxelGrid overflow) is final from here on: the caller may fork work that depends on it
     // exact std::sort: a few global levels (one workgroup per big segment), then per-segment completion in LDS
     run_exact_sort(h, n);
     // runs
+    const uint32_t ntile = std::max(1u, cdiv(n, 1024));
+    if (ntile <= 1024) {  // (a scan: ~120 tiles) two launches: tile totals, then heads -> run_begin with the tile's offset summed in place
+        LAUNCH(h, "q_runs", k_run_count, ntile, 256, (const uint32_t *)Q(h).qk_b.p, n, Q(h).qtops.p);
+        LAUNCH(h, "q_runs", k_run_emit, ntile, 256, (const uint32_t *)Q(h).qk_b.p, n, (const uint32_t *)Q(h).qtops.p, ntile, Q(h).run_begin.p,
+               Q(h).d_nvox.p);
+        return 0;
+    }
     if (n) LAUNCH(h, "q_runs", k_run_heads, cdiv(n, 256), 256, (const uint32_t *)Q(h).qk_b.p, n, Q(h).qflag.p);
     scan_u32(h, Q(h).qflag.p, Q(h).qpl.p, Q(h).qtops.p, n, n, nullptr, nullptr, "q_runs");
     LAUNCH(h, "q_runs", k_run_begin, cdiv((uint64_t)n + 1, 256), 256, (const uint32_t *)Q(h).qflag.p, (const uint32_t *)Q(h).qpl.p,
@@ -915,7 +926,7 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     if (passthrough && !prevox) {
         // PCL's VoxelGrid refuses this cloud (index overflow) and hands it back unchanged (utils.cpp:88-91): the chain verifies
         // that on the device (err 4 if not) and produces the un-voxelised query with the label search's answers
-        if (ns) LAUNCH(h, "q_bbox", k_bbox, std::min<uint32_t>(cdiv(ns, 256), 1024), 256, q.scan_in, ns, q.bb.p);
+        if (ns) LAUNCH(h, "q_bbox", k_bbox, bbox_grid(ns), 256, q.scan_in, ns, q.bb.p);
         LAUNCH(h, "q_passthrough", k_passthrough_check, 1, 64, (const uint32_t *)q.bb.p, ns, P.leaf_query, q.qgrid.p, qc);
         (void)hipEventRecord(q.ev_keys, qstream);
         rc = enqueue_passthrough(h, q.scan_in, ns, T_l2b, q.query.p, q.qkey.p);

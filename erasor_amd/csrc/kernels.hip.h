@@ -1639,6 +1639,56 @@ __global__ __launch_bounds__(256) void k_run_begin(const uint32_t *__restrict__ 
     if (flag[i]) run_begin[pl[i] + tops[i >> 10]] = i;
 }
 
+// The same in TWO launches instead of four, for up to 1024 tiles of 1024 keys (a scan is ~120 tiles): tile totals, then every
+// tile adds up the totals before it (<= 4 loads per thread), recomputes its heads and writes run_begin directly.
+__device__ __forceinline__ uint32_t run_heads4(const uint32_t *__restrict__ skeys, uint32_t n, uint32_t base, bool hd[4]) {
+    uint32_t prev = (base > 0 && base - 1 < n) ? skeys[base - 1] : 0u, c = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        hd[j] = false;
+        if (base + j < n) {
+            const uint32_t k = skeys[base + j];
+            hd[j] = (base + j == 0) || k != prev;
+            prev = k;
+            c += hd[j] ? 1u : 0u;
+        }
+    }
+    return c;
+}
+__global__ __launch_bounds__(256) void k_run_count(const uint32_t *__restrict__ skeys, uint32_t n, uint32_t *__restrict__ tops) {
+    __shared__ uint32_t sm[40];
+    bool hd[4];
+    const uint32_t c = run_heads4(skeys, n, blockIdx.x * 1024u + threadIdx.x * 4u, hd);
+    uint32_t tot;
+    block_excl_scan(c, sm, tot);
+    if (threadIdx.x == 0) tops[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_run_emit(const uint32_t *__restrict__ skeys, uint32_t n, const uint32_t *__restrict__ tops,
+                                                   uint32_t ntile, uint32_t *__restrict__ run_begin, uint32_t *nv_out) {
+    __shared__ uint32_t sm[40];
+    uint32_t before = 0, all = 0;
+    for (uint32_t i = threadIdx.x; i < ntile; i += blockDim.x) {
+        const uint32_t v = tops[i];
+        all += v;
+        if (i < blockIdx.x) before += v;
+    }
+    uint32_t off, nv;
+    block_excl_scan(before, sm, off);
+    block_excl_scan(all, sm, nv);
+    bool hd[4];
+    const uint32_t base = blockIdx.x * 1024u + threadIdx.x * 4u;
+    const uint32_t c = run_heads4(skeys, n, base, hd);
+    uint32_t tot;
+    uint32_t p = off + block_excl_scan(c, sm, tot);
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)
+        if (hd[j]) run_begin[p++] = base + j;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        run_begin[nv] = n;
+        *nv_out = nv;
+    }
+}
+
 __device__ __forceinline__ uint32_t vox_hash(uint32_t key, int hbits) { return (key * 2654435761u) >> (32 - hbits); }
 
 // CentroidPoint<PointXYZI>: float32 running sums in sorted order, each / (float)count
