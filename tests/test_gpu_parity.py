@@ -166,6 +166,13 @@ def test_voxelize_preserving_labels_standalone(gpu_mod, leaf):
     one = np.array([[1.0, 2.0, 3.0, 40.0]], np.float32)
     same(g.voxelize_preserving_labels(one, leaf), one)
     assert len(g.voxelize_preserving_labels(np.zeros((0, 4), np.float32), leaf)) == 0
+    # sizes around the 1024-key tiles of the run detection (tile totals -> offsets -> run_begin), all-distinct voxels and
+    # long runs (one voxel spanning tile borders)
+    for n in (2, 1023, 1024, 1025, 2047, 2048, 2049, 5000):
+        far = rng.uniform(-40, 40, (n, 4)).astype(np.float32)                       # nearly one point per voxel
+        same(g.voxelize_preserving_labels(far, leaf), orc.voxelize_preserving_labels(far, leaf), "n=%d spread" % n)
+        near = (rng.uniform(0, 0.9 * leaf, (n, 4)) + [5, 5, 1, 40]).astype(np.float32)  # ONE voxel holds all n points
+        same(g.voxelize_preserving_labels(near, leaf), orc.voxelize_preserving_labels(near, leaf), "n=%d one voxel" % n)
 
 
 # ---------------------------------------------------------------------------------------------
