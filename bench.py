@@ -160,11 +160,13 @@ class Sequence:
         self.lookahead = not args.no_lookahead
         self.LA = args.lookahead
         self.primed = False
+        # nodes are announced with their pose (scan + odometry, like erasor::node): the next step's VoI split is launched ahead
+        self.with_pose = not os.environ.get("ERASOR_BENCH_NO_POSE_AHEAD")
 
     def prime(self):
         if self.lookahead and not self.primed:
             for j in range(min(self.LA, self.n_frames)):
-                self.g.prefetch_device(self.d_ptr[j], self.n_pts[j], self.c_Tl)
+                self.g.prefetch_device(self.d_ptr[j], self.n_pts[j], self.c_Tl, self.c_Tb[j] if self.with_pose else None)
         self.primed = True
 
     def run(self, k):
@@ -172,7 +174,7 @@ class Sequence:
         # not depend on the map) overlap step k's map-side stages; step k returns with ITS results on the host as before
         g = self.g
         if self.lookahead and k + self.LA < self.n_frames:
-            g.prefetch_device(self.d_ptr[k + self.LA], self.n_pts[k + self.LA], self.c_Tl)
+            g.prefetch_device(self.d_ptr[k + self.LA], self.n_pts[k + self.LA], self.c_Tl, self.c_Tb[k + self.LA] if self.with_pose else None)
         return g.step_device(self.d_ptr[k], self.n_pts[k], self.c_Tl, self.c_Tb[k], self.c_To[k])
 
 

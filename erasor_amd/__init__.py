@@ -184,17 +184,24 @@ class Erasor:
         return self.get_cloud(CLOUD_MAP)
 
     # -- step --
-    def prefetch(self, scan, T_l2b):
+    def prefetch(self, scan, T_l2b, T_b2o=None):
         """announce the next scan (host array): its query chain starts now, beside the step in flight"""
         scan = _f32(scan).reshape(-1, 4)
         # every announced buffer stays alive until a step has consumed it (up to three scans can be announced ahead; a freed
         # buffer's address could be handed to the next np.ascontiguousarray)
         self._keep = (getattr(self, "_keep", []) + [scan])[-4:]
-        self._check(lib().erasor_hip_prefetch_scan(self._h, _p(scan), C.c_size_t(len(scan)), C.c_int(0), _p(_f32(T_l2b).reshape(16))))
+        if T_b2o is None:
+            self._check(lib().erasor_hip_prefetch_scan(self._h, _p(scan), C.c_size_t(len(scan)), C.c_int(0), _m(T_l2b)))
+        else:
+            self._check(lib().erasor_hip_prefetch_node(self._h, _p(scan), C.c_size_t(len(scan)), C.c_int(0), _m(T_l2b), _m(T_b2o)))
         return scan
 
-    def prefetch_device(self, d_ptr, n, T_l2b):
-        self._check(lib().erasor_hip_prefetch_scan(self._h, C.c_void_p(d_ptr), C.c_size_t(n), C.c_int(1), _m(T_l2b)))
+    def prefetch_device(self, d_ptr, n, T_l2b, T_b2o=None):
+        """announce the next scan (device buffer, read in place); with its pose the next step's VoI split is launched ahead"""
+        if T_b2o is None:
+            self._check(lib().erasor_hip_prefetch_scan(self._h, C.c_void_p(d_ptr), C.c_size_t(n), C.c_int(1), _m(T_l2b)))
+        else:
+            self._check(lib().erasor_hip_prefetch_node(self._h, C.c_void_p(d_ptr), C.c_size_t(n), C.c_int(1), _m(T_l2b), _m(T_b2o)))
 
     def step(self, scan, T_l2b, T_b2o, T_o2b):
         scan = _f32(scan).reshape(-1, 4)
@@ -306,6 +313,11 @@ class Erasor:
     def voi_split_bytes(self):
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._check(lib().erasor_hip_voi_split_bytes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def ahead_split_counts(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(lib().erasor_hip_ahead_split_counts(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def stream(self):

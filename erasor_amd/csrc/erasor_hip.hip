@@ -77,6 +77,8 @@ struct QSide {
     bool src_dev = false;             // src is a device pointer (read in place; not fingerprinted)
     uint64_t fp = 0;                  // host scans are copied when they are announced: fingerprint of that copy
     bool used = false;                // ev_done has been recorded at least once
+    bool pose_valid = false;          // the scan was announced together with its pose (erasor_hip_prefetch_node)
+    double pose_x = 0, pose_y = 0;    // T_body2origin translation (OMU.cpp:246-247): all fetch_VoI needs
 };
 
 struct erasor_hip_handle {
@@ -99,7 +101,21 @@ struct erasor_hip_handle {
         float Tl[16] = {0};
         int side = 0;
         uint64_t fp = 0;
+        bool pose_valid = false;
+        double pose_x = 0, pose_y = 0;
     } ann;
+    // the NEXT step's VoI split, launched ahead (behind this step's k_step_end) when the next scan was announced with its pose
+    struct {
+        bool valid = false;
+        double x = 0, y = 0;
+        unsigned long long seq = 0;      // h->step_seq when it was launched
+        unsigned long long epoch = 0;    // h->store_epoch then
+        int curF = 0;                    // the F buffer it read
+        uint32_t cap_chunks = 0;
+        const void *vmask = nullptr, *hmask = nullptr, *cinfo = nullptr;
+    } spec;
+    unsigned long long store_epoch = 0;  // bumped by everything that rewrites the map store outside a step
+    unsigned long long n_spec_used = 0, n_spec_launched = 0;
     // mapgen state (mapgen.hpp:27-46): cloud_curr, cloud_map, the finished submaps (cloud_maps, concatenated)
     DBuf<float4> mg_curr, mg_map, mg_done, mg_tmp;
     uint64_t mg_ncurr = 0, mg_nmap = 0, mg_ndone = 0;
@@ -448,6 +464,7 @@ int alloc_step(erasor_hip_handle *h, uint32_t n_voi, uint32_t nq) {
 
 // rebuild the outskirts region without tombstones at the end of the buffer (stable)
 int rebuild_outskirts(erasor_hip_handle *h, uint32_t min_front_room) {
+    ++h->store_epoch;
     const uint32_t span = h->capO - h->o_begin;
     DBuf<uint32_t> flag, pl, tops;
     DBuf<float4> tmp;
@@ -487,6 +504,7 @@ int push_state(erasor_hip_handle *h);
 // set_submap (OMU.cpp:360-379) over [F | outskirts | complement] in that (logical) order: stable partition by the box test
 // into the new submap (stored as outskirts, F empty) and the new complement.  Rare (every ~submap_size/2 of travel).
 int split_submap(erasor_hip_handle *h, double x, double y) {
+    ++h->store_epoch;
     const uint64_t total64 = (uint64_t)h->nF + h->o_valid + h->nC;
     if (total64 > 0x7FFFFFF0ull) {
         h->err = "map too large for 32-bit indexing";
@@ -708,6 +726,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
 const char *erasor_hip_last_error(const erasor_hip_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
 static int set_map_common(erasor_hip_handle *h, const void *src, size_t n, bool src_is_device) {
+    if (h) ++h->store_epoch;
     if (!h) return ERASOR_E_INVALID;
     if (!src && n) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
@@ -966,6 +985,7 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     q.src_n = ns;
     q.ns = ns;
     q.src_dev = src_is_device;
+    q.pose_valid = false;  // (flush_announced adds the pose of an announced node)
     if (!src_is_device) q.fp = staged ? h->ann.fp : scan_fingerprint(scan_src, ns);
     memcpy(q.Tl, T_l2b, sizeof(q.Tl));
     return ERASOR_OK;
@@ -978,6 +998,9 @@ static int flush_announced(erasor_hip_handle *h) {
     const int rc = enqueue_query_chain(h, h->ann.side, h->ann.src, (uint32_t)h->ann.n, h->ann.is_device, h->ann.Tl, false, /*staged=*/true,
                                        h->q_passthrough);
     if (rc) return rc;
+    h->q[h->ann.side].pose_valid = h->ann.pose_valid;
+    h->q[h->ann.side].pose_x = h->ann.pose_x;
+    h->q[h->ann.side].pose_y = h->ann.pose_y;
     h->pend[h->npend++] = h->ann.side;
     return ERASOR_OK;
 }
@@ -990,6 +1013,34 @@ static void q_drain(erasor_hip_handle *h) {
     for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(h->qstream[k]);
 }
 
+
+// The VoI split on the main stream.  dev == nullptr: a step's own pass (extents from the host mirror).  dev != nullptr: the
+// pass of the NEXT step, launched ahead; the kernel takes the extents the step in flight commits on the device.
+static void launch_voi_split(erasor_hip_handle *h, const float4 *F, uint32_t nF, uint32_t nFchunks, uint32_t o_begin, uint32_t o_chunk0,
+                             uint32_t nOchunks, uint32_t nchunks_grid, double xc, double yc, double voi_r2, const DevState *dev, uint32_t cap_chunks) {
+    // one chunk per wave while that needs <= 16 workgroups per CU: the hardware back-fills workgroups as they finish,
+    // which balances better than a grid-stride tail (measured, tools/bw_probe.hip)
+    const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nchunks_grid, 4), 256 * 16));
+    const uint32_t capO_chunks = h->capO / CHUNK;
+    if (h->prof == 2) {
+        // roofline measurement: the launch carries its own start / stop events (hipExtLaunchKernelGGL: they stamp the
+        // kernel's execution window itself, the figure rocprofv3 reports too).  A record / record bracket around the
+        // launch costs two extra barrier packets on a 17 us kernel and slows the step it is supposed to observe.
+        PendingEvt ke;
+        ke.name_id = prof_id(h, "voi_split");
+        ke.a = get_evt(h);
+        ke.b = get_evt(h);
+        hipExtLaunchKernelGGL(k_voi_split, dim3(grid), dim3(256), 0, h->stream, ke.a, ke.b, 0, F, nF, nFchunks, (const float2 *)h->Oxy.p, o_begin,
+                              o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks);
+        h->pending.push_back(ke);
+    } else {
+        hipStream_t keep = h->cur;
+        h->cur = h->stream;
+        LAUNCH(h, "voi_split", k_voi_split, grid, 256, F, nF, nFchunks, (const float2 *)h->Oxy.p, o_begin, o_chunk0, nOchunks, xc, yc, voi_r2,
+               h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks);
+        h->cur = keep;
+    }
+}
 
 static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan, bool src_is_device, const float T_l2b[16],
                        const float T_b2o[16], const float T_o2b[16], erasor_step_result *res, int flags = 0) {
@@ -1079,8 +1130,13 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     const uint32_t o_chunk0 = h->o_begin / CHUNK;
     const uint32_t nOchunks = h->capO / CHUNK - o_chunk0;
     const uint32_t nchunks = nFchunks + nOchunks;
-    if (ensure(h, h->vmask, (size_t)nchunks * CHUNK_TILES + 8) || ensure(h, h->hmask, (size_t)nchunks * CHUNK_TILES + 8) ||
-        ensure(h, h->cinfo, nchunks + 8) || ensure(h, h->pvl, nchunks + 8) || ensure(h, h->phl, nchunks + 8) ||
+    // (the masks and chunk counts also hold the NEXT step's split when it is launched ahead: its F region may be longer by
+    // this step's VoI + scan, its outskirts region may begin up to nF entries earlier)
+    const size_t chunks_room = (size_t)nchunks + cdiv((uint64_t)n_map_in + ns + 64, CHUNK) + cdiv(h->nF, CHUNK) + 8;
+    if (chunks_room * CHUNK_TILES + 8 > h->vmask.cap || chunks_room * CHUNK_TILES + 8 > h->hmask.cap || chunks_room + 8 > h->cinfo.cap)
+        h->spec.valid = false;  // (re-allocated below: a pass launched ahead wrote into the old buffers)
+    if (ensure(h, h->vmask, chunks_room * CHUNK_TILES + 8) || ensure(h, h->hmask, chunks_room * CHUNK_TILES + 8) ||
+        ensure(h, h->cinfo, chunks_room + 8) || ensure(h, h->pvl, nchunks + 8) || ensure(h, h->phl, nchunks + 8) ||
         ensure(h, h->topv, nchunks / 1024 + 8) || ensure(h, h->toph, nchunks / 1024 + 8))
         return ERASOR_E_NO_DEVICE;
     // No mid-step read-back: everything is launched on upper-bound grids and reads the actual counts
@@ -1106,23 +1162,16 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         h->cur = h->stream;
         h->bank = 1;
         {   // VoI split (OMU.cpp:254 fetch_VoI membership)
-            // one chunk per wave while that needs <= 16 workgroups per CU: the hardware back-fills workgroups as they finish,
-            // which balances better than a grid-stride tail (measured, tools/bw_probe.hip)
-            const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nchunks, 4), 256 * 16));
-            if (h->prof == 2) {
-                // roofline measurement: the launch carries its own start / stop events (hipExtLaunchKernelGGL: they stamp the
-                // kernel's execution window itself, the figure rocprofv3 reports too).  A record / record bracket around the
-                // launch costs two extra barrier packets on a 17 us kernel and slows the step it is supposed to observe.
-                PendingEvt ke;
-                ke.name_id = prof_id(h, "voi_split");
-                ke.a = get_evt(h);
-                ke.b = get_evt(h);
-                hipExtLaunchKernelGGL(k_voi_split, dim3(grid), dim3(256), 0, h->cur, ke.a, ke.b, 0, (const float4 *)h->F[h->curF].p, h->nF, nFchunks,
-                                      (const float2 *)h->Oxy.p, h->o_begin, o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p);
-                h->pending.push_back(ke);
-            } else
-                LAUNCH(h, "voi_split", k_voi_split, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, (const float2 *)h->Oxy.p, h->o_begin,
-                       o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p);
+            // ... unless it is already there: launched ahead by the previous step for exactly this pose and this store
+            const bool use_spec = h->spec.valid && !flags && h->spec.seq == h->step_seq && h->spec.epoch == h->store_epoch &&
+                                  h->spec.curF == h->curF && h->spec.x == xc && h->spec.y == yc && nchunks <= h->spec.cap_chunks &&
+                                  h->spec.vmask == (const void *)h->vmask.p && h->spec.hmask == (const void *)h->hmask.p &&
+                                  h->spec.cinfo == (const void *)h->cinfo.p;
+            h->spec.valid = false;
+            if (use_spec) ++h->n_spec_used;
+            else
+                launch_voi_split(h, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, h->o_begin, o_chunk0, nOchunks, nchunks, xc, yc, voi_r2,
+                                 (const DevState *)nullptr, 0u);
             const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));
             if (nchunks <= 16384) {
                 LAUNCH(h, "chunk_scan", k_chunk_scan_one, 1, 1024, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, ntop,
@@ -1221,12 +1270,46 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     const unsigned long long step_seq = ++h->step_seq;
     LAUNCH(h, "step_end", k_step_end, 1, 1, ds, dc, h->pin, (const unsigned long long *)h->lab_slots.p, (const Counters *)Q(h).d_qctr.p,
            (const uint32_t *)Q(h).d_nvox.p, step_seq);
+    {   // the NEXT step's VoI split goes right behind k_step_end when its pose is known (erasor_hip_prefetch_node): the main
+        // stream runs it while the host collects this step's results and the caller comes back with the next scan -- the pass
+        // reads the store this step has just written and the extents k_step_end commits; a step that finds anything else than
+        // what was assumed here (pose, store, buffers) simply runs its own pass
+        static const bool no_spec = getenv("ERASOR_HIP_NO_AHEAD_SPLIT") != nullptr;
+        bool have_pose = false;
+        double nx = 0, ny = 0;
+        if (h->npend > 0) {
+            const QSide &nq_ = h->q[h->pend[0]];
+            have_pose = nq_.pose_valid;
+            nx = nq_.pose_x;
+            ny = nq_.pose_y;
+        } else if (h->ann.valid) {
+            have_pose = h->ann.pose_valid;
+            nx = h->ann.pose_x;
+            ny = h->ann.pose_y;
+        }
+        if (have_pose && !no_spec && !flags && !h->P.is_large_scale) {
+            const size_t cap_chunks = std::min(std::min(h->vmask.cap, h->hmask.cap) / CHUNK_TILES, h->cinfo.cap) - 8;
+            launch_voi_split(h, (const float4 *)Fnew, 0u, 0u, 0u, 0u, 0u, nchunks + 64, nx, ny, P.voi_r2, (const DevState *)ds, (uint32_t)cap_chunks);
+            h->spec.valid = true;
+            h->spec.x = nx;
+            h->spec.y = ny;
+            h->spec.seq = h->step_seq;
+            h->spec.epoch = h->store_epoch;
+            h->spec.curF = h->curF ^ 1;
+            h->spec.cap_chunks = (uint32_t)cap_chunks;
+            h->spec.vmask = h->vmask.p;
+            h->spec.hmask = h->hmask.p;
+            h->spec.cinfo = h->cinfo.p;
+            ++h->n_spec_launched;
+        }
+    }
     {   // the NEXT scan's query chain goes into its queue now, behind this step's own launches; it runs while we wait
         const int keep_side = h->qi;
         const int rc_next = flush_announced(h);
         h->qi = keep_side;
         if (rc_next) {
             (void)hipStreamSynchronize(h->stream);
+            h->spec.valid = false;
             return rc_next;
         }
     }
@@ -1277,10 +1360,12 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     }
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
+        h->spec.valid = false;
         h->err = std::string("kernel launch: ") + hipGetErrorString(le);
         return ERASOR_E_NO_DEVICE;
     }
     if (h->ctr.err || h->ctr.sort_qoverflow) {
+        h->spec.valid = false;  // (launched ahead on the assumption that this step succeeds)
         // errors raised by the query chain (2, 3, 4) are seen by k_voi_gather before it touches the map store: the step left
         // no trace and the host mirror of the state is simply restored.
         h->st.nF = h->nF;
@@ -1354,7 +1439,18 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
 // Announce the NEXT scan: its query chain (voxelisation, label search, bucketing -- everything that does not depend on the
 // map) is enqueued now and runs beside the map-side stages of the step in flight.  The step call that follows must pass the
 // same (pointer, size, T_lidar2body); anything else simply drops the prefetch.
+static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device, const float T_l2b[16], const float *T_b2o);
 int erasor_hip_prefetch_scan(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device, const float T_l2b[16]) {
+    return prefetch_common(h, scan_xyzi, n, src_is_device, T_l2b, nullptr);
+}
+// The same with the node's pose (an erasor::node carries both, msg/node.msg:1-7): the step in flight then launches the next
+// step's VoI split (fetch_VoI's membership test around that pose, OMU.cpp:246-254) ahead, behind its own last kernel.
+int erasor_hip_prefetch_node(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device, const float T_l2b[16],
+                             const float T_body2origin[16]) {
+    if (!T_body2origin) return ERASOR_E_INVALID;
+    return prefetch_common(h, scan_xyzi, n, src_is_device, T_l2b, T_body2origin);
+}
+static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device, const float T_l2b[16], const float *T_b2o) {
     if (!h || !T_l2b || (!scan_xyzi && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
     if (h->ann.valid && h->npend >= 2) {
@@ -1379,6 +1475,9 @@ int erasor_hip_prefetch_scan(erasor_hip_handle *h, const void *scan_xyzi, size_t
     h->ann.fp = src_is_device ? 0ull : scan_fingerprint(scan_xyzi, n);
     h->ann.side = side;
     memcpy(h->ann.Tl, T_l2b, sizeof(h->ann.Tl));
+    h->ann.pose_valid = T_b2o != nullptr;
+    h->ann.pose_x = T_b2o ? (double)T_b2o[3] : 0.0;  // OMU.cpp:246-247
+    h->ann.pose_y = T_b2o ? (double)T_b2o[7] : 0.0;
     return ERASOR_OK;
 }
 
@@ -1849,6 +1948,12 @@ int erasor_hip_voi_split_bytes(erasor_hip_handle *h, uint64_t *algorithmic_bytes
     if (physical_entries) *physical_entries = (uint64_t)h->nF + oe;
     // F region streams 16 B/entry (float4), the outskirts region 8 B/entry ({x,y} only); + 16 B of masks per 64 entries
     if (algorithmic_bytes) *algorithmic_bytes = 16ull * h->nF + 8ull * oe + ((uint64_t)h->nF + oe) / 4;
+    return ERASOR_OK;
+}
+int erasor_hip_ahead_split_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t *used) {
+    if (!h) return ERASOR_E_INVALID;
+    if (launched) *launched = h->n_spec_launched;
+    if (used) *used = h->n_spec_used;
     return ERASOR_OK;
 }
 void *erasor_hip_stream(erasor_hip_handle *h) { return h ? (void *)h->stream : nullptr; }

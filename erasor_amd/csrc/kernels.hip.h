@@ -141,10 +141,21 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
                                                     const float2 *__restrict__ Oxy, uint32_t o_begin, uint32_t o_chunk0,
                                                     uint32_t nOchunks, double xc, double yc, double r2,
                                                     unsigned long long *__restrict__ vmask,
-                                                    unsigned long long *__restrict__ hmask, uint32_t *__restrict__ cinfo) {
+                                                    unsigned long long *__restrict__ hmask, uint32_t *__restrict__ cinfo,
+                                                    const DevState *__restrict__ dev, uint32_t capO_chunks, uint32_t cap_chunks) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    if (dev) {
+        // launched AHEAD of its step (right behind the previous step's k_step_end, while the host is still collecting that
+        // step's results): the extent of the two regions is what that step has just committed on the device
+        nF = dev->nF;
+        nFchunks = (nF + CHUNK - 1) / CHUNK;
+        o_begin = dev->o_begin;
+        o_chunk0 = o_begin / CHUNK;
+        nOchunks = capO_chunks - o_chunk0;
+        if (nFchunks + nOchunks > cap_chunks) return;  // (the step sees that too and runs the pass itself)
+    }
     const uint32_t nchunks = nFchunks + nOchunks;
     for (uint32_t c = wid; c < nchunks; c += nwaves) {
         unsigned long long myv = 0, myh = 0;

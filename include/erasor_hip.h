@@ -142,6 +142,12 @@ int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n
  * finished step: its query-derived outputs (erasor_hip_get_cloud / _get_bins) are gone from then on. */
 int erasor_hip_prefetch_scan(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device,
                              const float T_lidar2body[16]);
+/* The same for a whole node (msg/node.msg:1-7 carries the scan AND its pose): with T_body2origin known ahead, the step in
+ * flight also launches the next callback's VoI membership pass (fetch_VoI, OMU.cpp:246-254, 391-395) behind its own last
+ * kernel, so that the pass runs while the host collects the results.  The step that follows must pass the same pose; any
+ * other pose (or a map store touched in between) simply runs its own pass.  Results are unchanged. */
+int erasor_hip_prefetch_node(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device,
+                             const float T_lidar2body[16], const float T_body2origin[16]);
 
 /* replaces: the body of callback_node between OMU.cpp:237 and OMU.cpp:294:
  *   voxelize_preserving_labels(query) + transformPointCloud(tf_lidar2body_)   (OMU.cpp:238-241)
@@ -237,6 +243,8 @@ int erasor_hip_profile_get(erasor_hip_handle *h, const char **names, double *tot
                            uint64_t *launches, size_t cap, size_t *n);
 /* HBM bytes the voi_split kernel must read per launch for the current map: 16 * physical entries */
 int erasor_hip_voi_split_bytes(erasor_hip_handle *h, uint64_t *algorithmic_bytes, uint64_t *physical_entries);
+/* VoI splits launched ahead of their step (erasor_hip_prefetch_node) and how many of them the following step could use */
+int erasor_hip_ahead_split_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t *used);
 /* the hipStream_t the handle launches on (as void*) */
 void *erasor_hip_stream(erasor_hip_handle *h);
 
