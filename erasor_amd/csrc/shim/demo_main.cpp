@@ -111,7 +111,7 @@ static int config_mode(int argc, char **argv) {
     for (int i = drv.init_idx; have && i < (int)poses.size() && done < max_frames; ++i, ++done) {
         // offline: the next node's cloud is read (and announced) before this node is processed
         const bool have_next = i + 1 < (int)poses.size() && done + 1 < max_frames && load(i + 1, next);
-        if (have_next) updater.announce_next(next);
+        if (have_next) updater.announce_next(next, erasor_utils::eigen2geoPose(poses[i + 1]));
         updater.callback_node(i, erasor_utils::eigen2geoPose(poses[i]), scan);
         scan.points.swap(next.points);
         have = have_next;

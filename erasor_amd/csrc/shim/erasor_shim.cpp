@@ -379,13 +379,20 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
                (unsigned long long)last.n_static);
     }
 }
-void OfflineMapUpdater::announce_next(const Cloud &lidar) {
+void OfflineMapUpdater::announce_next(const Cloud &lidar) { announce(lidar, nullptr); }
+void OfflineMapUpdater::announce_next(const Cloud &lidar, const geometry_msgs::Pose &odom) { announce(lidar, &odom); }
+void OfflineMapUpdater::announce(const Cloud &lidar, const geometry_msgs::Pose *odom) {
     if ((stack_count_ + 1) % cfg_.params.removal_interval != 0) return;  // the next node will be gated out (OMU.cpp:206-209)
     if (has_next_) return;                                                 // one cloud ahead is what callback_node can honour
     next_xyzi_ = to_xyzi(lidar);
     float Tl[16];
     mat16(tf_lidar2body_, Tl);
-    check(h_, erasor_hip_prefetch_scan(h_, next_xyzi_.data(), lidar.size(), 0, Tl), "erasor_hip_prefetch_scan");
+    if (odom) {  // the whole node is known: the next callback's fetch_VoI pass can be launched ahead too
+        float Tb[16];
+        mat16(erasor_utils::geoPose2eigen(*odom), Tb);  // OMU.cpp:219
+        check(h_, erasor_hip_prefetch_node(h_, next_xyzi_.data(), lidar.size(), 0, Tl, Tb), "erasor_hip_prefetch_node");
+    } else
+        check(h_, erasor_hip_prefetch_scan(h_, next_xyzi_.data(), lidar.size(), 0, Tl), "erasor_hip_prefetch_scan");
     has_next_ = true;
 }
 void OfflineMapUpdater::get_map(Cloud &dst) {

@@ -137,6 +137,9 @@ public:
     // updater which cloud the NEXT callback_node will bring.  Its voxelisation / binning then overlap the current node's
     // map-side stages (erasor_hip_prefetch_scan); results are unchanged.  Ignored for nodes the removal_interval gate skips.
     void announce_next(const pcl::PointCloud<pcl::PointXYZI> &lidar);
+    // ... and its odometry, when the whole next node is known (erasor_hip_prefetch_node: the VoI pass of the next callback is
+    // launched ahead as well)
+    void announce_next(const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose &odom);
     void save_static_map(float voxel_size);                    // OMU.cpp:174-196
     void get_map(pcl::PointCloud<pcl::PointXYZI> &dst);        // *map_arranged_
     erasor_hip_handle *handle() { return h_; }                 // for adapters that read more of the last step (ros1_adapter.cpp)
@@ -152,6 +155,7 @@ private:
     int stack_count_ = 0;
     std::vector<float> next_xyzi_;  // the announced cloud (the step must pass this very buffer)
     bool has_next_ = false;
+    void announce(const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose *odom);
 };
 // main_in_your_env.cpp:66-70: the driver's own rosparams
 struct DriverConfig {
