@@ -1,0 +1,349 @@
+// Runs kernels of erasor_amd/csrc/kernels.hip.h UNMODIFIED on the CPU (tests/cpp/simt_emu: one thread per lane) and checks
+// them against plain references: the counting sort of the map bucketing against std::stable_sort, the run detection and the
+// chunk scan against loops, and the two per-bin kernels (R-GPF, per-bin voxelisation) against the CPU oracle's per-bin
+// functions (oracle/erasor_oracle.cpp -- the checker, linked here as such).  Built and run by tests/test_kernels_on_cpu.py.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../../erasor_amd/csrc/kernels.hip.h"
+#include "../../include/erasor_hip.h"
+
+extern "C" {
+int orc_extract_ground(const erasor_params *p, const float *xyzi, size_t n, uint8_t *ground_mask, float *normals, double *ds, uint32_t *n_degenerate);
+int orc_voxelize_preserving_labels(const float *xyzi, size_t n, double leaf, float *out, size_t cap, size_t *n_out);
+}
+
+using namespace ek;
+static int g_fail = 0;
+#define CHECK(cond, ...)                 \
+    do {                                 \
+        if (!(cond)) {                   \
+            printf("  FAILED: " __VA_ARGS__); \
+            printf("\n");               \
+            ++g_fail;                    \
+        }                                \
+    } while (0)
+
+static erasor_params seq05_params() {
+    erasor_params p;
+    memset(&p, 0, sizeof(p));
+    p.max_range = 80.0;
+    p.num_rings = 20;
+    p.num_sectors = 108;
+    p.max_h = 3.2;
+    p.min_h = -1.3;
+    p.th_bin_max_h = 0.05;
+    p.scan_ratio_threshold = 0.3;
+    p.num_lowest_pts = 5;
+    p.minimum_num_pts = 10;
+    p.rejection_ratio = 0.33;
+    p.gf_dist_thr = 0.15;
+    p.gf_iter = 3;
+    p.gf_num_lpr = 10;
+    p.gf_th_seeds_height = 0.5;
+    p.map_voxel_size = 0.2;
+    p.version = 3;
+    p.query_voxel_size = 0.2;
+    p.removal_interval = 1;
+    p.voi_max_range = 80.0;
+    p.submap_size = 200.0;
+    return p;
+}
+static DP make_dp(const erasor_params &p) {  // erasor_hip.hip: fill_dp
+    DP d;
+    memset(&d, 0, sizeof(d));
+    d.max_r = p.max_range;
+    d.R = p.num_rings;
+    d.S = p.num_sectors;
+    d.B = p.num_rings * p.num_sectors;
+    d.ring_size = p.max_range / p.num_rings;
+    d.sector_size = 2 * PI_REF / p.num_sectors;
+    d.max_h = p.max_h;
+    d.min_h = p.min_h;
+    d.th_bin_max_h = p.th_bin_max_h;
+    d.srt_thr = p.scan_ratio_threshold;
+    d.gf_dist = p.gf_dist_thr;
+    d.gf_seeds_h = p.gf_th_seeds_height;
+    d.voi_r2 = p.voi_max_range * p.voi_max_range;
+    d.num_lowest = p.num_lowest_pts;
+    d.min_pts = p.minimum_num_pts;
+    d.gf_iter = p.gf_iter;
+    d.gf_lpr = p.gf_num_lpr;
+    d.version = p.version;
+    d.leaf_map = (float)p.map_voxel_size;
+    d.leaf_query = (float)p.query_voxel_size;
+    return d;
+}
+
+// ---- map bucketing: k_mb_hist / k_mb_colscan / k_mb_scatter_w == a stable sort by key ------------------------------------
+static void test_map_bucketing(std::mt19937 &rng) {
+    const uint32_t cases[4][2] = {{1u, 40u}, {4095u, 300u}, {4097u, 300u}, {30000u, 2161u}};
+    for (const auto &cs : cases) {
+        const uint32_t n = cs[0], nb = cs[1];
+        std::vector<uint32_t> keys(n), src(n);
+        std::vector<float4> pts(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            keys[i] = (rng() % 7 == 0) ? nb - 1 : rng() % (nb / 3);  // a skewed distribution with long runs of one key
+            src[i] = 1000000u + i;
+            pts[i] = make_float4((float)i, 0.5f, -1.f, 40.f);
+        }
+        const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
+        std::vector<uint32_t> hist((size_t)ntile * nb + 8, 0xDEADu), tot(nb + 2, 0), off(nb + 2, 0), dsrc(n), dkeys(n), nd(1, n);
+        std::vector<float4> dpts(n);
+        int bits = 1;
+        while ((1u << bits) < nb) ++bits;
+        simt::run_grid(std::max(1u, ntile / 2), 1024, [&] { k_mb_hist(keys.data(), n + 100, nd.data(), nb, hist.data(), tot.data()); });
+        simt::run_grid((nb * 64 + 255) / 256, 256, [&] { k_mb_colscan(hist.data(), n + 100, nd.data(), nb, tot.data(), off.data()); });
+        simt::run_grid(std::max(1u, ntile / 2), 1024, [&] {
+            k_mb_scatter_w(keys.data(), pts.data(), src.data(), n + 100, nd.data(), nb, bits, hist.data(), dpts.data(), dsrc.data(), dkeys.data());
+        });
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+        bool ok = true;
+        for (uint32_t i = 0; ok && i < n; ++i) ok = dkeys[i] == keys[order[i]] && dsrc[i] == src[order[i]] && dpts[i].x == pts[order[i]].x;
+        for (uint32_t b = 0; ok && b <= nb; ++b) {
+            const uint32_t want = (uint32_t)(std::lower_bound(order.begin(), order.end(), b, [&](uint32_t a, uint32_t k) { return keys[a] < k; }) - order.begin());
+            ok = off[b] == want;
+        }
+        printf("map bucketing (hist / column scan / scatter)      n=%6u  %s\n", n, ok ? "ok" : "MISMATCH");
+        CHECK(ok, "map bucketing n=%u", n);
+    }
+}
+
+// ---- run detection: k_run_count / k_run_emit -----------------------------------------------------------------------
+static void test_runs(std::mt19937 &rng) {
+    for (uint32_t n : {0u, 1u, 1023u, 1024u, 1025u, 5000u}) {
+        std::vector<uint32_t> keys(n);
+        uint32_t k = 5;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (rng() % 3 == 0) k += 1 + rng() % 4;
+            keys[i] = k;
+        }
+        if (n > 3000) std::fill(keys.begin() + 900, keys.begin() + 2300, keys[900]);  // one run across two tile borders
+        const uint32_t ntile = std::max(1u, (n + 1023) / 1024);
+        std::vector<uint32_t> tops(ntile + 4, 0), run_begin(n + 2, 0xFFFFFFFFu), nv(1, 0xFFFFFFFFu);
+        simt::run_grid(ntile, 256, [&] { k_run_count(keys.data(), n, tops.data()); });
+        simt::run_grid(ntile, 256, [&] { k_run_emit(keys.data(), n, tops.data(), ntile, run_begin.data(), nv.data()); });
+        std::vector<uint32_t> want;
+        for (uint32_t i = 0; i < n; ++i)
+            if (i == 0 || keys[i] != keys[i - 1]) want.push_back(i);
+        bool ok = nv[0] == want.size() && run_begin[want.size()] == n;
+        for (size_t v = 0; ok && v < want.size(); ++v) ok = run_begin[v] == want[v];
+        printf("run detection (tile totals -> run_begin)           n=%6u  %s\n", n, ok ? "ok" : "MISMATCH");
+        CHECK(ok, "runs n=%u", n);
+    }
+}
+
+// ---- R-GPF and the per-bin voxelisation against the oracle's per-bin functions -----------------------------------------------
+static void test_per_bin(std::mt19937 &rng) {
+    const erasor_params p = seq05_params();
+    const DP P = make_dp(p);
+    const uint32_t B = (uint32_t)P.B;
+    std::uniform_real_distribution<float> u01(0.f, 1.f);
+    // a few reverted bins of different sizes: sloped ground quantised to 1 cm (ties in z), clutter above, something below min_h
+    const uint32_t sizes[] = {12, 40, 300, 900, 1700};
+    const uint32_t nbin = sizeof(sizes) / sizeof(sizes[0]);
+    std::vector<uint32_t> moff(B + 3, 0), qoff(B + 3, 0), rev_list, rev_key;
+    std::vector<float4> spts, sq;
+    std::vector<std::vector<float4>> map_bin(nbin), cur_bin(nbin);
+    for (uint32_t b = 0; b < nbin; ++b) {
+        const float x0 = 10.f + 4.f * b, y0 = 2.f;
+        for (uint32_t i = 0; i < sizes[b]; ++i) {
+            const float x = x0 + 3.9f * u01(rng), y = y0 + 1.5f * u01(rng);
+            float z;
+            const float r = u01(rng);
+            if (r < 0.7f) z = -1.70f + 0.02f * (x - x0) + 0.01f * (float)(int)(6.f * u01(rng));  // ground, 1 cm steps
+            else if (r < 0.97f) z = -1.5f + 3.5f * u01(rng);                                      // a wall / a car
+            else z = -1.9f - u01(rng);                                                            // below min_h
+            map_bin[b].push_back(make_float4(x, y, z, (rng() % 5 == 0) ? 252.f : 40.f));
+        }
+        for (uint32_t i = 0; i < sizes[b] / 3 + 2; ++i)
+            cur_bin[b].push_back(make_float4(x0 + 3.9f * u01(rng), y0 + 1.5f * u01(rng), -1.7f + 0.05f * u01(rng), 40.f));
+    }
+    // the bins sit at keys 7, 107, 207, ... of the sorted VoI / the sorted query
+    for (uint32_t key = 0, b = 0; key <= B; ++key) {
+        moff[key] = (uint32_t)spts.size();
+        qoff[key] = (uint32_t)sq.size();
+        if (b < nbin && key == 7 + 100 * b) {
+            spts.insert(spts.end(), map_bin[b].begin(), map_bin[b].end());
+            sq.insert(sq.end(), cur_bin[b].begin(), cur_bin[b].end());
+            rev_list.push_back(key);
+            ++b;
+        } else if (key % 50 == 3) {  // unrelated bins in between
+            spts.push_back(make_float4(1.f, 1.f, -1.7f, 40.f));
+        }
+    }
+    moff[B + 1] = moff[B + 2] = (uint32_t)spts.size();
+    qoff[B + 1] = qoff[B + 2] = (uint32_t)sq.size();
+    const size_t G = spts.size() + sq.size() + 64;
+    DevState st;
+    memset(&st, 0, sizeof(st));
+    st.n_rev = nbin;
+    Counters ctr;
+    memset(&ctr, 0, sizeof(ctr));
+    std::vector<uint32_t> gsK(G), gsV(G), gsL(G), gsR(G), gsH(G / 32 + 2 * B + 16), gsK2(G), gsV2(G), grank(G), glist(G), ng(nbin + 1, 0);
+    std::vector<uint8_t> gflag(G, 9);
+    std::vector<float> plane_n((size_t)nbin * P.gf_iter * 3 + 8, 0.f);
+    std::vector<double> plane_d((size_t)nbin * P.gf_iter + 8, 0.0);
+    simt::run_grid(2, 1024, [&] {
+        k_rgpf2(P, rev_list.data(), &st, moff.data(), spts.data(), gsK.data(), gsV.data(), gsL.data(), gsR.data(), gsH.data(), gsK2.data(),
+                gsV2.data(), gflag.data(), grank.data(), glist.data(), ng.data(), plane_n.data(), plane_d.data(), &ctr, nullptr);
+    });
+    for (uint32_t b = 0; b < nbin; ++b) {
+        const uint32_t M = sizes[b], o0 = moff[rev_list[b]];
+        std::vector<uint8_t> mask(M);
+        std::vector<float> normals(P.gf_iter * 3, 0.f);
+        std::vector<double> ds(P.gf_iter, 0.0);
+        uint32_t ndeg = 0;
+        orc_extract_ground(&p, &map_bin[b][0].x, M, mask.data(), normals.data(), ds.data(), &ndeg);
+        bool ok = true;
+        uint32_t ngr = 0;
+        for (uint32_t i = 0; i < M; ++i) {
+            ok = ok && gflag[o0 + i] == mask[i];
+            ngr += mask[i];
+        }
+        ok = ok && ng[b] == ngr;
+        for (int t = 0; ok && t < P.gf_iter * 3; ++t) ok = memcmp(&plane_n[(size_t)b * P.gf_iter * 3 + t], &normals[t], 4) == 0;
+        for (int t = 0; ok && t < P.gf_iter; ++t) ok = memcmp(&plane_d[(size_t)b * P.gf_iter + t], &ds[t], 8) == 0;
+        printf("R-GPF (k_rgpf2) vs the oracle's extract_ground    M=%6u  ground=%u  %s\n", M, ngr, ok ? "ok (mask, every iteration's plane bit-exact)" : "MISMATCH");
+        CHECK(ok, "rgpf bin %u", b);
+    }
+    // per-bin voxelisation of [curr bin | ground of the map bin] (erasor.cpp:512-528)
+    std::vector<uint32_t> vox_off(nbin + 1, 0), nvox(nbin + 1, 0);
+    for (uint32_t b = 0; b < nbin; ++b) vox_off[b + 1] = vox_off[b] + (uint32_t)(cur_bin[b].size() + sizes[b]);
+    std::vector<float4> gsC(G), vox_out(vox_off[nbin] + 8);
+    simt::run_grid(2, 1024, [&] {
+        k_binvox2(P, rev_list.data(), &st, moff.data(), spts.data(), qoff.data(), sq.data(), glist.data(), ng.data(), vox_off.data(), gsK.data(),
+                  gsV.data(), gsL.data(), gsR.data(), gsH.data(), gsK2.data(), gsV2.data(), gsC.data(), vox_out.data(), nvox.data(), &ctr, nullptr);
+    });
+    for (uint32_t b = 0; b < nbin; ++b) {
+        const uint32_t o0 = moff[rev_list[b]];
+        std::vector<float4> in(cur_bin[b]);
+        for (uint32_t k = 0; k < ng[b]; ++k) in.push_back(spts[o0 + glist[o0 + k]]);
+        std::vector<float4> want(in.size() + 1);
+        size_t nw = 0;
+        orc_voxelize_preserving_labels(&in[0].x, in.size(), p.map_voxel_size, &want[0].x, in.size(), &nw);
+        bool ok = nvox[b] == nw;
+        for (size_t v = 0; ok && v < nw; ++v) ok = memcmp(&vox_out[vox_off[b] + v], &want[v], 16) == 0;
+        printf("per-bin voxelisation (k_binvox2) vs the oracle    in=%6zu -> %zu voxels  %s\n", in.size(), nw, ok ? "ok (bit-exact, in order)" : "MISMATCH");
+        CHECK(ok, "binvox bin %u (got %u voxels, want %zu)", b, nvox[b], nw);
+    }
+    CHECK(ctr.err == 0 && ctr.sort_qoverflow == 0, "error flags %u %u", ctr.err, ctr.sort_qoverflow);
+}
+
+
+// ---- the map store: VoI split (a step's own and the one launched ahead), chunk scan, gather ---------------------------------
+static void test_map_store(std::mt19937 &rng) {
+    const erasor_params p = seq05_params();
+    DP P = make_dp(p);
+    P.voi_r2 = 30.0 * 30.0;
+    std::uniform_real_distribution<float> u(-60.f, 60.f), uz(-1.6f, 2.5f);
+    const uint32_t nF = 5 * CHUNK + 137, capO = 24 * CHUNK, o_begin = 7 * CHUNK + 311;
+    std::vector<float4> F(nF + CHUNK);
+    std::vector<float2> Oxy(capO), Ozi(capO);
+    for (uint32_t i = 0; i < nF; ++i) F[i] = make_float4(u(rng) * 0.6f, u(rng) * 0.6f, uz(rng), (rng() % 6 == 0) ? 252.f : 40.f);
+    uint32_t o_valid = 0;
+    for (uint32_t i = 0; i < capO; ++i) {
+        Oxy[i] = make_float2(u(rng), u(rng));
+        Ozi[i] = make_float2(uz(rng), (rng() % 6 == 0) ? 253.f : 44.f);
+        if (i >= o_begin) {
+            if (rng() % 9 == 0) reinterpret_cast<uint32_t *>(&Oxy[i])[0] = HOLE_BITS;  // tombstones of earlier steps
+            else ++o_valid;
+        }
+    }
+    const double xc = 3.25, yc = -2.5;
+    const float T[12] = {0.96f, 0.28f, 0.f, -2.42f, -0.28f, 0.96f, 0.f, 3.31f, 0.f, 0.f, 1.f, 0.1f};
+    Xf To2b;
+    memcpy(To2b.m, T, sizeof(T));
+    // scalar expectation, in the store's logical order [F | outskirts]
+    struct Want { float4 ego; uint32_t key, src; };
+    std::vector<Want> want;
+    std::vector<float4> leaving;
+    Counters rc;
+    memset(&rc, 0, sizeof(rc));
+    uint32_t voiF = 0, validO = 0;
+    for (uint32_t i = 0; i < nF; ++i) {
+        const double dx = (double)F[i].x - xc, dy = (double)F[i].y - yc;
+        if (dx * dx + dy * dy < P.voi_r2) {
+            const float4 e = xform(To2b, F[i]);
+            want.push_back({e, bin_key(P, e.x, e.y, e.z, &rc), i});
+            ++voiF;
+        } else
+            leaving.push_back(F[i]);
+    }
+    std::vector<uint32_t> tomb;
+    for (uint32_t i = o_begin; i < capO; ++i) {
+        if (__float_as_uint(Oxy[i].x) == HOLE_BITS) continue;
+        const double dx = (double)Oxy[i].x - xc, dy = (double)Oxy[i].y - yc;
+        if (dx * dx + dy * dy < P.voi_r2) {
+            const float4 e = xform(To2b, make_float4(Oxy[i].x, Oxy[i].y, Ozi[i].x, Ozi[i].y));
+            want.push_back({e, bin_key(P, e.x, e.y, e.z, &rc), nF + validO});
+            tomb.push_back(i);
+        }
+        ++validO;
+    }
+    for (int ahead = 0; ahead < 2; ++ahead) {
+        std::vector<float2> oxy(Oxy), ozi(Ozi);
+        const uint32_t nFchunks = (nF + CHUNK - 1) / CHUNK, o_chunk0 = o_begin / CHUNK, nOchunks = capO / CHUNK - o_chunk0, nchunks = nFchunks + nOchunks;
+        std::vector<unsigned long long> vmask((size_t)(nchunks + 4) * CHUNK_TILES, 0), hmask((size_t)(nchunks + 4) * CHUNK_TILES, 0), lab(128, 1);
+        std::vector<uint32_t> cinfo(nchunks + 8, 0), pvl(nchunks + 8, 0), phl(nchunks + 8, 0), topv(8, 9), toph(8, 9), mb_tot(64, 5);
+        DevState st, init;
+        memset(&init, 0, sizeof(init));
+        init.nF = nF;
+        init.o_begin = o_begin;
+        init.O_static = 1000000;
+        init.O_dynamic = 1000000;
+        st = init;
+        Counters ctr, qctr;
+        memset(&ctr, 0, sizeof(ctr));
+        memset(&qctr, 0, sizeof(qctr));
+        if (ahead)  // extents from the committed device state, upper-bound grid
+            simt::run_grid(3, 256, [&] {
+                k_voi_split(F.data(), 0u, 0u, oxy.data(), 0u, 0u, 0u, xc, yc, P.voi_r2, vmask.data(), hmask.data(), cinfo.data(), &st, capO / CHUNK, nchunks + 2);
+            });
+        else
+            simt::run_grid((nchunks + 3) / 4, 256, [&] {
+                k_voi_split(F.data(), nF, nFchunks, oxy.data(), o_begin, o_chunk0, nOchunks, xc, yc, P.voi_r2, vmask.data(), hmask.data(), cinfo.data(), nullptr, 0u, 0u);
+            });
+        simt::run_grid(1, 1024, [&] {
+            k_chunk_scan_one(cinfo.data(), nchunks, pvl.data(), phl.data(), topv.data(), toph.data(), 1u, nFchunks, &st, &ctr, init, lab.data(), mb_tot.data(), 64u);
+        });
+        bool ok = st.voi_total == want.size() && st.voiF == voiF && st.validF == nF && st.valid_total == nF + validO &&
+                  st.n_leaving == leaving.size() && st.o_new_begin == o_begin - (uint32_t)leaving.size() && lab[5] == 0 && mb_tot[7] == 0;
+        std::vector<float4> ego(want.size() + 8);
+        std::vector<uint32_t> key(want.size() + 8), src(want.size() + 8);
+        simt::run_grid(5, 256, [&] {
+            k_voi_gather(F.data(), nF, nFchunks, oxy.data(), ozi.data(), o_chunk0, nOchunks, vmask.data(), hmask.data(), cinfo.data(), pvl.data(),
+                         phl.data(), topv.data(), toph.data(), To2b, P, &st, &ctr, &qctr, ego.data(), key.data(), src.data());
+        });
+        for (size_t i = 0; ok && i < want.size(); ++i) ok = memcmp(&ego[i], &want[i].ego, 16) == 0 && key[i] == want[i].key && src[i] == want[i].src;
+        for (size_t i = 0; ok && i < leaving.size(); ++i) {  // [leaving (F order) | old outskirts]
+            const uint32_t d = st.o_new_begin + (uint32_t)i;
+            ok = oxy[d].x == leaving[i].x && oxy[d].y == leaving[i].y && ozi[d].x == leaving[i].z && ozi[d].y == leaving[i].w;
+        }
+        for (size_t i = 0; ok && i < tomb.size(); ++i) ok = __float_as_uint(oxy[tomb[i]].x) == HOLE_BITS;
+        long long dyn = 0, stat = 0;  // parse_dynamic_obj counters of the outskirts: + leaving, - entering
+        for (auto &q : leaving) (is_dynamic_label(q.w) ? dyn : stat) += 1;
+        for (uint32_t i : tomb) (is_dynamic_label(Ozi[i].y) ? dyn : stat) -= 1;
+        ok = ok && (long long)st.O_dynamic == 1000000 + dyn && (long long)st.O_static == 1000000 + stat;
+        printf("map store: split%s / chunk scan / gather     VoI %zu (%u resident), %zu leaving, %zu entering  %s\n",
+               ahead ? " (launched ahead)" : "                 ", want.size(), voiF, leaving.size(), tomb.size(), ok ? "ok" : "MISMATCH");
+        CHECK(ok, "map store ahead=%d", ahead);
+    }
+}
+
+int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    std::mt19937 rng(20210310);
+    test_runs(rng);
+    test_map_store(rng);
+    test_map_bucketing(rng);
+    test_per_bin(rng);
+    printf("%s\n", g_fail ? "FAILED" : "ALL OK");
+    return g_fail ? 1 : 0;
+}
