@@ -1,0 +1,51 @@
+"""Helper of tests/test_full_step_on_cpu.py (run as a subprocess): drives the library built by that test -- the product's
+erasor_hip.hip + kernels compiled unmodified against tests/cpp/simt_emu -- through the ctypes wrapper and compares every
+step with the oracle.  TEST INFRASTRUCTURE: the product never loads this library (erasor_amd.lib() loads liberasor_hip.so only)."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, sys.argv[2])
+sys.path.insert(0, sys.argv[2] + "/tests")
+import erasor_amd  # noqa: E402
+
+erasor_amd.LIB_PATH = sys.argv[1]  # the emulated build, for this process only
+erasor_amd._lib = None
+import scenarios  # noqa: E402
+from oracle import orc  # noqa: E402
+
+n_steps = int(sys.argv[3])
+sc = scenarios.small(n_frames=6, az=120, length=60.0)
+g = erasor_amd.Erasor(scenarios.to_product_params(sc["params"]))
+o = orc.Oracle(sc["params"])
+g.set_map(sc["map"])
+o.set_map(sc["map"])
+scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"]]
+ok = True
+g.prefetch(scans[0], sc["T_l2b"], sc["T_b2o"][0])  # nodes announced with their pose: look-ahead and the split launched ahead
+for k in range(n_steps):
+    if k + 1 < n_steps:
+        g.prefetch(scans[k + 1], sc["T_l2b"], sc["T_b2o"][k + 1])
+    t0 = time.time()
+    rg = g.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+    dt = time.time() - t0
+    ro = o.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+    dg, do = rg.as_dict(), ro.as_dict()
+    bad = {f: (dg[f], do[f]) for f in do if dg[f] != do[f] and f not in ("n_ambiguous", "n_sort_fallback")}
+    same = {"map": np.array_equal(g.get_map().view(np.uint32), o.get_cloud(7).view(np.uint32))}
+    for which, name in ((1, "map_voi"), (2, "static_estimate"), (4, "map_rejected"), (5, "curr_rejected")):
+        a, b = g.get_cloud(which), o.get_cloud(which)
+        same[name] = a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    same["status"] = np.array_equal(g.get_status(), o.get_status())
+    bg, ng, dg_ = g.get_planes()
+    bo, no, do_ = o.get_planes()
+    same["planes"] = np.array_equal(bg, bo) and np.array_equal(ng.view(np.uint32), no.view(np.uint32)) and np.array_equal(dg_, do_)
+    good = not bad and all(same.values())
+    ok = ok and good
+    print("step %d on the CPU stand-in in %.0f s: %d-pt VoI, %d reverted bins, %d rejected; differing result fields %s; bit-exact %s -> %s"
+          % (k, dt, dg["n_voi"], dg["n_reverted_bins"], dg["n_map_rejected"], bad, same, "ok" if good else "MISMATCH"), flush=True)
+launched, used = g.ahead_split_counts()
+print("VoI splits launched ahead: %d, used: %d" % (launched, used))
+ok = ok and launched == n_steps - 1  # (whether the next step could use it depends on scratch growth in the first steps)
+print("FULL-STEP-OK" if ok else "FULL-STEP-FAILED")

@@ -25,7 +25,7 @@ def test_device_sort_code_runs_lane_by_lane_on_the_cpu(tmp_path):
     barriers) and pinned to the real std::sort: sizes around every threshold (16 / 64 / 2048 keys), ties, sorted and
     reversed input, the median-of-3 adversary (heapsort fallback), a 256-thread workgroup."""
     exe = str(tmp_path / "esort_simt_check")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I" + os.path.join(HERE, "cpp", "simt_emu"), "-o", exe,
+    subprocess.check_call(["g++", "-O1", "-std=c++20", "-pthread", "-I" + os.path.join(HERE, "cpp", "simt_emu"), "-o", exe,
                            os.path.join(HERE, "cpp", "esort_simt_check.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     sys.stdout.write(out.stdout)

@@ -1,0 +1,54 @@
+"""The whole product path on the CPU: erasor_hip.hip (handle, map store, stream / event orchestration, look-ahead, the VoI
+split launched ahead) and every kernel of kernels.hip.h, compiled UNMODIFIED against tests/cpp/simt_emu -- a stand-in for the
+HIP runtime in which a launch runs its grid synchronously, workgroup by workgroup, the 64 lanes of a wavefront as fibers --
+driven through the C ABI and compared with the oracle.
+
+  * two steps of a small sequence with the nodes announced ahead (result block, map, VoI, static estimate, rejected clouds,
+    bin statuses and planes: all bit-exact);
+  * a part of the GPU parity suite itself (tests/test_gpu_parity.py, `-m gpu`) re-run against that library: the one-bin
+    known answers, the edge cases (empty / one-point / ragged inputs), the stable bucketing, the exact sort's heapsort
+    fallback, the API's error behaviour.  ERASOR_SIMT_MORE=1 adds the standalone voxelisation, the exact-sort sweep, the
+    VoxelGrid index-overflow pass-through and the NaN refusal (~5 more minutes).
+
+This is a checker, not a product: the library is built into the test's temporary directory, loaded by helper processes only
+(ERASOR_TEST_SIMT_LIB), and is four to five orders of magnitude slower than the device.  `erasor_amd.lib()` loads
+`liberasor_hip.so` and nothing else; a kernel change can be checked for parity here before a GPU is spent on it."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def simt_lib(tmp_path_factory):
+    lib = str(tmp_path_factory.mktemp("simt") / "liberasor_hip_simt.so")
+    subprocess.check_call(["g++", "-x", "c++", "-O1", "-std=c++20", "-pthread", "-ffp-contract=off", "-fPIC", "-shared",
+                           "-I" + os.path.join(HERE, "cpp", "simt_emu"), "-o", lib, os.path.join(ROOT, "erasor_amd", "csrc", "erasor_hip.hip")])
+    sys.path.insert(0, ROOT)
+    from oracle import orc
+    orc.build()
+    return lib
+
+
+def test_two_steps_of_the_real_host_code_and_kernels_match_the_oracle(simt_lib):
+    out = subprocess.run([sys.executable, os.path.join(HERE, "simt_full_step.py"), simt_lib, ROOT, "2"], capture_output=True, text=True, timeout=900)
+    sys.stdout.write(out.stdout)
+    assert "FULL-STEP-OK" in out.stdout, out.stdout + out.stderr[-3000:]
+
+
+def test_part_of_the_gpu_parity_suite_passes_on_the_cpu_stand_in(simt_lib):
+    keys = ["one_bin_known", "edge_cases", "stable_radix", "heapsort_fallback", "api_error"]
+    if os.environ.get("ERASOR_SIMT_MORE"):
+        keys += ["voxelize_preserving_labels_standalone", "exact_std_sort", "voxelgrid_index_overflow", "non_finite", "device_libm"]
+    env = dict(os.environ, ERASOR_TEST_SIMT_LIB=simt_lib)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k", " or ".join(keys),
+                          "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=2400, cwd=ROOT, env=env)
+    tail = out.stdout[-1500:]
+    sys.stdout.write(tail)
+    assert out.returncode == 0 and " passed" in tail and "failed" not in tail, out.stdout[-4000:] + out.stderr[-2000:]
+    n_passed = int(tail.split(" passed")[0].split()[-1])
+    assert n_passed >= 9, tail  # 1 + 1 + 5 + 1 + 1

@@ -25,7 +25,7 @@ def test_kernels_run_lane_by_lane_on_the_cpu(tmp_path):
     from oracle import orc
     orc.build()
     exe = str(tmp_path / "kernels_simt_check")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-ffp-contract=off", "-I" + os.path.join(HERE, "cpp", "simt_emu"), "-o", exe,
+    subprocess.check_call(["g++", "-O1", "-std=c++20", "-pthread", "-ffp-contract=off", "-I" + os.path.join(HERE, "cpp", "simt_emu"), "-o", exe,
                            os.path.join(HERE, "cpp", "kernels_simt_check.cpp"), "-L" + os.path.join(ROOT, "oracle"), "-lerasor_oracle",
                            "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=1200)
