@@ -10,3 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    # tests/test_full_step_on_cpu.py re-runs `-m gpu` tests in a helper process against the SAME host code and kernels compiled
+    # for the CPU stand-in of the HIP runtime (tests/cpp/simt_emu): in that process -- and only there -- the ctypes wrapper
+    # loads that library.  Test infrastructure; the product knows nothing of it.
+    simt = os.environ.get("ERASOR_TEST_SIMT_LIB")
+    if simt:
+        import erasor_amd
+        erasor_amd.LIB_PATH = simt
+        erasor_amd._lib = None
+        erasor_amd.build = lambda force=False: simt

@@ -56,3 +56,16 @@ def test_part_of_the_gpu_parity_suite_passes_on_the_cpu_stand_in(simt_lib):
     assert out.returncode == 0 and " passed" in tail and "failed" not in tail, out.stdout[-4000:] + out.stderr[-2000:]
     n_passed = int(tail.split(" passed")[0].split()[-1])
     assert n_passed >= 9, tail  # 1 + 1 + 5 + 1 + 1
+
+
+def test_the_references_own_vectors_are_reproduced_on_the_cpu_stand_in(simt_lib):
+    """tests/golden/ref_*.npz were written by the reference's unmodified sources (oracle/_ref, tests/golden/make_ref_golden.py);
+    tests/test_golden.py replays them through the C ABI with nothing but the committed data (-m gpu).  The same test, against
+    the device code on the CPU stand-in: one vector by default, all seven golden files with ERASOR_SIMT_MORE=1."""
+    expr = "hip_reproduces" if os.environ.get("ERASOR_SIMT_MORE") or os.environ.get("ERASOR_SIMT_ALL") else "reference_vectors and ref_seq05_v3"
+    env = dict(os.environ, ERASOR_TEST_SIMT_LIB=simt_lib)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_golden.py"), "-m", "gpu", "-q", "-x", "-k", expr, "-p", "no:cacheprovider"],
+                         capture_output=True, text=True, timeout=2400, cwd=ROOT, env=env)
+    tail = out.stdout[-1500:]
+    sys.stdout.write(tail)
+    assert out.returncode == 0 and " passed" in tail and "failed" not in tail, out.stdout[-4000:] + out.stderr[-2000:]

@@ -33,14 +33,7 @@ def same(a, b, what=""):
 @pytest.fixture(scope="module")
 def gpu_mod():
     import erasor_amd
-    simt = os.environ.get("ERASOR_TEST_SIMT_LIB")
-    if simt:
-        # tests/test_parity_on_cpu_emulation.py re-runs a part of this file against the SAME host code and kernels compiled
-        # for the CPU stand-in of the HIP runtime (tests/cpp/simt_emu).  Test infrastructure: in this process only.
-        erasor_amd.LIB_PATH = simt
-        erasor_amd._lib = None
-        return erasor_amd
-    erasor_amd.build()
+    erasor_amd.build()  # (a no-op under ERASOR_TEST_SIMT_LIB, see conftest.py)
     return erasor_amd
 
 
