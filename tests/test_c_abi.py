@@ -69,3 +69,6 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt, "%s mentions the oracle" % os.path.join(dirpath, f)
+                # ... nor of the CPU stand-in of the HIP runtime the tests compile the device code against (tests/cpp/simt_emu):
+                # the package loads liberasor_hip.so and nothing else
+                assert "simt" not in txt.lower(), "%s mentions the tests' CPU stand-in" % os.path.join(dirpath, f)
