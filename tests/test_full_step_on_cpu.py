@@ -69,3 +69,20 @@ def test_the_references_own_vectors_are_reproduced_on_the_cpu_stand_in(simt_lib)
     tail = out.stdout[-1500:]
     sys.stdout.write(tail)
     assert out.returncode == 0 and " passed" in tail and "failed" not in tail, out.stdout[-4000:] + out.stderr[-2000:]
+
+
+@pytest.mark.skipif(not (os.environ.get("ERASOR_SIMT_MORE") or os.environ.get("ERASOR_SIMT_ALL")), reason="~8 minutes: ERASOR_SIMT_MORE=1")
+def test_the_cpp_shim_suite_passes_on_the_cpu_stand_in(simt_lib, tmp_path):
+    """tests/test_gpu_shim.py (the reference-compatible C++ surface: OfflineMapUpdater through the offline driver, class ERASOR,
+    erasor_utils, class mapgen, the ROS1 node against stand-in ROS / PCL headers) with liberasor_shim.so and the driver built
+    against the stand-in library: all eleven tests."""
+    import shutil
+    d = str(tmp_path / "shim")
+    os.makedirs(d)
+    shutil.copy(simt_lib, os.path.join(d, "liberasor_hip.so"))
+    env = dict(os.environ, ERASOR_TEST_SIMT_LIB=os.path.join(d, "liberasor_hip.so"), ERASOR_TEST_SHIM_DIR=d)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_shim.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"],
+                         capture_output=True, text=True, timeout=3600, cwd=ROOT, env=env)
+    tail = out.stdout[-1500:]
+    sys.stdout.write(tail)
+    assert out.returncode == 0 and "11 passed" in tail, out.stdout[-4000:] + out.stderr[-2000:]

@@ -10,7 +10,10 @@ import scenarios
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEMO = os.path.join(ROOT, "erasor_amd", "erasor_offline_demo")
+# where liberasor_hip.so / liberasor_shim.so / erasor_offline_demo live.  ERASOR_TEST_SHIM_DIR: a directory that holds the
+# tests' CPU stand-in build of liberasor_hip.so (tests/test_full_step_on_cpu.py); the shim and the driver are then built there too
+LIBDIR = os.environ.get("ERASOR_TEST_SHIM_DIR") or os.path.join(ROOT, "erasor_amd")
+DEMO = os.path.join(LIBDIR, "erasor_offline_demo")
 
 
 def write_pcd_binary(path, c):
@@ -21,7 +24,10 @@ def write_pcd_binary(path, c):
 
 
 def ensure_demo():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "erasor_amd", "csrc", "shim"), "-s"])
+    cmd = ["make", "-C", os.path.join(ROOT, "erasor_amd", "csrc", "shim"), "-s"]
+    if os.environ.get("ERASOR_TEST_SHIM_DIR"):
+        cmd.append("LIBDIR=" + LIBDIR)
+    subprocess.check_call(cmd)
     assert os.path.exists(DEMO)
 
 
@@ -151,7 +157,7 @@ def test_free_function_voxelize_preserving_labels(tmp_path):
         assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-ADAPTER = os.path.join(ROOT, "tests", "cpp", "ros1_adapter_check")
+ADAPTER = os.path.join(LIBDIR if os.environ.get("ERASOR_TEST_SHIM_DIR") else os.path.join(ROOT, "tests", "cpp"), "ros1_adapter_check")
 
 
 def build_adapter_check():
@@ -160,8 +166,8 @@ def build_adapter_check():
     shim = os.path.join(ROOT, "erasor_amd", "csrc", "shim")
     cmd = ["g++", "-O1", "-std=c++17", "-DERASOR_SHIM_WITH_PCL", "-DERASOR_SHIM_WITH_ROS", "-I" + os.path.join(ROOT, "oracle", "stubs"), "-I" + shim,
            "-o", ADAPTER, os.path.join(ROOT, "tests", "cpp", "ros1_adapter_check.cpp"), os.path.join(shim, "erasor_shim.cpp"),
-           os.path.join(shim, "erasor_io.cpp"), "-L" + os.path.join(ROOT, "erasor_amd"), "-lerasor_hip",
-           "-Wl,-rpath," + os.path.join(ROOT, "erasor_amd")]
+           os.path.join(shim, "erasor_io.cpp"), "-L" + LIBDIR, "-lerasor_hip",
+           "-Wl,-rpath," + LIBDIR]
     subprocess.check_call(cmd)
 
 
@@ -251,7 +257,7 @@ def test_config_driver_like_main_in_your_env(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Static map building complete!" in out.stdout
     # the oracle, fed with the transforms the driver derives from the csv
-    shim = C.CDLL(os.path.join(ROOT, "erasor_amd", "liberasor_shim.so"))
+    shim = C.CDLL(os.path.join(LIBDIR, "liberasor_shim.so"))
     shim.erasor_shim_load_poses.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
     shim.erasor_shim_load_poses.restype = C.c_long
     T = np.zeros((n, 16), np.float32)
@@ -288,7 +294,7 @@ def test_mapgen_class_and_driver(tmp_path, large):
             f.write("%d, %.2f, %s\n" % (k, 0.1 * k, ", ".join("%.9f" % v for v in sc["poses"][k])))
     out = subprocess.run([DEMO, "--mapgen", d, str(n), "0.2", str(large)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    shim = C.CDLL(os.path.join(ROOT, "erasor_amd", "liberasor_shim.so"))
+    shim = C.CDLL(os.path.join(LIBDIR, "liberasor_shim.so"))
     shim.erasor_shim_load_poses.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
     shim.erasor_shim_load_poses.restype = C.c_long
     T = np.zeros((n, 16), np.float32)
