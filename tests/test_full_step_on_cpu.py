@@ -22,6 +22,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
+pytestmark = pytest.mark.timeout(7200)  # (pytest.ini's 300 s is for the device; the extended modes here take minutes to an hour)
 
 
 @pytest.fixture(scope="module")
