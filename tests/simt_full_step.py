@@ -45,6 +45,28 @@ for k in range(n_steps):
     ok = ok and good
     print("step %d on the CPU stand-in in %.0f s: %d-pt VoI, %d reverted bins, %d rejected; differing result fields %s; bit-exact %s -> %s"
           % (k, dt, dg["n_voi"], dg["n_reverted_bins"], dg["n_map_rejected"], bad, same, "ok" if good else "MISMATCH"), flush=True)
+# the call pattern of bench.py: scans resident in "device" memory (read in place), two nodes announced ahead with their poses
+g2 = erasor_amd.Erasor(scenarios.to_product_params(sc["params"]))
+o2 = orc.Oracle(sc["params"])
+g2.set_map(sc["map"])
+o2.set_map(sc["map"])
+ptr = [s.ctypes.data for s in scans]
+n3 = n_steps + 1
+for j in range(2):
+    g2.prefetch_device(ptr[j], len(scans[j]), sc["T_l2b"], sc["T_b2o"][j])
+for k in range(n3):
+    if k + 2 < n3:
+        g2.prefetch_device(ptr[k + 2], len(scans[k + 2]), sc["T_l2b"], sc["T_b2o"][k + 2])
+    rg = g2.step_device(ptr[k], len(scans[k]), sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+    ro = o2.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+    dg, do = rg.as_dict(), ro.as_dict()
+    bad = {f: (dg[f], do[f]) for f in do if dg[f] != do[f] and f not in ("n_ambiguous", "n_sort_fallback")}
+    ok = ok and not bad
+same_map = np.array_equal(g2.get_map().view(np.uint32), o2.get_cloud(7).view(np.uint32))
+l2, u2 = g2.ahead_split_counts()
+print("bench.py's call pattern (device scans, two nodes ahead), %d steps: result blocks equal %s, final map bit-exact %s; splits ahead %d launched / %d used"
+      % (n3, ok, same_map, l2, u2))
+ok = ok and same_map and l2 == n3 - 1
 launched, used = g.ahead_split_counts()
 print("VoI splits launched ahead: %d, used: %d" % (launched, used))
 ok = ok and launched == n_steps - 1  # (whether the next step could use it depends on scratch growth in the first steps)
