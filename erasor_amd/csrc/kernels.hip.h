@@ -2388,12 +2388,16 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {  // inverse of esort
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
+// PRE: some bins may have been z-sorted ahead of the Scan Ratio Test (k_rgpf_presort, experimental, ERASOR_HIP_PRESORT): a bin whose
+// pre_flag carries this step's tag takes its sorted keys / indices from preK / preV instead of sorting.
+template <bool PRE>
 __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict__ rev_list, const DevState *__restrict__ st,
                                                 const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *gsK,
                                                 uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
                                                 uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
                                                 uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
-                                                Counters *ctr, unsigned long long *dbg) {
+                                                Counters *ctr, unsigned long long *dbg, const uint32_t *__restrict__ preK,
+                                                const uint32_t *__restrict__ preV, const uint32_t *__restrict__ pre_flag, uint32_t pre_tag) {
     __shared__ uint32_t pool[4 * RG_LMAX];  // sort phase: K | V | posL | posR ; fit phase: glist | X | Y | Z
     __shared__ uint32_t sH[RG_LMAX / 32 + 2];
     __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
@@ -2433,6 +2437,16 @@ __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict
         }
         const unsigned long long t_a = dbg ? wall_clock64() : 0ull;
         // ---- (1) std::sort(src_copy, point_cmp), erasor.cpp:239-240: exact introsort emulation, level-synchronous in LDS ----
+        bool presorted = false;
+        if constexpr (PRE) presorted = pre_flag[key] == pre_tag;  // (workgroup-uniform)
+        if (presorted) {
+            for (uint32_t i = tid; i < M; i += bs) {
+                sL[i] = preK[o0 + i];
+                sR[i] = preV[o0 + i];
+            }
+            __syncthreads();
+            RG_STAMP(0);
+        } else {
         for (uint32_t i = tid; i < M; i += bs) {
             sK[i] = esort::float_key(__float_as_uint(pts[i].z));
             sV[i] = i;
@@ -2442,6 +2456,7 @@ __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict
         if (dbg && tid < 24) s_es[tid] = 0;
         esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
                            &ctr->n_sort_fallback, &ctr->sort_qoverflow, dbg ? s_es : nullptr);
+        }
         RG_STAMP(1);
         // sorted keys in sL, sorted bin-local indices in sR
         uint32_t drop = 0, ng = 0;
@@ -2766,6 +2781,45 @@ __device__ __forceinline__ void binvox_core(const DP &P, uint32_t m, uint32_t nc
         }
     }
     if (tid == 0) *nvox_slot = nv;
+}
+
+// EXPERIMENTAL (ERASOR_HIP_PRESORT=1, off by default; parity checked on the CPU stand-in, timing pending): the z-sort of R-GPF does
+// not depend on the Scan Ratio Test, and a scan's large reverted bins are mostly the ones of the scan before.  This kernel runs on a
+// side stream beside k_bin_stats / k_srt: it z-sorts the candidate bins (the previous step's reverted list) exactly like k_rgpf2 would
+// and leaves sorted keys / indices in preK / preV with the bin's pre_flag set to this step's tag; k_rgpf2<true> then skips the sort of
+// those bins.  A candidate that is not reverted this time costs nothing on the main stream.
+__global__ __launch_bounds__(1024) void k_rgpf_presort(const uint32_t *__restrict__ cand_list, const uint32_t *__restrict__ n_cand, uint32_t B,
+                                                       const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *__restrict__ preK,
+                                                       uint32_t *__restrict__ preV, uint32_t *__restrict__ pre_flag, uint32_t pre_tag, Counters *ctr) {
+    __shared__ uint32_t pool[4 * RG_LMAX];
+    __shared__ uint32_t sH[RG_LMAX / 32 + 2];
+    __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
+    __shared__ uint32_t qcnt[2];
+    uint32_t *sK = pool, *sV = pool + RG_LMAX, *sL = pool + 2 * RG_LMAX, *sR = pool + 3 * RG_LMAX;
+    const uint32_t tid = threadIdx.x, bs = blockDim.x;
+    const uint32_t n = min(*n_cand, B);
+    for (uint32_t c = blockIdx.x; c < n; c += gridDim.x) {
+        const uint32_t key = cand_list[c];
+        if (key >= B) continue;
+        const uint32_t o0 = moff[key], M = moff[key + 1] - o0;
+        __syncthreads();
+        if (M <= 64u || M > RG_LMAX) continue;  // (short bins sort in no time; longer ones take k_rgpf2's global path)
+        const float4 *pts = spts + o0;
+        for (uint32_t i = tid; i < M; i += bs) {
+            sK[i] = esort::float_key(__float_as_uint(pts[i].z));
+            sV[i] = i;
+        }
+        __syncthreads();
+        esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
+                           &ctr->n_sort_fallback, &ctr->sort_qoverflow);
+        for (uint32_t i = tid; i < M; i += bs) {
+            preK[o0 + i] = sL[i];
+            preV[o0 + i] = sR[i];
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) pre_flag[key] = pre_tag;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

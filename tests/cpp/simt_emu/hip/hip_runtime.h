@@ -501,6 +501,10 @@ inline hipError_t hipMemcpy(void *d, const void *s_, size_t n, hipMemcpyKind) {
     if (n) memmove(d, s_, n);
     return hipSuccess;
 }
+inline hipError_t hipMemset(void *d, int v, size_t n) {
+    if (n) memset(d, v, n);
+    return hipSuccess;
+}
 inline hipError_t hipMemcpyAsync(void *d, const void *s_, size_t n, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy(d, s_, n, k); }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t *s_, unsigned, int) {
     *s_ = new simt_stream_t{0};
