@@ -114,12 +114,6 @@ struct erasor_hip_handle {
         uint32_t cap_chunks = 0;
         const void *vmask = nullptr, *hmask = nullptr, *cinfo = nullptr;
     } spec;
-    // EXPERIMENTAL, off unless ERASOR_HIP_PRESORT=1: the previous step's reverted bins are z-sorted on a side stream beside
-    // k_bin_stats / k_srt (k_rgpf_presort), R-GPF then skips the sort of the bins it finds tagged
-    bool presort = false;
-    hipStream_t pstream = nullptr;
-    hipEvent_t ev_bucketed = nullptr, ev_presorted = nullptr;
-    DBuf<uint32_t> preK, preV, pre_flag, cand_list, cand_n;
     unsigned long long store_epoch = 0;  // bumped by everything that rewrites the map store outside a step
     unsigned long long n_spec_used = 0, n_spec_launched = 0;
     // mapgen state (mapgen.hpp:27-46): cloud_curr, cloud_map, the finished submaps (cloud_maps, concatenated)
@@ -393,13 +387,6 @@ int alloc_bins(erasor_hip_handle *h) {
     rc |= ensure(h, h->rej_off, B) | ensure(h, h->crej_off, B);
     rc |= ensure(h, h->plane_n, B * (size_t)std::max(h->P.gf_iter, 1) * 3) | ensure(h, h->plane_d, B * (size_t)std::max(h->P.gf_iter, 1));
     rc |= ensure(h, h->d_st, 1) | ensure(h, h->d_ctr, 1) | ensure(h, h->dn, 16) | ensure(h, h->lab_slots, 128) | ensure(h, h->mb_tot, B + 2);
-    if (h->presort && !rc) {
-        rc |= ensure(h, h->pre_flag, B + 2) | ensure(h, h->cand_list, B + 2) | ensure(h, h->cand_n, 4);
-        if (!rc) {  // (no bin is tagged, the candidate list is empty)
-            HIPC(h, hipMemset(h->pre_flag.p, 0, (B + 2) * sizeof(uint32_t)));
-            HIPC(h, hipMemset(h->cand_n.p, 0, 4 * sizeof(uint32_t)));
-        }
-    }
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
 
@@ -422,7 +409,6 @@ int alloc_map(erasor_hip_handle *h, uint32_t n) {
     rc |= ensure(h, h->voi_ego, V) | ensure(h, h->spts, V) | ensure(h, h->voi_key, V) | ensure(h, h->voi_src, V) | ensure(h, h->ssrc, V);
     rc |= ensure(h, h->rejected, V) | ensure(h, h->rejected_src, V) | ensure(h, h->grank, V) | ensure(h, h->glist, V) | ensure(h, h->gflag, V);
     rc |= ensure(h, h->rk_a, V) | ensure(h, h->rk_b, V) | ensure(h, h->rv_a, V) | ensure(h, h->rv_b, V);
-    if (h->presort) rc |= ensure(h, h->preK, V) | ensure(h, h->preV, V);
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
 
@@ -694,11 +680,6 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
     }
     memset(h->pin, 0, sizeof(HostOut));
     h->cur = h->stream;
-    if (getenv("ERASOR_HIP_PRESORT")) {  // experimental: see k_rgpf_presort
-        h->presort = hipStreamCreateWithPriority(&h->pstream, hipStreamNonBlocking, prio_hi) == hipSuccess &&
-                     hipEventCreateWithFlags(&h->ev_bucketed, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&h->ev_presorted, hipEventDisableTiming) == hipSuccess;
-    }
     if (alloc_bins(h)) {
         erasor_hip_destroy(h);
         return ERASOR_E_NO_DEVICE;
@@ -712,7 +693,6 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     (void)hipSetDevice(h->device);
     for (int k = 0; k < 2; ++k)
         if (h->qstream[k]) (void)hipStreamSynchronize(h->qstream[k]);
-    if (h->pstream) (void)hipStreamSynchronize(h->pstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     prof_collect(h, true);
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
@@ -732,10 +712,6 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->curr_rejected);
     release(h->gsK); release(h->gsV); release(h->gsL); release(h->gsR); release(h->gsK2); release(h->gsV2); release(h->gsH); release(h->gsC);
     release(h->vox_out); release(h->d_st); release(h->d_ctr);
-    release(h->preK); release(h->preV); release(h->pre_flag); release(h->cand_list); release(h->cand_n);
-    if (h->pstream) (void)hipStreamDestroy(h->pstream);
-    if (h->ev_bucketed) (void)hipEventDestroy(h->ev_bucketed);
-    if (h->ev_presorted) (void)hipEventDestroy(h->ev_presorted);
     for (int k = 0; k < NSIDE; ++k) {
         if (h->q[k].ev_keys) (void)hipEventDestroy(h->q[k].ev_keys);
         if (h->q[k].ev_done) (void)hipEventDestroy(h->q[k].ev_done);
@@ -1177,8 +1153,6 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
         if (ensure(h, h->hist2, nb_m) || ensure(h, h->hist2_l, nb_m) || ensure(h, h->hist2_t, cdiv(nb_m, 1024) + 2)) return ERASOR_E_NO_DEVICE;
     }
     const uint32_t *sm_keys = nullptr, *sm_perm = nullptr;
-    bool presorted = false;
-    uint32_t pre_tag = 0;
 
     // ---- map chain (the query chains run on their own streams; the two only meet at the Scan Ratio Test) ----
     auto enqueue_map_chain = [&]() {
@@ -1232,17 +1206,6 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
                 LAUNCH(h, "voi_bucket", k_mb_scatter, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
                        (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, B + 1, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p);
             sm_keys = h->rk_a.p;
-            if (h->presort && !flags) {  // experimental: z-sort the previous step's reverted bins beside k_bin_stats / k_srt
-                pre_tag = (uint32_t)(h->step_seq + 1);
-                (void)hipEventRecord(h->ev_bucketed, h->stream);
-                (void)hipStreamWaitEvent(h->pstream, h->ev_bucketed, 0);
-                h->cur = h->pstream;
-                LAUNCH(h, "rgpf_presort", k_rgpf_presort, std::min<uint32_t>(64u, B), 1024, (const uint32_t *)h->cand_list.p, (const uint32_t *)h->cand_n.p, B,
-                       (const uint32_t *)h->moff.p, (const float4 *)h->spts.p, h->preK.p, h->preV.p, h->pre_flag.p, pre_tag, dc);
-                h->cur = h->stream;
-                (void)hipEventRecord(h->ev_presorted, h->pstream);
-                presorted = true;
-            }
         } else {
             radix_sort(h, h->voi_key.p, n_voi, nvoi_dev, bits, h->rk_a.p, h->rk_b.p, h->rv_a.p, h->rv_b.p, &sm_keys, &sm_perm, "voi_bucket");
             if (n_voi) LAUNCH(h, "voi_bucket", k_gather, cdiv(n_voi, 256), 256, (const float4 *)h->voi_ego.p, (const uint32_t *)h->voi_src.p, sm_perm,
@@ -1269,16 +1232,9 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
            (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
     // R-GPF and the per-bin voxelisation walk the reverted-bin LIST on a small fixed grid (n_rev is on the device)
     static const uint32_t rev_grid = getenv("ERASOR_HIP_REV_GRID") ? (uint32_t)atoi(getenv("ERASOR_HIP_REV_GRID")) : 128u;
-    if (presorted) {
-        (void)hipStreamWaitEvent(h->stream, h->ev_presorted, 0);
-        LAUNCH(h, "rgpf", k_rgpf2<true>, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds,
-               (const uint32_t *)h->moff.p, (const float4 *)h->spts.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p, h->gflag.p,
-               h->grank.p, h->glist.p, h->ng.p, h->plane_n.p, h->plane_d.p, dc, h->dbg_stamps.p, (const uint32_t *)h->preK.p, (const uint32_t *)h->preV.p,
-               (const uint32_t *)h->pre_flag.p, pre_tag);
-    } else
-    LAUNCH(h, "rgpf", k_rgpf2<false>, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds, (const uint32_t *)h->moff.p,
+    LAUNCH(h, "rgpf", k_rgpf2, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds, (const uint32_t *)h->moff.p,
            (const float4 *)h->spts.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p, h->gflag.p, h->grank.p, h->glist.p,
-           h->ng.p, h->plane_n.p, h->plane_d.p, dc, h->dbg_stamps.p, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
+           h->ng.p, h->plane_n.p, h->plane_d.p, dc, h->dbg_stamps.p);
     if (P.version == 3)
         LAUNCH(h, "bin_voxelize", k_binvox2, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds,
                (const uint32_t *)h->moff.p, (const float4 *)h->spts.p, (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p,
@@ -1314,10 +1270,6 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     const unsigned long long step_seq = ++h->step_seq;
     LAUNCH(h, "step_end", k_step_end, 1, 1, ds, dc, h->pin, (const unsigned long long *)h->lab_slots.p, (const Counters *)Q(h).d_qctr.p,
            (const uint32_t *)Q(h).d_nvox.p, step_seq);
-    if (h->presort && !flags) {  // this step's reverted bins are the next step's candidates (rev_list is rewritten by its k_srt)
-        (void)hipMemcpyAsync(h->cand_list.p, h->rev_list.p, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream);
-        (void)hipMemcpyAsync(h->cand_n.p, &ds->n_rev, sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream);
-    }
     {   // the NEXT step's VoI split goes right behind k_step_end when its pose is known (erasor_hip_prefetch_node): the main
         // stream runs it while the host collects this step's results and the caller comes back with the next scan -- the pass
         // reads the store this step has just written and the extents k_step_end commits; a step that finds anything else than

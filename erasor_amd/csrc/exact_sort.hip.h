@@ -631,5 +631,242 @@ __device__ __forceinline__ uint32_t block_partition(KP K, VP V, PP posL, PP posR
     return cut;
 }
 
+// ------------------------------------------------------------------------------------------------
+// block_esort_sync: the same introsort, LEVEL-SYNCHRONOUS over a whole workgroup, for n <= EMAX * blockDim.x keys
+// that live in registers (position i = e * blockDim.x + tid holds k[e] / v[e]) and in an LDS mirror (sKV).
+//
+// Every position carries its segment [f, l) and depth budget d in registers; one loop iteration performs ONE partition of
+// EVERY segment longer than kThreshold at once.  What makes a level cheap is that nothing has to be searched:
+//   PL(i)  = # left stops  (!(key < pivot)) at positions <  i   (whole array; ballot + one 64-entry table scan)
+//   SG(i)  = # right stops (!(pivot < key)) at positions >  i
+//   A = PL(i) - PL(f+1) = rank of a left stop in its segment's list L;  G = SG(i) - SG(l-1) = rank of a right stop in R;
+//   a left stop is swapped  <=>  L[A] < R[A]  <=>  G > A;    a right stop is swapped  <=>  L[G] < R[G]  <=>  A > G
+//   (exact_sort_core.h: swaps = pairs (L[k], R[k]), k < m, the predicate is monotone); the stop lists carry the stops'
+//   (key, value) in global rank order, so the partner's pair is ONE read: R[A] resp. L[G];
+//   cut = min(L[m], R[m-1]) = the lowest position that is an UNswapped left stop or a SWAPPED right stop, found with one
+//   LDS atomicMin per (wavefront, segment).
+// A level is a chain of five dependent LDS round trips and four workgroup barriers, whatever the number of segments (the
+// table scan runs on DPP row shifts, not on ds_bpermute); the one-wavefront-per-segment formulation (block_esort) pays
+// >= 2.2 k cycles per partition and 10 k for the top level of a 1000-key bin.  A segment whose depth budget is exhausted
+// is heapsorted by one lane (exact, rare), like in block_esort.
+// Results: K2[0..n) / V2[0..n) (may alias sLL / sRR, not sKV).  sTab: 68 words.  Requires blockDim.x <= 1024, EMAX <= 4.
+// ------------------------------------------------------------------------------------------------
+struct KVKeyRef {
+    uint2 *p;
+    __device__ __forceinline__ uint32_t &operator[](size_t i) const { return p[i].x; }
+};
+struct KVValRef {
+    uint2 *p;
+    __device__ __forceinline__ uint32_t &operator[](size_t i) const { return p[i].y; }
+};
+
+// inclusive prefix sum over the 64 lanes on DPP (row_shr 1 / 2 / 4 / 8 inside rows of 16, then row_bcast:15 / :31 across rows):
+// six VALU operations, no LDS crossbar (a __shfl_up ladder is six dependent ds_bpermute round trips)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    uint32_t vv = x;
+    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x111, 0xf, 0xf, false);
+    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x112, 0xf, 0xf, false);
+    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x114, 0xf, 0xf, false);
+    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x118, 0xf, 0xf, false);
+    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x142, 0xa, 0xf, false);
+    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x143, 0xc, 0xf, false);
+    return vv;
+}
+
+template <int EMAX, class K2P, class V2P>
+__device__ __forceinline__ void block_esort_sync(uint32_t (&k)[EMAX], uint32_t (&v)[EMAX], uint32_t n, uint2 *sKV, uint2 *sLL, uint2 *sRR,
+                                                 uint32_t *sPS, uint32_t *sCut, uint32_t *sTab, K2P K2, V2P V2, uint32_t *n_fallback,
+                                                 unsigned long long *tstamp = nullptr) {
+    const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = bs >> 6;
+    const uint64_t lt = lanemask_lt();
+    const uint64_t gt = ~(lt | (1ull << lane));
+    const uint32_t E = (n + bs - 1) / bs;  // rows of positions in use (<= EMAX)
+    uint32_t f[EMAX], l[EMAX];
+    int32_t d[EMAX];
+    const int32_t depth0 = 2 * lg2_floor(n ? n : 1u);
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const uint32_t i = (uint32_t)e * bs + tid;
+        f[e] = 0;
+        l[e] = i < n ? n : 0u;  // (positions beyond n: an empty segment, never active)
+        d[e] = depth0;
+        if (i < n) sKV[i] = make_uint2(k[e], v[e]);
+    }
+    if (tid < 68) sTab[tid] = (tid == 64 && n > (uint32_t)kThreshold) ? 1u : 0u;  // [0, 64): (row, wavefront) counts; [64]: a segment is left; [65]: a heapsort is due
+    __syncthreads();
+    if (tstamp && tid == 0) tstamp[0] = clock64();
+    int lvl = 0;
+    for (;;) {
+        // ---- phase 0: pivot of my segment (std::__move_median_to_first), my key after the median move, stop flags ----
+        // (the loop's flags are fetched together with the median candidates: one round trip)
+        const uint32_t fl_any = sTab[64], fl_heap = sTab[65];
+        uint2 qf[EMAX], qa[EMAX], qb[EMAX], qc[EMAX];
+        bool act[EMAX];
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            act[e] = (uint32_t)e < E && l[e] - f[e] > (uint32_t)kThreshold;
+            qf[e] = qa[e] = qb[e] = qc[e] = make_uint2(0u, 0u);
+            if (act[e]) {
+                qf[e] = sKV[f[e]];
+                qa[e] = sKV[f[e] + 1];
+                qb[e] = sKV[f[e] + (l[e] - f[e]) / 2];
+                qc[e] = sKV[l[e] - 1];
+            }
+        }
+        if (!fl_any) break;
+        if (tstamp && tid == 0 && lvl < 14) tstamp[1 + lvl] = clock64();
+        ++lvl;
+        if (fl_heap) {  // (workgroup-uniform) depth budget exhausted somewhere: exact heapsort of those segments, one lane each
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                const uint32_t i = (uint32_t)e * bs + tid;
+                if (act[e] && d[e] == 0 && i == f[e]) {
+                    heapsort_exact(KVKeyRef{sKV}, KVValRef{sKV}, f[e], l[e]);
+                    atomicAdd(n_fallback, 1u);
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                const uint32_t i = (uint32_t)e * bs + tid;
+                if (act[e] && d[e] == 0) {  // fully sorted now: every key its own leaf
+                    const uint2 kv = sKV[i];
+                    k[e] = kv.x;
+                    v[e] = kv.y;
+                    f[e] = i;
+                    l[e] = i + 1;
+                    act[e] = false;
+                }
+            }
+        }
+        bool isL[EMAX], isR[EMAX], chg[EMAX];
+        uint64_t mL[EMAX], mR[EMAX];
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const uint32_t i = (uint32_t)e * bs + tid;
+            chg[e] = false;
+            isL[e] = isR[e] = false;
+            if (act[e]) {
+                const uint32_t a = f[e] + 1, b = f[e] + (l[e] - f[e]) / 2, c = l[e] - 1;
+                uint32_t mpos;
+                uint2 qm;
+                if (qa[e].x < qb[e].x) {
+                    if (qb[e].x < qc[e].x) { mpos = b; qm = qb[e]; }
+                    else if (qa[e].x < qc[e].x) { mpos = c; qm = qc[e]; }
+                    else { mpos = a; qm = qa[e]; }
+                } else if (qa[e].x < qc[e].x) { mpos = a; qm = qa[e]; }
+                else if (qb[e].x < qc[e].x) { mpos = c; qm = qc[e]; }
+                else { mpos = b; qm = qb[e]; }
+                const uint32_t p = qm.x;
+                if (i == f[e]) { k[e] = qm.x; v[e] = qm.y; chg[e] = true; }
+                else if (i == mpos) { k[e] = qf[e].x; v[e] = qf[e].y; chg[e] = true; }
+                const bool inr = i > f[e];
+                isL[e] = inr && !(k[e] < p);
+                isR[e] = inr && !(p < k[e]);
+            }
+            mL[e] = __ballot(isL[e]);
+            mR[e] = __ballot(isR[e]);
+            if (lane == 0 && (uint32_t)e < E) sTab[(uint32_t)e * nw + wave] = (uint32_t)__popcll(mL[e]) | ((uint32_t)__popcll(mR[e]) << 16);
+        }
+        __syncthreads();  // #1
+        // ---- phase 1: every wavefront scans the (row, wavefront) table itself: 64 entries, counts packed 16 | 16 ----
+        const uint32_t tv = sTab[lane];
+        const uint32_t inc = wave_incl_scan(tv);
+        const uint32_t totR = __builtin_amdgcn_readlane(inc, 63) >> 16;
+        uint32_t PL[EMAX], SG[EMAX];
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const uint32_t t = __builtin_amdgcn_readfirstlane(((uint32_t)e * nw + wave) & 63u);
+            const uint32_t it = __builtin_amdgcn_readlane(inc, t), xt = __builtin_amdgcn_readlane(tv, t);
+            PL[e] = ((it - xt) & 0xFFFFu) + (uint32_t)__popcll(mL[e] & lt);       // left stops before me
+            SG[e] = (totR - (it >> 16)) + (uint32_t)__popcll(mR[e] & gt);          // right stops after me
+        }
+        // ---- phase 2: stop lists (with their pairs) in global rank order, per-position counts, the keys the median move changed ----
+        if (tid == 0) { sTab[64] = 0; sTab[65] = 0; }
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const uint32_t i = (uint32_t)e * bs + tid;
+            if ((uint32_t)e < E && i < n) {
+                sPS[i] = PL[e] | (SG[e] << 16);
+                if (isL[e]) sLL[PL[e]] = make_uint2(k[e], v[e]);
+                if (isR[e]) sRR[SG[e]] = make_uint2(k[e], v[e]);
+                if (chg[e]) sKV[i] = make_uint2(k[e], v[e]);
+                if (act[e] && i == f[e]) sCut[i] = 0xFFFFFFFFu;
+            }
+        }
+        __syncthreads();  // #2
+        // ---- phase 3: swapped or not (no search), partner's pair, cut candidates ----
+        bool sw[EMAX];
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const uint32_t i = (uint32_t)e * bs + tid;
+            sw[e] = false;
+            bool cand = false;
+            if (act[e]) {
+                const uint32_t baseL = sPS[f[e] + 1] & 0xFFFFu, baseR = sPS[l[e] - 1] >> 16;
+                const uint32_t A = PL[e] - baseL, G = SG[e] - baseR;
+                const bool swL = isL[e] && G > A, swR = isR[e] && A > G;
+                sw[e] = swL || swR;
+                cand = (isL[e] && !swL) || swR;
+                if (sw[e]) {
+                    const uint2 kv = swL ? sRR[baseR + A] : sLL[baseL + G];
+                    k[e] = kv.x;
+                    v[e] = kv.y;
+                }
+            }
+            const uint64_t cm = __ballot(cand);
+            if (cand) {  // the lowest candidate of my segment inside this wavefront speaks for it
+                const uint32_t wbase = (uint32_t)e * bs + (wave << 6);
+                const uint32_t s0 = f[e] + 1 > wbase ? f[e] + 1 - wbase : 0u;  // first lane of my segment's range in this wavefront
+                const uint64_t range = lt & ~((s0 >= 64u) ? ~0ull : ((1ull << s0) - 1ull));
+                if ((cm & range) == 0ull) atomicMin(&sCut[f[e]], i);
+            }
+        }
+        __syncthreads();  // #3
+        // ---- phase 4: swapped keys land, segments split at the cut ----
+        bool more = false, heap = false;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const uint32_t i = (uint32_t)e * bs + tid;
+            if (sw[e]) sKV[i] = make_uint2(k[e], v[e]);
+            if (act[e]) {
+                const uint32_t cut = sCut[f[e]];
+                if (i < cut) l[e] = cut;
+                else f[e] = cut;
+                d[e] -= 1;
+                const bool a2 = l[e] - f[e] > (uint32_t)kThreshold;
+                more = more || a2;
+                heap = heap || (a2 && d[e] == 0);
+            }
+        }
+        if (__ballot(more) != 0ull && lane == 0) sTab[64] = 1;
+        if (__ballot(heap) != 0ull && lane == 0) sTab[65] = 1;
+        __syncthreads();  // #4
+    }
+    if (tstamp && tid == 0) tstamp[15] = clock64();
+    // ---- leaves (<= 16 keys): __final_insertion_sort == a stable sort of every leaf: rank inside [f, l) ----
+    // (K2 / V2 may alias the stop lists: every wavefront left the loop after barrier #4, nobody reads them any more)
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const uint32_t i = (uint32_t)e * bs + tid;
+        if ((uint32_t)e < E && i < n) {
+            const uint32_t ki = k[e], a = f[e], b = l[e];
+            uint32_t r = 0;
+#pragma unroll
+            for (int t = 0; t < kThreshold; ++t) {
+                const uint32_t j = a + (uint32_t)t;
+                const bool valid = j < b;
+                const uint32_t kj = valid ? sKV[j].x : 0u;
+                r += (valid && ((kj < ki) || (kj == ki && j < i))) ? 1u : 0u;
+            }
+            K2[a + r] = ki;
+            V2[a + r] = v[e];
+        }
+    }
+    __syncthreads();
+    if (tstamp && tid == 0) tstamp[16] = clock64();
+}
+
 }  // namespace esort
 #endif

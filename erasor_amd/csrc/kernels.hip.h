@@ -2384,21 +2384,44 @@ __device__ __forceinline__ void rgpf_after_sort(const DP &P, const float4 *__res
 // ------------------------------------------------------------------------------------------------
 static constexpr uint32_t RG_RS = RG_CH + 4;  // padded row stride of the product rows (floats)
 
+// Exact std::sort of n <= ESYNC_MAX (key, index) pairs by the whole workgroup, level-synchronous (esort::block_esort_sync): keys are
+// produced into registers by key_of(i); scratch = 16384 words of LDS (pool) laid out as pairs[2048] | left stops[2048] | right
+// stops[2048] | counts[2048] | cuts[2048]; sorted keys -> K2, their indices -> V2 (LDS; both may lie in pool beyond its first 4096 words).
+static constexpr uint32_t ESYNC_MAX = 2048;
+template <class KeyFn>
+__device__ __forceinline__ void lds_esort_sync(uint32_t n, KeyFn key_of, uint32_t *pool, uint32_t *stab, uint32_t *K2, uint32_t *V2,
+                                               uint32_t *n_fallback, unsigned long long *tstamp = nullptr) {
+    uint2 *sKV = reinterpret_cast<uint2 *>(pool), *sLL = reinterpret_cast<uint2 *>(pool + 2 * ESYNC_MAX), *sRR = reinterpret_cast<uint2 *>(pool + 4 * ESYNC_MAX);
+    uint32_t *sPS = pool + 6 * ESYNC_MAX, *sCut = pool + 7 * ESYNC_MAX;
+    const uint32_t tid = threadIdx.x, bs = blockDim.x;
+    if (n <= bs) {
+        uint32_t k[1], v[1];
+        k[0] = tid < n ? key_of(tid) : 0u;
+        v[0] = tid;
+        esort::block_esort_sync<1>(k, v, n, sKV, sLL, sRR, sPS, sCut, stab, K2, V2, n_fallback, tstamp);
+    } else {
+        uint32_t k[2], v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t i = (uint32_t)e * bs + tid;
+            k[e] = i < n ? key_of(i) : 0u;
+            v[e] = i;
+        }
+        esort::block_esort_sync<2>(k, v, n, sKV, sLL, sRR, sPS, sCut, stab, K2, V2, n_fallback, tstamp);
+    }
+}
+
 __device__ __forceinline__ float key_to_float(uint32_t k) {  // inverse of esort::float_key (-0 comes back as +0)
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-// PRE: some bins may have been z-sorted ahead of the Scan Ratio Test (k_rgpf_presort, experimental, ERASOR_HIP_PRESORT): a bin whose
-// pre_flag carries this step's tag takes its sorted keys / indices from preK / preV instead of sorting.
-template <bool PRE>
 __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict__ rev_list, const DevState *__restrict__ st,
                                                 const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *gsK,
                                                 uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
                                                 uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
                                                 uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
-                                                Counters *ctr, unsigned long long *dbg, const uint32_t *__restrict__ preK,
-                                                const uint32_t *__restrict__ preV, const uint32_t *__restrict__ pre_flag, uint32_t pre_tag) {
-    __shared__ uint32_t pool[4 * RG_LMAX];  // sort phase: K | V | posL | posR ; fit phase: glist | X | Y | Z
+                                                Counters *ctr, unsigned long long *dbg) {
+    __shared__ uint32_t pool[4 * RG_LMAX];  // sort phase: K | V | posL | posR (or lds_esort_sync's layout) ; fit phase: glist | X | Y | Z
     __shared__ uint32_t sH[RG_LMAX / 32 + 2];
     __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
     __shared__ uint32_t qcnt[2];
@@ -2408,6 +2431,7 @@ __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict
     __shared__ double s_th, s_lpr;
     __shared__ uint32_t s_carry;
     __shared__ uint32_t s_tab[64];
+    __shared__ uint32_t s_stab[68];
     __shared__ unsigned long long s_t[12];
     __shared__ unsigned long long s_es[24];  // diagnostics: block_esort's own stamps (shader clock)
 #define RG_STAMP(i) do { if (dbg && tid == 0) s_t[i] = wall_clock64(); } while (0)
@@ -2436,26 +2460,22 @@ __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict
             continue;
         }
         const unsigned long long t_a = dbg ? wall_clock64() : 0ull;
-        // ---- (1) std::sort(src_copy, point_cmp), erasor.cpp:239-240: exact introsort emulation, level-synchronous in LDS ----
-        bool presorted = false;
-        if constexpr (PRE) presorted = pre_flag[key] == pre_tag;  // (workgroup-uniform)
-        if (presorted) {
+        // ---- (1) std::sort(src_copy, point_cmp), erasor.cpp:239-240: exact introsort emulation in LDS ----
+        if (M <= ESYNC_MAX && M <= 2 * bs) {  // level-synchronous over the whole workgroup (the common case)
+            RG_STAMP(0);
+            if (dbg && tid < 24) s_es[tid] = 0;
+            lds_esort_sync(M, [&](uint32_t i) { return esort::float_key(__float_as_uint(pts[i].z)); }, pool, s_stab, sL, sR, &ctr->n_sort_fallback,
+                           dbg ? s_es : nullptr);
+        } else {
             for (uint32_t i = tid; i < M; i += bs) {
-                sL[i] = preK[o0 + i];
-                sR[i] = preV[o0 + i];
+                sK[i] = esort::float_key(__float_as_uint(pts[i].z));
+                sV[i] = i;
             }
             __syncthreads();
             RG_STAMP(0);
-        } else {
-        for (uint32_t i = tid; i < M; i += bs) {
-            sK[i] = esort::float_key(__float_as_uint(pts[i].z));
-            sV[i] = i;
-        }
-        __syncthreads();
-        RG_STAMP(0);
-        if (dbg && tid < 24) s_es[tid] = 0;
-        esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
-                           &ctr->n_sort_fallback, &ctr->sort_qoverflow, dbg ? s_es : nullptr);
+            if (dbg && tid < 24) s_es[tid] = 0;
+            esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
+                               &ctr->n_sort_fallback, &ctr->sort_qoverflow, dbg ? s_es : nullptr);
         }
         RG_STAMP(1);
         // sorted keys in sL, sorted bin-local indices in sR
@@ -2783,45 +2803,6 @@ __device__ __forceinline__ void binvox_core(const DP &P, uint32_t m, uint32_t nc
     if (tid == 0) *nvox_slot = nv;
 }
 
-// EXPERIMENTAL (ERASOR_HIP_PRESORT=1, off by default; parity checked on the CPU stand-in, timing pending): the z-sort of R-GPF does
-// not depend on the Scan Ratio Test, and a scan's large reverted bins are mostly the ones of the scan before.  This kernel runs on a
-// side stream beside k_bin_stats / k_srt: it z-sorts the candidate bins (the previous step's reverted list) exactly like k_rgpf2 would
-// and leaves sorted keys / indices in preK / preV with the bin's pre_flag set to this step's tag; k_rgpf2<true> then skips the sort of
-// those bins.  A candidate that is not reverted this time costs nothing on the main stream.
-__global__ __launch_bounds__(1024) void k_rgpf_presort(const uint32_t *__restrict__ cand_list, const uint32_t *__restrict__ n_cand, uint32_t B,
-                                                       const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *__restrict__ preK,
-                                                       uint32_t *__restrict__ preV, uint32_t *__restrict__ pre_flag, uint32_t pre_tag, Counters *ctr) {
-    __shared__ uint32_t pool[4 * RG_LMAX];
-    __shared__ uint32_t sH[RG_LMAX / 32 + 2];
-    __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
-    __shared__ uint32_t qcnt[2];
-    uint32_t *sK = pool, *sV = pool + RG_LMAX, *sL = pool + 2 * RG_LMAX, *sR = pool + 3 * RG_LMAX;
-    const uint32_t tid = threadIdx.x, bs = blockDim.x;
-    const uint32_t n = min(*n_cand, B);
-    for (uint32_t c = blockIdx.x; c < n; c += gridDim.x) {
-        const uint32_t key = cand_list[c];
-        if (key >= B) continue;
-        const uint32_t o0 = moff[key], M = moff[key + 1] - o0;
-        __syncthreads();
-        if (M <= 64u || M > RG_LMAX) continue;  // (short bins sort in no time; longer ones take k_rgpf2's global path)
-        const float4 *pts = spts + o0;
-        for (uint32_t i = tid; i < M; i += bs) {
-            sK[i] = esort::float_key(__float_as_uint(pts[i].z));
-            sV[i] = i;
-        }
-        __syncthreads();
-        esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
-                           &ctr->n_sort_fallback, &ctr->sort_qoverflow);
-        for (uint32_t i = tid; i < M; i += bs) {
-            preK[o0 + i] = sL[i];
-            preV[o0 + i] = sR[i];
-        }
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) pre_flag[key] = pre_tag;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_binvox2: per-bin voxelisation over the reverted-bin LIST, clouds of <= BV2_LMAX points entirely in LDS.
 // VoxelGrid's std::sort has equal keys by construction (the points of a voxel), so the exact introsort emulation stays;
@@ -2849,6 +2830,7 @@ __global__ __launch_bounds__(1024) void k_binvox2(DP P, const uint32_t *__restri
     __shared__ uint32_t sbb[6];
     __shared__ uint32_t s_carry;
     __shared__ uint32_t s_tab[64];
+    __shared__ uint32_t s_stab[68];
     uint32_t *sK = pool, *sV = pool + BV2_LMAX, *sL = pool + 2 * BV2_LMAX, *sR = pool + 3 * BV2_LMAX;
     const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = bs >> 6;
     const uint32_t n_rev = st->n_rev;
@@ -2926,14 +2908,18 @@ __global__ __launch_bounds__(1024) void k_binvox2(DP P, const uint32_t *__restri
             }
             continue;
         }
-        for (uint32_t j = tid; j < m; j += bs) {
-            const float4 p = sC[j];
-            sK[j] = vox_index(g, p.x, p.y, p.z);
-            sV[j] = j;
+        if (m <= ESYNC_MAX && m <= 2 * bs) {  // level-synchronous over the whole workgroup (the common case)
+            lds_esort_sync(m, [&](uint32_t j) { const float4 p = sC[j]; return vox_index(g, p.x, p.y, p.z); }, pool, s_stab, sL, sR, &ctr->n_sort_fallback);
+        } else {
+            for (uint32_t j = tid; j < m; j += bs) {
+                const float4 p = sC[j];
+                sK[j] = vox_index(g, p.x, p.y, p.z);
+                sV[j] = j;
+            }
+            __syncthreads();
+            esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, m, 2 * esort::lg2_floor(m), qa2, qb2, qcnt, (uint32_t)(BV2_LMAX / 16 + 2),
+                               &ctr->n_sort_fallback, &ctr->sort_qoverflow);
         }
-        __syncthreads();
-        esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, m, 2 * esort::lg2_floor(m), qa2, qb2, qcnt, (uint32_t)(BV2_LMAX / 16 + 2),
-                           &ctr->n_sort_fallback, &ctr->sort_qoverflow);
         __syncthreads();
         // ---- run heads: unique keys (ascending) -> sK, run begins -> sV ----
         const uint32_t E = (m + bs - 1) / bs;

@@ -146,7 +146,7 @@ static void test_per_bin(std::mt19937 &rng) {
     const uint32_t B = (uint32_t)P.B;
     std::uniform_real_distribution<float> u01(0.f, 1.f);
     // a few reverted bins of different sizes: sloped ground quantised to 1 cm (ties in z), clutter above, something below min_h
-    const uint32_t sizes[] = {12, 40, 300, 900, 1700};
+    const uint32_t sizes[] = {12, 40, 300, 900, 1700, 2300};  // <= 1024: one key per thread; <= 2048: two; beyond: one wavefront per segment (block_esort)
     const uint32_t nbin = sizeof(sizes) / sizeof(sizes[0]);
     std::vector<uint32_t> moff(B + 3, 0), qoff(B + 3, 0), rev_list, rev_key;
     std::vector<float4> spts, sq;
@@ -191,33 +191,9 @@ static void test_per_bin(std::mt19937 &rng) {
     std::vector<float> plane_n((size_t)nbin * P.gf_iter * 3 + 8, 0.f);
     std::vector<double> plane_d((size_t)nbin * P.gf_iter + 8, 0.0);
     simt::run_grid(2, 1024, [&] {
-        k_rgpf2<false>(P, rev_list.data(), &st, moff.data(), spts.data(), gsK.data(), gsV.data(), gsL.data(), gsR.data(), gsH.data(), gsK2.data(),
-                       gsV2.data(), gflag.data(), grank.data(), glist.data(), ng.data(), plane_n.data(), plane_d.data(), &ctr, nullptr, nullptr,
-                       nullptr, nullptr, 0u);
+        k_rgpf2(P, rev_list.data(), &st, moff.data(), spts.data(), gsK.data(), gsV.data(), gsL.data(), gsR.data(), gsH.data(), gsK2.data(),
+                       gsV2.data(), gflag.data(), grank.data(), glist.data(), ng.data(), plane_n.data(), plane_d.data(), &ctr, nullptr);
     });
-    {   // the experimental variant: some of the bins z-sorted ahead (k_rgpf_presort), R-GPF takes their order from there
-        std::vector<uint32_t> preK(G, 0xDEADu), preV(G, 0xDEADu), pre_flag(B + 2, 0), cand = {rev_list[1], rev_list[3], 5u, rev_list[4]}, ncand(1, 4);
-        std::vector<uint32_t> grank2(G), glist2(G), ng2(nbin + 1, 0);
-        std::vector<uint8_t> gflag2(G, 9);
-        std::vector<float> plane_n2(plane_n.size(), 0.f);
-        std::vector<double> plane_d2(plane_d.size(), 0.0);
-        simt::run_grid(3, 1024, [&] {
-            k_rgpf_presort(cand.data(), ncand.data(), B, moff.data(), spts.data(), preK.data(), preV.data(), pre_flag.data(), 77u, &ctr);
-        });
-        simt::run_grid(2, 1024, [&] {
-            k_rgpf2<true>(P, rev_list.data(), &st, moff.data(), spts.data(), gsK.data(), gsV.data(), gsL.data(), gsR.data(), gsH.data(), gsK2.data(),
-                          gsV2.data(), gflag2.data(), grank2.data(), glist2.data(), ng2.data(), plane_n2.data(), plane_d2.data(), &ctr, nullptr,
-                          preK.data(), preV.data(), pre_flag.data(), 77u);
-        });
-        const bool tagged = pre_flag[rev_list[1]] == 0u /* 40 points: not worth it */ && pre_flag[rev_list[3]] == 77u && pre_flag[rev_list[4]] == 77u && pre_flag[rev_list[0]] == 0u;
-        bool ok = tagged && ng2 == ng && gflag2 == gflag && plane_n2 == plane_n && plane_d2 == plane_d;
-        for (uint32_t b = 0; ok && b < nbin; ++b) {
-            const uint32_t o0 = moff[rev_list[b]];
-            for (uint32_t k = 0; ok && k < sizes[b]; ++k) ok = grank2[o0 + k] == grank[o0 + k] && (k >= ng[b] || glist2[o0 + k] == glist[o0 + k]);
-        }
-        printf("R-GPF with two of the five bins sorted ahead (experimental): identical masks, ranks, lists, planes  %s\n", ok ? "ok" : "MISMATCH");
-        CHECK(ok, "presorted R-GPF (tagged %d)", (int)tagged);
-    }
     for (uint32_t b = 0; b < nbin; ++b) {
         const uint32_t M = sizes[b], o0 = moff[rev_list[b]];
         std::vector<uint8_t> mask(M);

@@ -390,6 +390,26 @@ inline T __shfl_xor(T v, int m, int = 64) { return simt_shfl_from(v, (int)(simt_
 inline uint32_t __builtin_amdgcn_readlane(uint32_t v, uint32_t lane) { return simt_shfl_from(v, (int)(lane & 63u)); }
 inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t v) { return simt_shfl_from(v, 0); }
 
+// DPP controls used by esort::wave_incl_scan: row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143); a lane without a
+// source (or switched off by row_mask / bank_mask) keeps `old`
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool) {
+    const unsigned lane = simt_lane(), row = lane >> 4, bank = (lane >> 2) & 3u;
+    int from = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11F) {
+        const unsigned sh = (unsigned)ctrl - 0x110u;
+        if ((lane & 15u) >= sh) from = (int)(lane - sh);
+    } else if (ctrl == 0x142) {
+        if (row >= 1) from = (int)(row * 16u - 1u);
+    } else if (ctrl == 0x143) {
+        if (lane >= 32) from = 31;
+    } else {
+        fprintf(stderr, "simt_emu: DPP control 0x%x not modelled\n", ctrl);
+        abort();
+    }
+    const int got = simt_shfl_from(src, from < 0 ? (int)lane : from);  // (every lane takes part in the exchange)
+    const bool enabled = ((row_mask >> row) & 1) && ((bank_mask >> bank) & 1);
+    return (from >= 0 && enabled) ? got : old;
+}
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
@@ -426,6 +446,10 @@ struct float2 {
 struct alignas(16) float4 {
     float x, y, z, w;
 };
+struct alignas(8) uint2 {
+    uint32_t x, y;
+};
+inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline uint32_t __float_as_uint(float f) {

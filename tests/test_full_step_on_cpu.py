@@ -42,16 +42,6 @@ def test_two_steps_of_the_real_host_code_and_kernels_match_the_oracle(simt_lib):
     assert "FULL-STEP-OK" in out.stdout, out.stdout + out.stderr[-3000:]
 
 
-def test_the_experimental_presort_keeps_parity(simt_lib):
-    """ERASOR_HIP_PRESORT=1 (off by default, timing pending): the previous step's reverted bins are z-sorted on a side stream ahead
-    of the Scan Ratio Test, R-GPF reuses the order of the bins it finds tagged.  Same steps, same comparisons."""
-    env = dict(os.environ, ERASOR_HIP_PRESORT="1", SIMT_EMU_TRACE="1")
-    out = subprocess.run([sys.executable, os.path.join(HERE, "simt_full_step.py"), simt_lib, ROOT, "3"], capture_output=True, text=True, timeout=900, env=env)
-    sys.stdout.write(out.stdout)
-    assert "FULL-STEP-OK" in out.stdout, out.stdout + out.stderr[-3000:]
-    assert "k_rgpf_presort" in out.stderr and "k_rgpf2<true>" in out.stderr, "the experimental path did not run"
-
-
 def test_part_of_the_gpu_parity_suite_passes_on_the_cpu_stand_in(simt_lib):
     keys = ["one_bin_known", "edge_cases", "stable_radix", "heapsort_fallback", "api_error"]
     if os.environ.get("ERASOR_SIMT_MORE"):
