@@ -91,6 +91,62 @@ def respawn_under_torchrun(args):
     os.execv(sys.executable, cmd)
 
 
+def device_source_hash():
+    """sha256 over the device sources: profiles/ records it when the rocprofv3 passes are collected (tools/collect_profiles.sh);
+    a different hash here means a kernel has changed since, and the committed counters no longer describe this build"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "erasor_amd", "csrc")
+    for f in ("erasor_hip.hip", "kernels.hip.h", "exact_sort.hip.h", "exact_sort_core.h"):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_profile(prof_tag):
+    """what the separate rocprofv3 passes of THIS build measured (profiles/*_latest*): k_voi_split's PMC traffic and average
+    duration, and the kernel that tops the GPU-time table.  None for everything when the device sources have changed since."""
+    import csv
+    out = {"traffic": None, "voi_split_avg_us": None, "dominant": None, "stale": None}
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_meta%s.json" % prof_tag)) as f:
+            meta = json.load(f)
+        out["stale"] = meta.get("device_source_sha16") != device_source_hash()
+    except Exception:
+        out["stale"] = True
+    if out["stale"]:
+        return out
+    per_kernel = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest%s.json" % prof_tag)) as f:
+            j = json.load(f)
+        out["traffic"] = int(j["traffic_bytes_per_launch"])
+        per_kernel = j.get("per_kernel_traffic_bytes", {})
+    except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, "profiles", "kernel_stats_latest%s.csv" % prof_tag)) as f:
+            rows = [r for r in csv.DictReader(f) if r["Name"].startswith("ek::") or "ek::" in r["Name"]]
+        for r in rows:
+            if "k_voi_split" in r["Name"]:
+                out["voi_split_avg_us"] = round(float(r["AverageNs"]) / 1e3, 2)
+        steps = max([int(r["Calls"]) for r in rows if "k_step_end" in r["Name"]] + [1])
+        top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        name = top["Name"].split("(")[0].replace("void ", "").replace("ek::", "")
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        dom = {"name": name, "avg_us": round(float(top["AverageNs"]) / 1e3, 2), "launches_per_scan": round(int(top["Calls"]) / steps, 1),
+               "share_of_gpu_time": round(float(top["TotalDurationNs"]) / tot, 4), "source": "from_profiles (rocprofv3 --kernel-trace --stats)"}
+        tb = per_kernel.get(name)
+        if tb:
+            dom["traffic_bytes_per_launch"] = int(tb)
+            dom["achieved_GBps"] = round(tb / (float(top["AverageNs"]) * 1e-9) / 1e9, 1)
+            dom["frac_of_hbm_peak"] = round(dom["achieved_GBps"] / PEAK_HBM_GBPS, 4)
+        out["dominant"] = dom
+    except Exception:
+        pass
+    return out
+
+
 def host_identity():
     model = None
     try:
@@ -178,9 +234,11 @@ class Sequence:
         return g.step_device(self.d_ptr[k], self.n_pts[k], self.c_Tl, self.c_Tb[k], self.c_To[k])
 
 
-def cpu_baseline(args, P, m, seq, l2b7):
+def cpu_baseline(args, P, m, seq, l2b7, gpu_results=None, gpu_final=None):
     """the CPU path on this box's host cores, same workload, bounded sample.  Preferred: oracle/_ref = the reference's own
-    sources (kind "reference", with its own two wall-clock spans); the oracle port is timed beside it."""
+    sources (kind "reference", with its own two wall-clock spans); the oracle port is timed beside it -- over the very steps
+    the GPU has just run (warm-up + timed), and every step's erasor_step_result, the last step's dynamic-point mask and the
+    final map are compared with what the GPU produced: a mismatch fails the run."""
     import ctypes as C
     from oracle import orc, ref  # checker / baseline only — never on the product path
     po = orc.Params()
@@ -189,18 +247,39 @@ def cpu_baseline(args, P, m, seq, l2b7):
     o = orc.Oracle(po)
     o.set_map(m)
     ns, tcpu = 0, 0.0
-    for k in range(min(args.cpu_steps, seq.n_frames)):
+    n_want = len(gpu_results) if gpu_results else min(args.cpu_steps, seq.n_frames)
+    parity = {"parity_checked_steps": 0}
+    for k in range(min(n_want, seq.n_frames)):
         tc = time.perf_counter()
-        o.step(seq.scans[k], seq.Tl, seq.Tb[k], seq.To[k])
+        ro = o.step(seq.scans[k], seq.Tl, seq.Tb[k], seq.To[k])
         tcpu += time.perf_counter() - tc
         ns += 1
+        if gpu_results:
+            do, dg = ro.as_dict(), gpu_results[k].as_dict()
+            bad = [f for f in do if f not in ("n_ambiguous", "n_sort_fallback") and do[f] != dg[f]]
+            if bad or dg["n_ambiguous"]:
+                raise SystemExit("bench.py: PARITY FAILURE at step %d (GPU vs oracle): %s" % (k, {f: (dg[f], do[f]) for f in bad} or "n_ambiguous != 0"))
+            parity["parity_checked_steps"] = ns
         if tcpu > args.cpu_seconds / 2:
             break
+    if gpu_results:
+        parity["parity"] = "erasor_step_result of %d GPU steps (warm-up + timed pass, bench call pattern) == the oracle's" % ns
+        if gpu_final is not None and ns == len(gpu_results):
+            gm, grej = gpu_final
+            om, orej = o.get_map(), o.get_rejected_indices()
+            same_map = gm.shape == om.shape and bool((gm.view(np.uint32) == om.view(np.uint32)).all())
+            same_rej = grej.shape == orej.shape and bool((grej == orej).all())
+            if not (same_map and same_rej):
+                raise SystemExit("bench.py: PARITY FAILURE after the timed pass: final map identical %s, last dynamic-point mask identical %s" % (same_map, same_rej))
+            parity["parity"] += "; the %d-point map the timed pass leaves and its last dynamic-point mask (%d indices) are bit-identical" % (len(gm), len(grej))
+            parity["final_map_checked"] = True
+        else:
+            parity["final_map_checked"] = False
     o.close()
     port = {"value": round(ns / tcpu, 3), "unit": "scans/s", "cores": 1, "kind": "port",
             "sample": "%d steps of the same workload (same %d-pt map, same scans), oracle/erasor_oracle.cpp -O2 (copy-free restatement), 1 thread" % (ns, len(m))}
     if not ref.available():
-        return port, None
+        return port, None, parity
     r = ref.RefUpdater(po, m, l2b7)
     ns, tcpu, sv, se = 0, 0.0, 0.0, 0.0
     for k in range(min(args.cpu_steps, seq.n_frames)):
@@ -218,7 +297,7 @@ def cpu_baseline(args, P, m, seq, l2b7):
                       "PCL/Eigen/ROS underneath are the stand-ins of oracle/stubs (publishing is a no-op)" % (ns, len(m)),
             "ms_per_scan": round(tcpu / ns * 1e3, 1),
             "reference_spans_ms": {"Extracting VoI": round(sv / ns * 1e3, 1), "ERASOR": round(se / ns * 1e3, 1)}}
-    return refd, port
+    return refd, port, parity
 
 
 def _ref_sequence_worker(job):
@@ -332,10 +411,13 @@ def main():
     torch.cuda.synchronize()
     t_map = time.time() - t0
 
-    for _, s in seqs:
+    step_results = []  # erasor_step_result of every step of the first sequence, warm-up included (compared with the oracle's below)
+    for si, (_, s) in enumerate(seqs):
         s.prime()
         for k in range(W):
-            s.run(k)
+            r_ = s.run(k)
+            if si == 0:
+                step_results.append(r_)
     first = seqs[0][1] if seqs else None
     if first is not None:
         first.g.profile_reset()
@@ -352,6 +434,8 @@ def main():
             if si == 0:
                 split_bytes.append(s.g.voi_split_bytes())
             last = s.run(k)  # synchronous: returns after the step's results are on the host
+            if si == 0:
+                step_results.append(last)
             totals[0] += 1
             totals[1] += last.n_map_rejected
             totals[2] += last.n_reverted_bins
@@ -362,6 +446,9 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed_local = time.perf_counter() - t_start
+    gpu_final = None
+    if world_size == 1 and not args.no_cpu_baseline and args.mode == "replicas" and first is not None:
+        gpu_final = (first.g.get_map(), first.g.get_rejected_indices())  # (after the clock has stopped; compared with the oracle's below)
     prof = first.g.profile_get() if first is not None else {}
     if first is not None:
         first.g.profiling(0)
@@ -405,34 +492,32 @@ def main():
     alg_bytes = float(np.mean([b for b, _ in split_bytes])) if split_bytes else 0.0
     entries = float(np.mean([e for _, e in split_bytes])) if split_bytes else 0.0
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # traffic / rocprofv3 average: NOT measured in this run — read from the committed separate rocprofv3 passes (profiles/)
-    traffic = rocprof_avg = None
+    # traffic / rocprofv3 average: NOT measured in this run — read from the committed separate rocprofv3 passes (profiles/), and
+    # only while they describe THIS build (tools/collect_profiles.sh records a hash of the device sources)
     prof_tag = "" if args.workload == "seq05" else "_" + args.workload
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_latest%s.json" % prof_tag)) as f:
-            traffic = int(json.load(f)["traffic_bytes_per_launch"])
-    except Exception:
-        pass
-    try:
-        import csv
-        with open(os.path.join(ROOT, "profiles", "kernel_stats_latest%s.csv" % prof_tag)) as f:
-            for row in csv.DictReader(f):
-                if "k_voi_split" in row["Name"]:
-                    rocprof_avg = round(float(row["AverageNs"]) / 1e3, 2)
-    except Exception:
-        pass
+    cp = committed_profile(prof_tag)
+    traffic, rocprof_avg = cp["traffic"], cp["voi_split_avg_us"]
     # SURVEY §8(d) step-level figure: ALG_BYTES = 16*N_map + 16*n_scan + 16*N_voi_out (write-back of the updated VoI region)
     n_voi_out = int(last.n_static_estimate + last.n_complement)
     step_alg = 16.0 * N_map + 16.0 * n_scan + 16.0 * n_voi_out
     step_gbps = step_alg / (ms_per_step * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_voi_split", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+    in_l3 = alg_bytes < 256 * 2**20
+    src_note = ("STALE: the device sources changed since profiles/ was collected (tools/collect_profiles.sh) -> null" if cp["stale"]
+                else "from_profiles (separate rocprofv3 passes of this very build, profiles/*_latest%s.*)" % prof_tag)
+    roofline = {"bound": "l3+hbm" if in_l3 else "hbm", "kernel": "k_voi_split",
+                "kernel_role": "hbm_kernel: the step's one pass over the whole map store (fetch_VoI membership) -- NOT the kernel that "
+                               "dominates GPU time, see dominant_kernel and step_frac",
+                "bound_note": ("the %.0f MB this launch streams fit the 256 MiB Infinity Cache: the rate is an L3+HBM figure; "
+                               "--workload large_scale_05 (378 MB per launch) is the HBM-only measurement" % (alg_bytes / 1e6)) if in_l3
+                              else "%.0f MB per launch, beyond the 256 MiB Infinity Cache: HBM-bound" % (alg_bytes / 1e6),
+                "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": traffic,
-                "traffic_source": "from_profiles (separate rocprofv3 --pmc pass, profiles/pmc_latest%s.json)" % prof_tag,
+                "traffic_source": src_note, "dominant_kernel": cp["dominant"],
                 "bytes_per_launch": int(alg_bytes),
                 "bytes_note": "this layout streams {x,y} pairs (8 B) of the outskirts + float4 of the VoI-resident part + masks; "
                               "SURVEY §8(d)'s 16 B/pt assumed an AoS map (aos16_equiv_GBps is the rate in that currency)",
                 "entries_per_launch": int(entries), "avg_launch_us": round(avg_ms * 1e3, 2),
-                "rocprofv3_kernel_avg_us": rocprof_avg, "rocprofv3_source": "from_profiles (profiles/kernel_stats_latest%s.csv)" % prof_tag,
+                "rocprofv3_kernel_avg_us": rocprof_avg, "rocprofv3_source": src_note,
                 "launches": int(vs_n),
                 "aos16_equiv_GBps": round(16.0 * entries / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
                 "working_set_vs_L3": "%.0f MB streamed per launch vs 256 MiB Infinity Cache" % (alg_bytes / 1e6),
@@ -466,8 +551,9 @@ def main():
 
     # ---- CPU baseline: the reference's own sources (oracle/_ref) and the oracle port, one thread, bounded sample ----
     cpu = cpu_port = None
+    parity = {"parity_checked_steps": 0, "parity": "not checked in this run (no CPU leg)"}
     if world_size == 1 and not args.no_cpu_baseline and args.mode == "replicas":
-        cpu, cpu_port = cpu_baseline(args, P, m, first, l2b7)
+        cpu, cpu_port, parity = cpu_baseline(args, P, m, first, l2b7, step_results, gpu_final)
     elif world_size == 1 and not args.no_cpu_baseline:
         cpu = cpu_sequence_parallel(args, seqs, maps, l2b7)
 
@@ -485,6 +571,7 @@ def main():
         "map_points_x_scans_per_sec": round(value * N_map, 1),
         "ms_per_step_without_lookahead": None if sync_ms is None else round(sync_ms, 4),
         "roofline": roofline, "cpu_baseline": cpu, "cpu_port": cpu_port, "host": host_identity(),
+        "parity_checked_steps": parity["parity_checked_steps"], "parity": parity.get("parity"), "final_map_checked": parity.get("final_map_checked", False),
         "rccl_ranks": rccl_ranks, "backend": backend if dist is not None else None,
         "per_rank": [{"rank": i, "steps": int(v[0]), "map_rejected": int(v[1]), "reverted_bins": int(v[2]), "final_map_points": int(v[3]),
                       "static": int(v[4]), "dynamic": int(v[5]), "wall_ms": round(v[6] / 1e3, 2)} for i, v in enumerate(gathered)],

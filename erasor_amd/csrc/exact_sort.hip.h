@@ -740,108 +740,113 @@ __device__ __forceinline__ void block_esort_sync(uint32_t (&k)[EMAX], uint32_t (
                 }
             }
         }
-        bool isL[EMAX], isR[EMAX], chg[EMAX];
+        bool isL[EMAX], isR[EMAX], chg[EMAX], any_act = false;
         uint64_t mL[EMAX], mR[EMAX];
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) {
             const uint32_t i = (uint32_t)e * bs + tid;
             chg[e] = false;
             isL[e] = isR[e] = false;
+            any_act = any_act || act[e];
             if (act[e]) {
                 const uint32_t a = f[e] + 1, b = f[e] + (l[e] - f[e]) / 2, c = l[e] - 1;
-                uint32_t mpos;
-                uint2 qm;
-                if (qa[e].x < qb[e].x) {
-                    if (qb[e].x < qc[e].x) { mpos = b; qm = qb[e]; }
-                    else if (qa[e].x < qc[e].x) { mpos = c; qm = qc[e]; }
-                    else { mpos = a; qm = qa[e]; }
-                } else if (qa[e].x < qc[e].x) { mpos = a; qm = qa[e]; }
-                else if (qb[e].x < qc[e].x) { mpos = c; qm = qc[e]; }
-                else { mpos = b; qm = qb[e]; }
-                const uint32_t p = qm.x;
-                if (i == f[e]) { k[e] = qm.x; v[e] = qm.y; chg[e] = true; }
+                // median of (a, b, c) by key, std::__move_median_to_first's decision tree as selects
+                const bool ab = qa[e].x < qb[e].x, bc = qb[e].x < qc[e].x, ac = qa[e].x < qc[e].x;
+                const bool take_b = ab ? bc : (!ac && !bc), take_c = ab ? (!bc && ac) : (!ac && bc);
+                const uint32_t mpos = take_b ? b : (take_c ? c : a);
+                const uint32_t pk = take_b ? qb[e].x : (take_c ? qc[e].x : qa[e].x), pv = take_b ? qb[e].y : (take_c ? qc[e].y : qa[e].y);
+                if (i == f[e]) { k[e] = pk; v[e] = pv; chg[e] = true; }
                 else if (i == mpos) { k[e] = qf[e].x; v[e] = qf[e].y; chg[e] = true; }
                 const bool inr = i > f[e];
-                isL[e] = inr && !(k[e] < p);
-                isR[e] = inr && !(p < k[e]);
+                isL[e] = inr && !(k[e] < pk);
+                isR[e] = inr && !(pk < k[e]);
             }
             mL[e] = __ballot(isL[e]);
             mR[e] = __ballot(isR[e]);
             if (lane == 0 && (uint32_t)e < E) sTab[(uint32_t)e * nw + wave] = (uint32_t)__popcll(mL[e]) | ((uint32_t)__popcll(mR[e]) << 16);
         }
+        // a wavefront none of whose positions lies in a segment that is still being partitioned only keeps the barriers company
+        const bool wact = __ballot(any_act) != 0ull;
         __syncthreads();  // #1
-        // ---- phase 1: every wavefront scans the (row, wavefront) table itself: 64 entries, counts packed 16 | 16 ----
-        const uint32_t tv = sTab[lane];
-        const uint32_t inc = wave_incl_scan(tv);
-        const uint32_t totR = __builtin_amdgcn_readlane(inc, 63) >> 16;
+        if (tid == 0) { sTab[64] = 0; sTab[65] = 0; }  // (everybody has read the flags by now; they are raised again after barrier #3)
         uint32_t PL[EMAX], SG[EMAX];
+        if (wact) {
+            // ---- phase 1: every wavefront scans the (row, wavefront) table itself: 64 entries, counts packed 16 | 16 ----
+            const uint32_t tv = sTab[lane];
+            const uint32_t inc = wave_incl_scan(tv);
+            const uint32_t totR = __builtin_amdgcn_readlane(inc, 63) >> 16;
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
-            const uint32_t t = __builtin_amdgcn_readfirstlane(((uint32_t)e * nw + wave) & 63u);
-            const uint32_t it = __builtin_amdgcn_readlane(inc, t), xt = __builtin_amdgcn_readlane(tv, t);
-            PL[e] = ((it - xt) & 0xFFFFu) + (uint32_t)__popcll(mL[e] & lt);       // left stops before me
-            SG[e] = (totR - (it >> 16)) + (uint32_t)__popcll(mR[e] & gt);          // right stops after me
-        }
-        // ---- phase 2: stop lists (with their pairs) in global rank order, per-position counts, the keys the median move changed ----
-        if (tid == 0) { sTab[64] = 0; sTab[65] = 0; }
+            for (int e = 0; e < EMAX; ++e) {
+                const uint32_t t = __builtin_amdgcn_readfirstlane(((uint32_t)e * nw + wave) & 63u);
+                const uint32_t it = __builtin_amdgcn_readlane(inc, t), xt = __builtin_amdgcn_readlane(tv, t);
+                PL[e] = ((it - xt) & 0xFFFFu) + (uint32_t)__popcll(mL[e] & lt);       // left stops before me
+                SG[e] = (totR - (it >> 16)) + (uint32_t)__popcll(mR[e] & gt);          // right stops after me
+            }
+            // ---- phase 2: stop lists (with their pairs) in global rank order, per-position counts, the keys the median move changed ----
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
-            const uint32_t i = (uint32_t)e * bs + tid;
-            if ((uint32_t)e < E && i < n) {
-                sPS[i] = PL[e] | (SG[e] << 16);
-                if (isL[e]) sLL[PL[e]] = make_uint2(k[e], v[e]);
-                if (isR[e]) sRR[SG[e]] = make_uint2(k[e], v[e]);
-                if (chg[e]) sKV[i] = make_uint2(k[e], v[e]);
-                if (act[e] && i == f[e]) sCut[i] = 0xFFFFFFFFu;
+            for (int e = 0; e < EMAX; ++e) {
+                const uint32_t i = (uint32_t)e * bs + tid;
+                if ((uint32_t)e < E && i < n) {
+                    sPS[i] = PL[e] | (SG[e] << 16);
+                    if (isL[e]) sLL[PL[e]] = make_uint2(k[e], v[e]);
+                    if (isR[e]) sRR[SG[e]] = make_uint2(k[e], v[e]);
+                    if (chg[e]) sKV[i] = make_uint2(k[e], v[e]);
+                    if (act[e] && i == f[e]) sCut[i] = 0xFFFFFFFFu;
+                }
             }
         }
         __syncthreads();  // #2
         // ---- phase 3: swapped or not (no search), partner's pair, cut candidates ----
         bool sw[EMAX];
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
-            const uint32_t i = (uint32_t)e * bs + tid;
-            sw[e] = false;
-            bool cand = false;
-            if (act[e]) {
-                const uint32_t baseL = sPS[f[e] + 1] & 0xFFFFu, baseR = sPS[l[e] - 1] >> 16;
-                const uint32_t A = PL[e] - baseL, G = SG[e] - baseR;
-                const bool swL = isL[e] && G > A, swR = isR[e] && A > G;
-                sw[e] = swL || swR;
-                cand = (isL[e] && !swL) || swR;
-                if (sw[e]) {
-                    const uint2 kv = swL ? sRR[baseR + A] : sLL[baseL + G];
-                    k[e] = kv.x;
-                    v[e] = kv.y;
+        for (int e = 0; e < EMAX; ++e) sw[e] = false;
+        if (wact) {
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                const uint32_t i = (uint32_t)e * bs + tid;
+                bool cand = false;
+                if (act[e]) {
+                    const uint32_t baseL = sPS[f[e] + 1] & 0xFFFFu, baseR = sPS[l[e] - 1] >> 16;
+                    const uint32_t A = PL[e] - baseL, G = SG[e] - baseR;
+                    const bool swL = isL[e] && G > A, swR = isR[e] && A > G;
+                    sw[e] = swL || swR;
+                    cand = (isL[e] && !swL) || swR;
+                    if (sw[e]) {
+                        const uint2 kv = swL ? sRR[baseR + A] : sLL[baseL + G];
+                        k[e] = kv.x;
+                        v[e] = kv.y;
+                    }
                 }
-            }
-            const uint64_t cm = __ballot(cand);
-            if (cand) {  // the lowest candidate of my segment inside this wavefront speaks for it
-                const uint32_t wbase = (uint32_t)e * bs + (wave << 6);
-                const uint32_t s0 = f[e] + 1 > wbase ? f[e] + 1 - wbase : 0u;  // first lane of my segment's range in this wavefront
-                const uint64_t range = lt & ~((s0 >= 64u) ? ~0ull : ((1ull << s0) - 1ull));
-                if ((cm & range) == 0ull) atomicMin(&sCut[f[e]], i);
+                const uint64_t cm = __ballot(cand);
+                if (cand) {  // the lowest candidate of my segment inside this wavefront speaks for it
+                    const uint32_t wbase = (uint32_t)e * bs + (wave << 6);
+                    const uint32_t s0 = f[e] + 1 > wbase ? f[e] + 1 - wbase : 0u;  // first lane of my segment's range in this wavefront
+                    const uint64_t range = lt & ~((s0 >= 64u) ? ~0ull : ((1ull << s0) - 1ull));
+                    if ((cm & range) == 0ull) atomicMin(&sCut[f[e]], i);
+                }
             }
         }
         __syncthreads();  // #3
         // ---- phase 4: swapped keys land, segments split at the cut ----
-        bool more = false, heap = false;
+        if (wact) {
+            bool more = false, heap = false;
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
-            const uint32_t i = (uint32_t)e * bs + tid;
-            if (sw[e]) sKV[i] = make_uint2(k[e], v[e]);
-            if (act[e]) {
-                const uint32_t cut = sCut[f[e]];
-                if (i < cut) l[e] = cut;
-                else f[e] = cut;
-                d[e] -= 1;
-                const bool a2 = l[e] - f[e] > (uint32_t)kThreshold;
-                more = more || a2;
-                heap = heap || (a2 && d[e] == 0);
+            for (int e = 0; e < EMAX; ++e) {
+                const uint32_t i = (uint32_t)e * bs + tid;
+                if (sw[e]) sKV[i] = make_uint2(k[e], v[e]);
+                if (act[e]) {
+                    const uint32_t cut = sCut[f[e]];
+                    if (i < cut) l[e] = cut;
+                    else f[e] = cut;
+                    d[e] -= 1;
+                    const bool a2 = l[e] - f[e] > (uint32_t)kThreshold;
+                    more = more || a2;
+                    heap = heap || (a2 && d[e] == 0);
+                }
             }
+            if (__ballot(more) != 0ull && lane == 0) sTab[64] = 1;
+            if (__ballot(heap) != 0ull && lane == 0) sTab[65] = 1;
         }
-        if (__ballot(more) != 0ull && lane == 0) sTab[64] = 1;
-        if (__ballot(heap) != 0ull && lane == 0) sTab[65] = 1;
         __syncthreads();  // #4
     }
     if (tstamp && tid == 0) tstamp[15] = clock64();

@@ -2130,87 +2130,109 @@ __device__ __forceinline__ void rot_apply(float &x, float &y, float c, float s) 
     x = c * xi + s * yi;
     y = -s * xi + c * yi;
 }
-// Eigen 3.3 JacobiSVD<MatrixXf>(3x3, ComputeFullU): U (row-major) and singular values
-__device__ void jacobi_svd3(const float cov[9], float U[9], float sv[3]) {
+// Eigen 3.3 JacobiSVD<MatrixXf>(3x3, ComputeFullU): U (row-major) and singular values.
+// One (p, q) step of a sweep with COMPILE-TIME indices: W and U are nine scalars each and stay in registers (with run-time
+// indices the two arrays lived in scratch memory: every access a ~1 us round trip, 6.5 us per decomposition on one lane).
+template <int PP, int QQ>
+__device__ __forceinline__ void jacobi_step(float (&W)[9], float (&U)[9], float &maxDiag, bool &finished) {
     const float precision = 2.0f * 1.1920929e-07f;
     const float considerAsZero = 1.17549435e-38f;
+    const float threshold = fmaxf(considerAsZero, precision * maxDiag);
+    if (fabsf(W[PP * 3 + QQ]) > threshold || fabsf(W[QQ * 3 + PP]) > threshold) {
+        finished = false;
+        float m00 = W[PP * 3 + PP], m01 = W[PP * 3 + QQ], m10 = W[QQ * 3 + PP], m11 = W[QQ * 3 + QQ];
+        Rot rot1;
+        const float t = m00 + m11;
+        const float d = m10 - m01;
+        if (fabsf(d) < 1.17549435e-38f) {
+            rot1.s = 0.f;
+            rot1.c = 1.f;
+        } else {
+            const float u = t / d;
+            const float tmp = sqrtf(1.0f + u * u);
+            rot1.s = 1.0f / tmp;
+            rot1.c = u / tmp;
+        }
+        if (!(rot1.c == 1.f && rot1.s == 0.f)) {
+            rot_apply(m00, m10, rot1.c, rot1.s);
+            rot_apply(m01, m11, rot1.c, rot1.s);
+        }
+        const Rot jr = make_jacobi(m00, m01, m11);
+        const float oc = jr.c, os = -jr.s;
+        Rot jl;
+        jl.c = rot1.c * oc - rot1.s * os;
+        jl.s = rot1.c * os + rot1.s * oc;
+        if (!(jl.c == 1.f && jl.s == 0.f)) {
+#pragma unroll
+            for (int col = 0; col < 3; ++col) rot_apply(W[PP * 3 + col], W[QQ * 3 + col], jl.c, jl.s);
+#pragma unroll
+            for (int row = 0; row < 3; ++row) rot_apply(U[row * 3 + PP], U[row * 3 + QQ], jl.c, jl.s);
+        }
+        if (!(jr.c == 1.f && -jr.s == 0.f)) {
+#pragma unroll
+            for (int row = 0; row < 3; ++row) rot_apply(W[row * 3 + PP], W[row * 3 + QQ], jr.c, -jr.s);
+        }
+        maxDiag = fmaxf(maxDiag, fmaxf(fabsf(W[PP * 3 + PP]), fabsf(W[QQ * 3 + QQ])));
+    }
+}
+template <int A, int B>
+__device__ __forceinline__ void svd_swap_cols(float (&sv)[3], float (&U)[9]) {
+    const float ts = sv[A];
+    sv[A] = sv[B];
+    sv[B] = ts;
+#pragma unroll
+    for (int row = 0; row < 3; ++row) {
+        const float tu = U[row * 3 + A];
+        U[row * 3 + A] = U[row * 3 + B];
+        U[row * 3 + B] = tu;
+    }
+}
+__device__ __forceinline__ void jacobi_svd3(const float (&cov)[9], float (&U)[9], float (&sv)[3]) {
     float scale = 0.f;
+#pragma unroll
     for (int k = 0; k < 9; ++k) scale = fmaxf(scale, fabsf(cov[k]));
     if (scale == 0.f) scale = 1.f;
     float W[9];
+#pragma unroll
     for (int k = 0; k < 9; ++k) W[k] = cov[k] / scale;
+#pragma unroll
     for (int k = 0; k < 9; ++k) U[k] = (k % 4 == 0) ? 1.f : 0.f;
     float maxDiag = fmaxf(fabsf(W[0]), fmaxf(fabsf(W[4]), fabsf(W[8])));
     bool finished = false;
     int guard = 0;
-    while (!finished && guard++ < 1000) {
+    while (!finished && guard++ < 1000) {  // sweeps: (p, q) = (1, 0), (2, 0), (2, 1)
         finished = true;
-        for (int p = 1; p < 3; ++p) {
-            for (int q = 0; q < p; ++q) {
-                const float threshold = fmaxf(considerAsZero, precision * maxDiag);
-                if (fabsf(W[p * 3 + q]) > threshold || fabsf(W[q * 3 + p]) > threshold) {
-                    finished = false;
-                    float m00 = W[p * 3 + p], m01 = W[p * 3 + q], m10 = W[q * 3 + p], m11 = W[q * 3 + q];
-                    Rot rot1;
-                    const float t = m00 + m11;
-                    const float d = m10 - m01;
-                    if (fabsf(d) < 1.17549435e-38f) {
-                        rot1.s = 0.f;
-                        rot1.c = 1.f;
-                    } else {
-                        const float u = t / d;
-                        const float tmp = sqrtf(1.0f + u * u);
-                        rot1.s = 1.0f / tmp;
-                        rot1.c = u / tmp;
-                    }
-                    if (!(rot1.c == 1.f && rot1.s == 0.f)) {
-                        rot_apply(m00, m10, rot1.c, rot1.s);
-                        rot_apply(m01, m11, rot1.c, rot1.s);
-                    }
-                    const Rot jr = make_jacobi(m00, m01, m11);
-                    const float oc = jr.c, os = -jr.s;
-                    Rot jl;
-                    jl.c = rot1.c * oc - rot1.s * os;
-                    jl.s = rot1.c * os + rot1.s * oc;
-                    if (!(jl.c == 1.f && jl.s == 0.f)) {
-                        for (int col = 0; col < 3; ++col) rot_apply(W[p * 3 + col], W[q * 3 + col], jl.c, jl.s);
-                        for (int row = 0; row < 3; ++row) rot_apply(U[row * 3 + p], U[row * 3 + q], jl.c, jl.s);
-                    }
-                    if (!(jr.c == 1.f && -jr.s == 0.f)) {
-                        for (int row = 0; row < 3; ++row) rot_apply(W[row * 3 + p], W[row * 3 + q], jr.c, -jr.s);
-                    }
-                    maxDiag = fmaxf(maxDiag, fmaxf(fabsf(W[p * 3 + p]), fabsf(W[q * 3 + q])));
-                }
-            }
-        }
+        jacobi_step<1, 0>(W, U, maxDiag, finished);
+        jacobi_step<2, 0>(W, U, maxDiag, finished);
+        jacobi_step<2, 1>(W, U, maxDiag, finished);
     }
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float a = W[i * 3 + i];
         sv[i] = fabsf(a);
-        if (a < 0.f)
+        if (a < 0.f) {
+#pragma unroll
             for (int row = 0; row < 3; ++row) U[row * 3 + i] = -U[row * 3 + i];
-    }
-    for (int i = 0; i < 3; ++i) sv[i] *= scale;
-    for (int i = 0; i < 3; ++i) {
-        int pos = 0;
-        float mx = sv[i];
-        for (int k = i + 1; k < 3; ++k)
-            if (sv[k] > mx) {
-                mx = sv[k];
-                pos = k - i;
-            }
-        if (mx == 0.f) break;
-        if (pos) {
-            pos += i;
-            const float ts = sv[i];
-            sv[i] = sv[pos];
-            sv[pos] = ts;
-            for (int row = 0; row < 3; ++row) {
-                const float tu = U[row * 3 + i];
-                U[row * 3 + i] = U[row * 3 + pos];
-                U[row * 3 + pos] = tu;
-            }
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sv[i] *= scale;
+    // singular values in decreasing order (Eigen: selection by maxCoeff over the tail, first maximum wins; stops at a zero maximum)
+    {
+        int pos = 0;
+        float mx = sv[0];
+        if (sv[1] > mx) { mx = sv[1]; pos = 1; }
+        if (sv[2] > mx) { mx = sv[2]; pos = 2; }
+        if (mx == 0.f) return;
+        if (pos == 1) svd_swap_cols<0, 1>(sv, U);
+        else if (pos == 2) svd_swap_cols<0, 2>(sv, U);
+    }
+    {
+        float mx = sv[1];
+        bool second = false;
+        if (sv[2] > mx) { mx = sv[2]; second = true; }
+        if (mx == 0.f) return;
+        if (second) svd_swap_cols<1, 2>(sv, U);
     }
 }
 

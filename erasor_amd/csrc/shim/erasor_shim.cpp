@@ -197,7 +197,19 @@ void ERASOR::run(int version) {
     fetch_cloud(h, ERASOR_CLOUD_STATIC_ESTIMATE, arranged_);
     status.assign((size_t)P_.num_rings * P_.num_sectors, 0.0);
     check(h, erasor_hip_get_status(h, status.data()), "erasor_hip_get_status");
+    n_ambiguous = res.n_ambiguous;
+    n_neg_sector = res.n_neg_sector;
+    n_degenerate_plane = res.n_degenerate_plane;
+    if (res.n_ambiguous)
+        fprintf(stderr, "[erasor shim] %u point(s) within 1e-11 of a sector boundary: their bin is not provably the reference's (device atan2 vs glibc)\n",
+                res.n_ambiguous);
+    last_run_ = version == 2 ? 0 : 1;
+    if (keep_rpods) fetch_rpods();
+}
+void ERASOR::fetch_rpods() {
     // the public R-PODs (erasor.h:143-145)
+    erasor_hip_handle *h = last_run_ >= 0 ? h_[last_run_] : nullptr;
+    if (!h) return;
     const size_t B = (size_t)P_.num_rings * P_.num_sectors;
     std::vector<uint32_t> begin(B), count(B);
     R_POD *pods[3] = {&r_pod_map, &r_pod_curr, &r_pod_selected};
@@ -369,6 +381,9 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
     }
     has_next_ = false;
     check(h_, erasor_hip_step(h_, scan, lidar.size(), Tl, Tb, To, &last), "erasor_hip_step");
+    if (last.n_ambiguous)  // (never seen on transformed clouds; said aloud because bin equality is only PROVABLE when it is zero)
+        fprintf(stderr, "[erasor shim] node %d: %u point(s) within 1e-11 of a sector boundary: their bin is not provably the reference's (device atan2 vs glibc)\n",
+                seq, last.n_ambiguous);
     fetch_cloud(h_, ERASOR_CLOUD_MAP_REJECTED, map_rejected);
     fetch_cloud(h_, ERASOR_CLOUD_CURR_REJECTED, query_rejected);
     ++num_processed;

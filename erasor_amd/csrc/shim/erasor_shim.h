@@ -79,6 +79,15 @@ public:
     // erasor.h:143-145, filled by compare_*: r_pod[ring][sector]; Bin::points are the device's bin lists (egocentric),
     // max_h / min_h / is_occupied / status as the reference leaves them (x, y: the bin's highest point, erasor.cpp:91-94)
     R_POD r_pod_map, r_pod_curr, r_pod_selected;
+    // Rebuilding the three R-PODs costs six read-backs (each with a stream synchronisation) and a per-point host loop after
+    // EVERY compare_* call.  A caller that only wants get_static_estimate / get_outliers sets this to false; fetch_rpods()
+    // fills them on demand for the last compare_* call.
+    bool keep_rpods = true;
+    void fetch_rpods();
+    // guard counters of the last compare_* call (erasor_step_result): a non-zero n_ambiguous means a point sat within 1e-11 of a
+    // sector boundary, where the device's atan2 may round differently from glibc's -- bin membership of that point is then not
+    // provably the reference's
+    unsigned n_ambiguous = 0, n_neg_sector = 0, n_degenerate_plane = 0;
     // public members of the reference (erasor.h:127,139-141)
     pcl::PointCloud<pcl::PointXYZI> ground_viz, debug_curr_rejected, debug_map_rejected, map_complement;
     // r_pod_selected[r][theta].status after compare_* (erasor.h:145), index = ring*num_sectors + sector
@@ -89,6 +98,7 @@ private:
     erasor_params P_;
     int device_;
     erasor_hip_handle *h_[2] = {nullptr, nullptr};  // one handle per algorithm version
+    int last_run_ = -1;                             // which of the two the last compare_* call used
     pcl::PointCloud<pcl::PointXYZI> map_voi_, query_voi_, arranged_;
 };
 

@@ -51,9 +51,11 @@ public:
         pub_viz_bin_marker_ = nh.advertise<jsk_recognition_msgs::PolygonArray>("/SCDR/debug/polygons_marker", 100);
         set_params();
         updater_.reset(new OfflineMapUpdater(cfg_));  // loads /MapUpdater/initial_map_path (OMU.cpp:107-167)
-        if (!cfg_.is_large_scale && pub_map_init_.getNumSubscribers() > 0) {
+        if (!cfg_.is_large_scale) {
+            // the reference keeps map_init_ from load time on and publishes it at load and after every step (OMU.cpp:162-165,
+            // 322-324); a subscriber cannot be there yet inside the constructor, so the copy is taken unconditionally
             updater_->get_map(map_init_);
-            publish(map_init_, pub_map_init_);  // OMU.cpp:163-166
+            publish(map_init_, pub_map_init_);
         }
     }
     void save_static_map(float voxel_size) { updater_->save_static_map(voxel_size); }

@@ -136,7 +136,10 @@ int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n
  *   for k: erasor_hip_prefetch_scan(h, scan[k+2]);  erasor_hip_step*(h, scan[k], ...);      (or one ahead: k+1)
  * The following step must pass the same pointer, size and T_lidar2body (otherwise every announcement is dropped;
  * their chains have run out when that step returns).  A host
- * scan is copied at once; a device scan (src_is_device != 0) is read in place and must stay valid until the step that
+ * scan is copied at once, so the buffer MUST NOT CHANGE between the announcement and the step that consumes it: the step
+ * recognises its scan by pointer, size, T_lidar2body and a fingerprint of ~258 sampled points -- a buffer refilled at the same
+ * address that differs only in unsampled points would be taken for the announced scan and the step would run on the copy
+ * (hashing all 2 MB would cost more than the step's own enqueue).  A device scan (src_is_device != 0) is read in place and must stay valid until the step that
  * consumes it has returned.  Up to three scans can be announced ahead of a step (three query sides); the chains of
  * different scans run on their own streams.  When every side is taken, a new announcement re-uses the side of the last
  * finished step: its query-derived outputs (erasor_hip_get_cloud / _get_bins) are gone from then on. */

@@ -545,6 +545,51 @@ def test_full_size_parity_and_properties(gpu_mod):
         compare_step(g, o, rg, ro, full=(k == 0))
 
 
+def test_full_size_bench_call_pattern_device_scans_two_nodes_ahead(gpu_mod):
+    """exactly what bench.py times (Sequence.prime / Sequence.run): the ~10 M-point map set from a device buffer, scans resident
+    in HBM and read in place, every node announced TWO ahead with its pose (erasor_hip_prefetch_node: the query chains of the
+    next two scans run beside the step, the next step's VoI split is launched behind the step's last kernel), steps through
+    erasor_hip_step_device -- every step's results and the map it leaves against the oracle."""
+    torch = pytest.importorskip("torch")
+    if os.environ.get("ERASOR_TEST_SIMT_LIB") or not torch.cuda.is_available():
+        pytest.skip("needs device buffers (the CPU stand-in runs this pattern in tests/simt_full_step.py)")
+    from oracle import orc
+    w = synth.World(seed=20210305 + 5, length=1000.0, n_streets=5, street_gap=50.0, n_moving=10, n_peds=6)
+    lid = synth.Lidar.hdl64(2000)
+    m = w.sample_map(spacing=0.2, frames=range(0, 320, 2))
+    assert len(m) > 9_000_000
+    p = orc.params_default()
+    synth.apply_params(p, "05", max_range=80.0, num_rings=20, num_sectors=108)
+    g, o = make_pair(gpu_mod, p)
+    dev = torch.device("cuda", 0)
+    d_map = torch.from_numpy(m).to(dev)
+    g.set_map_device(d_map.data_ptr(), len(m))
+    o.set_map(m)
+    jr = np.random.default_rng(1234)
+    Tl = gpu_mod.c_mat(gpu_mod.geopose2eigen([0, 0, synth.LIDAR_HEIGHT, 0, 0, 0, 1]))
+    n, LA = 6, 2
+    scans, Tb, To = [], [], []
+    for k in range(n):
+        p7 = w.pose(k, 1.0, x0=0.0, jitter_rng=jr)
+        scans.append(w.cast(p7, lid, k))
+        Tb.append(gpu_mod.geopose2eigen(p7))
+        To.append(gpu_mod.invert_rigid(Tb[-1]))
+    d_scans = [torch.from_numpy(s).to(dev) for s in scans]
+    torch.cuda.synchronize()
+    cTb, cTo = [gpu_mod.c_mat(t) for t in Tb], [gpu_mod.c_mat(t) for t in To]
+    for j in range(LA):
+        g.prefetch_device(d_scans[j].data_ptr(), len(scans[j]), Tl, cTb[j])
+    for k in range(n):
+        if k + LA < n:
+            g.prefetch_device(d_scans[k + LA].data_ptr(), len(scans[k + LA]), Tl, cTb[k + LA])
+        rg = g.step_device(d_scans[k].data_ptr(), len(scans[k]), Tl, cTb[k], cTo[k])
+        ro = o.step(scans[k], np.asarray(Tl, np.float32), Tb[k], To[k])
+        assert rg.n_reverted_bins > 0 or k == 0
+        compare_step(g, o, rg, ro, full=(k == n - 1))
+    launched, used = g.ahead_split_counts()
+    assert launched == n - 1 and used >= 1, (launched, used)
+
+
 @pytest.mark.parametrize("large_scale", [0, 1])
 def test_config4_dense_40M_map_parity(gpu_mod, large_scale):
     """BASELINE config 4: config/large_scale_05.yaml on a ~40 M-point un-voxelised map (640 MB > the 256 MiB L3), with

@@ -21,3 +21,8 @@ timeout 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/rp_fetch -- $
 timeout 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -- $BENCH --steps 6 --no-cpu-baseline > /dev/null 2>&1
 cd $ROOT && python tools/summarize_profiles.py /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write $OUT
 ls -la $OUT
+# the files bench.py reads (roofline.traffic, rocprofv3_kernel_avg_us, dominant_kernel): copies of this tag, with the build they describe
+SUF=""; case "$EXTRA" in *large_scale_05*) SUF="_large_scale_05";; esac
+cp $OUT/rocprofv3_kernel_stats.csv $ROOT/gpurun_out/kernel_stats_latest$SUF.csv 2>/dev/null
+cp $OUT/pmc_latest.json $ROOT/gpurun_out/pmc_latest$SUF.json 2>/dev/null
+cp $OUT/latest_meta.json $ROOT/gpurun_out/latest_meta$SUF.json 2>/dev/null

@@ -50,8 +50,19 @@ if fs:
         "gfx950_correction": "FETCH_SIZE x2 (128-B requests tallied at 64 B)",
         "traffic_bytes_per_launch": int(fs["mean_KiB"] * 1024 * 2 + (ws["mean_KiB"] * 1024 if ws else 0)),
     }
+    # every kernel's corrected traffic per launch (bench.py reports the figure of the kernel that tops the GPU-time table)
+    latest["per_kernel_traffic_bytes"] = {
+        k.replace("void ", "").replace("ek::", "").split("<")[0]: int(v["mean_KiB"] * 1024 * 2 + (res["WRITE_SIZE"].get(k, {}).get("mean_KiB", 0.0)) * 1024)
+        for k, v in res["FETCH_SIZE"].items() if "ek::" in k}
     cal = res["FETCH_SIZE"].get("ek::k_store_outskirts")
     if cal:
         latest["calibration_k_store_outskirts_fetch_KiB"] = cal["max_KiB"]
     json.dump(latest, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
+# which build these passes describe: bench.py prints the committed counters only while the device sources are the same
+import hashlib
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+hh = hashlib.sha256()
+for f in ("erasor_hip.hip", "kernels.hip.h", "exact_sort.hip.h", "exact_sort_core.h"):
+    hh.update(open(os.path.join(root, "erasor_amd", "csrc", f), "rb").read())
+json.dump({"device_source_sha16": hh.hexdigest()[:16]}, open(os.path.join(out, "latest_meta.json"), "w"))
 print(json.dumps({"kernel_stats": ks, "voi_split_fetch": fs, "voi_split_write": ws}))
