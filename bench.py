@@ -72,6 +72,9 @@ def parse_args():
     ap.add_argument("--lookahead", type=int, default=2, choices=[1, 2], help="scans announced ahead (erasor_hip_prefetch_scan)")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not announce the next scan (erasor_hip_prefetch_scan): every step runs its own query chain first")
+    ap.add_argument("--interleave", choices=["async", "threads", "off"], default="async",
+                    help="seq-per-gpu with several sequences on one rank: async = one host thread keeps every sequence's step in flight "
+                         "(erasor_hip_step_async / _wait); threads = one host thread per sequence, blocking steps; off = one sequence after the other")
     ap.add_argument("--eval", action="store_true", help="seq-per-gpu: PR/RR of every sequence's final map (erasor_amd.evalmap)")
     return ap.parse_args()
 
@@ -232,6 +235,16 @@ class Sequence:
         if self.lookahead and k + self.LA < self.n_frames:
             g.prefetch_device(self.d_ptr[k + self.LA], self.n_pts[k + self.LA], self.c_Tl, self.c_Tb[k + self.LA] if self.with_pose else None)
         return g.step_device(self.d_ptr[k], self.n_pts[k], self.c_Tl, self.c_Tb[k], self.c_To[k])
+
+    def run_async(self, k):
+        """the same step in two halves (erasor_hip_step_async / erasor_hip_step_wait): announce, enqueue, return"""
+        g = self.g
+        if self.lookahead and k + self.LA < self.n_frames:
+            g.prefetch_device(self.d_ptr[k + self.LA], self.n_pts[k + self.LA], self.c_Tl, self.c_Tb[k + self.LA] if self.with_pose else None)
+        g.step_async(self.d_ptr[k], self.n_pts[k], self.c_Tl, self.c_Tb[k], self.c_To[k], device=True)
+
+    def wait(self):
+        return self.g.step_wait()
 
 
 def cpu_baseline(args, P, m, seq, l2b7, gpu_results=None, gpu_final=None):
@@ -429,19 +442,63 @@ def main():
     t_start = time.perf_counter()
     last = None
     totals = np.zeros(6, np.int64)  # steps, map_rejected, reverted_bins, final map size, static, dynamic
-    for si, (_, s) in enumerate(seqs):
+    interleave = args.interleave if len(seqs) > 1 else "off"
+    if interleave == "async":
+        # independent sequences are independent updaters: ONE host thread keeps a step of every sequence in flight
         for k in range(W, W + K):
-            if si == 0:
-                split_bytes.append(s.g.voi_split_bytes())
-            last = s.run(k)  # synchronous: returns after the step's results are on the host
-            if si == 0:
-                step_results.append(last)
-            totals[0] += 1
-            totals[1] += last.n_map_rejected
-            totals[2] += last.n_reverted_bins
-        totals[3] += last.n_map_out
-        totals[4] += last.n_static
-        totals[5] += last.n_dynamic
+            for si, (_, s) in enumerate(seqs):
+                if si == 0:
+                    split_bytes.append(s.g.voi_split_bytes())
+                s.run_async(k)
+            for si, (_, s) in enumerate(seqs):
+                last = s.wait()
+                if si == 0:
+                    step_results.append(last)
+                totals[0] += 1
+                totals[1] += last.n_map_rejected
+                totals[2] += last.n_reverted_bins
+        for _, s in seqs:
+            r_ = s.g.last_result()
+            totals[3] += r_.n_map_out
+            totals[4] += r_.n_static
+            totals[5] += r_.n_dynamic
+    elif interleave == "threads":
+        import threading
+        per_seq = [None] * len(seqs)
+
+        def drive(i, s):
+            t = np.zeros(6, np.int64)
+            r_ = None
+            for k in range(W, W + K):
+                r_ = s.run(k)  # (ctypes releases the GIL for the call: the host-side enqueue of the sequences runs in parallel)
+                t[0] += 1
+                t[1] += r_.n_map_rejected
+                t[2] += r_.n_reverted_bins
+            t[3], t[4], t[5] = r_.n_map_out, r_.n_static, r_.n_dynamic
+            per_seq[i] = (t, r_)
+
+        ths = [threading.Thread(target=drive, args=(i, s)) for i, (_, s) in enumerate(seqs)]
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join()
+        for t, r_ in per_seq:
+            totals += t
+            last = r_
+    else:
+        for si, (_, s) in enumerate(seqs):
+            for k in range(W, W + K):
+                if si == 0:
+                    split_bytes.append(s.g.voi_split_bytes())
+                last = s.run(k)  # synchronous: returns after the step's results are on the host
+                if si == 0:
+                    step_results.append(last)
+                totals[0] += 1
+                totals[1] += last.n_map_rejected
+                totals[2] += last.n_reverted_bins
+            totals[3] += last.n_map_out
+            totals[4] += last.n_static
+            totals[5] += last.n_dynamic
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -567,7 +624,8 @@ def main():
                    "max_range": float(P.max_range), "is_large_scale": int(P.is_large_scale), "mode": args.mode,
                    "sharding": ("scan-parallel replicas, one RCCL broadcast of the map, no data-path collective" if args.mode == "replicas"
                                 else "one KITTI-shaped sequence per GPU (00/01/02/05/07 dealt round-robin), no map exchange"),
-                   "lookahead_scans": first.LA if first.lookahead else 0},
+                   "lookahead_scans": first.LA if first.lookahead else 0,
+                   "sequences_on_this_rank": len(seqs), "interleave": interleave},
         "map_points_x_scans_per_sec": round(value * N_map, 1),
         "ms_per_step_without_lookahead": None if sync_ms is None else round(sync_ms, 4),
         "roofline": roofline, "cpu_baseline": cpu, "cpu_port": cpu_port, "host": host_identity(),

@@ -215,6 +215,31 @@ class Erasor:
         self._check(lib().erasor_hip_step_device(self._h, C.c_void_p(dptr), C.c_size_t(n), _m(T_l2b), _m(T_b2o), _m(T_o2b), C.byref(res)))
         return res
 
+    def step_async(self, scan, n=None, T_l2b=None, T_b2o=None, T_o2b=None, device=False):
+        """first half of a step (erasor_hip_step_async): everything is enqueued, nothing is waited for.  scan: a host array, or a
+        device pointer with its point count (device=True).  step_wait() collects the results."""
+        if device:
+            ptr, cnt = C.c_void_p(scan), C.c_size_t(n)
+        else:
+            scan = _f32(scan).reshape(-1, 4)
+            self._fly_keep = scan  # (must stay valid until step_wait has returned)
+            ptr, cnt = _p(scan), C.c_size_t(len(scan))
+        self._check(lib().erasor_hip_step_async(self._h, ptr, cnt, C.c_int(1 if device else 0), _m(T_l2b), _m(T_b2o), _m(T_o2b)))
+
+    def step_wait(self):
+        res = StepResult()
+        self._check(lib().erasor_hip_step_wait(self._h, C.byref(res)))
+        self._fly_keep = None
+        self._last_res = res
+        return res
+
+    def last_result(self):
+        """erasor_step_result of the last collected step (kept by the wrapper)"""
+        return self._last_res
+
+    def step_done(self):
+        return bool(lib().erasor_hip_step_done(self._h))
+
     # -- read-back --
     def get_cloud(self, which):
         n = C.c_size_t(0)
@@ -322,6 +347,18 @@ class Erasor:
 
     def stream(self):
         return lib().erasor_hip_stream(self._h)
+
+    def device_array(self, a):
+        """a host array copied into a device buffer of the handle's device (erasor_hip_device_alloc / _upload); returns the
+        device pointer.  Freed with device_free (or with the process)."""
+        a = np.ascontiguousarray(a)
+        p = C.c_void_p()
+        self._check(lib().erasor_hip_device_alloc(self._h, C.c_size_t(a.nbytes), C.byref(p)))
+        self._check(lib().erasor_hip_device_upload(self._h, p, _p(a), C.c_size_t(a.nbytes)))
+        return p.value
+
+    def device_free(self, ptr):
+        self._check(lib().erasor_hip_device_free(self._h, C.c_void_p(ptr)))
 
     # -- test hooks --
     def probe_math(self, x, y):

@@ -45,6 +45,58 @@ struct DBuf {
 
 }  // namespace
 
+// ---- a launch sequence as a hipGraph -------------------------------------------------------------------------------------------
+// A query chain is ~45 launches of a fixed topology; enqueued one by one they cost the host ~130 us per scan (2.3-3 us each) --
+// two thirds of a step's host time, and THE limit once several sequences share one host thread (erasor_hip_step_async).  The chain
+// is therefore RECORDED (kernel, grid, arguments; nothing launched), kept as an instantiated graph per query side and segment, and
+// replayed with hipGraphLaunch; arguments that differ from the recorded ones (the scan's address and size) are patched into the
+// executable graph node by node.  A different kernel sequence (another sort depth, the pass-through chain) rebuilds the graph.
+struct GNode {
+    const void *func = nullptr;
+    dim3 grid, block;
+    std::vector<uint8_t> blob;   // the arguments, each converted to the kernel's parameter type, at aligned offsets
+    std::vector<uint32_t> off;
+};
+struct GSeg {
+    std::vector<GNode> nodes;
+#ifndef ERASOR_NO_HIPGRAPH
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<hipGraphNode_t> gnodes;
+#endif
+    uint64_t n_launch = 0, n_rebuild = 0, n_patch = 0;
+};
+template <class... KP, class... A>
+static void rec_add(std::vector<GNode> *rec, void (*kern)(KP...), dim3 g, dim3 b, A &&...a) {
+    static_assert(sizeof...(KP) == sizeof...(A), "argument count");
+    rec->emplace_back();
+    GNode &n = rec->back();
+    n.func = (const void *)kern;
+    n.grid = g;
+    n.block = b;
+    size_t off = 0;
+    auto put = [&](auto v) {
+        using T = decltype(v);
+        off = (off + alignof(T) - 1) & ~(alignof(T) - 1);
+        n.off.push_back((uint32_t)off);
+        n.blob.resize(off + sizeof(T));
+        memcpy(&n.blob[off], &v, sizeof(T));
+        off += sizeof(T);
+    };
+    (put(static_cast<KP>(std::forward<A>(a))), ...);
+}
+
+static void graph_release(GSeg &seg) {
+#ifndef ERASOR_NO_HIPGRAPH
+    if (seg.exec) (void)hipGraphExecDestroy(seg.exec);
+    if (seg.graph) (void)hipGraphDestroy(seg.graph);
+    seg.exec = nullptr;
+    seg.graph = nullptr;
+    seg.gnodes.clear();
+#endif
+    seg.nodes.clear();
+}
+
 // The query side of a step (see erasor_hip_handle::q)
 static constexpr int NSIDE = 3;  // the scan being stepped + two announced ahead
 struct QSide {
@@ -79,6 +131,7 @@ struct QSide {
     bool used = false;                // ev_done has been recorded at least once
     bool pose_valid = false;          // the scan was announced together with its pose (erasor_hip_prefetch_node)
     double pose_x = 0, pose_y = 0;    // T_body2origin translation (OMU.cpp:246-247): all fetch_VoI needs
+    GSeg gseg[2];                     // the chain as two graphs: up to the voxel keys (ev_keys), the rest (ev_done)
 };
 
 struct erasor_hip_handle {
@@ -91,6 +144,8 @@ struct erasor_hip_handle {
     hipStream_t qstream[2] = {nullptr, nullptr};
     unsigned n_chain = 0;
     hipStream_t cur = nullptr;      // stream LAUNCH() currently targets
+    std::vector<GNode> *rec = nullptr;  // non-null: LAUNCH() records instead of launching (the query chain as a graph)
+    bool use_graph = false;
     int pend[2] = {0, 0};           // query sides with a prefetched chain in flight, oldest first
     int npend = 0;
     // a scan announced by erasor_hip_prefetch_scan whose chain is not enqueued yet (the step in flight goes first)
@@ -125,6 +180,19 @@ struct erasor_hip_handle {
     DBuf<uint32_t> mb_hist, mb_tot;   // the map's bucketing as a counting sort: [tiles][B + 1] table, [B + 1] totals
     DBuf<unsigned long long> lab_slots;  // [16][8] label tallies of the assemble kernels (one cache line per slot)
     unsigned long long step_seq = 0;  // steps issued so far (k_step_end echoes it into the pinned block)
+    // a step that has been enqueued (erasor_hip_step_async) and not collected yet (erasor_hip_step_wait)
+    struct {
+        bool active = false;
+        unsigned long long seq = 0;
+        uint64_t n_map_in = 0;
+        uint32_t ns = 0;
+        const uint32_t *sm_keys = nullptr;
+        int flags = 0;
+        const void *scan_src = nullptr;
+        size_t n_scan = 0;
+        bool src_is_device = false;
+        float Tl[16], Tb[16], To[16];
+    } fly;
     HostOut *pin = nullptr;         // pinned host block k_step_end reports into
     int bank = 0;                   // scratch bank of scan/radix helpers (0: query chains, 1: map chain)
     std::string err;
@@ -158,6 +226,7 @@ struct erasor_hip_handle {
     DBuf<uint32_t> rk_a, rk_b, rv_a, rv_b, hist, hist_l, hist_t, hist2, hist2_l, hist2_t, dn;
     // ---- bins ----
     DBuf<uint32_t> moff, mcnt, rev_idx, rev_list, vox_off, nvox, ng, out_off, ground_off, rej_off, crej_off;
+    DBuf<uint32_t> out_off0, rev_before;  // the layout's R-GPF-independent part (k_srt4 -> k_assemble_map<., true>)
     DBuf<float> mmin, mmax, plane_n;
     DBuf<double> plane_d;
     DBuf<uint8_t> st1, status, action;
@@ -190,6 +259,15 @@ struct erasor_hip_handle {
 };
 
 #define Q(h) ((h)->q[(h)->qi])
+// between erasor_hip_step_async and erasor_hip_step_wait the handle takes no other call: the step's scratch, query side and
+// host mirror are in use
+#define NOFLY(h)                                                                                              \
+    do {                                                                                                      \
+        if ((h) && (h)->fly.active) {                                                                         \
+            (h)->err = "a step is in flight (erasor_hip_step_async): call erasor_hip_step_wait first";        \
+            return ERASOR_E_STATE;                                                                            \
+        }                                                                                                     \
+    } while (0)
 
 namespace {
 
@@ -269,6 +347,10 @@ void prof_collect(erasor_hip_handle *h, bool force = false) {
 // kernel launch with optional event bracketing on the handle's stream
 #define LAUNCH(h, name, kern, grid, block, ...)                                   \
     do {                                                                          \
+        if ((h)->rec) {                                                           \
+            rec_add((h)->rec, kern, dim3(grid), dim3(block), __VA_ARGS__);        \
+            break;                                                                \
+        }                                                                         \
         PendingEvt pe_;                                                           \
         const bool prof_ = (h)->prof == 1 || ((h)->prof == 2 && strncmp(name, "voi_split", 9) == 0); \
         if (prof_) {                                                              \
@@ -383,6 +465,7 @@ int alloc_bins(erasor_hip_handle *h) {
     rc |= ensure(h, h->moff, B + 2) | ensure(h, h->mcnt, B);
     rc |= ensure(h, h->mmin, B) | ensure(h, h->mmax, B);
     rc |= ensure(h, h->st1, B) | ensure(h, h->status, B) | ensure(h, h->action, B) | ensure(h, h->rev_idx, B) | ensure(h, h->rev_list, B);
+    rc |= ensure(h, h->out_off0, B + 2) | ensure(h, h->rev_before, B + 2);
     rc |= ensure(h, h->vox_off, B) | ensure(h, h->nvox, B) | ensure(h, h->ng, B) | ensure(h, h->out_off, B) | ensure(h, h->ground_off, B);
     rc |= ensure(h, h->rej_off, B) | ensure(h, h->crej_off, B);
     rc |= ensure(h, h->plane_n, B * (size_t)std::max(h->P.gf_iter, 1) * 3) | ensure(h, h->plane_d, B * (size_t)std::max(h->P.gf_iter, 1));
@@ -680,6 +763,12 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
     }
     memset(h->pin, 0, sizeof(HostOut));
     h->cur = h->stream;
+#ifndef ERASOR_NO_HIPGRAPH
+    // measured on MI355X / ROCm 7.2 (gpurun_out/r03f): replaying the chain as two graphs costs the host 88-95 us per scan instead of
+    // 120-130 us launch by launch, yet end to end it is no faster: one sequence 0.276-0.282 vs 0.271-0.275 ms per scan, five
+    // interleaved sequences (erasor_hip_step_async) 3000-3100 vs 3540-3590 scans/s.  OFF unless ERASOR_HIP_GRAPH=1.
+    h->use_graph = getenv("ERASOR_HIP_GRAPH") != nullptr;
+#endif
     if (alloc_bins(h)) {
         erasor_hip_destroy(h);
         return ERASOR_E_NO_DEVICE;
@@ -706,6 +795,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->rejected_src); release(h->grank); release(h->glist); release(h->gflag);
     release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->lab_slots); release(h->mb_hist); release(h->mb_tot); release(h->mg_curr); release(h->mg_map); release(h->mg_done); release(h->mg_tmp);
     release(h->moff); release(h->mcnt); release(h->rev_idx); release(h->rev_list); release(h->vox_off);
+    release(h->out_off0); release(h->rev_before);
     release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
     release(h->mmin); release(h->mmax); release(h->plane_n); release(h->plane_d);
     release(h->st1); release(h->status); release(h->action);
@@ -715,6 +805,8 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     for (int k = 0; k < NSIDE; ++k) {
         if (h->q[k].ev_keys) (void)hipEventDestroy(h->q[k].ev_keys);
         if (h->q[k].ev_done) (void)hipEventDestroy(h->q[k].ev_done);
+        graph_release(h->q[k].gseg[0]);
+        graph_release(h->q[k].gseg[1]);
     }
     for (int k = 0; k < 2; ++k)
         if (h->qstream[k]) (void)hipStreamDestroy(h->qstream[k]);
@@ -726,6 +818,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
 const char *erasor_hip_last_error(const erasor_hip_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
 static int set_map_common(erasor_hip_handle *h, const void *src, size_t n, bool src_is_device) {
+    NOFLY(h);
     if (h) ++h->store_epoch;
     if (!h) return ERASOR_E_INVALID;
     if (!src && n) return ERASOR_E_INVALID;
@@ -839,6 +932,77 @@ static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf, co
 
 enum { STEP_QUERY_PREVOXELIZED = 1, STEP_VOI_EVERYTHING = 2, STEP_RETRIED = 4 };
 
+// Replays what LAUNCH() has recorded into `rec` as a graph on `stream`: first use (or another kernel sequence) builds and
+// instantiates it, afterwards only the nodes whose grid or arguments differ are patched.  Any failure of the graph API falls back
+// to launching the recorded kernels one by one (same order, same stream).
+static int graph_flush(erasor_hip_handle *h, GSeg &seg, std::vector<GNode> &rec, hipStream_t stream) {
+#ifndef ERASOR_NO_HIPGRAPH
+    if (rec.empty()) return ERASOR_OK;
+    std::vector<void *> ptrs;
+    auto params = [&](GNode &n) {
+        hipKernelNodeParams p;
+        memset(&p, 0, sizeof(p));
+        p.func = const_cast<void *>(n.func);
+        p.gridDim = n.grid;
+        p.blockDim = n.block;
+        p.sharedMemBytes = 0;
+        ptrs.resize(n.off.size());
+        for (size_t k = 0; k < n.off.size(); ++k) ptrs[k] = &n.blob[n.off[k]];
+        p.kernelParams = ptrs.data();
+        p.extra = nullptr;
+        return p;
+    };
+    bool same = seg.exec != nullptr && seg.nodes.size() == rec.size();
+    for (size_t i = 0; same && i < rec.size(); ++i) same = seg.nodes[i].func == rec[i].func && seg.nodes[i].blob.size() == rec[i].blob.size();
+    bool ok = true;
+    if (!same) {
+        graph_release(seg);
+        ok = hipGraphCreate(&seg.graph, 0) == hipSuccess;
+        hipGraphNode_t prev = nullptr;
+        for (size_t i = 0; ok && i < rec.size(); ++i) {
+            hipKernelNodeParams p = params(rec[i]);
+            hipGraphNode_t gn = nullptr;
+            ok = hipGraphAddKernelNode(&gn, seg.graph, prev ? &prev : nullptr, prev ? 1 : 0, &p) == hipSuccess;
+            seg.gnodes.push_back(gn);
+            prev = gn;
+        }
+        ok = ok && hipGraphInstantiate(&seg.exec, seg.graph, nullptr, nullptr, 0) == hipSuccess;
+        if (ok) seg.nodes = std::move(rec);
+        ++seg.n_rebuild;
+    } else {
+        for (size_t i = 0; ok && i < rec.size(); ++i) {
+            GNode &o = seg.nodes[i], &n = rec[i];
+            if (o.grid.x == n.grid.x && o.grid.y == n.grid.y && o.grid.z == n.grid.z && o.block.x == n.block.x && o.blob == n.blob) continue;
+            hipKernelNodeParams p = params(n);
+            ok = hipGraphExecKernelNodeSetParams(seg.exec, seg.gnodes[i], &p) == hipSuccess;
+            o = std::move(n);
+            ++seg.n_patch;
+        }
+    }
+    if (ok) ok = hipGraphLaunch(seg.exec, stream) == hipSuccess;
+    if (ok) {
+        ++seg.n_launch;
+        rec.clear();
+        return ERASOR_OK;
+    }
+    (void)hipGetLastError();
+    std::vector<GNode> &src = rec.empty() ? seg.nodes : rec;  // (after a failed patch / launch the recorded arguments are in seg.nodes)
+    for (GNode &n : src) {
+        hipKernelNodeParams p = params(n);
+        if (hipLaunchKernel(p.func, p.gridDim, p.blockDim, p.kernelParams, 0, stream) != hipSuccess) {
+            h->err = "kernel launch failed (graph fallback)";
+            return ERASOR_E_NO_DEVICE;
+        }
+    }
+    graph_release(seg);
+    h->use_graph = false;  // (do not try again on this handle)
+    rec.clear();
+#else
+    (void)h; (void)seg; (void)rec; (void)stream;
+#endif
+    return ERASOR_OK;
+}
+
 // a query side no announced / in-flight chain owns; the side of the last finished step only if nothing else is free
 // (its query-derived outputs are then gone)
 static int pick_side(const erasor_hip_handle *h) {
@@ -862,6 +1026,7 @@ struct SideGuard {
     ~SideGuard() {
         h->qi = qi;
         h->cur = cur;
+        h->rec = nullptr;  // (a recording never outlives the function that started it)
     }
 };
 
@@ -939,6 +1104,11 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     if (q.used) (void)hipStreamWaitEvent(qstream, q.ev_done, 0);
     Counters *qc = q.d_qctr.p;
     const uint32_t *nq_dev = q.d_nvox.p;
+    // the voxelising chain as two graphs (see GSeg): recorded by the very LAUNCH() calls below, replayed at the two event records
+    std::vector<GNode> recorded;
+#ifndef ERASOR_NO_HIPGRAPH
+    if (h->use_graph && h->prof != 1 && !g_debug_sync && !passthrough && !prevox && B + 1 <= QB_NB_MAX && ns) h->rec = &recorded;
+#endif
     LAUNCH(h, "q_begin", k_query_begin, 1, 256, qc, q.bb.p, B + 1 <= QB_NB_MAX ? q.qb_tot.p : (uint32_t *)nullptr, B + 1 <= QB_NB_MAX ? B + 1 : 0u,
            q.d_nvox.p, (prevox || passthrough) ? ns : 0u);
     // ---- part 1: bounding box, voxel keys, exact std::sort, runs ----
@@ -950,7 +1120,14 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
         (void)hipEventRecord(q.ev_keys, qstream);
         rc = enqueue_passthrough(h, q.scan_in, ns, T_l2b, q.query.p, q.qkey.p);
         if (rc) return rc;
-    } else if (!prevox) voxelize_query_part1(h, ns, P.leaf_query, [&] { (void)hipEventRecord(q.ev_keys, qstream); });
+    } else if (!prevox) {
+        int rc_g = ERASOR_OK;
+        voxelize_query_part1(h, ns, P.leaf_query, [&] {
+            if (h->rec) rc_g = graph_flush(h, q.gseg[0], recorded, qstream);
+            (void)hipEventRecord(q.ev_keys, qstream);
+        });
+        if (rc_g) return rc_g;
+    }
     else (void)hipEventRecord(q.ev_keys, qstream);
     // ---- part 2: centroids, label NN, lidar->body, R-POD key ----
     const uint32_t *sq_keys = nullptr, *sq_perm = nullptr;
@@ -979,6 +1156,11 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     }
     LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)q.sq.p, (const uint32_t *)q.qoff.p, B, q.ccnt.p, q.cmin.p,
            q.cmax.p);
+    if (h->rec) {
+        rc = graph_flush(h, q.gseg[1], recorded, qstream);
+        h->rec = nullptr;
+        if (rc) return rc;
+    }
     (void)hipEventRecord(q.ev_done, qstream);
     q.used = true;
     q.src = scan_src;
@@ -1042,9 +1224,16 @@ static void launch_voi_split(erasor_hip_handle *h, const float4 *F, uint32_t nF,
     }
 }
 
-static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan, bool src_is_device, const float T_l2b[16],
-                       const float T_b2o[16], const float T_o2b[16], erasor_step_result *res, int flags = 0) {
+static int step_collect(erasor_hip_handle *h, erasor_step_result *res);
+// First half of a step: everything is ENQUEUED (this scan's query chain unless it is in flight already, the map chain, Scan Ratio
+// Test .. write-back, k_step_end, the next step's VoI split and the next announced scan's query chain); nothing is waited for.
+static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_scan, bool src_is_device, const float T_l2b[16],
+                        const float T_b2o[16], const float T_o2b[16], int flags = 0) {
     if (!h) return ERASOR_E_INVALID;
+    if (h->fly.active) {
+        h->err = "erasor_hip_step_async: the previous step has not been collected (erasor_hip_step_wait)";
+        return ERASOR_E_STATE;
+    }
     if (!h->have_map) {
         h->err = h->poisoned ? "an earlier step failed after it had modified the map store: call erasor_hip_set_map again"
                              : "erasor_hip_step before erasor_hip_set_map";
@@ -1224,9 +1413,14 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     HIPC(h, hipStreamWaitEvent(h->stream, Q(h).ev_done, 0));  // join: the query's bins are ready
 
     // ---- Scan Ratio Test, R-GPF, per-bin voxelisation (erasor.cpp:332-571) ----
+    // up to 4096 bins the output layout has no launch of its own: k_srt4 prepares what does not depend on R-GPF, every workgroup of
+    // the write-back finishes it (ERASOR_HIP_NO_FOLD=1: the separate k_layout4 launch, for A/B)
+    static const bool no_fold = getenv("ERASOR_HIP_NO_FOLD") != nullptr;
+    const bool fold = B <= 1024 * SRT_KPT && !no_fold && n_voi > 0;
     if (B <= 1024 * SRT_KPT)
         LAUNCH(h, "srt", k_srt4, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
-           (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
+           (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds,
+           fold ? h->out_off0.p : (uint32_t *)nullptr, fold ? h->rev_before.p : (uint32_t *)nullptr, fold ? h->crej_off.p : (uint32_t *)nullptr);
     else
         LAUNCH(h, "srt", k_srt, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
            (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
@@ -1240,7 +1434,9 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
                (const uint32_t *)h->moff.p, (const float4 *)h->spts.p, (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p,
                (const uint32_t *)h->glist.p, (const uint32_t *)h->ng.p, (const uint32_t *)h->vox_off.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p,
                h->gsH.p, h->gsK2.p, h->gsV2.p, h->gsC.p, h->vox_out.p, h->nvox.p, dc, h->dbg_stamps.p);
-    if (B <= 1024 * SRT_KPT)
+    if (fold) {
+        // (no launch)
+    } else if (B <= 1024 * SRT_KPT)
         LAUNCH(h, "layout", k_layout4, 1, 1024, P, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, (const uint32_t *)h->mcnt.p,
            (const uint32_t *)Q(h).ccnt.p, (const uint32_t *)h->moff.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->ng.p, h->out_off.p,
            h->ground_off.p, h->rej_off.p, h->crej_off.p, ds);
@@ -1254,13 +1450,16 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     {
         // v3: the voxelised reverted bins are written by `tail` extra workgroups of the same launch (from the reverted list)
         const uint32_t tail = (P.version == 3 && n_voi) ? 32u : 0u;
-        if (n_voi)
-            LAUNCH(h, "assemble", k_assemble_map<true>, std::min<uint32_t>(cdiv(n_voi, 256), 2048) + tail, 256, P, h->Tb2o, (const uint8_t *)h->action.p,
-                   (const uint32_t *)h->rev_idx.p, sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p,
-                   (const uint32_t *)Q(h).ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p, (const uint32_t *)h->out_off.p,
-                   (const uint32_t *)h->ground_off.p, (const uint32_t *)h->rej_off.p, (const DevState *)ds, Fnew, h->rejected.p, h->rejected_src.p,
-                   h->lab_slots.p, tail, (const uint32_t *)h->rev_list.p, (const uint32_t *)Q(h).qoff.p, (const uint32_t *)h->nvox.p,
-                   (const uint32_t *)h->vox_off.p, (const float4 *)h->vox_out.p);
+#define ASM_ARGS(FOLDPTR)                                                                                                                   \
+    P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p, sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, \
+        (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p, h->out_off.p,   \
+        h->ground_off.p, h->rej_off.p, ds, Fnew, h->rejected.p, h->rejected_src.p, h->lab_slots.p, tail, (const uint32_t *)h->rev_list.p,      \
+        (const uint32_t *)Q(h).qoff.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p, (const float4 *)h->vox_out.p,              \
+        (const uint32_t *)(FOLDPTR ? h->out_off0.p : nullptr), (const uint32_t *)(FOLDPTR ? h->rev_before.p : nullptr), (const uint32_t *)h->ng.p
+        const uint32_t asm_grid = std::min<uint32_t>(cdiv(n_voi, 256), 2048) + tail;
+        if (n_voi && fold) LAUNCH(h, "assemble", (k_assemble_map<true, true>), asm_grid, 256, ASM_ARGS(true));
+        else if (n_voi) LAUNCH(h, "assemble", (k_assemble_map<true, false>), asm_grid, 256, ASM_ARGS(false));
+#undef ASM_ARGS
         if (!tail)
             LAUNCH(h, "assemble", k_assemble_bins<true>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
                    (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
@@ -1313,6 +1512,41 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
             return rc_next;
         }
     }
+    h->fly.active = true;
+    h->fly.seq = step_seq;
+    h->fly.n_map_in = n_map_in;
+    h->fly.ns = ns;
+    h->fly.sm_keys = sm_keys;
+    h->fly.flags = flags;
+    h->fly.scan_src = scan_src;
+    h->fly.n_scan = n_scan;
+    h->fly.src_is_device = src_is_device;
+    memcpy(h->fly.Tl, T_l2b, sizeof(h->fly.Tl));
+    memcpy(h->fly.Tb, T_b2o, sizeof(h->fly.Tb));
+    memcpy(h->fly.To, T_o2b, sizeof(h->fly.To));
+    if (host_timing) {
+        for (auto &m : marks) fprintf(stderr, "   %-20s %.1f us\n", m.first, m.second);
+        fprintf(stderr, "[step host] enqueue %.1f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count());
+    }
+    return ERASOR_OK;
+}
+
+// Second half: wait for the step's results (k_step_end's last store into the pinned block is the step's number), commit the host
+// mirror of the map store, report.  A VoxelGrid pass-through flip re-runs the step here, synchronously.
+static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
+    if (!h) return ERASOR_E_INVALID;
+    if (!h->fly.active) {
+        h->err = "erasor_hip_step_wait without a step in flight";
+        return ERASOR_E_STATE;
+    }
+    HIPC(h, hipSetDevice(h->device));
+    h->fly.active = false;
+    const unsigned long long step_seq = h->fly.seq;
+    const uint64_t n_map_in = h->fly.n_map_in;
+    const uint32_t ns = h->fly.ns;
+    const uint32_t *sm_keys = h->fly.sm_keys;
+    const int flags = h->fly.flags;
+    static const bool host_timing = getenv("ERASOR_HIP_HOST_TIMING") != nullptr;
     const auto t_host1 = std::chrono::steady_clock::now();
     {   // k_step_end's last store into the pinned block is the step's number: poll it (a blocking stream wait wakes up tens
         // of microseconds late, a visible share of a 0.35 ms step), then fall back to the stream wait
@@ -1331,12 +1565,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     }
     h->st = h->pin->st;
     h->ctr = h->pin->ctr;
-    if (host_timing) {
-        for (auto &m : marks) fprintf(stderr, "   %-20s %.1f us\n", m.first, m.second);
-        const auto t_host2 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[step host] enqueue %.1f us, wait %.1f us\n", std::chrono::duration<double, std::micro>(t_host1 - t_host0).count(),
-                std::chrono::duration<double, std::micro>(t_host2 - t_host1).count());
-    }
+    if (host_timing)
+        fprintf(stderr, "[step host] wait %.1f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host1).count());
     if (h->dbg_stamps.p) {
         unsigned long long t[64];
         (void)hipMemcpy(t, h->dbg_stamps.p, sizeof(t), hipMemcpyDeviceToHost);
@@ -1377,7 +1607,8 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
             h->q_passthrough = h->ctr.err == 2;
             if (!(flags & STEP_RETRIED)) {
                 q_drain(h);  // chains announced ahead were enqueued in the other mode: dropped, their steps enqueue their own
-                return step_common(h, scan_src, n_scan, src_is_device, T_l2b, T_b2o, T_o2b, res, flags | STEP_RETRIED);
+                const int rc_again = step_enqueue(h, h->fly.scan_src, h->fly.n_scan, h->fly.src_is_device, h->fly.Tl, h->fly.Tb, h->fly.To, flags | STEP_RETRIED);
+                return rc_again ? rc_again : step_collect(h, res);
             }
             h->err = "VoxelGrid pass-through decision did not settle";
             return ERASOR_E_INTERNAL;
@@ -1436,6 +1667,12 @@ static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan
     return ERASOR_OK;
 }
 
+static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan, bool src_is_device, const float T_l2b[16],
+                       const float T_b2o[16], const float T_o2b[16], erasor_step_result *res, int flags = 0) {
+    const int rc = step_enqueue(h, scan_src, n_scan, src_is_device, T_l2b, T_b2o, T_o2b, flags);
+    return rc ? rc : step_collect(h, res);
+}
+
 // Announce the NEXT scan: its query chain (voxelisation, label search, bucketing -- everything that does not depend on the
 // map) is enqueued now and runs beside the map-side stages of the step in flight.  The step call that follows must pass the
 // same (pointer, size, T_lidar2body); anything else simply drops the prefetch.
@@ -1451,6 +1688,7 @@ int erasor_hip_prefetch_node(erasor_hip_handle *h, const void *scan_xyzi, size_t
     return prefetch_common(h, scan_xyzi, n, src_is_device, T_l2b, T_body2origin);
 }
 static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device, const float T_l2b[16], const float *T_b2o) {
+    NOFLY(h);
     if (!h || !T_l2b || (!scan_xyzi && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
     if (h->ann.valid && h->npend >= 2) {
@@ -1489,8 +1727,20 @@ int erasor_hip_step_device(erasor_hip_handle *h, const void *d_scan_xyzi, size_t
                            const float T_body2origin[16], const float T_origin2body[16], erasor_step_result *res) {
     return step_common(h, d_scan_xyzi, n_scan, true, T_lidar2body, T_body2origin, T_origin2body, res);
 }
+// SURVEY 8(b), threading row: the step in two halves, so that ONE host thread can keep several handles (independent sequences,
+// OMU.cpp:203 is one callback per node per updater) busy: async enqueues everything and returns, wait collects.
+int erasor_hip_step_async(erasor_hip_handle *h, const void *scan_xyzi, size_t n_scan, int src_is_device, const float T_lidar2body[16],
+                          const float T_body2origin[16], const float T_origin2body[16]) {
+    return step_enqueue(h, scan_xyzi, n_scan, src_is_device != 0, T_lidar2body, T_body2origin, T_origin2body);
+}
+int erasor_hip_step_wait(erasor_hip_handle *h, erasor_step_result *res) { return step_collect(h, res); }
+int erasor_hip_step_done(erasor_hip_handle *h) {
+    if (!h || !h->fly.active) return 1;
+    return *(volatile unsigned long long *)&h->pin->seq == h->fly.seq ? 1 : 0;
+}
 
 int erasor_hip_map_size(erasor_hip_handle *h, size_t *n) {
+    NOFLY(h);
     if (!h || !n) return ERASOR_E_INVALID;
     if (!h->have_map) return ERASOR_E_STATE;
     *n = (size_t)h->nF + (size_t)h->o_valid + (size_t)h->nC;  // large-scale: *map_arranged_ + *map_arranged_complement_ (OMU.cpp:181)
@@ -1507,6 +1757,7 @@ static int out_cloud(erasor_hip_handle *h, const float4 *d, size_t cnt, float *d
 }
 
 int erasor_hip_get_map(erasor_hip_handle *h, float *dst, size_t cap, size_t *n) {
+    NOFLY(h);
     if (!h) return ERASOR_E_INVALID;
     if (!h->have_map) return ERASOR_E_STATE;
     HIPC(h, hipSetDevice(h->device));
@@ -1545,12 +1796,13 @@ static int assemble_egocentric(erasor_hip_handle *h, float4 **out) {
     const DP &P = h->dp;
     const uint32_t B = h->B, n_voi = h->last_n_voi;
     if (n_voi)
-        LAUNCH(h, "get_cloud", k_assemble_map<false>, std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p,
+        LAUNCH(h, "get_cloud", (k_assemble_map<false, false>), std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p,
                (const uint32_t *)h->rev_idx.p, h->last_skeys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p,
                (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p,
-               (const uint32_t *)h->out_off.p, (const uint32_t *)h->ground_off.p, (const uint32_t *)h->rej_off.p,
-               (const DevState *)h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr, 0u, (const uint32_t *)nullptr,
-               (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const float4 *)nullptr);
+               h->out_off.p, h->ground_off.p, h->rej_off.p,
+               h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr, 0u, (const uint32_t *)nullptr,
+               (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const float4 *)nullptr, (const uint32_t *)nullptr,
+               (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     LAUNCH(h, "get_cloud", k_assemble_bins<false>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,
            (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
            (const float4 *)h->vox_out.p, (const uint32_t *)h->out_off.p, (const uint32_t *)h->crej_off.p, tmp, (float4 *)nullptr, (unsigned long long *)nullptr);
@@ -1560,6 +1812,7 @@ static int assemble_egocentric(erasor_hip_handle *h, float4 **out) {
 }
 
 int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap, size_t *n) {
+    NOFLY(h);
     if (!h) return ERASOR_E_INVALID;
     if (which == ERASOR_CLOUD_MAP) return erasor_hip_get_map(h, dst, cap, n);
     if (!h->have_step) return ERASOR_E_STATE;
@@ -1591,6 +1844,7 @@ int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap
 }
 
 int erasor_hip_get_rejected_indices(erasor_hip_handle *h, uint64_t *dst, size_t cap, size_t *n) {
+    NOFLY(h);
     if (!h) return ERASOR_E_INVALID;
     if (!h->have_step) return ERASOR_E_STATE;
     HIPC(h, hipSetDevice(h->device));
@@ -1605,6 +1859,7 @@ int erasor_hip_get_rejected_indices(erasor_hip_handle *h, uint64_t *dst, size_t 
 }
 
 int erasor_hip_get_bins(erasor_hip_handle *h, int which, uint32_t *count, double *min_h, double *max_h) {
+    NOFLY(h);
     if (!h || !count || !min_h || !max_h || (which != 0 && which != 1)) return ERASOR_E_INVALID;
     if (!h->have_step) return ERASOR_E_STATE;
     HIPC(h, hipSetDevice(h->device));
@@ -1625,6 +1880,7 @@ int erasor_hip_get_bins(erasor_hip_handle *h, int which, uint32_t *count, double
 }
 
 int erasor_hip_get_status(erasor_hip_handle *h, double *status) {
+    NOFLY(h);
     if (!h || !status) return ERASOR_E_INVALID;
     if (!h->have_step) return ERASOR_E_STATE;
     HIPC(h, hipSetDevice(h->device));
@@ -1640,6 +1896,7 @@ int erasor_hip_get_status(erasor_hip_handle *h, double *status) {
 // The point lists of an R-POD of the last step (erasor.h:143-145), egocentric, theta-major (the order r_pod2pc walks,
 // erasor.cpp:309-320): which 0 = r_pod_map, 1 = r_pod_curr, 2 = r_pod_selected.  begin / count: per bin, index ring*S+sector.
 int erasor_hip_get_rpod(erasor_hip_handle *h, int which, float *xyzi, size_t cap, size_t *n, uint32_t *begin, uint32_t *count) {
+    NOFLY(h);
     if (!h || which < 0 || which > 2) return ERASOR_E_INVALID;
     if (!h->have_step) return ERASOR_E_STATE;
     HIPC(h, hipSetDevice(h->device));
@@ -1681,6 +1938,7 @@ int erasor_hip_get_rpod(erasor_hip_handle *h, int which, float *xyzi, size_t cap
 }
 
 int erasor_hip_get_planes(erasor_hip_handle *h, uint32_t *bin_index, float *normal, double *d, size_t cap_bins, size_t *n_bins) {
+    NOFLY(h);
     if (!h) return ERASOR_E_INVALID;
     if (!h->have_step) return ERASOR_E_STATE;
     HIPC(h, hipSetDevice(h->device));
@@ -1753,6 +2011,7 @@ static int voxelize_device(erasor_hip_handle *h, const float4 *d_src, uint32_t n
 
 int erasor_hip_voxelize_preserving_labels(erasor_hip_handle *h, const float *src, size_t n, double leaf_size, float *dst, size_t cap,
                                           size_t *n_out) {
+    NOFLY(h);
     if (!h || (!src && n) || !(leaf_size > 0) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
     prof_collect(h);
@@ -1794,6 +2053,7 @@ static int mg_append(erasor_hip_handle *h, DBuf<float4> &dst, uint64_t &ndst, co
 }
 
 int erasor_hip_mapgen_begin(erasor_hip_handle *h, double leafsize, int is_large_scale) {
+    NOFLY(h);
     if (!h || !(leafsize > 0)) return ERASOR_E_INVALID;
     h->mg_leaf = leafsize;
     h->mg_large = is_large_scale != 0;
@@ -1806,6 +2066,7 @@ int erasor_hip_mapgen_begin(erasor_hip_handle *h, double leafsize, int is_large_
 
 int erasor_hip_mapgen_accum(erasor_hip_handle *h, const float *scan_xyzi, size_t n, const float T_pose[16], const float T_lidar2origin[16],
                             size_t *n_curr) {
+    NOFLY(h);
     if (!h || (!scan_xyzi && n) || !T_pose || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     if (!h->mg_active) {
         h->err = "erasor_hip_mapgen_accum before erasor_hip_mapgen_begin";
@@ -1861,6 +2122,7 @@ int erasor_hip_mapgen_accum(erasor_hip_handle *h, const float *scan_xyzi, size_t
 }
 
 int erasor_hip_mapgen_get(erasor_hip_handle *h, int which, float *dst, size_t cap, size_t *n_out) {
+    NOFLY(h);
     if (!h || which < 0 || which > 2) return ERASOR_E_INVALID;
     if (!h->mg_active) return ERASOR_E_STATE;
     HIPC(h, hipSetDevice(h->device));
@@ -1882,6 +2144,7 @@ int erasor_hip_mapgen_get(erasor_hip_handle *h, int which, float *dst, size_t ca
 }
 
 int erasor_hip_mapgen_save(erasor_hip_handle *h, float *dst, size_t cap, size_t *n_out) {
+    NOFLY(h);
     if (!h) return ERASOR_E_INVALID;
     if (!h->mg_active) return ERASOR_E_STATE;
     HIPC(h, hipSetDevice(h->device));
@@ -1907,6 +2170,7 @@ int erasor_hip_mapgen_save(erasor_hip_handle *h, float *dst, size_t cap, size_t 
 }
 
 int erasor_hip_count_static_dynamic(erasor_hip_handle *h, uint64_t *n_static, uint64_t *n_dynamic) {
+    NOFLY(h);
     if (!h || !n_static || !n_dynamic) return ERASOR_E_INVALID;
     if (!h->have_map) return ERASOR_E_STATE;
     *n_static = h->st.F_static + h->st.O_static;
@@ -1958,8 +2222,31 @@ int erasor_hip_ahead_split_counts(erasor_hip_handle *h, uint64_t *launched, uint
 }
 void *erasor_hip_stream(erasor_hip_handle *h) { return h ? (void *)h->stream : nullptr; }
 
+// device buffers for callers that keep their scans (or the map) resident in HBM and have no HIP of their own (the C++ bench, the
+// Python tests): plain hipMalloc / hipMemcpy / hipFree on the handle's device
+int erasor_hip_device_alloc(erasor_hip_handle *h, size_t bytes, void **d_ptr) {
+    if (!h || !d_ptr) return ERASOR_E_INVALID;
+    HIPC(h, hipSetDevice(h->device));
+    *d_ptr = nullptr;
+    HIPC(h, hipMalloc(d_ptr, bytes ? bytes : 1));
+    return ERASOR_OK;
+}
+int erasor_hip_device_upload(erasor_hip_handle *h, void *d_dst, const void *src, size_t bytes) {
+    if (!h || (!d_dst && bytes) || (!src && bytes)) return ERASOR_E_INVALID;
+    HIPC(h, hipSetDevice(h->device));
+    if (bytes) HIPC(h, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return ERASOR_OK;
+}
+int erasor_hip_device_free(erasor_hip_handle *h, void *d_ptr) {
+    if (!h) return ERASOR_E_INVALID;
+    HIPC(h, hipSetDevice(h->device));
+    if (d_ptr) HIPC(h, hipFree(d_ptr));
+    return ERASOR_OK;
+}
+
 // test hook: device libm probe (sqrt / div / atan2 in double)
 int erasor_hip_probe_math(erasor_hip_handle *h, const double *x, const double *y, size_t n, double *o_sqrt, double *o_div, double *o_atan2) {
+    NOFLY(h);
     if (!h || !x || !y || !o_sqrt || !o_div || !o_atan2) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
     double *d = nullptr;
@@ -1978,6 +2265,7 @@ int erasor_hip_probe_math(erasor_hip_handle *h, const double *x, const double *y
 
 // test hook: exact std::sort emulation of (key,payload) pairs on the device
 int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *vals, size_t n, uint32_t *n_fallback) {
+    NOFLY(h);
     if (!h || (!keys && n) || (!vals && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
     h->have_step = false;  // borrows the last step's query side
@@ -2020,6 +2308,7 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
 
 int erasor_hip_erasor_run(erasor_hip_handle *h, const float *map_voi_xyzi, size_t n_map, const float *query_voi_xyzi, size_t n_query,
                           erasor_step_result *res) {
+    NOFLY(h);
     int rc = set_map_common(h, map_voi_xyzi, n_map, false);
     if (rc) return rc;
     const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -2028,6 +2317,7 @@ int erasor_hip_erasor_run(erasor_hip_handle *h, const float *map_voi_xyzi, size_
 
 // test hook: force the tombstone-free rebuild of the outskirts region (normally triggered by hole / room heuristics)
 int erasor_hip_debug_rebuild_outskirts(erasor_hip_handle *h) {
+    NOFLY(h);
     if (!h) return ERASOR_E_INVALID;
     if (!h->have_map) return ERASOR_E_STATE;
     HIPC(h, hipSetDevice(h->device));
@@ -2036,6 +2326,7 @@ int erasor_hip_debug_rebuild_outskirts(erasor_hip_handle *h) {
 
 // test hook: the stable LSD radix sort used for R-POD bucketing
 int erasor_hip_radix_sort_u32(erasor_hip_handle *h, const uint32_t *keys, size_t n, int bits, uint32_t *keys_out, uint32_t *perm_out) {
+    NOFLY(h);
     if (!h || (!keys && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
     h->have_step = false;  // borrows the last step's query side

@@ -58,7 +58,8 @@ struct DevState {
     // SRT / R-GPF
     uint32_t n_rev, vox_scratch_total;
     // assembly
-    uint32_t total_bins, n_static_est, n_ground, n_compl, n_rejected, nF_new, n_curr_rejected, pad1;
+    uint32_t total_bins, n_static_est, n_ground, n_compl, n_rejected, nF_new, n_curr_rejected;
+    uint32_t total_bins0;  // k_srt4: size of the bin part of the output WITHOUT the reverted bins (k_assemble_map<., true> adds them)
     // label counters
     unsigned long long F_static, F_dynamic, O_static, O_dynamic;
 };
@@ -109,24 +110,20 @@ __device__ __forceinline__ uint32_t bin_key(const DP &P, float x, float y, float
 }
 
 // ---- small block-level helpers -------------------------------------------------------------------
-// exclusive scan of one value per thread; sm >= 34 uint32; returns prefix, writes block total
+// exclusive scan of one value per thread; sm >= 34 uint32; returns prefix, writes block total.
+// Round 3: both levels on DPP row shifts (esort::wave_incl_scan) -- the shuffle ladder this replaces was six dependent
+// ds_bpermute round trips plus a 16-step serial loop over the wavefront totals, ~2 us per call in the single-workgroup kernels
+// of the dependency chain (k_srt4, k_layout4, the chunk scan), which call it two to five times each.
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *sm, uint32_t &total) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    uint32_t inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off, 64);
-        if ((int)lane >= off) inc += t;
-    }
-    __syncthreads();
+    const uint32_t inc = esort::wave_incl_scan(v);
+    __syncthreads();  // (sm may still be read by the previous call's second level)
     if (lane == 63) sm[wave] = inc;
     __syncthreads();
-    uint32_t pre = 0, tot = 0;
-    for (uint32_t w = 0; w < nw; ++w) {
-        const uint32_t t = sm[w];
-        if (w < wave) pre += t;
-        tot += t;
-    }
-    total = tot;
+    const uint32_t wt = lane < nw ? sm[lane] : 0u;
+    const uint32_t wi = esort::wave_incl_scan(wt);
+    total = __builtin_amdgcn_readlane(wi, 63);
+    const uint32_t pre = __builtin_amdgcn_readlane(wi - wt, __builtin_amdgcn_readfirstlane(wave));
     return pre + inc - v;
 }
 
@@ -317,84 +314,98 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ 
 // Both levels in ONE launch (maps of up to ~16 M entries: <= 16384 chunks): a single workgroup, 16 consecutive chunk counts
 // per thread, writes ABSOLUTE prefixes (the per-group tops are all zero) and opens the step's state exactly like
 // k_chunk_scan_top.  One kernel boundary less on the main stream's dependency chain.
+// Round 3: the thread's 16 counts come and go as four 128-bit accesses each way (a wavefront then touches 32 cache lines per
+// access, all of them fully used within the four), both sums are scanned together on DPP row shifts -- no LDS transposes, two
+// workgroup barriers in all (the staged version took 13.9 us for 10.4 k counts).
 __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restrict__ cinfo, uint32_t nchunks, uint32_t *__restrict__ pvl,
                                                           uint32_t *__restrict__ phl, uint32_t *__restrict__ topv, uint32_t *__restrict__ toph,
                                                           uint32_t ntop, uint32_t nFchunks, DevState *st, Counters *ctr, DevState init,
                                                           unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n) {
     __shared__ uint32_t sm[40];
     __shared__ uint32_t s_voiF, s_validF;
-    if (lab_slots && threadIdx.x < 128) lab_slots[threadIdx.x] = 0;
-    for (uint32_t b = threadIdx.x; b < mb_n; b += blockDim.x) mb_tot[b] = 0;
-    for (uint32_t t = threadIdx.x; t < ntop; t += blockDim.x) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t base = tid * 16;
+    uint32_t ci[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t b4 = base + g * 4;
+        if (b4 + 3 < nchunks) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(cinfo + b4);
+            ci[g * 4 + 0] = q.x;
+            ci[g * 4 + 1] = q.y;
+            ci[g * 4 + 2] = q.z;
+            ci[g * 4 + 3] = q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ci[g * 4 + j] = b4 + j < nchunks ? cinfo[b4 + j] : 0u;
+        }
+    }
+    // (the step's housekeeping rides in the shadow of the loads)
+    if (lab_slots && tid < 128) lab_slots[tid] = 0;
+    for (uint32_t b = tid; b < mb_n; b += blockDim.x) mb_tot[b] = 0;
+    for (uint32_t t = tid; t < ntop; t += blockDim.x) {
         topv[t] = 0;
         toph[t] = 0;
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
         ctr->sort_qoverflow = ctr->err = 0;
     }
-    // Every thread owns 16 CONSECUTIVE chunks for the scan (ONE pair of block scans for the whole table), but global memory
-    // is touched in coalesced strips only (element k * 1024 + tid): both directions go through a padded LDS stage
-    // (16 consecutive words per thread would put a wavefront's 64 lanes on 64 different cache lines per access).
-    __shared__ uint32_t stage[16384 + 1024];
-    uint32_t cv = 0, ch = 0;
-    {
-        const uint32_t base = threadIdx.x * 16;
+    uint32_t sv = 0, sh = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const uint32_t e = k * 1024 + threadIdx.x;
-            stage[e + (e >> 4)] = e < nchunks ? cinfo[e] : 0u;
-        }
-        __syncthreads();
-        uint32_t ci[16];
+    for (int j = 0; j < 16; ++j) {
+        sv += ci[j] & 0xFFFFu;
+        sh += ci[j] >> 16;
+    }
+    const uint32_t iv = esort::wave_incl_scan(sv), ih = esort::wave_incl_scan(sh);
+    if (lane == 63) {
+        sm[wave] = iv;
+        sm[16 + wave] = ih;
+    }
+    __syncthreads();
+    const uint32_t nw = blockDim.x >> 6;
+    const uint32_t wv = lane < nw ? sm[lane] : 0u, wh = lane < nw ? sm[16 + lane] : 0u;
+    const uint32_t wiv = esort::wave_incl_scan(wv), wih = esort::wave_incl_scan(wh);
+    const uint32_t cv = __builtin_amdgcn_readlane(wiv, 63), ch = __builtin_amdgcn_readlane(wih, 63);  // totals
+    const uint32_t w_ = __builtin_amdgcn_readfirstlane(wave);
+    uint32_t pv = __builtin_amdgcn_readlane(wiv - wv, w_) + iv - sv;  // exclusive prefixes of this thread's first chunk
+    uint32_t ph = __builtin_amdgcn_readlane(wih - wh, w_) + ih - sh;
+    if (nFchunks >= base && nFchunks < base + 16) {  // the F region's share of the totals
+        uint32_t a = pv, b2 = ph;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) ci[j] = stage[threadIdx.x * 17 + j];
-        uint32_t sv = 0, sh = 0;
+        for (uint32_t j = 0; j < 16; ++j)  // (static indices: a run-time index would put ci[] into scratch memory for every thread)
+            if (base + j < nFchunks) {
+                a += ci[j] & 0xFFFFu;
+                b2 += ci[j] >> 16;
+            }
+        s_voiF = a;
+        s_validF = b2;
+    }
+    uint32_t ov[16], oh[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            sv += ci[j] & 0xFFFFu;
-            sh += ci[j] >> 16;
-        }
-        uint32_t pv = block_excl_scan(sv, sm, cv);
-        uint32_t ph = block_excl_scan(sh, sm, ch);
-        if (nFchunks >= base && nFchunks < base + 16) {  // the F region's share of the totals
-            uint32_t a = pv, b2 = ph;
+    for (int j = 0; j < 16; ++j) {
+        ov[j] = pv;
+        oh[j] = ph;
+        pv += ci[j] & 0xFFFFu;
+        ph += ci[j] >> 16;
+    }
 #pragma unroll
-            for (uint32_t j = 0; j < 16; ++j)  // (static indices: a run-time index would put ci[] into scratch memory for every thread)
-                if (base + j < nFchunks) {
-                    a += ci[j] & 0xFFFFu;
-                    b2 += ci[j] >> 16;
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t b4 = base + g * 4;
+        if (b4 + 3 < nchunks) {
+            *reinterpret_cast<uint4 *>(pvl + b4) = make_uint4(ov[g * 4], ov[g * 4 + 1], ov[g * 4 + 2], ov[g * 4 + 3]);
+            *reinterpret_cast<uint4 *>(phl + b4) = make_uint4(oh[g * 4], oh[g * 4 + 1], oh[g * 4 + 2], oh[g * 4 + 3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (b4 + j < nchunks) {
+                    pvl[b4 + j] = ov[g * 4 + j];
+                    phl[b4 + j] = oh[g * 4 + j];
                 }
-            s_voiF = a;
-            s_validF = b2;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            stage[threadIdx.x * 17 + j] = pv;
-            pv += ci[j] & 0xFFFFu;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const uint32_t e = k * 1024 + threadIdx.x;
-            if (e < nchunks) pvl[e] = stage[e + (e >> 4)];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            stage[threadIdx.x * 17 + j] = ph;
-            ph += ci[j] >> 16;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const uint32_t e = k * 1024 + threadIdx.x;
-            if (e < nchunks) phl[e] = stage[e + (e >> 4)];
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         DevState s = init;
         const uint32_t voi_total = cv, valid_total = ch;
         uint32_t voiF = voi_total, validF = valid_total;
@@ -2045,7 +2056,12 @@ __global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict_
                                                 const float *__restrict__ mmax, const uint32_t *__restrict__ ccnt,
                                                 const float *__restrict__ cmin, const float *__restrict__ cmax, uint8_t *__restrict__ st1,
                                                 uint8_t *__restrict__ status, uint8_t *__restrict__ action, uint32_t *__restrict__ rev_idx,
-                                                uint32_t *__restrict__ rev_list, uint32_t *__restrict__ vox_off, DevState *st) {
+                                                uint32_t *__restrict__ rev_list, uint32_t *__restrict__ vox_off, DevState *st,
+                                                // the part of the output layout (k_layout4) that does not depend on R-GPF / the per-bin
+                                                // voxelisation: offsets with the reverted bins counted as empty, how many reverted bins precede a
+                                                // bin, curr_rejected offsets (final).  nullptr: not wanted (k_layout4 runs later)
+                                                uint32_t *__restrict__ out_off0, uint32_t *__restrict__ rev_before,
+                                                uint32_t *__restrict__ crej_off) {
     __shared__ uint32_t sm[40];
     __shared__ uint8_t s_st1[1024 * SRT_KPT];
     const int B = P.B;
@@ -2096,6 +2112,43 @@ __global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict_
     if (threadIdx.x == 0) {
         st->n_rev = t0;
         st->vox_scratch_total = t1;
+    }
+    if (out_off0) {
+        uint32_t sz[SRT_KPT], cr[SRT_KPT], ssz = 0, scr = 0;
+#pragma unroll
+        for (int j = 0; j < SRT_KPT; ++j) {
+            sz[j] = cr[j] = 0;
+            if (k0 + j < B) {
+                const uint32_t mc = bs[j].mc, cc = bs[j].cc;
+                if (act[j] == 1) sz[j] = 0;             // curr + ground, voxelised (v3) or not (v2): known after R-GPF
+                else if (act[j] == 2) sz[j] = cc + mc;  // merge_bins: curr then map (erasor.cpp:296-307)
+                else if (act[j] == 3) sz[j] = cc;
+                else {
+                    sz[j] = mc;
+                    if (act[j] == 4) cr[j] = cc;
+                }
+                ssz += sz[j];
+                scr += cr[j];
+            }
+        }
+        uint32_t t2, t3;
+        uint32_t p2 = block_excl_scan(ssz, sm, t2);
+        uint32_t p3 = block_excl_scan(scr, sm, t3);
+        uint32_t pr = block_excl_scan(nrv, sm, t0);  // (the reverted bins before this thread's first bin, again: p0 has moved on)
+#pragma unroll
+        for (int j = 0; j < SRT_KPT; ++j)
+            if (k0 + j < B) {
+                out_off0[k0 + j] = p2;
+                crej_off[k0 + j] = p3;
+                rev_before[k0 + j] = pr;
+                p2 += sz[j];
+                p3 += cr[j];
+                pr += act[j] == 1 ? 1u : 0u;
+            }
+        if (threadIdx.x == 0) {
+            st->total_bins0 = t2;
+            st->n_curr_rejected = t3;
+        }
     }
 }
 
@@ -3260,21 +3313,141 @@ __device__ __forceinline__ void block_commit_labels(uint32_t d, uint32_t s, unsi
     }
 }
 
-template <bool XFORM>
+// FOLD: the output layout is finished HERE instead of in a launch of its own (k_layout4, 8.8 us on the dependency chain): k_srt4 has
+// left the offsets with the reverted bins counted as empty (out_off0), the number of reverted bins before every bin (rev_before)
+// and the size of that part (st->total_bins0); every workgroup adds what R-GPF / the per-bin voxelisation have produced since --
+// exclusive prefixes over the (few) reverted bins of their output sizes, their ground and their rejected points, in LDS -- and
+// workgroup 0 also leaves the final tables and totals for the getters and k_step_end.
+static constexpr uint32_t ASM_RVMAX = 1024;  // reverted bins whose prefixes fit the LDS tables (more: summed on the fly, correct and slow)
+template <bool XFORM, bool FOLD>
 __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8_t *__restrict__ action,
                                                        const uint32_t *__restrict__ rev_idx, const uint32_t *__restrict__ skeys,
                                                        const float4 *__restrict__ spts, const uint32_t *__restrict__ ssrc,
                                                        const uint32_t *__restrict__ moff, const uint32_t *__restrict__ ccnt,
                                                        const uint8_t *__restrict__ gflag, const uint32_t *__restrict__ grank,
-                                                       const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ ground_off,
-                                                       const uint32_t *__restrict__ rej_off, const DevState *st,
+                                                       uint32_t *__restrict__ out_off, uint32_t *__restrict__ ground_off,
+                                                       uint32_t *__restrict__ rej_off, DevState *st,
                                                        float4 *__restrict__ Fnew, float4 *__restrict__ rejected,
                                                        uint32_t *__restrict__ rejected_src, unsigned long long *cnt,
                                                        // v3 only: the last `tail` workgroups write the voxelised reverted bins (k_assemble_bins' v3
                                                        // branch) from the reverted-bin list -- one launch less on the dependency chain
                                                        uint32_t tail, const uint32_t *__restrict__ rev_list, const uint32_t *__restrict__ qoff,
                                                        const uint32_t *__restrict__ nvox, const uint32_t *__restrict__ vox_off,
-                                                       const float4 *__restrict__ vox_out) {
+                                                       const float4 *__restrict__ vox_out,
+                                                       // FOLD only
+                                                       const uint32_t *__restrict__ out_off0, const uint32_t *__restrict__ rev_before,
+                                                       const uint32_t *__restrict__ ng_arr) {
+    __shared__ uint32_t s_cv[FOLD ? ASM_RVMAX + 1 : 1], s_cg[FOLD ? ASM_RVMAX + 1 : 1], s_cr[FOLD ? ASM_RVMAX + 1 : 1];
+    __shared__ uint32_t s_sm[40];
+    __shared__ uint32_t s_carry[3];
+    uint32_t total_bins = 0, n_static_est = 0, n_rev_all = 0;
+    // size of reverted bin rk in the output, its ground and its rejected points
+    auto rev_sizes = [&](uint32_t rk, uint32_t &sz, uint32_t &g, uint32_t &rj) {
+        const uint32_t key = rev_list[rk];
+        const uint32_t cc = ccnt[key], mc = moff[key + 1] - moff[key];
+        g = ng_arr[rk];
+        rj = mc - g;
+        sz = cc > 0 ? (P.version == 3 ? nvox[rk] : cc + g) : 0u;  // an unoccupied bin_curr: r_pod2pc skips the bin (erasor.cpp:313)
+    };
+    if constexpr (FOLD) {
+        n_rev_all = st->n_rev;
+        if (n_rev_all < 64u) {  // the usual handful: one wavefront, three DPP scans, one barrier
+            if (threadIdx.x < 64u) {
+                const uint32_t rk = threadIdx.x;
+                uint32_t sz = 0, g = 0, rj = 0;
+                if (rk < n_rev_all) rev_sizes(rk, sz, g, rj);
+                const uint32_t i0 = esort::wave_incl_scan(sz), i1 = esort::wave_incl_scan(g), i2 = esort::wave_incl_scan(rj);
+                if (rk <= n_rev_all) {
+                    s_cv[rk] = i0 - sz;
+                    s_cg[rk] = i1 - g;
+                    s_cr[rk] = i2 - rj;
+                }
+                if (rk == 63u) {
+                    s_carry[0] = i0;
+                    s_carry[1] = i1;
+                    s_carry[2] = i2;
+                }
+            }
+            __syncthreads();
+        } else {
+            if (threadIdx.x < 3) s_carry[threadIdx.x] = 0;
+            __syncthreads();
+            for (uint32_t base = 0; base < n_rev_all; base += blockDim.x) {
+                const uint32_t rk = base + threadIdx.x;
+                uint32_t sz = 0, g = 0, rj = 0;
+                if (rk < n_rev_all) rev_sizes(rk, sz, g, rj);
+                uint32_t t0, t1, t2;
+                const uint32_t p0 = block_excl_scan(sz, s_sm, t0);
+                const uint32_t p1 = block_excl_scan(g, s_sm, t1);
+                const uint32_t p2 = block_excl_scan(rj, s_sm, t2);
+                const uint32_t c0 = s_carry[0], c1 = s_carry[1], c2 = s_carry[2];
+                if (rk < n_rev_all && rk < ASM_RVMAX) {
+                    s_cv[rk] = c0 + p0;
+                    s_cg[rk] = c1 + p1;
+                    s_cr[rk] = c2 + p2;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    s_carry[0] = c0 + t0;
+                    s_carry[1] = c1 + t1;
+                    s_carry[2] = c2 + t2;
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0 && n_rev_all <= ASM_RVMAX) {
+                s_cv[n_rev_all] = s_carry[0];
+                s_cg[n_rev_all] = s_carry[1];
+                s_cr[n_rev_all] = s_carry[2];
+            }
+            __syncthreads();
+        }
+        total_bins = st->total_bins0 + s_carry[0];
+        n_static_est = total_bins + s_carry[1];
+    } else {
+        total_bins = st->total_bins;
+        n_static_est = st->n_static_est;
+    }
+    // exclusive prefix (over the reverted bins before rk) of: 0 output sizes, 1 ground, 2 rejected
+    auto cum = [&](uint32_t rk, int which) -> uint32_t {
+        if (n_rev_all <= ASM_RVMAX) return which == 0 ? s_cv[rk] : (which == 1 ? s_cg[rk] : s_cr[rk]);
+        uint32_t a = 0;  // (more reverted bins than the tables hold: walk them)
+        for (uint32_t r = 0; r < rk; ++r) {
+            uint32_t sz, g, rj;
+            rev_sizes(r, sz, g, rj);
+            a += which == 0 ? sz : (which == 1 ? g : rj);
+        }
+        return a;
+    };
+    auto OUT_OFF = [&](uint32_t key) -> uint32_t {
+        if constexpr (FOLD) return out_off0[key] + cum(rev_before[key], 0);
+        else return out_off[key];
+    };
+    auto GROUND_OFF = [&](uint32_t rk) -> uint32_t {
+        if constexpr (FOLD) return cum(rk, 1);
+        else return ground_off[rk];
+    };
+    auto REJ_OFF = [&](uint32_t rk) -> uint32_t {
+        if constexpr (FOLD) return cum(rk, 2);
+        else return rej_off[rk];
+    };
+    if constexpr (FOLD) {
+        if (blockIdx.x == 0) {  // the final tables and totals, for the getters and k_step_end
+            for (uint32_t key = threadIdx.x; key < (uint32_t)P.B; key += blockDim.x) out_off[key] = OUT_OFF(key);
+            for (uint32_t rk = threadIdx.x; rk < n_rev_all; rk += blockDim.x) {
+                ground_off[rk] = GROUND_OFF(rk);
+                rej_off[rk] = REJ_OFF(rk);
+            }
+            if (threadIdx.x == 0) {
+                const uint32_t ncompl = moff[P.B + 1] - moff[P.B];
+                st->total_bins = total_bins;
+                st->n_ground = s_carry[1];
+                st->n_rejected = s_carry[2];
+                st->n_static_est = n_static_est;
+                st->n_compl = ncompl;
+                st->nF_new = n_static_est + ncompl;
+            }
+        }
+    }
     uint32_t nd = 0, nst = 0;  // label tallies of the copies this thread wrote to Fnew
     const uint32_t gmap = gridDim.x - tail;
     if (blockIdx.x >= gmap) {
@@ -3282,7 +3455,7 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
         for (uint32_t rk = blockIdx.x - gmap; rk < n_rev; rk += tail) {
             const uint32_t key = rev_list[rk];
             if (qoff[key + 1] == qoff[key]) continue;  // selected = an unoccupied bin_curr: r_pod2pc skips it
-            const uint32_t nv = nvox[rk], vo = vox_off[rk], oo = out_off[key];
+            const uint32_t nv = nvox[rk], vo = vox_off[rk], oo = OUT_OFF(key);
             for (uint32_t v = threadIdx.x; v < nv; v += blockDim.x) {
                 const float4 p = vox_out[vo + v];
                 Fnew[oo + v] = XFORM ? xform(Tb2o, p) : p;
@@ -3299,7 +3472,7 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
         const float4 p = spts[i];
         const float4 w = XFORM ? xform(Tb2o, p) : p;
         if (key == (uint32_t)P.B) {
-            Fnew[st->n_static_est + (i - moff[P.B])] = w;
+            Fnew[n_static_est + (i - moff[P.B])] = w;
             nwr = 1;
         } else {
             const uint8_t act = action[key];
@@ -3308,23 +3481,23 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
                 const uint32_t rk = rev_idx[key];
                 const uint32_t gr = grank[i];
                 if (gflag[i]) {
-                    Fnew[st->total_bins + ground_off[rk] + gr] = w;  // ground_viz copy
+                    Fnew[total_bins + GROUND_OFF(rk) + gr] = w;  // ground_viz copy
                     nwr = 1;
                     if (P.version == 2 && ccnt[key] > 0) {
-                        Fnew[out_off[key] + ccnt[key] + gr] = w;  // v2: inside the bin too
+                        Fnew[OUT_OFF(key) + ccnt[key] + gr] = w;  // v2: inside the bin too
                         nwr = 2;
                     }
                 } else if (rejected) {
-                    rejected[rej_off[rk] + gr] = xform(Tb2o, p);  // map_rejected_ is handed out in the map frame (OMU.cpp:287)
-                    rejected_src[rej_off[rk] + gr] = ssrc[i];
+                    rejected[REJ_OFF(rk) + gr] = xform(Tb2o, p);  // map_rejected_ is handed out in the map frame (OMU.cpp:287)
+                    rejected_src[REJ_OFF(rk) + gr] = ssrc[i];
                 }
             } else if (act == 2) {
-                Fnew[out_off[key] + ccnt[key] + r] = w;  // merged bin: curr points first
+                Fnew[OUT_OFF(key) + ccnt[key] + r] = w;  // merged bin: curr points first
                 nwr = 1;
             } else if (act == 3) {
                 // map bin empty by construction
             } else {
-                Fnew[out_off[key] + r] = w;
+                Fnew[OUT_OFF(key) + r] = w;
                 nwr = 1;
             }
         }

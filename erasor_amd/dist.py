@@ -5,6 +5,15 @@ OfflineMapUpdater.cpp:290 -> :393), so the only sharding without changing semant
 independent replicas / sequences.  The path therefore has exactly one exchange step: the RCCL broadcast
 of the global map from rank 0 over xGMI (160 MB for a 10 M-point map), then zero per-scan communication,
 then a MAX-reduce of the wall time (bench) or a gather of per-rank results.
+
+SURVEY 8(e)(ii), the result exchange of scan-parallel replicas: when N replicas work on scans of ONE sequence at the same
+time they cannot fold the map the way the reference does (scan k+1 would have to see what scan k removed).  What they can
+do is the Jacobi-style variant -- every scan is applied to the SAME initial map, each yields the initial-map indices of the
+points it rejects (erasor_hip_get_rejected_indices on a freshly set map), the ranks exchange their index lists with ONE
+all_gather and the union is removed from the initial map (`jacobi_removed_indices`, `allgather_indices`, `united_static_map`).
+That is a DEVIATION from the reference's sequential fold -- nothing a scan adds (voxelised reverted bins, OMU.cpp:281-290)
+enters the united map, and a scan never sees another scan's removals -- so it is reported beside the sequential result
+(PR / RR of both, bench.py --union-eval), never instead of it.
 """
 import os
 
@@ -72,3 +81,49 @@ def gather_counts(dist, world, values, device):
     out = [torch.zeros_like(v) for _ in range(world)]
     dist.all_gather(out, v)
     return [o.tolist() for o in out]
+
+
+# ---- union of the replicas' removals (Jacobi-style deviation, see the module docstring) ----------------------
+def jacobi_removed_indices(g, set_initial_map, scans, T_l2b, T_b2o, T_o2b, device_scans=None):
+    """Every scan of `scans` against the SAME initial map: `set_initial_map()` puts the initial map back into handle `g`
+    before each step (the step's pre-step indices are then initial-map indices).  Returns the sorted union of the
+    rejected initial-map indices (uint64) and the number of steps run."""
+    removed = []
+    for k in range(len(scans)):
+        set_initial_map()
+        if device_scans is not None:
+            g.step_device(device_scans[k], len(scans[k]), T_l2b, T_b2o[k], T_o2b[k])
+        else:
+            g.step(scans[k], T_l2b, T_b2o[k], T_o2b[k])
+        removed.append(g.get_rejected_indices())
+    if not removed:
+        return np.zeros(0, np.uint64), 0
+    return np.unique(np.concatenate(removed)).astype(np.uint64), len(scans)
+
+
+def allgather_indices(dist, world, idx, device):
+    """ONE exchange of variable-length index lists: sizes first (8 bytes per rank), then the lists padded to the longest.
+    Returns the per-rank arrays (on every rank)."""
+    import torch
+    idx = np.ascontiguousarray(idx, np.int64)
+    if dist is None:
+        return [idx.copy()]
+    n = torch.tensor([len(idx)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    mine = torch.full((cap,), -1, dtype=torch.int64, device=device)
+    if len(idx):
+        mine[: len(idx)] = torch.from_numpy(idx).to(device)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [o[:sizes[r]].cpu().numpy() for r, o in enumerate(out)]
+
+
+def united_static_map(initial_map, per_rank_indices):
+    """initial map minus the union of every rank's removed indices; returns (united map, union)"""
+    union = np.unique(np.concatenate([np.asarray(a, np.int64) for a in per_rank_indices])) if per_rank_indices else np.zeros(0, np.int64)
+    keep = np.ones(len(initial_map), bool)
+    keep[union] = False
+    return np.ascontiguousarray(initial_map[keep]), union

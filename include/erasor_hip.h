@@ -168,6 +168,26 @@ int erasor_hip_step_device(erasor_hip_handle *h, const void *d_scan_xyzi, size_t
                            const float T_lidar2body[16], const float T_body2origin[16],
                            const float T_origin2body[16], erasor_step_result *res);
 
+/* The same step in two halves (threading row).  erasor_hip_step_async enqueues everything a step enqueues -- this
+ * scan's query chain unless it was announced, the map chain, Scan Ratio Test .. write-back, the next announced scan's chain --
+ * and returns without waiting; erasor_hip_step_wait blocks until the results are on the host, commits them and fills *res
+ * exactly like erasor_hip_step.  erasor_hip_step_done polls (1: the wait would not block).  One host thread can so keep several
+ * handles busy: independent sequences are independent updaters (one callback per node per updater, OMU.cpp:203), and one step
+ * leaves most of the chip idle.  Between the two calls the handle accepts NO other call (ERASOR_E_STATE): announce the scans
+ * ahead BEFORE erasor_hip_step_async.  A host scan buffer must stay valid until erasor_hip_step_wait has returned (a VoxelGrid
+ * pass-through flip re-runs the step there). */
+int erasor_hip_step_async(erasor_hip_handle *h, const void *scan_xyzi, size_t n_scan, int src_is_device,
+                          const float T_lidar2body[16], const float T_body2origin[16], const float T_origin2body[16]);
+int erasor_hip_step_wait(erasor_hip_handle *h, erasor_step_result *res);
+int erasor_hip_step_done(erasor_hip_handle *h);
+
+/* Device buffers for callers that keep scans (erasor_hip_step_device, erasor_hip_prefetch_* with src_is_device) or the map
+ * (erasor_hip_set_map_device) resident in HBM but have no HIP of their own: hipMalloc / blocking hipMemcpy / hipFree on the
+ * handle's device.  (A ROS node hands over host clouds, OMU.cpp:237; these are for offline drivers and benchmarks.) */
+int erasor_hip_device_alloc(erasor_hip_handle *h, size_t bytes, void **d_ptr);
+int erasor_hip_device_upload(erasor_hip_handle *h, void *d_dst, const void *src, size_t bytes);
+int erasor_hip_device_free(erasor_hip_handle *h, void *d_ptr);
+
 /* replaces: the ERASOR class used on its own (erasor.h:109-141): set_inputs(map_voi, query_voi) +
  * compare_vois_and_revert_ground[_w_block] on caller-provided EGOCENTRIC clouds (query already voxelised and
  * in the body frame).  Results: erasor_hip_get_cloud(STATIC_ESTIMATE / COMPLEMENT / MAP_REJECTED /

@@ -38,6 +38,7 @@
 #include <thread>
 #include <vector>
 
+#define ERASOR_NO_HIPGRAPH 1  // (the stand-in has no graph API: the product code launches kernel by kernel)
 #define __device__
 #define __host__
 #define __global__
@@ -450,6 +451,10 @@ struct alignas(8) uint2 {
     uint32_t x, y;
 };
 inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+struct alignas(16) uint4 {
+    uint32_t x, y, z, w;
+};
+inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline uint32_t __float_as_uint(float f) {

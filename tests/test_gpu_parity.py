@@ -550,9 +550,6 @@ def test_full_size_bench_call_pattern_device_scans_two_nodes_ahead(gpu_mod):
     in HBM and read in place, every node announced TWO ahead with its pose (erasor_hip_prefetch_node: the query chains of the
     next two scans run beside the step, the next step's VoI split is launched behind the step's last kernel), steps through
     erasor_hip_step_device -- every step's results and the map it leaves against the oracle."""
-    torch = pytest.importorskip("torch")
-    if os.environ.get("ERASOR_TEST_SIMT_LIB") or not torch.cuda.is_available():
-        pytest.skip("needs device buffers (the CPU stand-in runs this pattern in tests/simt_full_step.py)")
     from oracle import orc
     w = synth.World(seed=20210305 + 5, length=1000.0, n_streets=5, street_gap=50.0, n_moving=10, n_peds=6)
     lid = synth.Lidar.hdl64(2000)
@@ -561,9 +558,9 @@ def test_full_size_bench_call_pattern_device_scans_two_nodes_ahead(gpu_mod):
     p = orc.params_default()
     synth.apply_params(p, "05", max_range=80.0, num_rings=20, num_sectors=108)
     g, o = make_pair(gpu_mod, p)
-    dev = torch.device("cuda", 0)
-    d_map = torch.from_numpy(m).to(dev)
-    g.set_map_device(d_map.data_ptr(), len(m))
+    d_map = g.device_array(m)
+    g.set_map_device(d_map, len(m))
+    g.device_free(d_map)  # (set_map_device copies into the map store)
     o.set_map(m)
     jr = np.random.default_rng(1234)
     Tl = gpu_mod.c_mat(gpu_mod.geopose2eigen([0, 0, synth.LIDAR_HEIGHT, 0, 0, 0, 1]))
@@ -574,15 +571,14 @@ def test_full_size_bench_call_pattern_device_scans_two_nodes_ahead(gpu_mod):
         scans.append(w.cast(p7, lid, k))
         Tb.append(gpu_mod.geopose2eigen(p7))
         To.append(gpu_mod.invert_rigid(Tb[-1]))
-    d_scans = [torch.from_numpy(s).to(dev) for s in scans]
-    torch.cuda.synchronize()
+    d_scans = [g.device_array(s) for s in scans]
     cTb, cTo = [gpu_mod.c_mat(t) for t in Tb], [gpu_mod.c_mat(t) for t in To]
     for j in range(LA):
-        g.prefetch_device(d_scans[j].data_ptr(), len(scans[j]), Tl, cTb[j])
+        g.prefetch_device(d_scans[j], len(scans[j]), Tl, cTb[j])
     for k in range(n):
         if k + LA < n:
-            g.prefetch_device(d_scans[k + LA].data_ptr(), len(scans[k + LA]), Tl, cTb[k + LA])
-        rg = g.step_device(d_scans[k].data_ptr(), len(scans[k]), Tl, cTb[k], cTo[k])
+            g.prefetch_device(d_scans[k + LA], len(scans[k + LA]), Tl, cTb[k + LA])
+        rg = g.step_device(d_scans[k], len(scans[k]), Tl, cTb[k], cTo[k])
         ro = o.step(scans[k], np.asarray(Tl, np.float32), Tb[k], To[k])
         assert rg.n_reverted_bins > 0 or k == 0
         compare_step(g, o, rg, ro, full=(k == n - 1))
@@ -698,6 +694,44 @@ def test_prefetched_scans_give_the_same_results(gpu_mod, version, ahead):
     rg = g.step(held, sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
     ro = o.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
     compare_step(g, o, rg, ro, full=True)
+
+
+def test_api_error_two_handles_interleaved_with_step_async(gpu_mod):
+    """erasor_hip_step_async / erasor_hip_step_wait: one host thread keeps two independent handles (two sequences) busy --
+    A.async, B.async, A.wait, B.wait -- with their nodes announced ahead; every step of either sequence is the oracle's, the
+    handle refuses other calls while its step is in flight, and a wait without a step is an error."""
+    sca, scb = scenarios.small(), scenarios.small(version=2)
+    ga, oa = make_pair(gpu_mod, sca["params"])
+    gb, ob = make_pair(gpu_mod, scb["params"])
+    for g, o, sc in ((ga, oa, sca), (gb, ob, scb)):
+        g.set_map(sc["map"])
+        o.set_map(sc["map"])
+    n = 5
+    sa = [np.ascontiguousarray(s, np.float32) for s in sca["scans"][:n]]
+    sb = [np.ascontiguousarray(s, np.float32) for s in scb["scans"][:n]]
+    ga.prefetch(sa[0], sca["T_l2b"], sca["T_b2o"][0])
+    gb.prefetch(sb[0], scb["T_l2b"], scb["T_b2o"][0])
+    with pytest.raises(gpu_mod.ErasorError) as e:
+        ga.step_wait()
+    assert e.value.rc == -4
+    for k in range(n):
+        if k + 1 < n:
+            ga.prefetch(sa[k + 1], sca["T_l2b"], sca["T_b2o"][k + 1])
+            gb.prefetch(sb[k + 1], scb["T_l2b"], scb["T_b2o"][k + 1])
+        ga.step_async(sa[k], T_l2b=sca["T_l2b"], T_b2o=sca["T_b2o"][k], T_o2b=sca["T_o2b"][k])
+        gb.step_async(sb[k], T_l2b=scb["T_l2b"], T_b2o=scb["T_b2o"][k], T_o2b=scb["T_o2b"][k])
+        for call in (ga.get_map, ga.get_status, lambda: ga.prefetch(sa[0], sca["T_l2b"]), lambda: ga.set_map(sca["map"]),
+                     lambda: ga.step_async(sa[k], T_l2b=sca["T_l2b"], T_b2o=sca["T_b2o"][k], T_o2b=sca["T_o2b"][k])):
+            with pytest.raises(gpu_mod.ErasorError) as e:
+                call()
+            assert e.value.rc == -4, "a handle with a step in flight must refuse other calls"
+        rga = ga.step_wait()
+        rgb = gb.step_wait()
+        assert ga.step_done() and gb.step_done()
+        roa = oa.step(sa[k], sca["T_l2b"], sca["T_b2o"][k], sca["T_o2b"][k])
+        rob = ob.step(sb[k], scb["T_l2b"], scb["T_b2o"][k], scb["T_o2b"][k])
+        compare_step(ga, oa, rga, roa, full=(k % 2 == 0))
+        compare_step(gb, ob, rgb, rob, full=(k % 2 == 1))
 
 
 @pytest.mark.parametrize("version,ahead", [(3, 1), (3, 2), (2, 2)])
