@@ -75,6 +75,9 @@ def parse_args():
     ap.add_argument("--interleave", choices=["async", "threads", "off"], default="async",
                     help="seq-per-gpu with several sequences on one rank: async = one host thread keeps every sequence's step in flight "
                          "(erasor_hip_step_async / _wait); threads = one host thread per sequence, blocking steps; off = one sequence after the other")
+    ap.add_argument("--python-loop", action="store_true",
+                    help="drive the timed steps from a Python loop (prefetch + step per node) instead of ONE erasor_hip_run_nodes call "
+                         "(the offline driver's node loop in native code: the same calls, without ~20 us of interpreter time between two steps)")
     ap.add_argument("--eval", action="store_true", help="seq-per-gpu: PR/RR of every sequence's final map (erasor_amd.evalmap)")
     return ap.parse_args()
 
@@ -221,6 +224,16 @@ class Sequence:
         self.primed = False
         # nodes are announced with their pose (scan + odometry, like erasor::node): the next step's VoI split is launched ahead
         self.with_pose = not os.environ.get("ERASOR_BENCH_NO_POSE_AHEAD")
+        # the whole sequence as arrays for erasor_hip_run_nodes (the node loop in native code)
+        import ctypes as C
+        self.na = erasor_amd.Erasor.node_arrays(self.d_ptr, self.n_pts, self.Tb, self.To)
+        self.announced = C.c_size_t(0)
+
+    def run_block(self, first, count):
+        """nodes [first, first + count) in ONE native call: each announced LA ahead with its pose, stepped one after the other"""
+        P, N, Tb, To = self.na
+        self.primed = True
+        return self.g.run_nodes(P, N, self.c_Tl, Tb, To, first, count, self.LA if self.lookahead else 0, self.announced)
 
     def prime(self):
         if self.lookahead and not self.primed:
@@ -425,7 +438,11 @@ def main():
     t_map = time.time() - t0
 
     step_results = []  # erasor_step_result of every step of the first sequence, warm-up included (compared with the oracle's below)
+    native_loop = not args.python_loop and len(seqs) == 1 and not os.environ.get("ERASOR_BENCH_NO_POSE_AHEAD")
     for si, (_, s) in enumerate(seqs):
+        if native_loop:
+            step_results.extend(s.run_block(0, W))
+            continue
         s.prime()
         for k in range(W):
             r_ = s.run(k)
@@ -434,7 +451,10 @@ def main():
     first = seqs[0][1] if seqs else None
     if first is not None:
         first.g.profile_reset()
-        first.g.profiling(2)  # HIP events around voi_split only, on the handle's stream, during the timed region
+        if not os.environ.get("ERASOR_BENCH_NO_SPLIT_EVENTS"):  # (A/B switch: what the roofline's own measurement costs the step)
+            # start / stop HIP events attached to every FOURTH k_voi_split launch of the timed region, on the handle's stream (the
+            # bracket costs the step it observes ~9 us: measured 0.276 vs 0.267 ms per scan with every launch bracketed / none)
+            first.g.profiling(3)
     split_bytes = []
     torch.cuda.synchronize()
     if dist is not None:
@@ -443,7 +463,21 @@ def main():
     last = None
     totals = np.zeros(6, np.int64)  # steps, map_rejected, reverted_bins, final map size, static, dynamic
     interleave = args.interleave if len(seqs) > 1 else "off"
-    if interleave == "async":
+    if native_loop:
+        # ONE call for the K timed nodes (erasor_hip_run_nodes = the offline driver's node loop, main_in_your_env.cpp:92-123)
+        s = seqs[0][1]
+        split_bytes.append(s.g.voi_split_bytes())
+        rs = s.run_block(W, K)
+        split_bytes.append(s.g.voi_split_bytes())
+        step_results.extend(rs)
+        last = rs[-1]
+        totals[0] += K
+        totals[1] += sum(r.n_map_rejected for r in rs)
+        totals[2] += sum(r.n_reverted_bins for r in rs)
+        totals[3] += last.n_map_out
+        totals[4] += last.n_static
+        totals[5] += last.n_dynamic
+    elif interleave == "async":
         # independent sequences are independent updaters: ONE host thread keeps a step of every sequence in flight
         for k in range(W, W + K):
             for si, (_, s) in enumerate(seqs):
@@ -575,7 +609,7 @@ def main():
                               "SURVEY §8(d)'s 16 B/pt assumed an AoS map (aos16_equiv_GBps is the rate in that currency)",
                 "entries_per_launch": int(entries), "avg_launch_us": round(avg_ms * 1e3, 2),
                 "rocprofv3_kernel_avg_us": rocprof_avg, "rocprofv3_source": src_note,
-                "launches": int(vs_n),
+                "launches": int(vs_n), "launches_note": "every fourth k_voi_split launch of the timed region carries the start / stop events",
                 "aos16_equiv_GBps": round(16.0 * entries / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
                 "working_set_vs_L3": "%.0f MB streamed per launch vs 256 MiB Infinity Cache" % (alg_bytes / 1e6),
                 "step_alg_bytes": int(step_alg), "step_achieved": round(step_gbps, 1), "step_frac": round(step_gbps / PEAK_HBM_GBPS, 4),
@@ -625,7 +659,8 @@ def main():
                    "sharding": ("scan-parallel replicas, one RCCL broadcast of the map, no data-path collective" if args.mode == "replicas"
                                 else "one KITTI-shaped sequence per GPU (00/01/02/05/07 dealt round-robin), no map exchange"),
                    "lookahead_scans": first.LA if first.lookahead else 0,
-                   "sequences_on_this_rank": len(seqs), "interleave": interleave},
+                   "sequences_on_this_rank": len(seqs), "interleave": interleave,
+                   "node_loop": "native (erasor_hip_run_nodes: one call for the timed nodes)" if native_loop else "python (prefetch + step per node)"},
         "map_points_x_scans_per_sec": round(value * N_map, 1),
         "ms_per_step_without_lookahead": None if sync_ms is None else round(sync_ms, 4),
         "roofline": roofline, "cpu_baseline": cpu, "cpu_port": cpu_port, "host": host_identity(),

@@ -233,6 +233,26 @@ class Erasor:
         self._last_res = res
         return res
 
+    def run_nodes(self, scan_ptrs, n_pts, T_l2b, Tb, To, first, count, lookahead, announced, device=True):
+        """erasor_hip_run_nodes: nodes [first, first + count) of a sequence in ONE native call (the offline driver's loop).
+        scan_ptrs / n_pts: ctypes arrays over the whole sequence (see node_arrays); announced: a ctypes c_size_t carried
+        between calls.  Returns the list of StepResult."""
+        res = (StepResult * count)()
+        self._check(lib().erasor_hip_run_nodes(self._h, scan_ptrs, n_pts, C.c_size_t(len(n_pts)), C.c_int(1 if device else 0), _m(T_l2b), Tb, To,
+                                               C.c_size_t(first), C.c_size_t(count), C.c_int(lookahead), C.byref(announced), res))
+        self._last_res = res[count - 1] if count else None
+        return list(res)
+
+    @staticmethod
+    def node_arrays(ptrs, sizes, Tb_list, To_list):
+        """the arguments of run_nodes from Python lists: device (or host) pointers, point counts, 4x4 matrices"""
+        n = len(ptrs)
+        P = (C.c_void_p * n)(*ptrs)
+        N = (C.c_size_t * n)(*sizes)
+        Tb = (C.c_float * (16 * n))(*[float(v) for t in Tb_list for v in np.asarray(t, np.float32).reshape(16)])
+        To = (C.c_float * (16 * n))(*[float(v) for t in To_list for v in np.asarray(t, np.float32).reshape(16)])
+        return P, N, Tb, To
+
     def last_result(self):
         """erasor_step_result of the last collected step (kept by the wrapper)"""
         return self._last_res

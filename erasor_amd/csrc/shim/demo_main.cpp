@@ -1,6 +1,7 @@
 // erasor_offline_demo — ROS-free driver shaped like src/offline_map_updater/main_in_your_env.cpp:61-127:
 //   <dir>/map.pcd, <dir>/pcds/%06d.pcd, <dir>/poses.csv (header line; idx,?,x,y,z,qx,qy,qz,qw per line, cols 2..8)
 // processes every node through erasor::OfflineMapUpdater and writes <dir>/<data_name>_result.pcd and map_final.pcd.
+#include <array>
 #include <cstdio>
 #include <fstream>
 #include <sstream>
@@ -161,7 +162,135 @@ static int voxelize_mode(int argc, char **argv) {
     return 0;
 }
 
+// --bench <dir> <n_timed> <n_warmup>: what a caller of the drop-in surface gets, timed in C++ (no Python in the loop) on the workload
+// tools/export_cpp_bench.py wrote (bench.py's config 2).  Three passes over the same nodes, each on a fresh map:
+//   1. erasor::OfflineMapUpdater::callback_node, host cloud in (OMU.cpp:237 fromROSMsg has just produced it), map_rejected /
+//      query_rejected clouds out on the host (what OMU.cpp:316-320 publishes) -- nothing announced;
+//   2. the same with the next node announced (announce_next: what an offline driver or a node holding one message back can do);
+//   3. the C ABI itself with the scans resident in HBM and nodes announced two ahead (bench.py's loop, minus Python).
+// Prints ONE JSON line.
+#include <chrono>
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static int bench_mode(int argc, char **argv) {
+    if (argc < 5) return 2;
+    const std::string dir = argv[2];
+    const int K = atoi(argv[3]), W = atoi(argv[4]);
+    erasor::OfflineMapUpdater::Config cfg;
+    {
+        std::ifstream f(dir + "/params.bin", std::ios::binary);
+        if (!f.read(reinterpret_cast<char *>(&cfg.params), sizeof(cfg.params))) return 3;
+    }
+    std::vector<double> poses, l2b(7);
+    {
+        std::ifstream f(dir + "/poses.bin", std::ios::binary | std::ios::ate);
+        if (!f) return 3;
+        poses.resize((size_t)f.tellg() / 8);
+        f.seekg(0);
+        f.read(reinterpret_cast<char *>(poses.data()), (std::streamsize)(poses.size() * 8));
+        std::ifstream g(dir + "/l2b.bin", std::ios::binary);
+        if (!g.read(reinterpret_cast<char *>(l2b.data()), 56)) return 3;
+    }
+    const int n_nodes = (int)(poses.size() / 7);
+    if (n_nodes < K + W + 2) {
+        fprintf(stderr, "need %d nodes, %d exported\n", K + W + 2, n_nodes);
+        return 3;
+    }
+    for (int k = 0; k < 7; ++k) cfg.lidar2body[k] = l2b[k];
+    cfg.params.removal_interval = 1;
+    cfg.verbose = false;
+    pcl::PointCloud<pcl::PointXYZI> map0;
+    if (!read_bin(dir + "/map.bin", map0)) return 3;
+    std::vector<pcl::PointCloud<pcl::PointXYZI>> scans(K + W + 2);
+    std::vector<geometry_msgs::Pose> odom(K + W + 2);
+    for (int i = 0; i < K + W + 2; ++i) {
+        char name[64];
+        snprintf(name, sizeof(name), "/scan_%06d.bin", i);
+        if (!read_bin(dir + name, scans[i])) return 3;
+        const double *v = &poses[(size_t)i * 7];
+        odom[i].position.x = v[0]; odom[i].position.y = v[1]; odom[i].position.z = v[2];
+        odom[i].orientation.x = v[3]; odom[i].orientation.y = v[4]; odom[i].orientation.z = v[5]; odom[i].orientation.w = v[6];
+    }
+    double ms_cb[2] = {0, 0}, ms_announce = 0;
+    unsigned long long rejected[2] = {0, 0}, map_out[2] = {0, 0};
+    for (int pass = 0; pass < 2; ++pass) {
+        erasor::OfflineMapUpdater updater(cfg);
+        updater.set_global_map(map0);
+        double t0 = 0;
+        for (int i = 0; i < W + K; ++i) {
+            if (i == W) t0 = now_ms();
+            if (pass == 1) {
+                const double ta = now_ms();
+                updater.announce_next(scans[i + 1], odom[i + 1]);
+                if (i >= W) ms_announce += now_ms() - ta;
+            }
+            updater.callback_node(i, odom[i], scans[i]);
+            if (i >= W) rejected[pass] += updater.map_rejected.size();  // (the host copies of what the node publishes)
+        }
+        ms_cb[pass] = (now_ms() - t0) / K;
+        map_out[pass] = updater.last.n_map_out;
+    }
+    // pass 3: the C ABI, device-resident scans, nodes announced two ahead
+    double ms_dev = 0;
+    unsigned long long rejected_dev = 0, map_out_dev = 0;
+    {
+        erasor_hip_handle *h = nullptr;
+        if (erasor_hip_create(&cfg.params, 0, &h) != ERASOR_OK) return 4;
+        std::vector<float> buf(map0.size() * 4);
+        for (size_t i = 0; i < map0.size(); ++i) { buf[4 * i] = map0.points[i].x; buf[4 * i + 1] = map0.points[i].y; buf[4 * i + 2] = map0.points[i].z; buf[4 * i + 3] = map0.points[i].intensity; }
+        if (erasor_hip_set_map(h, buf.data(), map0.size()) != ERASOR_OK) return 4;
+        std::vector<void *> d_scan(K + W + 2, nullptr);
+        std::vector<size_t> n_scan(K + W + 2);
+        std::vector<std::array<float, 16>> Tb(K + W + 2), To(K + W + 2);
+        float Tl[16];
+        geometry_msgs::Pose l2bp;
+        l2bp.position.x = l2b[0]; l2bp.position.y = l2b[1]; l2bp.position.z = l2b[2];
+        l2bp.orientation.x = l2b[3]; l2bp.orientation.y = l2b[4]; l2bp.orientation.z = l2b[5]; l2bp.orientation.w = l2b[6];
+        const Eigen::Matrix4f TL = erasor_utils::geoPose2eigen(l2bp);
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Tl[4 * r + c] = TL(r, c);
+        for (int i = 0; i < K + W + 2; ++i) {
+            n_scan[i] = scans[i].size();
+            buf.resize(n_scan[i] * 4);
+            for (size_t j = 0; j < n_scan[i]; ++j) { buf[4 * j] = scans[i].points[j].x; buf[4 * j + 1] = scans[i].points[j].y; buf[4 * j + 2] = scans[i].points[j].z; buf[4 * j + 3] = scans[i].points[j].intensity; }
+            if (erasor_hip_device_alloc(h, n_scan[i] * 16, &d_scan[i]) != ERASOR_OK || erasor_hip_device_upload(h, d_scan[i], buf.data(), n_scan[i] * 16) != ERASOR_OK) return 4;
+            const Eigen::Matrix4f T = erasor_utils::geoPose2eigen(odom[i]), Ti = erasor_utils::inverse(T);
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { Tb[i][4 * r + c] = T(r, c); To[i][4 * r + c] = Ti(r, c); }
+        }
+        for (int j = 0; j < 2; ++j) erasor_hip_prefetch_node(h, d_scan[j], n_scan[j], 1, Tl, Tb[j].data());
+        double t0 = 0;
+        erasor_step_result res;
+        for (int i = 0; i < W + K; ++i) {
+            if (i == W) t0 = now_ms();
+            if (i + 2 < W + K + 2) erasor_hip_prefetch_node(h, d_scan[i + 2], n_scan[i + 2], 1, Tl, Tb[i + 2].data());
+            if (erasor_hip_step_device(h, d_scan[i], n_scan[i], Tl, Tb[i].data(), To[i].data(), &res) != ERASOR_OK) {
+                fprintf(stderr, "step %d: %s\n", i, erasor_hip_last_error(h));
+                return 4;
+            }
+            if (i >= W) rejected_dev += res.n_map_rejected;
+        }
+        ms_dev = (now_ms() - t0) / K;
+        map_out_dev = res.n_map_out;
+        for (void *p : d_scan) erasor_hip_device_free(h, p);
+        erasor_hip_destroy(h);
+    }
+    const bool same = rejected[0] == rejected[1] && rejected[0] == rejected_dev && map_out[0] == map_out[1] && map_out[0] == map_out_dev;
+    printf("{\"bench\": \"erasor_offline_demo --bench (C++, no Python in the loop)\", \"nodes_timed\": %d, \"warmup\": %d, \"map_points\": %zu, "
+           "\"scan_points\": %zu, \"ms_per_callback\": %.4f, \"ms_per_callback_next_node_announced\": %.4f, "
+           "\"of_which_announce_next\": %.4f, \"ms_per_step_device_resident_two_ahead\": %.4f, \"callback_note\": \"OfflineMapUpdater::callback_node: host PointXYZI cloud in "
+           "(32-byte points repacked to xyzi, copied to the device), map_rejected / query_rejected clouds copied back to the host\", "
+           "\"map_rejected_points\": %llu, \"final_map_points\": %llu, \"three_passes_agree\": %s}\n",
+           K, W, map0.size(), scans[W].size(), ms_cb[0], ms_cb[1], ms_announce / K, ms_dev, rejected[0], map_out[0], same ? "true" : "false");
+    return same ? 0 : 5;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 2 && std::string(argv[1]) == "--bench") {
+        try {
+            return bench_mode(argc, argv);
+        } catch (const std::exception &e) {
+            fprintf(stderr, "error: %s\n", e.what());
+            return 1;
+        }
+    }
     if (argc >= 2 && std::string(argv[1]) == "--voxelize") {
         try {
             return voxelize_mode(argc, argv);

@@ -355,49 +355,65 @@ void OfflineMapUpdater::set_global_map(const Cloud &map_init) {
     const std::vector<float> v = to_xyzi(map_init);
     check(h_, erasor_hip_set_map(h_, v.data(), map_init.size()), "erasor_hip_set_map");
 }
+// is `lidar` the cloud whose xyzi copy `v` holds?  (bitwise; stops at the first difference)
+static bool same_cloud(const Cloud &lidar, const std::vector<float> &v) {
+    if (v.size() != 4 * lidar.size()) return false;
+    for (size_t i = 0; i < lidar.size(); ++i) {
+        const pcl::PointXYZI &p = lidar.points[i];
+        const float q[4] = {p.x, p.y, p.z, p.intensity};
+        if (memcmp(q, &v[4 * i], sizeof(q)) != 0) return false;
+    }
+    return true;
+}
 void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, const Cloud &lidar) {
-    (void)seq;
     stack_count_++;
     if (stack_count_ % cfg_.params.removal_interval != 0) {  // OMU.cpp:206-209,327-329 "PASS!"
         if (cfg_.verbose) printf(" PASS! \n");
-        return;
+    } else {
+        if (cfg_.environment != "outdoor") throw std::invalid_argument("Other modes are not supported");  // OMU.cpp:312
+        tf_body2origin_ = erasor_utils::geoPose2eigen(odom);  // OMU.cpp:219
+        const Eigen::Matrix4f tf_origin2body = erasor_utils::inverse(tf_body2origin_);
+        float Tl[16], Tb[16], To[16];
+        mat16(tf_lidar2body_, Tl);
+        mat16(tf_body2origin_, Tb);
+        mat16(tf_origin2body, To);
+        std::vector<float> own;
+        const float *scan = nullptr;
+        // the cloud announced before the PREVIOUS callback is this one's: the step must get that very buffer (its query chain is
+        // in flight under that address); anything else goes in as a fresh scan (the handle then drops what was announced)
+        if (have_cur_ && same_cloud(lidar, cur_xyzi_)) scan = cur_xyzi_.data();
+        if (!scan) {
+            own = to_xyzi(lidar);
+            scan = own.data();
+        }
+        check(h_, erasor_hip_step(h_, scan, lidar.size(), Tl, Tb, To, &last), "erasor_hip_step");
+        if (last.n_ambiguous)  // (never seen on transformed clouds; said aloud because bin equality is only PROVABLE when it is zero)
+            fprintf(stderr, "[erasor shim] node %d: %u point(s) within 1e-11 of a sector boundary: their bin is not provably the reference's (device atan2 vs glibc)\n",
+                    seq, last.n_ambiguous);
+        fetch_cloud(h_, ERASOR_CLOUD_MAP_REJECTED, map_rejected);
+        fetch_cloud(h_, ERASOR_CLOUD_CURR_REJECTED, query_rejected);
+        ++num_processed;
+        if (cfg_.verbose) {  // print_status (OMU.cpp:451-465)
+            printf("ERASOR Input: %llu = %llu + %llu - %llu\n", (unsigned long long)last.n_voi, (unsigned long long)last.n_static_estimate,
+                   (unsigned long long)last.n_complement, (unsigned long long)last.n_map_rejected);
+            printf("[Debug] Total: %llu  dynamic %llu  static %llu\n", (unsigned long long)last.n_map_out, (unsigned long long)last.n_dynamic,
+                   (unsigned long long)last.n_static);
+        }
     }
-    if (cfg_.environment != "outdoor") throw std::invalid_argument("Other modes are not supported");  // OMU.cpp:312
-    tf_body2origin_ = erasor_utils::geoPose2eigen(odom);  // OMU.cpp:219
-    const Eigen::Matrix4f tf_origin2body = erasor_utils::inverse(tf_body2origin_);
-    float Tl[16], Tb[16], To[16];
-    mat16(tf_lidar2body_, Tl);
-    mat16(tf_body2origin_, Tb);
-    mat16(tf_origin2body, To);
-    std::vector<float> own;
-    const float *scan = nullptr;
-    if (has_next_ && next_xyzi_.size() == 4 * lidar.size()) {
-        own = to_xyzi(lidar);
-        if (own.empty() || memcmp(own.data(), next_xyzi_.data(), own.size() * sizeof(float)) == 0) scan = next_xyzi_.data();  // as announced
-    }
-    if (!scan) {
-        if (own.empty()) own = to_xyzi(lidar);
-        scan = own.data();
-    }
-    has_next_ = false;
-    check(h_, erasor_hip_step(h_, scan, lidar.size(), Tl, Tb, To, &last), "erasor_hip_step");
-    if (last.n_ambiguous)  // (never seen on transformed clouds; said aloud because bin equality is only PROVABLE when it is zero)
-        fprintf(stderr, "[erasor shim] node %d: %u point(s) within 1e-11 of a sector boundary: their bin is not provably the reference's (device atan2 vs glibc)\n",
-                seq, last.n_ambiguous);
-    fetch_cloud(h_, ERASOR_CLOUD_MAP_REJECTED, map_rejected);
-    fetch_cloud(h_, ERASOR_CLOUD_CURR_REJECTED, query_rejected);
-    ++num_processed;
-    if (cfg_.verbose) {  // print_status (OMU.cpp:451-465)
-        printf("ERASOR Input: %llu = %llu + %llu - %llu\n", (unsigned long long)last.n_voi, (unsigned long long)last.n_static_estimate,
-               (unsigned long long)last.n_complement, (unsigned long long)last.n_map_rejected);
-        printf("[Debug] Total: %llu  dynamic %llu  static %llu\n", (unsigned long long)last.n_map_out, (unsigned long long)last.n_dynamic,
-               (unsigned long long)last.n_static);
+    // what announce_next brought for the node AFTER this one is the next callback's cloud (the two buffers swap roles: the
+    // address the handle knows stays valid)
+    have_cur_ = false;
+    if (has_next_) {
+        cur_xyzi_.swap(next_xyzi_);
+        have_cur_ = true;
+        has_next_ = false;
     }
 }
 void OfflineMapUpdater::announce_next(const Cloud &lidar) { announce(lidar, nullptr); }
 void OfflineMapUpdater::announce_next(const Cloud &lidar, const geometry_msgs::Pose &odom) { announce(lidar, &odom); }
 void OfflineMapUpdater::announce(const Cloud &lidar, const geometry_msgs::Pose *odom) {
-    if ((stack_count_ + 1) % cfg_.params.removal_interval != 0) return;  // the next node will be gated out (OMU.cpp:206-209)
+    // called BEFORE callback_node(current) with the cloud of the node after it: current is callback number stack_count_ + 1
+    if ((stack_count_ + 2) % cfg_.params.removal_interval != 0) return;  // that node will be gated out (OMU.cpp:206-209)
     if (has_next_) return;                                                 // one cloud ahead is what callback_node can honour
     next_xyzi_ = to_xyzi(lidar);
     float Tl[16];

@@ -143,8 +143,8 @@ public:
     void set_global_map(const pcl::PointCloud<pcl::PointXYZI> &map_init);  // load_global_map's copy, OMU.cpp:133
     // one erasor::node message: header.seq, odom, lidar (msg/node.msg:1-4) — OMU.cpp:203-330
     void callback_node(int seq, const geometry_msgs::Pose &odom, const pcl::PointCloud<pcl::PointXYZI> &lidar);
-    // Offline look-ahead (no counterpart in the reference, which learns about a node when its message arrives): tell the
-    // updater which cloud the NEXT callback_node will bring.  Its voxelisation / binning then overlap the current node's
+    // Offline look-ahead (no counterpart in the reference, which learns about a node when its message arrives): called BEFORE
+    // callback_node(k) with the cloud of node k + 1 -- tell the updater which cloud the callback after the upcoming one brings.  Its voxelisation / binning then overlap the current node's
     // map-side stages (erasor_hip_prefetch_scan); results are unchanged.  Ignored for nodes the removal_interval gate skips.
     void announce_next(const pcl::PointCloud<pcl::PointXYZI> &lidar);
     // ... and its odometry, when the whole next node is known (erasor_hip_prefetch_node: the VoI pass of the next callback is
@@ -163,8 +163,9 @@ private:
     erasor_hip_handle *h_ = nullptr;
     Eigen::Matrix4f tf_lidar2body_, tf_body2origin_;
     int stack_count_ = 0;
-    std::vector<float> next_xyzi_;  // the announced cloud (the step must pass this very buffer)
-    bool has_next_ = false;
+    std::vector<float> next_xyzi_, cur_xyzi_;  // announced for the node after the upcoming one / for the upcoming one (the step must
+                                               // pass the very buffer that was announced)
+    bool has_next_ = false, have_cur_ = false;
     void announce(const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose *odom);
 };
 // main_in_your_env.cpp:66-70: the driver's own rosparams

@@ -58,6 +58,7 @@ public:
             publish(map_init_, pub_map_init_);
         }
     }
+    ~OfflineMapUpdaterNode() { flush_held(); }
     void save_static_map(float voxel_size) { updater_->save_static_map(voxel_size); }
     OfflineMapUpdater &updater() { return *updater_; }
 
@@ -97,6 +98,7 @@ private:
         nh.param("/erasor/max_range", voi_range, 60.0);
         p.voi_max_range = voi_range;
         nh.param("/verbose", cfg_.verbose, true);
+        nh.param<bool>("/MapUpdater/lookahead_hold", hold_, false);
         std::vector<double> lidar2body;
         if (nh.getParam("/tf/lidar2body", lidar2body) && lidar2body.size() == 7)  // OMU.cpp:89-104
             for (int k = 0; k < 7; ++k) cfg_.lidar2body[k] = lidar2body[k];
@@ -107,9 +109,36 @@ private:
         tf_lidar2body_ = erasor_utils::geoPose2eigen(l2b);
     }
 
-    void callback_flag(const std_msgs::Float32::ConstPtr &msg) { save_static_map(msg->data); }  // OMU.cpp:169-172
+    void callback_flag(const std_msgs::Float32::ConstPtr &msg) {  // OMU.cpp:169-172
+        flush_held();
+        save_static_map(msg->data);
+    }
 
+    // /MapUpdater/lookahead_hold (default false = the reference's timing: node k is processed when it arrives).  When true the node
+    // keeps ONE message back: node k is processed when node k+1 arrives, and k+1 is announced first (OfflineMapUpdater::announce_next
+    // -> erasor_hip_prefetch_node), so that its voxelisation / binning and the next VoI pass overlap node k's map-side stages --
+    // the look-ahead the offline driver uses, under ROS.  Results are unchanged; every publication is one message late, and the
+    // last node is processed when /saveflag arrives (or at shutdown).
     void callback_node(const erasor::node::ConstPtr &msg) {
+        if (!hold_) {
+            process(*msg);
+            return;
+        }
+        if (held_) {
+            pcl::PointCloud<pcl::PointXYZI> next;
+            pcl::fromROSMsg(msg->lidar, next);
+            updater_->announce_next(next, msg->odom);
+            process(*held_);
+        }
+        held_ = msg;
+    }
+    void flush_held() {
+        if (held_) process(*held_);
+        held_.reset();
+    }
+
+    void process(const erasor::node &node) {
+        const erasor::node *msg = &node;
         pcl::PointCloud<pcl::PointXYZI> query;
         pcl::fromROSMsg(msg->lidar, query);  // OMU.cpp:237
         const size_t before = updater_->num_processed;
@@ -224,6 +253,8 @@ private:
     pcl::PointCloud<pcl::PointXYZI> map_init_;
     sensor_msgs::PointCloud2 pc2_map_;
     nav_msgs::Path path_;
+    bool hold_ = false;
+    erasor::node::ConstPtr held_;
 };
 
 }  // namespace erasor

@@ -181,6 +181,15 @@ int erasor_hip_step_async(erasor_hip_handle *h, const void *scan_xyzi, size_t n_
 int erasor_hip_step_wait(erasor_hip_handle *h, erasor_step_result *res);
 int erasor_hip_step_done(erasor_hip_handle *h);
 
+/* replaces: the node loop of the offline driver (main_in_your_env.cpp:92-123): nodes [first, first + count) of a sequence of n_total,
+ * every node announced `lookahead` (0..2) nodes ahead with its pose, stepped one after the other -- the very calls a host loop would
+ * make (erasor_hip_prefetch_node, erasor_hip_step[_device]), minus the caller's own time between two steps.  *announced (in / out):
+ * nodes [0, *announced) are announced already, so a sequence can be split over several calls.  T_body2origin / T_origin2body: n_total
+ * row-major 4x4 matrices each; res: `count` result blocks (may be NULL). */
+int erasor_hip_run_nodes(erasor_hip_handle *h, const void *const *scans, const size_t *n_pts, size_t n_total, int src_is_device,
+                         const float T_lidar2body[16], const float *T_body2origin, const float *T_origin2body, size_t first, size_t count,
+                         int lookahead, size_t *announced, erasor_step_result *res);
+
 /* Device buffers for callers that keep scans (erasor_hip_step_device, erasor_hip_prefetch_* with src_is_device) or the map
  * (erasor_hip_set_map_device) resident in HBM but have no HIP of their own: hipMalloc / blocking hipMemcpy / hipFree on the
  * handle's device.  (A ROS node hands over host clouds, OMU.cpp:237; these are for offline drivers and benchmarks.) */

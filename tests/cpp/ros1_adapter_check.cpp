@@ -28,6 +28,7 @@ int main(int argc, char **argv) {
     P["/MapUpdater/data_name"] = std::string("05"); P["/MapUpdater/initial_map_path"] = d + "/map.pcd"; P["/MapUpdater/save_path"] = d;
     P["/tf/lidar2body"] = std::vector<double>{0.0, 0.0, 1.73, 0.0, 0.0, 0.0, 1.0};
     P["/verbose"] = false;
+    if (argc > 5 && atoi(argv[5])) P["/MapUpdater/lookahead_hold"] = true;  // node k processed when node k+1 arrives (announced first)
     for (const char *t : {"/MapUpdater/map_rejected", "/MapUpdater/curr_rejected", "/MapUpdater/static", "/MapUpdater/dynamic", "/MapUpdater/debug/map_body",
                           "/MapUpdater/debug/pc_curr_body", "/MapUpdater/pc2_curr", "/MapUpdater/path_corrected", "/SCDR/debug/polygons_marker"})
         ros::stub::capture_topics()[t] = true;
@@ -36,23 +37,9 @@ int main(int argc, char **argv) {
     erasor::OfflineMapUpdaterNode node;
     std::ifstream poses(d + "/poses.txt");
     int processed = 0;
-    for (int k = 0; k < n; ++k) {
-        boost::shared_ptr<erasor::node> msg(new erasor::node());
-        msg->header.seq = (uint32_t)k;
-        double p[7];
-        for (double &v : p) poses >> v;
-        msg->odom.position.x = p[0]; msg->odom.position.y = p[1]; msg->odom.position.z = p[2];
-        msg->odom.orientation.x = p[3]; msg->odom.orientation.y = p[4]; msg->odom.orientation.z = p[5]; msg->odom.orientation.w = p[6];
-        std::ifstream f(d + "/scan" + std::to_string(k) + ".bin", std::ios::binary | std::ios::ate);
-        const size_t nf = (size_t)f.tellg() / 4;
-        f.seekg(0);
-        msg->lidar.xyzi.resize(nf);
-        f.read(reinterpret_cast<char *>(msg->lidar.xyzi.data()), (std::streamsize)(nf * 4));
-        msg->lidar.width = (uint32_t)(nf / 4);
-        ros::stub::published().clear();
-        if (!ros::stub::dispatch<erasor::node>("/node/combined/optimized", msg)) return 3;
+    auto dump_published = [&](int k) {
         auto &pub = ros::stub::published();
-        if (!pub.count("/MapUpdater/map_rejected")) continue;  // gated out (PASS!)
+        if (!pub.count("/MapUpdater/map_rejected")) return;  // gated out (PASS!) -- or held back (lookahead_hold)
         const std::string tag = "_" + std::to_string(processed++) + ".bin";
         dump(d + "/out_map_rejected" + tag, std::any_cast<const sensor_msgs::PointCloud2 &>(pub["/MapUpdater/map_rejected"]));
         dump(d + "/out_curr_rejected" + tag, std::any_cast<const sensor_msgs::PointCloud2 &>(pub["/MapUpdater/curr_rejected"]));
@@ -72,11 +59,30 @@ int main(int argc, char **argv) {
         }
         const auto &path = std::any_cast<const nav_msgs::Path &>(pub["/MapUpdater/path_corrected"]);
         printf("node %d: path poses %zu, polygons %zu\n", k, path.poses.size(), pa.polygons.size());
+    };
+    for (int k = 0; k < n; ++k) {
+        boost::shared_ptr<erasor::node> msg(new erasor::node());
+        msg->header.seq = (uint32_t)k;
+        double p[7];
+        for (double &v : p) poses >> v;
+        msg->odom.position.x = p[0]; msg->odom.position.y = p[1]; msg->odom.position.z = p[2];
+        msg->odom.orientation.x = p[3]; msg->odom.orientation.y = p[4]; msg->odom.orientation.z = p[5]; msg->odom.orientation.w = p[6];
+        std::ifstream f(d + "/scan" + std::to_string(k) + ".bin", std::ios::binary | std::ios::ate);
+        const size_t nf = (size_t)f.tellg() / 4;
+        f.seekg(0);
+        msg->lidar.xyzi.resize(nf);
+        f.read(reinterpret_cast<char *>(msg->lidar.xyzi.data()), (std::streamsize)(nf * 4));
+        msg->lidar.width = (uint32_t)(nf / 4);
+        ros::stub::published().clear();
+        if (!ros::stub::dispatch<erasor::node>("/node/combined/optimized", msg)) return 3;
+        dump_published(k);
     }
     // /saveflag -> save_static_map (OMU.cpp:169-196)
     boost::shared_ptr<std_msgs::Float32> flag(new std_msgs::Float32());
     flag->data = 0.2f;
+    ros::stub::published().clear();
     if (!ros::stub::dispatch<std_msgs::Float32>("/saveflag", flag)) return 4;
+    dump_published(n);  // (lookahead_hold: the node held back is processed when the flag arrives)
     printf("processed %d\n", processed);
     return 0;
 }

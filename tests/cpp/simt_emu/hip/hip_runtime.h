@@ -539,6 +539,10 @@ inline hipError_t hipStreamCreateWithPriority(hipStream_t *s_, unsigned, int) {
     *s_ = new simt_stream_t{0};
     return hipSuccess;
 }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s_, unsigned) {
+    *s_ = new simt_stream_t{0};
+    return hipSuccess;
+}
 inline hipError_t hipStreamDestroy(hipStream_t s_) {
     delete s_;
     return hipSuccess;

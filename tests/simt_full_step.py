@@ -67,6 +67,16 @@ l2, u2 = g2.ahead_split_counts()
 print("bench.py's call pattern (device scans, two nodes ahead), %d steps: result blocks equal %s, final map bit-exact %s; splits ahead %d launched / %d used"
       % (n3, ok, same_map, l2, u2))
 ok = ok and same_map and l2 == n3 - 1
+# the same nodes through erasor_hip_run_nodes (the node loop in native code), split over two calls like bench.py (warm-up, timed part)
+import ctypes as C
+g3 = erasor_amd.Erasor(scenarios.to_product_params(sc["params"]))
+g3.set_map(sc["map"])
+P_, N_, Tb_, To_ = erasor_amd.Erasor.node_arrays(ptr[:n3], [len(s) for s in scans[:n3]], sc["T_b2o"][:n3], sc["T_o2b"][:n3])
+ann = C.c_size_t(0)
+rs = g3.run_nodes(P_, N_, sc["T_l2b"], Tb_, To_, 0, 1, 2, ann) + g3.run_nodes(P_, N_, sc["T_l2b"], Tb_, To_, 1, n3 - 1, 2, ann)
+same3 = np.array_equal(g3.get_map().view(np.uint32), o2.get_cloud(7).view(np.uint32)) and len(rs) == n3 and ann.value == n3
+print("erasor_hip_run_nodes (two calls, %d nodes, two ahead): final map bit-exact %s" % (n3, same3))
+ok = ok and same3
 launched, used = g.ahead_split_counts()
 print("VoI splits launched ahead: %d, used: %d" % (launched, used))
 ok = ok and launched == n_steps - 1  # (whether the next step could use it depends on scratch growth in the first steps)

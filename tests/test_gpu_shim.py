@@ -2,6 +2,7 @@
 by the ROS-free offline driver, and the ERASOR class used on its own — both against the CPU oracle."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -171,8 +172,8 @@ def build_adapter_check():
     subprocess.check_call(cmd)
 
 
-@pytest.mark.parametrize("version,interval", [(3, 1), (3, 2), (2, 1)])
-def test_ros1_adapter_node(tmp_path, version, interval):
+@pytest.mark.parametrize("version,interval,hold", [(3, 1, 0), (3, 2, 0), (2, 1, 0), (3, 1, 1)])
+def test_ros1_adapter_node(tmp_path, version, interval, hold):
     """The thin ROS1 node (erasor_amd/csrc/shim/ros1_adapter.cpp): erasor::node messages in through the subscribed callback,
     the reference's topics out (OMU.cpp:5-23, 316-326; SRT polygons erasor.cpp:496-570, 630-670) — against the oracle."""
     from oracle import orc
@@ -185,7 +186,9 @@ def test_ros1_adapter_node(tmp_path, version, interval):
         for k in range(n):
             np.ascontiguousarray(sc["scans"][k], np.float32).tofile(os.path.join(d, "scan%d.bin" % k))
             f.write(" ".join("%.17g" % v for v in sc["poses"][k]) + "\n")
-    out = subprocess.run([ADAPTER, d, str(n), str(version), str(interval)], capture_output=True, text=True, timeout=600)
+    # hold = 1: /MapUpdater/lookahead_hold -- node k is processed when node k+1 arrives (announced first: look-ahead under ROS), the
+    # last one when /saveflag arrives; the publications are the same, one message later
+    out = subprocess.run([ADAPTER, d, str(n), str(version), str(interval), str(hold)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     o = orc.Oracle(sc["params"])
     o.set_map(sc["map"])
@@ -316,3 +319,17 @@ def test_mapgen_class_and_driver(tmp_path, large):
     assert np.allclose(saved[:, :3], ref[:, :3], rtol=2e-7, atol=1e-7) and np.array_equal(saved[:, 3], ref[:, 3].astype(np.float64))
     naive = np.loadtxt(os.path.join(d, "05_original.pcd"), skiprows=11, dtype=np.float64).reshape(-1, 4)
     assert naive.shape == o.naive_map().shape
+
+
+def test_cpp_bench_mode_of_the_offline_driver(tmp_path):
+    """erasor_offline_demo --bench: OfflineMapUpdater::callback_node with host clouds in and the rejected clouds out (with and
+    without the next node announced) and the C ABI loop with device-resident scans, timed in C++ -- here on a small export of
+    bench.py's workload: the three passes must agree on what they rejected and on the final map size, and print one JSON line."""
+    import json
+    d = str(tmp_path / "cppbench")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "export_cpp_bench.py"), d, "9", "--small"])
+    out = subprocess.run([DEMO, "--bench", d, "5", "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    j = json.loads(out.stdout.strip().split("\n")[-1])
+    assert j["three_passes_agree"] is True and j["nodes_timed"] == 5
+    assert j["ms_per_callback"] > 0 and j["ms_per_callback_next_node_announced"] > 0 and j["ms_per_step_device_resident_two_ahead"] > 0
