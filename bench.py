@@ -72,12 +72,19 @@ def parse_args():
     ap.add_argument("--lookahead", type=int, default=2, choices=[1, 2], help="scans announced ahead (erasor_hip_prefetch_scan)")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not announce the next scan (erasor_hip_prefetch_scan): every step runs its own query chain first")
+    ap.add_argument("--seqs", type=int, default=len(SEQS), help="seq-per-gpu: use only the first N of the five sequences (e.g. 2: what one GPU of config 3's four gets)")
     ap.add_argument("--interleave", choices=["async", "threads", "off"], default="async",
                     help="seq-per-gpu with several sequences on one rank: async = one host thread keeps every sequence's step in flight "
                          "(erasor_hip_step_async / _wait); threads = one host thread per sequence, blocking steps; off = one sequence after the other")
     ap.add_argument("--python-loop", action="store_true",
                     help="drive the timed steps from a Python loop (prefetch + step per node) instead of ONE erasor_hip_run_nodes call "
                          "(the offline driver's node loop in native code: the same calls, without ~20 us of interpreter time between two steps)")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="default run (1 GPU, seq05, replicas) only: do not append the short passes over BASELINE configs 4 / 2-yaml / 5")
+    ap.add_argument("--union-eval", type=int, default=0, metavar="N",
+                    help="replicas mode: after the timed pass, SURVEY 8(e)(ii)'s result exchange -- every rank applies N scans of its shard to the "
+                         "INITIAL map each (Jacobi-style), ONE all_gather of the removed initial-map indices, PR / RR of the united map next to the "
+                         "sequential fold's (erasor_amd/dist.py)")
     ap.add_argument("--eval", action="store_true", help="seq-per-gpu: PR/RR of every sequence's final map (erasor_amd.evalmap)")
     return ap.parse_args()
 
@@ -425,7 +432,7 @@ def main():
         maps = {"replica%d" % rank: m}
     else:
         maps = {}
-        for i in ed.deal_round_robin(len(SEQS), rank, world_size):
+        for i in ed.deal_round_robin(min(max(args.seqs, 1), len(SEQS)), rank, world_size):
             sid = SEQS[i]
             world = synth.World(seed=20210305 + int(sid), length=args.street_length, n_streets=args.streets, street_gap=50.0,
                                 n_moving=10, n_peds=6)
@@ -562,6 +569,31 @@ def main():
         evals = [e for per in ed.gather_counts(dist, world_size, [v for row in mine for v in row], dev)
                  for e in np.array(per).reshape(-1, 3).tolist() if e[0] >= 0]
 
+    # ---- what scan-parallel replicas can exchange -- the union of their removals (a DEVIATION from the sequential fold)
+    union_eval = None
+    if args.union_eval > 0 and args.mode == "replicas":
+        from erasor_amd import evalmap
+        s0 = first
+        nU = min(args.union_eval, s0.n_frames)
+        removed, _ = ed.jacobi_removed_indices(s0.g, lambda: s0.g.set_map_device(d_map.data_ptr(), int(d_map.shape[0])), s0.scans[:nU], s0.c_Tl,
+                                               s0.c_Tb[:nU], s0.c_To[:nU], device_scans=s0.d_ptr[:nU])
+        per_rank = ed.allgather_indices(dist, world_size, removed, dev)  # ONE RCCL all_gather of the removed initial-map indices
+        if rank == 0:
+            united, union = ed.united_static_map(m, per_rank)
+            # the sequential fold over rank 0's shard (what the reference does with these scans), same handle
+            s0.g.set_map_device(d_map.data_ptr(), int(d_map.shape[0]))
+            for k in range(nU):
+                s0.g.step_device(s0.d_ptr[k], s0.n_pts[k], s0.c_Tl, s0.c_Tb[k], s0.c_To[k])
+            seq_map = s0.g.get_map()
+            gt = s0.g.voxelize_preserving_labels(m, 0.2)
+            ev_u = evalmap.evaluate_clouds(gt, s0.g.voxelize_preserving_labels(united, 0.2), 0.2)
+            ev_s = evalmap.evaluate_clouds(gt, s0.g.voxelize_preserving_labels(seq_map, 0.2), 0.2)
+            union_eval = {"scans_per_rank": nU, "ranks": world_size, "removed_per_rank": [int(len(a)) for a in per_rank], "union": int(len(union)),
+                          "united_map_points": int(len(united)),
+                          "united_PR_RR": [round(ev_u["PR"], 3), round(ev_u["RR"], 3)],
+                          "sequential_rank0_shard_PR_RR": [round(ev_s["PR"], 3), round(ev_s["RR"], 3)],
+                          "note": "Jacobi-style DEVIATION from the reference's sequential fold (OfflineMapUpdater.cpp:290 -> :393): every scan sees "
+                                  "the initial map, nothing a scan adds enters the united map; reported beside the sequential result, not instead of it"}
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -672,8 +704,33 @@ def main():
         "setup_s": {"map_build_and_upload": round(t_map, 2), "rccl_broadcast": None if t_bcast is None else round(t_bcast, 4),
                     "rccl_broadcast_bytes": None if t_bcast is None else 16 * N_map},
     }
+    if union_eval is not None:
+        out["union_exchange"] = union_eval
     if evals is not None:
         out["pr_rr"] = [{"seq": "%02d" % e[0], "PR": e[1] / 1e2, "RR": e[2] / 1e2} for e in sorted(evals)]
+    # ---- the other single-GPU BASELINE configs, measured in the same run (short passes, each its own process: a clean device state
+    # and exactly the code path above).  config 4 is the only workload whose VoI pass streams more than the 256 MiB Infinity Cache.
+    if (world_size == 1 and args.workload == "seq05" and args.mode == "replicas" and not args.no_extra_workloads and not args.no_cpu_baseline
+            and not args.profile_all):
+        import subprocess
+        extra = []
+        for wname, label in (("large_scale_05", "config 4"), ("seq05_yaml", "config 2, config/seq_05.yaml verbatim"), ("ouster128", "config 5 shape, 1 GPU")):
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", wname, "--steps", "12", "--warmup", "3", "--no-cpu-baseline",
+                   "--no-extra-workloads"]
+            t_sub = time.time()
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                d = json.loads(r.stdout.strip().split("\n")[-1])
+                rf = d["roofline"]
+                extra.append({"workload": wname, "baseline_config": label, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                              "ms_per_step_without_lookahead": d["ms_per_step_without_lookahead"], "steps": d["steps"], "warmup": d["warmup"],
+                              "map_points": d["config"]["map_points"], "scan_points": d["config"]["scan_points"],
+                              "roofline": {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "avg_launch_us",
+                                                             "launches", "step_alg_bytes", "step_achieved", "step_frac")},
+                              "wall_s": round(time.time() - t_sub, 1)})
+            except Exception as e:  # (an extra pass must never take the headline line down with it)
+                extra.append({"workload": wname, "baseline_config": label, "error": str(e)[:200]})
+        out["other_workloads"] = extra
     print(json.dumps(out))
     if dist is not None:
         dist.barrier()
