@@ -73,9 +73,11 @@ def parse_args():
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not announce the next scan (erasor_hip_prefetch_scan): every step runs its own query chain first")
     ap.add_argument("--seqs", type=int, default=len(SEQS), help="seq-per-gpu: use only the first N of the five sequences (e.g. 2: what one GPU of config 3's four gets)")
-    ap.add_argument("--interleave", choices=["async", "threads", "off"], default="async",
-                    help="seq-per-gpu with several sequences on one rank: async = one host thread keeps every sequence's step in flight "
-                         "(erasor_hip_step_async / _wait); threads = one host thread per sequence, blocking steps; off = one sequence after the other")
+    ap.add_argument("--interleave", choices=["async", "threads", "off"], default="off",
+                    help="seq-per-gpu with several sequences on one rank: off = one sequence after the other (default: measured fastest on one "
+                         "MI355X -- the chains of two sequences slow each other down more than the overlap gains: 2 sequences 3864 scans/s one "
+                         "after the other vs 3145 interleaved, 5 sequences 3766 vs 2877, gpurun_out/r03n); async = one host thread keeps every "
+                         "sequence's step in flight (erasor_hip_step_async / _wait); threads = one host thread per sequence, blocking steps")
     ap.add_argument("--python-loop", action="store_true",
                     help="drive the timed steps from a Python loop (prefetch + step per node) instead of ONE erasor_hip_run_nodes call "
                          "(the offline driver's node loop in native code: the same calls, without ~20 us of interpreter time between two steps)")

@@ -912,7 +912,11 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
     }
     const int bigcur = mid_done ? 1 : nlev % 3;  // after k_esort_mid queue 0 is spent: hand the (empty) queue 1 to the final kernel
     esort::Seg *qs3[3] = {Q(h).esq0.p, Q(h).esq1.p, Q(h).esq2.p};
-    LAUNCH(h, "q_esort_final", k_esort_final, 2048, 1024, Q(h).qk_a.p, Q(h).qv_a.p, Q(h).qposL.p, Q(h).qposR.p, Q(h).qhead.p, Q(h).qk_b.p, Q(h).qv_b.p,
+    // a scan leaves ~120 segments for the finisher: 128 workgroups of 1024 threads take them in one round and leave the compute units
+    // to the chains running beside this one (2048 measured 1.5 % slower per scan, gpurun_out/r03o); a whole map keeps the wide grid
+    static const uint32_t final_grid_env = getenv("ERASOR_HIP_FINAL_GRID") ? (uint32_t)atoi(getenv("ERASOR_HIP_FINAL_GRID")) : 0u;
+    const uint32_t final_grid = final_grid_env ? final_grid_env : (n <= (1u << 20) ? 128u : 2048u);
+    LAUNCH(h, "q_esort_final", k_esort_final, final_grid, 1024, Q(h).qk_a.p, Q(h).qv_a.p, Q(h).qposL.p, Q(h).qposR.p, Q(h).qhead.p, Q(h).qk_b.p, Q(h).qv_b.p,
            (const esort::Seg *)Q(h).essmall.p, (const esort::Seg *)qs3[bigcur], Q(h).esqs.p, bigcur, dc, h->dbg_stamps.p);
 }
 

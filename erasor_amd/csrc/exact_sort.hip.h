@@ -676,14 +676,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
 template <int EMAX, class K2P, class V2P>
 __device__ __forceinline__ void block_esort_sync(uint32_t (&k)[EMAX], uint32_t (&v)[EMAX], uint32_t n, uint2 *sKV, uint2 *sLL, uint2 *sRR,
                                                  uint32_t *sPS, uint32_t *sCut, uint32_t *sTab, K2P K2, V2P V2, uint32_t *n_fallback,
-                                                 unsigned long long *tstamp = nullptr) {
+                                                 unsigned long long *tstamp = nullptr, int32_t depth_budget = -1) {
     const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = bs >> 6;
     const uint64_t lt = lanemask_lt();
     const uint64_t gt = ~(lt | (1ull << lane));
     const uint32_t E = (n + bs - 1) / bs;  // rows of positions in use (<= EMAX)
     uint32_t f[EMAX], l[EMAX];
     int32_t d[EMAX];
-    const int32_t depth0 = 2 * lg2_floor(n ? n : 1u);
+    // (a segment of a larger sort arrives with what is left of ITS introsort depth budget)
+    const int32_t depth0 = depth_budget >= 0 ? depth_budget : 2 * lg2_floor(n ? n : 1u);
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
         const uint32_t i = (uint32_t)e * bs + tid;
@@ -692,7 +693,8 @@ __device__ __forceinline__ void block_esort_sync(uint32_t (&k)[EMAX], uint32_t (
         d[e] = depth0;
         if (i < n) sKV[i] = make_uint2(k[e], v[e]);
     }
-    if (tid < 68) sTab[tid] = (tid == 64 && n > (uint32_t)kThreshold) ? 1u : 0u;  // [0, 64): (row, wavefront) counts; [64]: a segment is left; [65]: a heapsort is due
+    // [0, 64): (row, wavefront) counts; [64]: a segment is left; [65]: a heapsort is due (a segment that arrives with no budget left)
+    if (tid < 68) sTab[tid] = ((tid == 64 || (tid == 65 && depth0 == 0)) && n > (uint32_t)kThreshold) ? 1u : 0u;
     __syncthreads();
     if (tstamp && tid == 0) tstamp[0] = clock64();
     int lvl = 0;

@@ -1224,6 +1224,38 @@ __global__ __launch_bounds__(256) void k_dup_label_passthrough(const float4 *__r
 }
 
 // ---- exact std::sort of the (idx, point) pairs, global memory -----------------------------------
+// Exact std::sort of n <= ESYNC_MAX (key, index) pairs by the whole workgroup, level-synchronous (esort::block_esort_sync): keys are
+// produced into registers by key_of(i); scratch = 16384 words of LDS (pool) laid out as pairs[2048] | left stops[2048] | right
+// stops[2048] | counts[2048] | cuts[2048]; sorted keys -> K2, their indices -> V2 (LDS; both may lie in pool beyond its first 4096 words).
+static constexpr uint32_t ESYNC_MAX = 2048;
+template <class KeyFn, class ValFn, class K2P, class V2P>
+__device__ __forceinline__ void lds_esort_sync_kv(uint32_t n, KeyFn key_of, ValFn val_of, uint32_t *pool, uint32_t *stab, K2P K2, V2P V2,
+                                                  uint32_t *n_fallback, unsigned long long *tstamp = nullptr, int32_t depth_budget = -1) {
+    uint2 *sKV = reinterpret_cast<uint2 *>(pool), *sLL = reinterpret_cast<uint2 *>(pool + 2 * ESYNC_MAX), *sRR = reinterpret_cast<uint2 *>(pool + 4 * ESYNC_MAX);
+    uint32_t *sPS = pool + 6 * ESYNC_MAX, *sCut = pool + 7 * ESYNC_MAX;
+    const uint32_t tid = threadIdx.x, bs = blockDim.x;
+    if (n <= bs) {
+        uint32_t k[1], v[1];
+        k[0] = tid < n ? key_of(tid) : 0u;
+        v[0] = tid < n ? val_of(tid) : 0u;
+        esort::block_esort_sync<1>(k, v, n, sKV, sLL, sRR, sPS, sCut, stab, K2, V2, n_fallback, tstamp, depth_budget);
+    } else {
+        uint32_t k[2], v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t i = (uint32_t)e * bs + tid;
+            k[e] = i < n ? key_of(i) : 0u;
+            v[e] = i < n ? val_of(i) : 0u;
+        }
+        esort::block_esort_sync<2>(k, v, n, sKV, sLL, sRR, sPS, sCut, stab, K2, V2, n_fallback, tstamp, depth_budget);
+    }
+}
+template <class KeyFn>
+__device__ __forceinline__ void lds_esort_sync(uint32_t n, KeyFn key_of, uint32_t *pool, uint32_t *stab, uint32_t *K2, uint32_t *V2,
+                                               uint32_t *n_fallback, unsigned long long *tstamp = nullptr) {
+    lds_esort_sync_kv(n, key_of, [](uint32_t i) { return i; }, pool, stab, K2, V2, n_fallback, tstamp);
+}
+
 static constexpr uint32_t ES_LMAX = 2048;   // segments up to this size are finished inside LDS
 struct EsQueues {
     uint32_t cnt[3];      // three rotating level queues: level l reads [l%3], appends to [(l+1)%3], clears [(l+2)%3]
@@ -1591,10 +1623,11 @@ __global__ __launch_bounds__(1024) void k_esort_mid(uint32_t *K, uint32_t *V, ui
 __global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, uint32_t *head,
                                                       uint32_t *K2, uint32_t *V2, const esort::Seg *smallq, const esort::Seg *bigq,
                                                       EsQueues *qs, int bigcur, Counters *ctr, unsigned long long *dbg) {  // bigcur: queue index (0..2) still holding big segments
-    __shared__ uint32_t sK[ES_LMAX], sV[ES_LMAX], sL[ES_LMAX], sR[ES_LMAX];
-    __shared__ uint32_t sH[ES_LMAX / 32 + 2];
-    __shared__ esort::Seg qa[ES_LMAX / 16 + 2], qb[ES_LMAX / 16 + 2];
+    __shared__ uint32_t pool[8 * ESYNC_MAX];  // lds_esort_sync_kv's scratch (pairs | left stops | right stops | counts | cuts)
+    __shared__ uint32_t s_stab[68];
+    __shared__ esort::Seg qa[ES_LMAX / 16 + 2], qb[ES_LMAX / 16 + 2];  // (the global-memory path's queues)
     __shared__ uint32_t qcnt[2];
+    static_assert(ES_LMAX <= ESYNC_MAX, "the finisher's LDS-resident segments go through the level-synchronous sort");
     const uint32_t nsmall = qs->small_cnt, nbig = qs->cnt[bigcur];
     if (dbg && threadIdx.x == 0) atomicMin(&dbg[28], wall_clock64());  // diagnostics: first workgroup start (100 MHz ticks)
     if (dbg && threadIdx.x == 0 && blockIdx.x == 0) {
@@ -1607,15 +1640,14 @@ __global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, 
         const esort::Seg sg = s < nsmall ? smallq[s] : bigq[s - nsmall];
         const uint32_t len = sg.last - sg.first;
         if (len <= ES_LMAX) {
-            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-                sK[i] = K[sg.first + i];
-                sV[i] = V[sg.first + i];
-            }
-            __syncthreads();
+            // round 3: level-synchronous over the whole workgroup (esort::block_esort_sync), keys straight from global memory into
+            // registers, results straight back; the segment brings what is left of its introsort depth budget
             __shared__ unsigned long long s_stamps[24];
             const unsigned long long t_a = clock64();
-            esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, len, sg.depth, qa, qb, qcnt, (uint32_t)(ES_LMAX / 16 + 2),
-                               &ctr->n_sort_fallback, &ctr->sort_qoverflow, dbg ? s_stamps : nullptr);
+            const uint32_t *Kg = K + sg.first, *Vg = V + sg.first;
+            __syncthreads();  // (the previous segment's ranking may still be reading the pool)
+            lds_esort_sync_kv(len, [&](uint32_t i) { return Kg[i]; }, [&](uint32_t i) { return Vg[i]; }, pool, s_stab, K2 + sg.first, V2 + sg.first,
+                              &ctr->n_sort_fallback, dbg ? s_stamps : nullptr, sg.depth);
             if (dbg && threadIdx.x == 0) {  // diagnostics: keep the stamps of the slowest segment
                 const unsigned long long dur = clock64() - t_a;
                 if (atomicMax(&dbg[31], dur) < dur) {
@@ -1623,10 +1655,6 @@ __global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, 
                     dbg[30] = ((unsigned long long)len << 32) | (unsigned)sg.depth;
                     dbg[29] = (unsigned long long)(nsmall + nbig);
                 }
-            }
-            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-                K2[sg.first + i] = sL[i];
-                V2[sg.first + i] = sR[i];
             }
             __syncthreads();
         } else {
@@ -2458,33 +2486,6 @@ __device__ __forceinline__ void rgpf_after_sort(const DP &P, const float4 *__res
 // Larger bins take the global-memory path (rgpf_after_sort on global scratch, same arithmetic).
 // ------------------------------------------------------------------------------------------------
 static constexpr uint32_t RG_RS = RG_CH + 4;  // padded row stride of the product rows (floats)
-
-// Exact std::sort of n <= ESYNC_MAX (key, index) pairs by the whole workgroup, level-synchronous (esort::block_esort_sync): keys are
-// produced into registers by key_of(i); scratch = 16384 words of LDS (pool) laid out as pairs[2048] | left stops[2048] | right
-// stops[2048] | counts[2048] | cuts[2048]; sorted keys -> K2, their indices -> V2 (LDS; both may lie in pool beyond its first 4096 words).
-static constexpr uint32_t ESYNC_MAX = 2048;
-template <class KeyFn>
-__device__ __forceinline__ void lds_esort_sync(uint32_t n, KeyFn key_of, uint32_t *pool, uint32_t *stab, uint32_t *K2, uint32_t *V2,
-                                               uint32_t *n_fallback, unsigned long long *tstamp = nullptr) {
-    uint2 *sKV = reinterpret_cast<uint2 *>(pool), *sLL = reinterpret_cast<uint2 *>(pool + 2 * ESYNC_MAX), *sRR = reinterpret_cast<uint2 *>(pool + 4 * ESYNC_MAX);
-    uint32_t *sPS = pool + 6 * ESYNC_MAX, *sCut = pool + 7 * ESYNC_MAX;
-    const uint32_t tid = threadIdx.x, bs = blockDim.x;
-    if (n <= bs) {
-        uint32_t k[1], v[1];
-        k[0] = tid < n ? key_of(tid) : 0u;
-        v[0] = tid;
-        esort::block_esort_sync<1>(k, v, n, sKV, sLL, sRR, sPS, sCut, stab, K2, V2, n_fallback, tstamp);
-    } else {
-        uint32_t k[2], v[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const uint32_t i = (uint32_t)e * bs + tid;
-            k[e] = i < n ? key_of(i) : 0u;
-            v[e] = i;
-        }
-        esort::block_esort_sync<2>(k, v, n, sKV, sLL, sRR, sPS, sCut, stab, K2, V2, n_fallback, tstamp);
-    }
-}
 
 __device__ __forceinline__ float key_to_float(uint32_t k) {  // inverse of esort::float_key (-0 comes back as +0)
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
