@@ -544,8 +544,10 @@ int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
 int alloc_step(erasor_hip_handle *h, uint32_t n_voi, uint32_t nq) {
     const size_t G = (size_t)n_voi + nq + 8;
     int rc = 0;
-    rc |= ensure(h, h->gsK, G) | ensure(h, h->gsV, G) | ensure(h, h->gsL, G) | ensure(h, h->gsR, G) | ensure(h, h->gsK2, G) | ensure(h, h->gsV2, G);
-    rc |= ensure(h, h->gsH, G / 32 + 2 * (size_t)h->B + 16) | ensure(h, h->gsC, G) | ensure(h, h->vox_out, G);
+    // (twice: in the fused launch k_revert_bins the per-bin voxelisation's global-memory path works in the upper half, see there)
+    rc |= ensure(h, h->gsK, 2 * G) | ensure(h, h->gsV, 2 * G) | ensure(h, h->gsL, 2 * G) | ensure(h, h->gsR, 2 * G) | ensure(h, h->gsK2, 2 * G) |
+          ensure(h, h->gsV2, 2 * G);
+    rc |= ensure(h, h->gsH, 2 * (G / 32 + 2 * (size_t)h->B + 16)) | ensure(h, h->gsC, G) | ensure(h, h->vox_out, G);
     const size_t needF = 2 * (size_t)n_voi + nq + 64;
     rc |= ensure(h, h->F[h->curF ^ 1], needF);
     return rc ? ERASOR_E_NO_DEVICE : 0;
@@ -1466,6 +1468,15 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
            (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
     // R-GPF and the per-bin voxelisation walk the reverted-bin LIST on a small fixed grid (n_rev is on the device)
     static const uint32_t rev_grid = getenv("ERASOR_HIP_REV_GRID") ? (uint32_t)atoi(getenv("ERASOR_HIP_REV_GRID")) : 128u;
+    // v3: R-GPF and the per-bin voxelisation of a reverted bin in ONE launch (k_revert_bins); ERASOR_HIP_NO_FUSE=1: two launches (A/B)
+    static const bool no_fuse = getenv("ERASOR_HIP_NO_FUSE") != nullptr;
+    if (P.version == 3 && !no_fuse && h->prof != 1) {
+        LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds,
+               (const uint32_t *)h->moff.p, (const float4 *)h->spts.p, (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, h->gsK.p, h->gsV.p,
+               h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p, h->gsC.p, h->gflag.p, h->grank.p, h->glist.p, h->ng.p, h->plane_n.p, h->plane_d.p,
+               (const uint32_t *)h->vox_off.p, h->vox_out.p, h->nvox.p, dc, h->dbg_stamps.p, (uint32_t)((size_t)n_voi + nq + 8),
+               (uint32_t)(((size_t)n_voi + nq + 8) / 32 + 2 * (size_t)B + 16));
+    } else {
     LAUNCH(h, "rgpf", k_rgpf2, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds, (const uint32_t *)h->moff.p,
            (const float4 *)h->spts.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p, h->gflag.p, h->grank.p, h->glist.p,
            h->ng.p, h->plane_n.p, h->plane_d.p, dc, h->dbg_stamps.p);
@@ -1474,6 +1485,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                (const uint32_t *)h->moff.p, (const float4 *)h->spts.p, (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p,
                (const uint32_t *)h->glist.p, (const uint32_t *)h->ng.p, (const uint32_t *)h->vox_off.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p,
                h->gsH.p, h->gsK2.p, h->gsV2.p, h->gsC.p, h->vox_out.p, h->nvox.p, dc, h->dbg_stamps.p);
+    }
     if (fold) {
         // (no launch)
     } else if (B <= 1024 * SRT_KPT)

@@ -2491,18 +2491,19 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {  // inverse of esort
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-__global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict__ rev_list, const DevState *__restrict__ st,
-                                                const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *gsK,
-                                                uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
-                                                uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
-                                                uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
-                                                Counters *ctr, unsigned long long *dbg) {
-    __shared__ uint32_t pool[4 * RG_LMAX];  // sort phase: K | V | posL | posR (or lds_esort_sync's layout) ; fit phase: glist | X | Y | Z
+// The workgroup's two large LDS buffers come from the caller: `pool` (4 * RG_LMAX words: sort phase K | V | posL | posR or
+// lds_esort_sync's layout; fit phase glist | X | Y | Z) and `sProd` (9 * RG_RS floats, 16-byte aligned), so that the fused kernel
+// (k_revert_bins) can hand the same storage to the per-bin voxelisation afterwards.  Bins rk0, rk0 + rk_step, ... of the list.
+__device__ __forceinline__ void rgpf_bins(const DP &P, uint32_t rk0, uint32_t rk_step, const uint32_t *__restrict__ rev_list,
+                                          const DevState *__restrict__ st, const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
+                                          uint32_t *gsK, uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
+                                          uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
+                                          uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d, Counters *ctr,
+                                          unsigned long long *dbg, uint32_t *pool, float *sProd) {
     __shared__ uint32_t sH[RG_LMAX / 32 + 2];
     __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
     __shared__ uint32_t qcnt[2];
     __shared__ uint32_t sm[40];
-    __shared__ __attribute__((aligned(16))) float sProd[9 * RG_RS];
     __shared__ float s_n[3];
     __shared__ double s_th, s_lpr;
     __shared__ uint32_t s_carry;
@@ -2514,7 +2515,7 @@ __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict
     uint32_t *sK = pool, *sV = pool + RG_LMAX, *sL = pool + 2 * RG_LMAX, *sR = pool + 3 * RG_LMAX;
     const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = bs >> 6;
     const uint32_t n_rev = st->n_rev;
-    for (uint32_t rk = blockIdx.x; rk < n_rev; rk += gridDim.x) {
+    for (uint32_t rk = rk0; rk < n_rev; rk += rk_step) {
         const uint32_t key = rev_list[rk];
         const uint32_t o0 = moff[key], M = moff[key + 1] - o0;
         const float4 *pts = spts + o0;
@@ -2741,6 +2742,17 @@ __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict
     }
 #undef RG_STAMP
 }
+__global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict__ rev_list, const DevState *__restrict__ st,
+                                                const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *gsK,
+                                                uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
+                                                uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
+                                                uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
+                                                Counters *ctr, unsigned long long *dbg) {
+    __shared__ uint32_t pool[4 * RG_LMAX];
+    __shared__ __attribute__((aligned(16))) float sProd[9 * RG_RS];
+    rgpf_bins(P, blockIdx.x, gridDim.x, rev_list, st, moff, spts, gsK, gsV, gsL, gsR, gsH, gsK2, gsV2, gflag, grank, glist_out, ng_out, plane_n,
+              plane_d, ctr, dbg, pool, sProd);
+}
 
 // ================================================================================================
 // per-bin voxelize_preserving_labels(curr points + reverted ground, /erasor/map_voxel_size) —
@@ -2889,17 +2901,16 @@ __device__ __forceinline__ void binvox_core(const DP &P, uint32_t m, uint32_t nc
 // ------------------------------------------------------------------------------------------------
 static constexpr uint32_t BV2_LMAX = 4096;
 
-__global__ __launch_bounds__(1024) void k_binvox2(DP P, const uint32_t *__restrict__ rev_list, const DevState *__restrict__ st,
-                                                  const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
-                                                  const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq,
-                                                  const uint32_t *__restrict__ glist, const uint32_t *__restrict__ ng_arr,
-                                                  const uint32_t *__restrict__ vox_off, uint32_t *gsK, uint32_t *gsV, uint32_t *gsL,
-                                                  uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
-                                                  float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr,
-                                                  unsigned long long *dbg) {
-    __shared__ uint32_t pool[4 * BV2_LMAX];  // K | V | posL (-> sorted keys) | posR (-> sorted indices); after the sort K -> unique keys, V -> run begins
+// (`pool`: 4 * BV2_LMAX words -- K | V | posL (-> sorted keys) | posR (-> sorted indices); after the sort K -> unique keys, V -> run
+// begins -- and `sC`: BV2_LMAX points, both from the caller, see rgpf_bins)
+__device__ __forceinline__ void binvox_bins(const DP &P, uint32_t rk0, uint32_t rk_step, const uint32_t *__restrict__ rev_list,
+                                            const DevState *__restrict__ st, const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
+                                            const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq, const uint32_t *__restrict__ glist,
+                                            const uint32_t *__restrict__ ng_arr, const uint32_t *__restrict__ vox_off, uint32_t *gsK, uint32_t *gsV,
+                                            uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
+                                            float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr, unsigned long long *dbg,
+                                            uint32_t *pool, float4 *sC) {
     __shared__ uint32_t sH[BV2_LMAX / 32 + 2];
-    __shared__ float4 sC[BV2_LMAX];
     __shared__ esort::Seg qa2[BV2_LMAX / 16 + 2], qb2[BV2_LMAX / 16 + 2];
     __shared__ uint32_t qcnt[2];
     __shared__ uint32_t sm[40];
@@ -2910,7 +2921,7 @@ __global__ __launch_bounds__(1024) void k_binvox2(DP P, const uint32_t *__restri
     uint32_t *sK = pool, *sV = pool + BV2_LMAX, *sL = pool + 2 * BV2_LMAX, *sR = pool + 3 * BV2_LMAX;
     const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = bs >> 6;
     const uint32_t n_rev = st->n_rev;
-    for (uint32_t rk = blockIdx.x; rk < n_rev; rk += gridDim.x) {
+    for (uint32_t rk = rk0; rk < n_rev; rk += rk_step) {
         const uint32_t key = rev_list[rk];
         const uint32_t mo = moff[key], qo = qoff[key];
         const uint32_t nc = qoff[key + 1] - qo, ngr = ng_arr[rk];
@@ -3137,6 +3148,50 @@ __global__ __launch_bounds__(1024) void k_binvox2(DP P, const uint32_t *__restri
                 dbg[22] = nv;
             }
         }
+    }
+}
+__global__ __launch_bounds__(1024) void k_binvox2(DP P, const uint32_t *__restrict__ rev_list, const DevState *__restrict__ st,
+                                                  const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
+                                                  const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq,
+                                                  const uint32_t *__restrict__ glist, const uint32_t *__restrict__ ng_arr,
+                                                  const uint32_t *__restrict__ vox_off, uint32_t *gsK, uint32_t *gsV, uint32_t *gsL,
+                                                  uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
+                                                  float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr,
+                                                  unsigned long long *dbg) {
+    __shared__ uint32_t pool[4 * BV2_LMAX];
+    __shared__ float4 sC[BV2_LMAX];
+    binvox_bins(P, blockIdx.x, gridDim.x, rev_list, st, moff, spts, qoff, sq, glist, ng_arr, vox_off, gsK, gsV, gsL, gsR, gsH, gsK2, gsV2, gsC, vox_out,
+                nvox_out, ctr, dbg, pool, sC);
+}
+
+// v3's two per-bin stages in ONE launch (erasor.cpp:521-528: extract_ground, then voxelize_preserving_labels of curr + ground): a
+// workgroup runs R-GPF on its bin and voxelises it right away -- the ground list it has just written is its own, so no kernel boundary
+// is needed in between, and a small bin is through both stages while the largest one is still fitting planes.  The two stages share the
+// workgroup's LDS (64 KB pool + 64 KB for the covariance products / the cloud).
+__global__ __launch_bounds__(1024) void k_revert_bins(DP P, const uint32_t *__restrict__ rev_list, const DevState *__restrict__ st,
+                                                      const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
+                                                      const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq, uint32_t *gsK, uint32_t *gsV,
+                                                      uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
+                                                      uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *glist,
+                                                      uint32_t *ng_arr, float *__restrict__ plane_n, double *__restrict__ plane_d,
+                                                      const uint32_t *__restrict__ vox_off, float4 *__restrict__ vox_out,
+                                                      uint32_t *__restrict__ nvox_out, Counters *ctr, unsigned long long *dbg,
+                                                      // the global-memory paths of the two stages (bins beyond the LDS-resident sizes) index the same
+                                                      // scratch arrays, R-GPF by map offsets, the voxelisation by its own: with both stages in flight in
+                                                      // different workgroups the voxelisation works `vox_base` entries (`h_base` flag words) further up
+                                                      uint32_t vox_base, uint32_t h_base) {
+    static_assert(RG_LMAX == BV2_LMAX && 9 * RG_RS * sizeof(float) <= BV2_LMAX * sizeof(float4), "the two stages share their LDS");
+    __shared__ uint32_t pool[4 * RG_LMAX];
+    __shared__ float4 big[BV2_LMAX];
+    const uint32_t n_rev = st->n_rev;
+    for (uint32_t rk = blockIdx.x; rk < n_rev; rk += gridDim.x) {
+        rgpf_bins(P, rk, 0x7FFFFFFFu, rev_list, st, moff, spts, gsK, gsV, gsL, gsR, gsH, gsK2, gsV2, gflag, grank, glist, ng_arr, plane_n, plane_d, ctr,
+                  dbg, pool, reinterpret_cast<float *>(big));
+        __threadfence_block();
+        __syncthreads();  // the bin's ground list and count (global memory, written by this workgroup) are read below
+        binvox_bins(P, rk, 0x7FFFFFFFu, rev_list, st, moff, spts, qoff, sq, glist, ng_arr, vox_off, gsK + vox_base, gsV + vox_base, gsL + vox_base,
+                    gsR + vox_base, gsH + h_base, gsK2 + vox_base, gsV2 + vox_base, gsC, vox_out, nvox_out, ctr, dbg, pool, big);
+        __syncthreads();
     }
 }
 
