@@ -235,7 +235,7 @@ struct erasor_hip_handle {
     DBuf<uint32_t> out_off0, rev_before;  // the layout's R-GPF-independent part (k_srt4 -> k_assemble_map<., true>)
     DBuf<float> mmin, mmax, plane_n;
     DBuf<double> plane_d;
-    DBuf<uint8_t> st1, status, action;
+    DBuf<uint8_t> st1, st1b, status, action;  // (st1b: first-pass status | 0x80 written by k_bin_stats_srt)
     // ---- query side: everything the voxelisation / bucketing of ONE scan owns.  Two sets, so that the query chain of the
     // next scan (erasor_hip_prefetch_scan) can run while the current step is in its map-side stages ----
     QSide q[NSIDE];
@@ -471,7 +471,7 @@ int alloc_bins(erasor_hip_handle *h) {
     rc |= ensure(h, h->moff, B + 2) | ensure(h, h->mcnt, B);
     rc |= ensure(h, h->mmin, B) | ensure(h, h->mmax, B);
     rc |= ensure(h, h->st1, B) | ensure(h, h->status, B) | ensure(h, h->action, B) | ensure(h, h->rev_idx, B) | ensure(h, h->rev_list, B);
-    rc |= ensure(h, h->out_off0, B + 2) | ensure(h, h->rev_before, B + 2);
+    rc |= ensure(h, h->out_off0, B + 2) | ensure(h, h->rev_before, B + 2) | ensure(h, h->st1b, B + 8);
     rc |= ensure(h, h->vox_off, B) | ensure(h, h->nvox, B) | ensure(h, h->ng, B) | ensure(h, h->out_off, B) | ensure(h, h->ground_off, B);
     rc |= ensure(h, h->rej_off, B) | ensure(h, h->crej_off, B);
     rc |= ensure(h, h->plane_n, B * (size_t)std::max(h->P.gf_iter, 1) * 3) | ensure(h, h->plane_d, B * (size_t)std::max(h->P.gf_iter, 1));
@@ -805,7 +805,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->rejected_src); release(h->grank); release(h->glist); release(h->gflag);
     release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->lab_slots); release(h->mb_hist); release(h->mb_tot); release(h->mg_curr); release(h->mg_map); release(h->mg_done); release(h->mg_tmp);
     release(h->moff); release(h->mcnt); release(h->rev_idx); release(h->rev_list); release(h->vox_off);
-    release(h->out_off0); release(h->rev_before);
+    release(h->out_off0); release(h->rev_before); release(h->st1b);
     release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
     release(h->mmin); release(h->mmax); release(h->plane_n); release(h->plane_d);
     release(h->st1); release(h->status); release(h->action);
@@ -1384,6 +1384,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         if (ensure(h, h->hist2, nb_m) || ensure(h, h->hist2_l, nb_m) || ensure(h, h->hist2_t, cdiv(nb_m, 1024) + 2)) return ERASOR_E_NO_DEVICE;
     }
     const uint32_t *sm_keys = nullptr, *sm_perm = nullptr;
+    bool st1_ahead = false;
 
     // ---- map chain (the query chains run on their own streams; the two only meet at the Scan Ratio Test) ----
     auto enqueue_map_chain = [&]() {
@@ -1443,6 +1444,14 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                               n_voi, nvoi_dev, h->spts.p, h->ssrc.p);
             LAUNCH(h, "voi_bucket", k_bin_offsets, cdiv((uint64_t)std::max(n_voi, B + 2) + 1, 256), 256, sm_keys, n_voi, nvoi_dev, B + 1, h->moff.p);
         }
+        // v3: the Scan Ratio Test's first pass rides along, bin by bin (the query's statistics are needed: the join with its chain
+        // comes before this launch instead of after it; with nodes announced ahead the chain finished long ago)
+        st1_ahead = P.version == 3 && B <= 1024 * SRT_KPT && !getenv("ERASOR_HIP_NO_SRT_AHEAD");
+        if (st1_ahead) {
+            (void)hipStreamWaitEvent(h->stream, Q(h).ev_done, 0);
+            LAUNCH(h, "bin_stats", k_bin_stats_srt, cdiv((uint64_t)B * 64, 256), 256, P, (const float4 *)h->spts.p, (const uint32_t *)h->moff.p, B, h->mcnt.p,
+                   h->mmin.p, h->mmax.p, (const uint32_t *)Q(h).ccnt.p, (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1b.p);
+        } else
         LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->spts.p, (const uint32_t *)h->moff.p, B, h->mcnt.p,
                h->mmin.p, h->mmax.p);
         MARK("  mapchain_end");
@@ -1462,7 +1471,8 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     if (B <= 1024 * SRT_KPT)
         LAUNCH(h, "srt", k_srt4, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
            (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds,
-           fold ? h->out_off0.p : (uint32_t *)nullptr, fold ? h->rev_before.p : (uint32_t *)nullptr, fold ? h->crej_off.p : (uint32_t *)nullptr);
+           fold ? h->out_off0.p : (uint32_t *)nullptr, fold ? h->rev_before.p : (uint32_t *)nullptr, fold ? h->crej_off.p : (uint32_t *)nullptr,
+           st1_ahead ? (const uint8_t *)h->st1b.p : (const uint8_t *)nullptr);
     else
         LAUNCH(h, "srt", k_srt, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
            (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);

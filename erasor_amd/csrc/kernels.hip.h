@@ -857,13 +857,9 @@ __global__ __launch_bounds__(256) void k_mb_colscan(uint32_t *__restrict__ hist 
 #pragma unroll
         for (uint32_t r = 0; r < 4; ++r) {
             const uint32_t t = t0 + r * 64 + lane;
-            uint32_t inc = c[r];
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t v = __shfl_up(inc, o, 64);
-                if ((int)lane >= o) inc += v;
-            }
+            const uint32_t inc = esort::wave_incl_scan(c[r]);  // (DPP row shifts: no LDS crossbar round trips)
             if (t < ntile) hist[(size_t)t * nb + b] = run + inc - c[r];
-            run += __shfl(inc, 63, 64);
+            run += __builtin_amdgcn_readlane(inc, 63);
         }
     }
 }
@@ -1973,6 +1969,57 @@ __device__ __forceinline__ uint8_t srt_first(const DP &P, const BinStat &b) {
     }
     return s;
 }
+// k_bin_stats of the MAP side with the Scan Ratio Test's first pass folded in (round 3): the wavefront that has a bin's map
+// statistics also reads the query's (its chain is done: the main stream has waited for it) and leaves the bin's first-pass status in
+// st1 -- bit 7: the map bin is taller than 0.5 m (the v3 revert gate, erasor.cpp:511).  540 workgroups share the float64
+// divisions that k_srt4's ONE workgroup used to run for all 2160 bins (2700 instructions on one compute unit, 18 us).
+__global__ __launch_bounds__(256) void k_bin_stats_srt(DP P, const float4 *__restrict__ spts, const uint32_t *__restrict__ off, uint32_t B,
+                                                        uint32_t *__restrict__ cnt, float *__restrict__ minz, float *__restrict__ maxz,
+                                                        const uint32_t *__restrict__ ccnt, const float *__restrict__ cmin,
+                                                        const float *__restrict__ cmax, uint8_t *__restrict__ st1) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= B) return;
+    const uint32_t s = off[b], e = off[b + 1];
+    float mn = __int_as_float(0x7F800000), mx = __int_as_float(0xFF800000);
+    uint32_t i = s + lane;
+    for (; i + 192 < e; i += 256) {
+        const float z0 = spts[i].z, z1 = spts[i + 64].z, z2 = spts[i + 128].z, z3 = spts[i + 192].z;
+        mn = z0 < mn ? z0 : mn;
+        mx = z0 > mx ? z0 : mx;
+        mn = z1 < mn ? z1 : mn;
+        mx = z1 > mx ? z1 : mx;
+        mn = z2 < mn ? z2 : mn;
+        mx = z2 > mx ? z2 : mx;
+        mn = z3 < mn ? z3 : mn;
+        mx = z3 > mx ? z3 : mx;
+    }
+    for (; i < e; i += 64) {
+        const float z = spts[i].z;
+        mn = z < mn ? z : mn;
+        mx = z > mx ? z : mx;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float a = __shfl_down(mn, o, 64), c = __shfl_down(mx, o, 64);
+        mn = a < mn ? a : mn;
+        mx = c > mx ? c : mx;
+    }
+    if (lane == 0) {
+        cnt[b] = e - s;
+        minz[b] = mn;
+        maxz[b] = mx;
+        BinStat bsx;  // exactly what srt_load would read back
+        bsx.mc = e - s;
+        bsx.cc = ccnt[b];
+        bsx.mmaxh = bsx.mc ? (double)mx : -INF_H;
+        bsx.mminh = bsx.mc ? (double)mn : INF_H;
+        bsx.cmaxh = bsx.cc ? (double)cmax[b] : -INF_H;
+        bsx.cminh = bsx.cc ? (double)cmin[b] : INF_H;
+        const uint8_t s1 = srt_first(P, bsx);
+        st1[b] = (uint8_t)(s1 | (((bsx.mmaxh - bsx.mminh) > 0.5) ? 0x80u : 0u));
+    }
+}
+
 // second pass (erasor.cpp:503-560 for v3, :332-434 for v2): final status and the action of the bin.  ST1: st1[] accessor
 template <class ST1>
 __device__ __forceinline__ void srt_second(const DP &P, int key, const BinStat &b, uint8_t s, ST1 st1, uint8_t &fs, uint8_t &act) {
@@ -2089,22 +2136,39 @@ __global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict_
                                                 // voxelisation: offsets with the reverted bins counted as empty, how many reverted bins precede a
                                                 // bin, curr_rejected offsets (final).  nullptr: not wanted (k_layout4 runs later)
                                                 uint32_t *__restrict__ out_off0, uint32_t *__restrict__ rev_before,
-                                                uint32_t *__restrict__ crej_off) {
+                                                uint32_t *__restrict__ crej_off,
+                                                // v3: the first pass has been done bin by bin in k_bin_stats_srt (status | 0x80 if the map bin is taller
+                                                // than 0.5 m); nullptr: done here
+                                                const uint8_t *__restrict__ st1_in) {
     __shared__ uint32_t sm[40];
     __shared__ uint8_t s_st1[1024 * SRT_KPT];
     const int B = P.B;
     const int k0 = threadIdx.x * SRT_KPT;
     BinStat bs[SRT_KPT];
+    if (st1_in && P.version == 3) {
 #pragma unroll
-    for (int j = 0; j < SRT_KPT; ++j)
-        if (k0 + j < B) bs[j] = srt_load(k0 + j, mcnt, mmin, mmax, ccnt, cmin, cmax);
+        for (int j = 0; j < SRT_KPT; ++j)
+            if (k0 + j < B) {
+                const uint8_t v = st1_in[k0 + j];
+                bs[j].mc = mcnt[k0 + j];
+                bs[j].cc = ccnt[k0 + j];
+                bs[j].mmaxh = (v & 0x80u) ? 1.0 : 0.0;  // (all the second pass asks of the heights: is the map bin taller than 0.5 m?)
+                bs[j].mminh = 0.0;
+                bs[j].cmaxh = bs[j].cminh = 0.0;
+                s_st1[k0 + j] = (uint8_t)(v & 0x7Fu);
+            }
+    } else {
 #pragma unroll
-    for (int j = 0; j < SRT_KPT; ++j)
-        if (k0 + j < B) {
-            const uint8_t s = srt_first(P, bs[j]);
-            s_st1[k0 + j] = s;
-            st1[k0 + j] = s;
-        }
+        for (int j = 0; j < SRT_KPT; ++j)
+            if (k0 + j < B) bs[j] = srt_load(k0 + j, mcnt, mmin, mmax, ccnt, cmin, cmax);
+#pragma unroll
+        for (int j = 0; j < SRT_KPT; ++j)
+            if (k0 + j < B) {
+                const uint8_t s = srt_first(P, bs[j]);
+                s_st1[k0 + j] = s;
+                st1[k0 + j] = s;
+            }
+    }
     __syncthreads();
     uint8_t act[SRT_KPT];
     uint32_t nrv = 0, ncap = 0;
