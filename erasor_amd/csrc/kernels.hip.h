@@ -85,7 +85,9 @@ __device__ __forceinline__ bool is_dynamic_label(float intensity) {
 }
 
 // R-POD bin of an egocentric point (erasor.cpp:104-110, 11-21).  Returns theta-major key
-// sector*R + ring, or B if the point fails a gate.
+// sector*R + ring, or B if the point fails a gate.  The reference's arithmetic, operation by operation, in float64.
+// (Round 3 measured a variant that decides ring and sector on float32 estimates and runs this path only near a boundary: bit-exact on
+// the whole GPU suite, but k_voi_gather is not bound by these ~250 float64 instructions per point -- 28 us either way -- so it was dropped.)
 __device__ __forceinline__ uint32_t bin_key(const DP &P, float x, float y, float z, Counters *ctr) {
     uint32_t key = (uint32_t)P.B;
     const double dx = (double)x, dy = (double)y;
@@ -108,7 +110,6 @@ __device__ __forceinline__ uint32_t bin_key(const DP &P, float x, float y, float
     }
     return key;
 }
-
 // ---- small block-level helpers -------------------------------------------------------------------
 // exclusive scan of one value per thread; sm >= 34 uint32; returns prefix, writes block total.
 // Round 3: both levels on DPP row shifts (esort::wave_incl_scan) -- the shuffle ladder this replaces was six dependent
@@ -3711,30 +3712,45 @@ __global__ void k_query_begin(Counters *qctr, uint32_t *bb, uint32_t *qb_tot, ui
 // end of a step: fold in the query side's counters and voxel count, commit the map sizes, report to the pinned host block
 __global__ void k_step_end(DevState *st, Counters *ctr, HostOut *out, const unsigned long long *lab_slots, const Counters *qctr,
                            const uint32_t *q_nvox, unsigned long long seq) {
+    // round 3: everything is READ first (one memory round trip: the loads are independent and nothing is stored in between), then
+    // computed, then written -- interleaved read-modify-writes of st / ctr cost a round trip each (6 us for this one-thread kernel)
+    DevState s = *st;
+    Counters c = *ctr;
+    const Counters q = *qctr;
+    const uint32_t nv = *q_nvox;
+    unsigned long long ns = 0, nd = 0;
     if (lab_slots) {
-        unsigned long long ns = 0, nd = 0;
+        unsigned long long a[16], b[16];
+#pragma unroll
         for (int i = 0; i < 16; ++i) {
-            ns += lab_slots[i * 8];
-            nd += lab_slots[i * 8 + 1];
+            a[i] = lab_slots[i * 8];
+            b[i] = lab_slots[i * 8 + 1];
         }
-        st->F_static = ns;
-        st->F_dynamic = nd;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ns += a[i];
+            nd += b[i];
+        }
+        s.F_static = ns;
+        s.F_dynamic = nd;
     }
-    ctr->n_neg_sector += qctr->n_neg_sector;
-    ctr->n_ambiguous += qctr->n_ambiguous;
-    ctr->n_degenerate += qctr->n_degenerate;
-    ctr->n_voxel_overflow += qctr->n_voxel_overflow;
-    ctr->n_sort_fallback += qctr->n_sort_fallback;
-    if (qctr->sort_qoverflow) ctr->sort_qoverflow = qctr->sort_qoverflow;
-    if (qctr->err) ctr->err = qctr->err;
-    st->q_nvox = *q_nvox;
-    if (!(ctr->err || ctr->sort_qoverflow)) {
-        st->nF = st->nF_new;
-        st->o_begin = st->o_new_begin;
+    c.n_neg_sector += q.n_neg_sector;
+    c.n_ambiguous += q.n_ambiguous;
+    c.n_degenerate += q.n_degenerate;
+    c.n_voxel_overflow += q.n_voxel_overflow;
+    c.n_sort_fallback += q.n_sort_fallback;
+    if (q.sort_qoverflow) c.sort_qoverflow = q.sort_qoverflow;
+    if (q.err) c.err = q.err;
+    s.q_nvox = nv;
+    if (!(c.err || c.sort_qoverflow)) {
+        s.nF = s.nF_new;
+        s.o_begin = s.o_new_begin;
     }
+    *st = s;
+    *ctr = c;
     if (out) {
-        out->st = *st;
-        out->ctr = *ctr;
+        out->st = s;
+        out->ctr = c;
         __threadfence_system();
         *(volatile unsigned long long *)&out->seq = seq;
     }
