@@ -792,3 +792,56 @@ def test_nodes_announced_with_their_pose_split_ahead(gpu_mod, version, ahead):
     compare_step(g, o, rg, ro, full=True)
     l2, u2 = g.ahead_split_counts()
     assert l2 == l1 + 1 and u2 == u1, (l1, u1, l2, u2)  # (never usable: the store was replaced)
+
+
+ALT_PATH_WORKER = """
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r + "/tests")
+import os
+import erasor_amd
+if os.environ.get("ERASOR_TEST_SIMT_LIB"):  # (the CPU stand-in build, when the suite itself runs on it)
+    erasor_amd.LIB_PATH = os.environ["ERASOR_TEST_SIMT_LIB"]
+    erasor_amd._lib = None
+import scenarios
+from oracle import orc
+for version in (3, 2):
+    sc = scenarios.small(version=version)
+    g = erasor_amd.Erasor(scenarios.to_product_params(sc["params"]))
+    o = orc.Oracle(sc["params"])
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"][:5]]
+    g.prefetch(scans[0], sc["T_l2b"], sc["T_b2o"][0])
+    for k in range(5):
+        if k + 1 < 5:
+            g.prefetch(scans[k + 1], sc["T_l2b"], sc["T_b2o"][k + 1])
+        rg = g.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        ro = o.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        dg, do = rg.as_dict(), ro.as_dict()
+        assert all(dg[f] == do[f] for f in do if f not in ("n_ambiguous", "n_sort_fallback")), (version, k, dg, do)
+        assert np.array_equal(g.get_map().view(np.uint32), o.get_map().view(np.uint32)), (version, k)
+        assert np.array_equal(g.get_rejected_indices(), o.get_rejected_indices())
+        assert np.array_equal(g.get_status(), o.get_status())
+        assert np.array_equal(g.get_cloud(2).view(np.uint32), o.get_cloud(2).view(np.uint32))
+print("ALT-PATH-OK")
+"""
+
+
+@pytest.mark.parametrize("env", [{"ERASOR_HIP_GRAPH": "1"}, {"ERASOR_HIP_NO_FUSE": "1", "ERASOR_HIP_NO_FOLD": "1", "ERASOR_HIP_NO_SRT_AHEAD": "1"}],
+                         ids=["query_chain_as_hipgraphs", "separate_rgpf_binvox_layout_srt_launches"])
+def test_alternative_launch_paths_keep_parity(gpu_mod, tmp_path, env):
+    """The paths behind the library's A/B switches are product code too: the query chain replayed as two hipGraphs per side
+    (ERASOR_HIP_GRAPH=1: measured, no gain, opt-in) and the unfused launches (R-GPF and per-bin voxelisation apart, k_layout4,
+    the Scan Ratio Test's first pass inside k_srt4) -- five look-ahead steps of a v3 and a v2 sequence each, in a process of its
+    own (the switches are read once), every step against the oracle."""
+    import subprocess
+    import sys
+    if os.environ.get("ERASOR_TEST_SIMT_LIB") and "ERASOR_HIP_GRAPH" in env:
+        pytest.skip("the CPU stand-in has no graph API")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "alt_worker.py"
+    script.write_text(ALT_PATH_WORKER % (root, root))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=280, env=dict(os.environ, **env))
+    assert out.returncode == 0 and "ALT-PATH-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
