@@ -24,6 +24,19 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
     return lane == 0 ? 0ull : (~0ull >> (64u - lane));
 }
 
+// inclusive prefix sum over the 64 lanes on DPP (row_shr 1 / 2 / 4 / 8 inside rows of 16, then row_bcast:15 / :31 across rows):
+// six VALU operations, no LDS crossbar (a __shfl_up ladder is six dependent ds_bpermute round trips)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    uint32_t vv = x;
+    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x111, 0xf, 0xf, false);
+    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x112, 0xf, 0xf, false);
+    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x114, 0xf, 0xf, false);
+    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x118, 0xf, 0xf, false);
+    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x142, 0xa, 0xf, false);
+    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x143, 0xc, 0xf, false);
+    return vv;
+}
+
 // intra-wave visibility of LDS/global writes made by other lanes of the same wave
 __device__ __forceinline__ void wave_sync() { __threadfence_block(); }
 
@@ -538,26 +551,17 @@ __device__ __forceinline__ uint32_t block_partition(KP K, VP V, PP posL, PP posR
         }
         const uint32_t cl = __popc(fl), cr = __popc(fr);
         // wave-inclusive scans of (cl, cr) packed in one 32-bit word (each < 2^16 per wave: 64*EPT)
-        uint32_t inc = cl | (cr << 16);
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(inc, off, 64);
-            if ((int)lane >= off) inc += t;
-        }
+        const uint32_t inc = wave_incl_scan(cl | (cr << 16));  // (DPP row shifts; round 2: a six-step __shfl_up ladder through the LDS crossbar)
         if (lane == 63) {
             sm[wave] = inc & 0xFFFFu;
             sm[nwaves + wave] = inc >> 16;
         }
         __syncthreads();
-        uint32_t preL = 0, preR = 0, totL = 0, totR = 0;
-        for (uint32_t w = 0; w < nwaves; ++w) {
-            const uint32_t a = sm[w], b = sm[nwaves + w];
-            if (w < wave) {
-                preL += a;
-                preR += b;
-            }
-            totL += a;
-            totR += b;
-        }
+        // second level on DPP as well (a tile holds at most bs * EPT <= 8192 stops of either kind: the packed halves cannot carry)
+        const uint32_t wt = lane < nwaves ? (sm[lane] | (sm[nwaves + lane] << 16)) : 0u;
+        const uint32_t wi = wave_incl_scan(wt);
+        const uint32_t tot2 = __builtin_amdgcn_readlane(wi, 63), pre2 = __builtin_amdgcn_readlane(wi - wt, __builtin_amdgcn_readfirstlane(wave));
+        const uint32_t preL = pre2 & 0xFFFFu, preR = pre2 >> 16, totL = tot2 & 0xFFFFu, totR = tot2 >> 16;
         uint32_t oL = lo + carryL + preL + (inc & 0xFFFFu) - cl;
         uint32_t oR = lo + carryR + preR + (inc >> 16) - cr;
 #pragma unroll
@@ -586,11 +590,10 @@ __device__ __forceinline__ uint32_t block_partition(KP K, VP V, PP posL, PP posR
 #pragma unroll
         for (int u = 0; u < 4; ++u) cnt += (l4[u] < r4[u]) ? 1u : 0u;
     }
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    cnt = __builtin_amdgcn_readlane(wave_incl_scan(cnt), 63);
     if (lane == 0) sm[wave] = cnt;
     __syncthreads();
-    uint32_t m = 0;
-    for (uint32_t w = 0; w < nwaves; ++w) m += sm[w];
+    const uint32_t m = __builtin_amdgcn_readlane(wave_incl_scan(lane < nwaves ? sm[lane] : 0u), 63);
     __syncthreads();
     uint32_t cut = 0xFFFFFFFFu;
     if (m < nL) cut = posL[lo + m];
@@ -659,19 +662,6 @@ struct KVValRef {
     uint2 *p;
     __device__ __forceinline__ uint32_t &operator[](size_t i) const { return p[i].y; }
 };
-
-// inclusive prefix sum over the 64 lanes on DPP (row_shr 1 / 2 / 4 / 8 inside rows of 16, then row_bcast:15 / :31 across rows):
-// six VALU operations, no LDS crossbar (a __shfl_up ladder is six dependent ds_bpermute round trips)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
-    uint32_t vv = x;
-    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x111, 0xf, 0xf, false);
-    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x112, 0xf, 0xf, false);
-    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x114, 0xf, 0xf, false);
-    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x118, 0xf, 0xf, false);
-    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x142, 0xa, 0xf, false);
-    vv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vv, 0x143, 0xc, 0xf, false);
-    return vv;
-}
 
 template <int EMAX, class K2P, class V2P>
 __device__ __forceinline__ void block_esort_sync(uint32_t (&k)[EMAX], uint32_t (&v)[EMAX], uint32_t n, uint2 *sKV, uint2 *sLL, uint2 *sRR,
