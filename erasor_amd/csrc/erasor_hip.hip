@@ -887,12 +887,12 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
         const int wl = std::min(std::min(esort::lg2_floor(n / WIDE_MIN) + ESORT_WIDE_SLACK, 16), level_cap);
         for (int l = 0; l < wl; ++l) {
             const int cur = l & 1;
-            LAUNCH(h, "q_esort_wide", k_esort_wide_mark, 256, 256, (const uint32_t *)Q(h).qk_a.p, Q(h).qposL.p, Q(h).qposR.p,
-                   (const WideSeg *)(cur ? Q(h).wseg1.p : Q(h).wseg0.p), (const WideState *)Q(h).wstate.p, cur, Q(h).wtileL.p, Q(h).wtileR.p);
+            // two launches per level (round 2: three -- the children's routing and median move had a kernel of their own)
+            LAUNCH(h, "q_esort_wide", k_esort_wide_mark, 256, 256, (const uint32_t *)Q(h).qk_a.p, (const uint32_t *)Q(h).qv_a.p, Q(h).qposL.p, Q(h).qposR.p,
+                   cur ? Q(h).wseg1.p : Q(h).wseg0.p, Q(h).wstate.p, cur, Q(h).wtileL.p, Q(h).wtileR.p);
             LAUNCH(h, "q_esort_wide", k_esort_wide_swap, 256, 256, Q(h).qk_a.p, Q(h).qv_a.p, (const uint32_t *)Q(h).qposL.p, (const uint32_t *)Q(h).qposR.p,
-                   cur ? Q(h).wseg1.p : Q(h).wseg0.p, (const WideState *)Q(h).wstate.p, cur, (const uint32_t *)Q(h).wtileL.p, (const uint32_t *)Q(h).wtileR.p);
-            LAUNCH(h, "q_esort_wide", k_esort_wide_children, 1, 64, Q(h).qk_a.p, Q(h).qv_a.p, (const WideSeg *)(cur ? Q(h).wseg1.p : Q(h).wseg0.p),
-                   cur ? Q(h).wseg0.p : Q(h).wseg1.p, Q(h).wstate.p, cur, Q(h).esq0.p, Q(h).essmall.p, Q(h).esqs.p, 65536u, l == wl - 1 ? 1 : 0, dc);
+                   cur ? Q(h).wseg1.p : Q(h).wseg0.p, cur ? Q(h).wseg0.p : Q(h).wseg1.p, Q(h).wstate.p, cur, (const uint32_t *)Q(h).wtileL.p,
+                   (const uint32_t *)Q(h).wtileR.p, Q(h).esq0.p, Q(h).essmall.p, Q(h).esqs.p, 65536u, l == wl - 1 ? 1 : 0, dc);
         }
     }
     bool mid_done = false;

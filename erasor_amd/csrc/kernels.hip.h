@@ -128,6 +128,24 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *sm, ui
     return pre + inc - v;
 }
 
+// wave-wide reductions on DPP row shifts (the value every lane gets back is lane 63's inclusive result): a __shfl_down / __shfl_xor
+// ladder is six dependent ds_bpermute round trips (~100 cycles each) at the end of a wavefront that lives a few microseconds
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) { return __builtin_amdgcn_readlane(esort::wave_incl_scan(x), 63); }
+__device__ __forceinline__ float wave_min_f(float x) {
+    const int id = 0x7F800000;  // +inf: what a lane without a source contributes
+    float v = x;
+#define ERASOR_DPP_MINSTEP(ctrl, rmask) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(id, __float_as_int(v), ctrl, rmask, 0xf, false)))
+    ERASOR_DPP_MINSTEP(0x111, 0xf);
+    ERASOR_DPP_MINSTEP(0x112, 0xf);
+    ERASOR_DPP_MINSTEP(0x114, 0xf);
+    ERASOR_DPP_MINSTEP(0x118, 0xf);
+    ERASOR_DPP_MINSTEP(0x142, 0xa);
+    ERASOR_DPP_MINSTEP(0x143, 0xc);
+#undef ERASOR_DPP_MINSTEP
+    return __int_as_float((int)__builtin_amdgcn_readlane((uint32_t)__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f(float x) { return -wave_min_f(-x); }
+
 // ================================================================================================
 // (1) voi_split — THE HBM-bound kernel.  fetch_VoI's membership test (OMU.cpp:391-395) over every
 // physical entry of the map store.  One wavefront per 1024-entry chunk (CHUNK), 16 loads in flight per lane.
@@ -465,13 +483,10 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
         const unsigned long long mv = lane < CHUNK_TILES ? vmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
         const unsigned long long mh = lane < CHUNK_TILES ? hmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
         if (t_lo > 0) {  // entries of the chunk's tiles before this piece
-            uint32_t av = (int)lane < t_lo ? (uint32_t)__popcll(mv) : 0u, ah = (int)lane < t_lo ? (uint32_t)__popcll(mh) : 0u;
-            for (int o = 32; o > 0; o >>= 1) {  // (lanes >= CHUNK_TILES hold empty masks; every lane ends with the total)
-                av += __shfl_xor(av, o, 64);
-                ah += __shfl_xor(ah, o, 64);
-            }
-            pv += av;
-            ph += ah;
+            // (lanes >= CHUNK_TILES hold empty masks; both counts are < 2^16: one packed DPP reduction)
+            const uint32_t a2 = wave_sum(((int)lane < t_lo) ? ((uint32_t)__popcll(mv) | ((uint32_t)__popcll(mh) << 16)) : 0u);
+            pv += a2 & 0xFFFFu;
+            ph += a2 >> 16;
         }
         for (int t = t_lo; t < t_hi; ++t) {
             const unsigned long long vm = __shfl(mv, t, 64), hm = __shfl(mh, t, 64);
@@ -517,12 +532,10 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
     }
     (void)voiF;
     // outskirts label counters (parse_dynamic_obj is maintained incrementally, OMU.cpp:294)
-    for (int off = 32; off > 0; off >>= 1) {
-        dyn_leave += __shfl_down(dyn_leave, off, 64);
-        stat_leave += __shfl_down(stat_leave, off, 64);
-        dyn_enter += __shfl_down(dyn_enter, off, 64);
-        stat_enter += __shfl_down(stat_enter, off, 64);
-    }
+    dyn_leave = wave_sum(dyn_leave);
+    stat_leave = wave_sum(stat_leave);
+    dyn_enter = wave_sum(dyn_enter);
+    stat_enter = wave_sum(stat_enter);
     if (lane == 0) {
         if (dyn_leave | dyn_enter) atomicAdd(&st->O_dynamic, (unsigned long long)dyn_leave - (unsigned long long)dyn_enter);
         if (stat_leave | stat_enter) atomicAdd(&st->O_static, (unsigned long long)stat_leave - (unsigned long long)stat_enter);
@@ -1027,11 +1040,8 @@ __global__ __launch_bounds__(256) void k_bin_stats(const float4 *__restrict__ sp
         mn = z < mn ? z : mn;
         mx = z > mx ? z : mx;
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        const float a = __shfl_down(mn, o, 64), c = __shfl_down(mx, o, 64);
-        mn = a < mn ? a : mn;
-        mx = c > mx ? c : mx;
-    }
+    mn = wave_min_f(mn);  // (z values are finite: the scan was checked for NaN / Inf, so fminf == the compare chain)
+    mx = wave_max_f(mx);
     if (lane == 0) {
         cnt[b] = e - s;
         minz[b] = mn;
@@ -1277,7 +1287,15 @@ static constexpr int32_t MED_DONE = 0x40000000;  // flag in Seg::depth: median a
 struct WideSeg {
     uint32_t first, last;
     int32_t depth;
-    uint32_t tile0, ntiles, cut, pad0, pad1;
+    uint32_t tile0, ntiles, cut;
+    // round 3: the median move (std::__move_median_to_first) of a wide segment is VIRTUAL while the level is marked -- k_esort_wide_mark
+    // decides it from memory, patches the one key it moves into its reads and records it here; k_esort_wide_swap makes it physical
+    // together with the partition's swaps.  (A kernel of its own used to do it between two levels: 9 launches per scan.)
+    uint32_t pk, pv;    // the pivot: key and value that belong at `first`
+    uint32_t kf, vf;    // the old head: key and value that belong at `mpos`
+    uint32_t mpos;      // where the median was
+    uint32_t mL, mR;    // index of mpos in its tile's left / right stop list (0xFFFFFFFF: not a stop of that kind)
+    uint32_t pad0, pad1, pad2;
 };
 struct WideState {
     uint32_t nseg[2];
@@ -1297,8 +1315,7 @@ __global__ void k_esort_init(uint32_t *K, uint32_t *V, esort::Seg *q0, esort::Se
     s.depth = 2 * esort::lg2_floor(n);
     const uint32_t nt = (n - 1 + WTILE - 1) / WTILE;
     if (n >= WIDE_MIN && nt <= WTILES_MAX) {
-        esort::move_median_to_first(K, V, 0u, n);
-        w0[0].first = 0;
+        w0[0].first = 0;  // (its median move is the first level's business, like every wide segment's)
         w0[0].last = n;
         w0[0].depth = s.depth;
         w0[0].tile0 = 0;
@@ -1314,13 +1331,16 @@ __global__ void k_esort_init(uint32_t *K, uint32_t *V, esort::Seg *q0, esort::Se
     }
 }
 
-__global__ __launch_bounds__(256) void k_esort_wide_mark(const uint32_t *__restrict__ K, uint32_t *__restrict__ posL,
-                                                          uint32_t *__restrict__ posR, const WideSeg *__restrict__ wseg,
-                                                          const WideState *ws, int cur, uint32_t *__restrict__ tileL,
-                                                          uint32_t *__restrict__ tileR) {
+__global__ __launch_bounds__(256) void k_esort_wide_mark(const uint32_t *__restrict__ K, const uint32_t *__restrict__ V, uint32_t *__restrict__ posL,
+                                                          uint32_t *__restrict__ posR, WideSeg *__restrict__ wseg, WideState *ws, int cur,
+                                                          uint32_t *__restrict__ tileL, uint32_t *__restrict__ tileR) {
     __shared__ uint32_t sm[40];
     __shared__ uint32_t s_si;
-    const uint32_t nseg = ws->nseg[cur], ntot = ws->ntiles[cur];
+    const uint32_t nseg = min(ws->nseg[cur], WSEG_MAX), ntot = min(ws->ntiles[cur], WTILES_MAX);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the next level's list is filled by this level's swap kernel (atomics): start it empty
+        ws->nseg[cur ^ 1] = 0;
+        ws->ntiles[cur ^ 1] = 0;
+    }
     for (uint32_t gt = blockIdx.x; gt < ntot; gt += gridDim.x) {
         // which segment owns tile gt?  (slots and tile ranges are handed out by atomics: no ordering to rely on)
         if (threadIdx.x == 0) s_si = 0xFFFFFFFFu;
@@ -1332,15 +1352,34 @@ __global__ __launch_bounds__(256) void k_esort_wide_mark(const uint32_t *__restr
         __syncthreads();
         const uint32_t si = s_si;
         if (si == 0xFFFFFFFFu) continue;  // tile ids of children that were routed to the level queue instead
-        const WideSeg sg = wseg[si];
-        const uint32_t t = gt - sg.tile0;
-        const uint32_t p = K[sg.first];
-        const uint32_t lo = sg.first + 1 + t * WTILE;
-        const uint32_t hi = min(lo + WTILE, sg.last);
+        const uint32_t first = wseg[si].first, last = wseg[si].last, tile0 = wseg[si].tile0;
+        const uint32_t t = gt - tile0;
+        // std::__move_median_to_first(first, first + 1, mid, last - 1), decided but not performed
+        const uint32_t ma = first + 1, mb = first + (last - first) / 2, mc = last - 1;
+        const uint32_t kf = K[first], ka = K[ma], kb = K[mb], kc = K[mc];
+        uint32_t mpos, p;
+        if (ka < kb) {
+            if (kb < kc) { mpos = mb; p = kb; }
+            else if (ka < kc) { mpos = mc; p = kc; }
+            else { mpos = ma; p = ka; }
+        } else if (ka < kc) { mpos = ma; p = ka; }
+        else if (kb < kc) { mpos = mc; p = kc; }
+        else { mpos = mb; p = kb; }
+        if (t == 0 && threadIdx.x == 0) {
+            wseg[si].pk = p;
+            wseg[si].kf = kf;
+            wseg[si].vf = V[first];
+            wseg[si].mpos = mpos;
+        }
+        const uint32_t lo = first + 1 + t * WTILE;
+        const uint32_t hi = min(lo + WTILE, last);
         const uint32_t i0 = lo + threadIdx.x * 8;
         uint32_t k[8], fl = 0, fr = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) k[j] = (i0 + j < hi) ? K[i0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i0 + j == mpos) k[j] = kf;  // (the median's place holds the old head)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool valid = i0 + j < hi;
@@ -1353,6 +1392,11 @@ __global__ __launch_bounds__(256) void k_esort_wide_mark(const uint32_t *__restr
         uint32_t oR = lo + block_excl_scan(cr, sm, tr);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            if (i0 + j == mpos && i0 + j < hi) {  // where the median was, as the swap kernel will look for it
+                wseg[si].pv = V[mpos];
+                wseg[si].mL = (fl & (1u << j)) ? oL - lo : 0xFFFFFFFFu;
+                wseg[si].mR = (fr & (1u << j)) ? oR - lo : 0xFFFFFFFFu;
+            }
             if (fl & (1u << j)) posL[oL++] = i0 + j;
             if (fr & (1u << j)) posR[oR++] = i0 + j;
         }
@@ -1374,13 +1418,16 @@ __device__ __forceinline__ uint32_t wide_lookup(const uint32_t *pre, uint32_t nt
     return list[base + lo * WTILE + (asc - pre[lo])];
 }
 
+// The level's swaps -- the median move made physical on the way -- and, by the workgroup that owns a segment's first share, the
+// routing of its two children: next wide list (slots and tile ranges by atomics on the level state), level queue, finisher queue.
 __global__ __launch_bounds__(256) void k_esort_wide_swap(uint32_t *K, uint32_t *V, const uint32_t *__restrict__ posL,
-                                                          const uint32_t *__restrict__ posR, WideSeg *wseg, const WideState *ws, int cur,
-                                                          const uint32_t *__restrict__ tileL, const uint32_t *__restrict__ tileR) {
+                                                          const uint32_t *__restrict__ posR, WideSeg *wseg, WideSeg *wnext, WideState *ws, int cur,
+                                                          const uint32_t *__restrict__ tileL, const uint32_t *__restrict__ tileR, esort::Seg *q0,
+                                                          esort::Seg *smallq, EsQueues *qs, uint32_t qcap, int last_level, Counters *ctr) {
     __shared__ uint32_t preL[WTILES_MAX + 1], preR[WTILES_MAX + 1];
     __shared__ uint32_t sm[40];
     __shared__ uint32_t s_lo, s_hi;
-    const uint32_t nseg = ws->nseg[cur];
+    const uint32_t nseg = min(ws->nseg[cur], WSEG_MAX);
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
     if (nseg == 0) return;
     const uint32_t parts = max(1u, gridDim.x / nseg);  // workgroups sharing one segment's swaps (all of the grid at level 0)
@@ -1388,6 +1435,8 @@ __global__ __launch_bounds__(256) void k_esort_wide_swap(uint32_t *K, uint32_t *
         const uint32_t si = w / parts, part = w % parts;
         const WideSeg sg = wseg[si];
         const uint32_t nt = sg.ntiles, base = sg.first + 1;
+        __syncthreads();  // (the previous segment's tables are still being read)
+        if (nt == 0) continue;  // (a slot that could not get its tiles: see the routing below)
         // tile prefixes (exclusive), entry nt = total
         uint32_t carryL = 0, carryR = 0;
         for (uint32_t t0 = 0; t0 < nt; t0 += bs) {
@@ -1446,64 +1495,69 @@ __global__ __launch_bounds__(256) void k_esort_wide_swap(uint32_t *K, uint32_t *
                 if (r < cut) cut = r;
             }
             wseg[si].cut = cut;
+            // ---- the median move, made physical: the pivot goes to `first` (nobody else touches it); the old head goes to the
+            // median's place unless that place takes part in a swap -- the pair that holds it then moves the old head along ----
+            K[sg.first] = sg.pk;
+            V[sg.first] = sg.pv;
+            const uint32_t tm = (sg.mpos - base) / WTILE;
+            const bool swapped = (sg.mL != 0xFFFFFFFFu && preL[tm] + sg.mL < m) || (sg.mR != 0xFFFFFFFFu && nR - 1u - (preR[tm] + sg.mR) < m);
+            if (!swapped) {
+                K[sg.mpos] = sg.kf;
+                V[sg.mpos] = sg.vf;
+            }
+            // ---- the two children (what k_esort_wide_children did): queue order is irrelevant, slots by atomics ----
+            const esort::Seg ch[2] = {{sg.first, cut, sg.depth - 1}, {cut, sg.last, sg.depth - 1}};
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t len = ch[t].last - ch[t].first;
+                if (len == 0) continue;
+                const uint32_t cnt_t = len > 1 ? (len - 1 + WTILE - 1) / WTILE : 0;
+                bool wide = ch[t].depth > 0 && len >= WIDE_MIN && !last_level;
+                if (wide) {
+                    const uint32_t slot = atomicAdd(&ws->nseg[cur ^ 1], 1u);
+                    if (slot >= WSEG_MAX) wide = false;  // over capacity: the level queue takes it (the counter only over-counts: clamped where read)
+                    else {
+                        const uint32_t t0 = atomicAdd(&ws->ntiles[cur ^ 1], cnt_t);
+                        WideSeg nx;
+                        nx.first = ch[t].first;
+                        nx.last = ch[t].last;
+                        nx.depth = ch[t].depth;
+                        nx.tile0 = t0;
+                        nx.ntiles = cnt_t;
+                        nx.cut = 0;
+                        nx.pk = nx.pv = nx.kf = nx.vf = nx.mpos = 0;
+                        nx.mL = nx.mR = 0xFFFFFFFFu;
+                        nx.pad0 = nx.pad1 = nx.pad2 = 0;
+                        if (t0 + cnt_t > WTILES_MAX) {  // no tiles left: the slot stays, empty, and the level queue takes the segment
+                            nx.first = nx.last = 0;
+                            nx.ntiles = 0;
+                            wide = false;
+                        }
+                        wnext[slot] = nx;
+                    }
+                }
+                if (!wide) {
+                    if (len > ES_LMAX && ch[t].depth > 0) {
+                        const uint32_t at = atomicAdd(&qs->cnt[0], 1u);
+                        if (at < qcap) q0[at] = ch[t]; else ctr->sort_qoverflow = 1;
+                    } else {
+                        const uint32_t at = atomicAdd(&qs->small_cnt, 1u);
+                        if (at < qcap) smallq[at] = ch[t]; else ctr->sort_qoverflow = 1;
+                    }
+                }
+            }
         }
         const uint32_t k_begin = (uint32_t)(((uint64_t)m * part) / parts), k_end = (uint32_t)(((uint64_t)m * (part + 1)) / parts);
         for (uint32_t k = k_begin + tid; k < k_end; k += bs) {
             const uint32_t a = wide_lookup(preL, nt, posL, base, k), b = wide_lookup(preR, nt, posR, base, nR - 1 - k);
-            esort::swap_kv(K, V, a, b);
+            uint32_t ka = K[a], va = V[a], kb = K[b], vb = V[b];
+            if (a == sg.mpos) { ka = sg.kf; va = sg.vf; }  // (the median's place holds the old head)
+            if (b == sg.mpos) { kb = sg.kf; vb = sg.vf; }
+            K[a] = kb;
+            V[a] = vb;
+            K[b] = ka;
+            V[b] = va;
         }
         __syncthreads();
-    }
-}
-
-// single workgroup, one thread per wide segment: route its two children (queue order is irrelevant, slots by atomics)
-__global__ __launch_bounds__(64) void k_esort_wide_children(uint32_t *K, uint32_t *V, const WideSeg *wcur, WideSeg *wnext, WideState *ws,
-                                                             int cur, esort::Seg *q0, esort::Seg *smallq, EsQueues *qs, uint32_t qcap,
-                                                             int last_level, Counters *ctr) {
-    __shared__ uint32_t s_nn, s_nt;
-    const uint32_t nseg = ws->nseg[cur];
-    if (threadIdx.x == 0) {
-        s_nn = 0;
-        s_nt = 0;
-    }
-    __syncthreads();
-    for (uint32_t si = threadIdx.x; si < nseg; si += blockDim.x) {
-        const WideSeg sg = wcur[si];
-        const esort::Seg ch[2] = {{sg.first, sg.cut, sg.depth - 1}, {sg.cut, sg.last, sg.depth - 1}};
-        for (int t = 0; t < 2; ++t) {
-            const uint32_t len = ch[t].last - ch[t].first;
-            if (len == 0) continue;
-            const uint32_t nt = len > 1 ? (len - 1 + WTILE - 1) / WTILE : 0;
-            bool wide = ch[t].depth > 0 && len >= WIDE_MIN && !last_level;
-            uint32_t slot = 0, t0 = 0;
-            if (wide) {
-                slot = atomicAdd(&s_nn, 1u);
-                t0 = atomicAdd(&s_nt, nt);
-                if (slot >= WSEG_MAX || t0 + nt > WTILES_MAX) wide = false;  // over capacity: the level queue takes it (counters only over-count)
-            }
-            if (wide) {
-                esort::move_median_to_first(K, V, ch[t].first, ch[t].last);
-                wnext[slot].first = ch[t].first;
-                wnext[slot].last = ch[t].last;
-                wnext[slot].depth = ch[t].depth;
-                wnext[slot].tile0 = t0;
-                wnext[slot].ntiles = nt;
-            } else if (len > ES_LMAX && ch[t].depth > 0) {
-                const uint32_t at = atomicAdd(&qs->cnt[0], 1u);
-                if (at < qcap) q0[at] = ch[t]; else ctr->sort_qoverflow = 1;
-            } else {
-                const uint32_t at = atomicAdd(&qs->small_cnt, 1u);
-                if (at < qcap) smallq[at] = ch[t]; else ctr->sort_qoverflow = 1;
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // capacity overflow would leave holes in wnext: only possible beyond WSEG_MAX / WTILES_MAX, which the init sizing excludes
-        ws->nseg[cur ^ 1] = min(s_nn, WSEG_MAX);
-        ws->ntiles[cur ^ 1] = min(s_nt, WTILES_MAX);
-        ws->nseg[cur] = 0;
-        ws->ntiles[cur] = 0;
     }
 }
 
@@ -2000,11 +2054,8 @@ __global__ __launch_bounds__(256) void k_bin_stats_srt(DP P, const float4 *__res
         mn = z < mn ? z : mn;
         mx = z > mx ? z : mx;
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        const float a = __shfl_down(mn, o, 64), c = __shfl_down(mx, o, 64);
-        mn = a < mn ? a : mn;
-        mx = c > mx ? c : mx;
-    }
+    mn = wave_min_f(mn);  // (z values are finite: the scan was checked for NaN / Inf, so fminf == the compare chain)
+    mx = wave_max_f(mx);
     if (lane == 0) {
         cnt[b] = e - s;
         minz[b] = mn;
@@ -3412,10 +3463,8 @@ __global__ __launch_bounds__(1024) void k_layout4(DP P, const uint8_t *__restric
 __device__ __forceinline__ void block_commit_labels(uint32_t d, uint32_t s, unsigned long long *cnt /* [16][8]: {static, dynamic, pad} */) {
     __shared__ uint32_t sd[16], ss[16];
     if (!cnt) return;
-    for (int o = 32; o > 0; o >>= 1) {
-        d += __shfl_down(d, o, 64);
-        s += __shfl_down(s, o, 64);
-    }
+    d = wave_sum(d);
+    s = wave_sum(s);
     if ((threadIdx.x & 63u) == 0) {
         sd[threadIdx.x >> 6] = d;
         ss[threadIdx.x >> 6] = s;
