@@ -1911,39 +1911,67 @@ __global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts
         done = (gmin > 0.0 && (double)best <= gmin * gmin);
     }
     const uint32_t hmask = (1u << hbits) - 1u;
+    // one cell of a shell: pruned by its squared distance d2c from the centroid (a cell whose nearest corner / face is farther than
+    // the current best cannot hold a closer or tied point), found through the voxel hash, its points taken
+    auto visit = [&](int ii, int jj, int kk, double d2c, float shell_best) {
+        if (d2c > (double)shell_best) return;
+        const uint32_t q = (uint32_t)ii + (uint32_t)jj * (uint32_t)dx + (uint32_t)kk * (uint32_t)dx * (uint32_t)dy;
+        uint32_t sl = vox_hash(q, hbits), hk;
+        while ((hk = hkey[sl]) != q && hk != 0xFFFFFFFFu) sl = (sl + 1) & hmask;
+        if (hk != q) return;  // empty cell
+        const uint32_t w = hval[sl];
+        for (uint32_t li = run_begin[w]; li < run_begin[w + 1]; ++li) {
+            const uint32_t pi = sperm[li];
+            const float4 p = pts[pi];
+            nn_take(l2_simple(c.x, c.y, c.z, p.x, p.y, p.z), pi, best, best_i);
+        }
+    };
+    // squared distance from the centroid to the slab of cells `cell_a` along axis a (the summand of d2c)
+    auto slab_d2 = [&](int a, int cell_a) -> double {
+        const double lo_a = (double)(g.min_b[a] + cell_a) * L, hi_a = (double)(g.min_b[a] + cell_a + 1) * L;
+        const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
+        const double da = fmax(0.0, fmax(lo_a - cc[a], cc[a] - hi_a) - margin);
+        return da * da;
+    };
     for (int rho = 1; !done; ++rho) {
         const float shell_best = best;  // pruning bound for this shell (the same in all eight lanes; a looser bound only prunes less)
-        uint32_t turn = 0;
-        for (int kk = ck - rho; kk <= ck + rho; ++kk) {
-            if (kk < 0 || kk >= dz) continue;
-            for (int jj = cj - rho; jj <= cj + rho; ++jj) {
-                if (jj < 0 || jj >= dy) continue;
-                const bool shell_jk = (abs(jj - cj) == rho) || (abs(kk - ck) == rho);
-                for (int ii = ci - rho; ii <= ci + rho; ++ii) {
-                    if (ii < 0 || ii >= dx) continue;
-                    if (!shell_jk && abs(ii - ci) < rho) continue;  // interior cells were visited by earlier stages (rho-1, ..., 0)
-                    if ((turn++ & (NN_SUB - 1)) != sub) continue;   // this cell belongs to another lane
-                    {   // a cell whose nearest corner/face is farther than the current best cannot hold a closer or tied point
-                        const int cell[3] = {ii, jj, kk};
-                        double d2c = 0.0;
+        if (rho == 1) {
+            // round 3: the first shell (where nearly every search ends) without the triple loop: the 26 neighbours are dealt to the
+            // eight lanes by their number (which lane takes which cell does not matter: candidates merge by (distance, index)), and
+            // the three summands of d2c come from a 3 x 3 table of slab distances instead of 24 float64 operations per cell
+            double tab[3][3];
 #pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            const double lo_a = (double)(g.min_b[a] + cell[a]) * L, hi_a = (double)(g.min_b[a] + cell[a] + 1) * L;
-                            const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
-                            const double da = fmax(0.0, fmax(lo_a - cc[a], cc[a] - hi_a) - margin);
-                            d2c += da * da;
-                        }
-                        if (d2c > (double)shell_best) continue;
-                    }
-                    const uint32_t q = (uint32_t)ii + (uint32_t)jj * (uint32_t)dx + (uint32_t)kk * (uint32_t)dx * (uint32_t)dy;
-                    uint32_t sl = vox_hash(q, hbits), hk;
-                    while ((hk = hkey[sl]) != q && hk != 0xFFFFFFFFu) sl = (sl + 1) & hmask;
-                    if (hk != q) continue;  // empty cell
-                    const uint32_t w = hval[sl];
-                    for (uint32_t li = run_begin[w]; li < run_begin[w + 1]; ++li) {
-                        const uint32_t pi = sperm[li];
-                        const float4 p = pts[pi];
-                        nn_take(l2_simple(c.x, c.y, c.z, p.x, p.y, p.z), pi, best, best_i);
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int o = 0; o < 3; ++o) tab[a][o] = slab_d2(a, cidx[a] + o - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = (int)sub + 8 * r;  // cell number: (kk - ck + 1) * 9 + (jj - cj + 1) * 3 + (ii - ci + 1)
+                const int oi = n % 3, oj = (n / 3) % 3, ok = n / 9;
+                const int ii = ci + oi - 1, jj = cj + oj - 1, kk = ck + ok - 1;
+                if (n >= 27 || n == 13 || ii < 0 || ii >= dx || jj < 0 || jj >= dy || kk < 0 || kk >= dz) continue;
+                double d2c = 0.0;
+                d2c += oi == 0 ? tab[0][0] : (oi == 1 ? tab[0][1] : tab[0][2]);
+                d2c += oj == 0 ? tab[1][0] : (oj == 1 ? tab[1][1] : tab[1][2]);
+                d2c += ok == 0 ? tab[2][0] : (ok == 1 ? tab[2][1] : tab[2][2]);
+                visit(ii, jj, kk, d2c, shell_best);
+            }
+        } else {
+            uint32_t turn = 0;
+            for (int kk = ck - rho; kk <= ck + rho; ++kk) {
+                if (kk < 0 || kk >= dz) continue;
+                for (int jj = cj - rho; jj <= cj + rho; ++jj) {
+                    if (jj < 0 || jj >= dy) continue;
+                    const bool shell_jk = (abs(jj - cj) == rho) || (abs(kk - ck) == rho);
+                    for (int ii = ci - rho; ii <= ci + rho; ++ii) {
+                        if (ii < 0 || ii >= dx) continue;
+                        if (!shell_jk && abs(ii - ci) < rho) continue;  // interior cells were visited by earlier stages (rho-1, ..., 0)
+                        if ((turn++ & (NN_SUB - 1)) != sub) continue;   // this cell belongs to another lane
+                        double d2c = 0.0;
+                        d2c += slab_d2(0, ii);
+                        d2c += slab_d2(1, jj);
+                        d2c += slab_d2(2, kk);
+                        visit(ii, jj, kk, d2c, shell_best);
                     }
                 }
             }
@@ -3169,7 +3197,16 @@ __device__ __forceinline__ void binvox_bins(const DP &P, uint32_t rk0, uint32_t 
             if (v >= nv) continue;  // (the eight lanes of a voxel take the same branch; no barrier inside this loop)
             const uint32_t rs = sV[v], re = (v + 1 < nv) ? sV[v + 1] : m;
             float sx = 0.f, sy = 0.f, sz = 0.f;
-            for (uint32_t li = rs; li < re; ++li) {  // (the averaged intensity is overwritten by the nearest input point's label)
+            uint32_t li = rs;
+            for (; li + 3 < re; li += 4) {  // four points' two dependent LDS reads in flight at a time; the additions keep their order
+                const uint32_t i0 = sR[li], i1 = sR[li + 1], i2 = sR[li + 2], i3 = sR[li + 3];
+                const float4 p0 = sC[i0], p1 = sC[i1], p2 = sC[i2], p3 = sC[i3];
+                sx += p0.x; sy += p0.y; sz += p0.z;
+                sx += p1.x; sy += p1.y; sz += p1.z;
+                sx += p2.x; sy += p2.y; sz += p2.z;
+                sx += p3.x; sy += p3.y; sz += p3.z;
+            }
+            for (; li < re; ++li) {  // (the averaged intensity is overwritten by the nearest input point's label)
                 const float4 p = sC[sR[li]];
                 sx += p.x;
                 sy += p.y;
@@ -3201,43 +3238,67 @@ __device__ __forceinline__ void binvox_bins(const DP &P, uint32_t rk0, uint32_t 
                 }
                 done = (gmin > 0.0 && (double)best <= gmin * gmin);
             }
+            // one cell of a shell: pruned by its squared distance d2c from the centroid, found by binary search in the ascending
+            // unique keys, its points taken
+            auto visit = [&](int ii, int jj, int kk, double d2c, float shell_best) {
+                if (d2c > (double)shell_best) return;
+                const uint32_t q = (uint32_t)ii + (uint32_t)jj * (uint32_t)dx + (uint32_t)kk * (uint32_t)dx * (uint32_t)dy;
+                uint32_t lo = 0, hi = nv;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (sK[mid] < q) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo >= nv || sK[lo] != q) return;  // empty cell
+                const uint32_t ws = sV[lo], we = (lo + 1 < nv) ? sV[lo + 1] : m;
+                for (uint32_t li = ws; li < we; ++li) {
+                    const uint32_t pi = sR[li];
+                    const float4 p = sC[pi];
+                    nn_take(l2_simple(cx, cy, cz, p.x, p.y, p.z), pi, best, best_i);
+                }
+            };
+            auto slab_d2 = [&](int a, int cell_a) -> double {
+                const double lo_a = (double)(g.min_b[a] + cell_a) * L, hi_a = (double)(g.min_b[a] + cell_a + 1) * L;
+                const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
+                const double da = fmax(0.0, fmax(lo_a - cc[a], cc[a] - hi_a) - margin);
+                return da * da;
+            };
             for (int rho = 1; !done; ++rho) {
                 const float shell_best = best;
-                uint32_t turn = 0;
-                for (int kk = ck - rho; kk <= ck + rho; ++kk) {
-                    if (kk < 0 || kk >= dz) continue;
-                    for (int jj = cj - rho; jj <= cj + rho; ++jj) {
-                        if (jj < 0 || jj >= dy) continue;
-                        const bool shell_jk = (abs(jj - cj) == rho) || (abs(kk - ck) == rho);
-                        for (int ii = ci - rho; ii <= ci + rho; ++ii) {
-                            if (ii < 0 || ii >= dx) continue;
-                            if (!shell_jk && abs(ii - ci) < rho) continue;
-                            if ((turn++ & (NN_SUB - 1)) != sub) continue;
-                            {
-                                const int cell[3] = {ii, jj, kk};
-                                double d2c = 0.0;
+                if (rho == 1) {  // (the first shell by cell number, slab distances from a 3 x 3 table: see k_query_nn)
+                    double tab[3][3];
 #pragma unroll
-                                for (int a = 0; a < 3; ++a) {
-                                    const double lo_a = (double)(g.min_b[a] + cell[a]) * L, hi_a = (double)(g.min_b[a] + cell[a] + 1) * L;
-                                    const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
-                                    const double da = fmax(0.0, fmax(lo_a - cc[a], cc[a] - hi_a) - margin);
-                                    d2c += da * da;
-                                }
-                                if (d2c > (double)shell_best) continue;
-                            }
-                            const uint32_t q = (uint32_t)ii + (uint32_t)jj * (uint32_t)dx + (uint32_t)kk * (uint32_t)dx * (uint32_t)dy;
-                            uint32_t lo = 0, hi = nv;  // binary search in the ascending unique keys
-                            while (lo < hi) {
-                                const uint32_t mid = (lo + hi) >> 1;
-                                if (sK[mid] < q) lo = mid + 1;
-                                else hi = mid;
-                            }
-                            if (lo >= nv || sK[lo] != q) continue;  // empty cell
-                            const uint32_t ws = sV[lo], we = (lo + 1 < nv) ? sV[lo + 1] : m;
-                            for (uint32_t li = ws; li < we; ++li) {
-                                const uint32_t pi = sR[li];
-                                const float4 p = sC[pi];
-                                nn_take(l2_simple(cx, cy, cz, p.x, p.y, p.z), pi, best, best_i);
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int o = 0; o < 3; ++o) tab[a][o] = slab_d2(a, cidx[a] + o - 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = (int)sub + 8 * r;
+                        const int oi = n % 3, oj = (n / 3) % 3, ok = n / 9;
+                        const int ii = ci + oi - 1, jj = cj + oj - 1, kk = ck + ok - 1;
+                        if (n >= 27 || n == 13 || ii < 0 || ii >= dx || jj < 0 || jj >= dy || kk < 0 || kk >= dz) continue;
+                        double d2c = 0.0;
+                        d2c += oi == 0 ? tab[0][0] : (oi == 1 ? tab[0][1] : tab[0][2]);
+                        d2c += oj == 0 ? tab[1][0] : (oj == 1 ? tab[1][1] : tab[1][2]);
+                        d2c += ok == 0 ? tab[2][0] : (ok == 1 ? tab[2][1] : tab[2][2]);
+                        visit(ii, jj, kk, d2c, shell_best);
+                    }
+                } else {
+                    uint32_t turn = 0;
+                    for (int kk = ck - rho; kk <= ck + rho; ++kk) {
+                        if (kk < 0 || kk >= dz) continue;
+                        for (int jj = cj - rho; jj <= cj + rho; ++jj) {
+                            if (jj < 0 || jj >= dy) continue;
+                            const bool shell_jk = (abs(jj - cj) == rho) || (abs(kk - ck) == rho);
+                            for (int ii = ci - rho; ii <= ci + rho; ++ii) {
+                                if (ii < 0 || ii >= dx) continue;
+                                if (!shell_jk && abs(ii - ci) < rho) continue;
+                                if ((turn++ & (NN_SUB - 1)) != sub) continue;
+                                double d2c = 0.0;
+                                d2c += slab_d2(0, ii);
+                                d2c += slab_d2(1, jj);
+                                d2c += slab_d2(2, kk);
+                                visit(ii, jj, kk, d2c, shell_best);
                             }
                         }
                     }
