@@ -313,6 +313,22 @@ static void test_map_store(std::mt19937 &rng) {
         simt::run_grid(1, 1024, [&] {
             k_chunk_scan_one(cinfo.data(), nchunks, pvl.data(), phl.data(), topv.data(), toph.data(), 1u, nFchunks, &st, &ctr, init, lab.data(), mb_tot.data(), 64u);
         });
+        {   // the two-level scan (maps beyond 16384 chunks) opens the step with the same state and the same prefixes
+            std::vector<uint32_t> pvl2(nchunks + 8, 0), phl2(nchunks + 8, 0), topv2(8, 0), toph2(8, 0), mb2(64, 5);
+            std::vector<unsigned long long> lab2(128, 1);
+            DevState st2 = init;
+            Counters ctr2;
+            memset(&ctr2, 0, sizeof(ctr2));
+            const uint32_t ntop = (nchunks + 1023) / 1024;
+            simt::run_grid(ntop, 256, [&] { k_chunk_scan_local(cinfo.data(), nchunks, pvl2.data(), phl2.data(), topv2.data(), toph2.data()); });
+            simt::run_grid(1, 1024, [&] {
+                k_chunk_scan_top(topv2.data(), toph2.data(), ntop, pvl2.data(), phl2.data(), nchunks, nFchunks, &st2, &ctr2, init, lab2.data(), mb2.data(), 64u);
+            });
+            bool same = memcmp(&st2, &st, sizeof(st)) == 0;
+            for (uint32_t c = 0; same && c < nchunks; ++c)
+                same = pvl2[c] + topv2[c >> 10] == pvl[c] + topv[c >> 10] && phl2[c] + toph2[c >> 10] == phl[c] + toph[c >> 10];
+            CHECK(same, "two-level chunk scan == one-launch chunk scan (ahead=%d)", ahead);
+        }
         bool ok = st.voi_total == want.size() && st.voiF == voiF && st.validF == nF && st.valid_total == nF + validO &&
                   st.n_leaving == leaving.size() && st.o_new_begin == o_begin - (uint32_t)leaving.size() && lab[5] == 0 && mb_tot[7] == 0;
         std::vector<float4> ego(want.size() + 8);

@@ -19,3 +19,9 @@ for r in main[a:b + 1]:
     print("  +%7.1f  gap %5.1f  dur %6.1f  %s" % ((s - t0) / 1e3, (s - last) / 1e3, (e - s) / 1e3, r["Kernel_Name"].split("(")[0][:40]))
     last = e
 print("step span on the main stream: %.1f us" % ((last - t0) / 1e3))
+# kernels of OTHER queues that ran inside the step's window and are part of the map chain (the outskirts part of the next VoI split)
+for r in rows:
+    if r["Queue_Id"] != q and "k_voi_split" in r["Kernel_Name"]:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if t0 <= s <= last:
+            print("  side stream: +%7.1f  dur %6.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, r["Kernel_Name"].split("(")[0][:40]))
