@@ -234,6 +234,34 @@ static void test_per_bin(std::mt19937 &rng) {
         CHECK(ok, "binvox bin %u (got %u voxels, want %zu)", b, nvox[b], nw);
     }
     CHECK(ctr.err == 0 && ctr.sort_qoverflow == 0, "error flags %u %u", ctr.err, ctr.sort_qoverflow);
+    // the fused kernel of v3 (R-GPF and the per-bin voxelisation of a bin back to back in one workgroup) must leave exactly what the two
+    // separate kernels left -- bins of every size class: level-synchronous sort, one wavefront per segment
+    {
+        std::vector<uint32_t> gsK_(2 * G), gsV_(2 * G), gsL_(2 * G), gsR_(2 * G), gsH_(2 * (G / 32 + 2 * B + 16)), gsK2_(2 * G), gsV2_(2 * G), grank_(G), glist_(G),
+            ng_(nbin + 1, 0), nvox_(nbin + 1, 0);
+        std::vector<uint8_t> gflag_(G, 9);
+        std::vector<float> plane_n_(plane_n.size(), 0.f);
+        std::vector<double> plane_d_(plane_d.size(), 0.0);
+        std::vector<float4> gsC_(G), vox_out_(vox_out.size());
+        Counters ctr_;
+        memset(&ctr_, 0, sizeof(ctr_));
+        uint32_t n_rare = 0;
+        for (uint32_t b = 0; b < nbin; ++b) n_rare += (sizes[b] > ESYNC_MAX || sizes[b] + cur_bin[b].size() > ESYNC_MAX) ? 1u : 0u;
+        simt::run_grid(3, 1024, [&] {
+            k_revert_bins(P, rev_list.data(), &st, moff.data(), spts.data(), qoff.data(), sq.data(), gsK_.data(), gsV_.data(), gsL_.data(), gsR_.data(), gsH_.data(),
+                          gsK2_.data(), gsV2_.data(), gsC_.data(), gflag_.data(), grank_.data(), glist_.data(), ng_.data(), plane_n_.data(), plane_d_.data(),
+                          vox_off.data(), vox_out_.data(), nvox_.data(), &ctr_, nullptr, (uint32_t)G, (uint32_t)(G / 32 + 2 * B + 16));
+        });
+        bool same = ng_ == ng && nvox_ == nvox && memcmp(plane_n_.data(), plane_n.data(), plane_n.size() * 4) == 0 &&
+                    memcmp(plane_d_.data(), plane_d.data(), plane_d.size() * 8) == 0;
+        for (uint32_t b = 0; same && b < nbin; ++b) {
+            const uint32_t o0 = moff[rev_list[b]];
+            same = memcmp(&gflag_[o0], &gflag[o0], sizes[b]) == 0 && memcmp(&grank_[o0], &grank[o0], sizes[b] * 4) == 0 &&
+                   memcmp(&glist_[o0], &glist[o0], ng[b] * 4) == 0 && memcmp(&vox_out_[vox_off[b]], &vox_out[vox_off[b]], (size_t)nvox[b] * 16) == 0;
+        }
+        printf("k_revert_bins (%u of %u bins beyond the level-synchronous sort's size) == k_rgpf2 + k_binvox2  %s\n", n_rare, nbin, same ? "ok" : "MISMATCH");
+        CHECK(same && n_rare > 0 && n_rare < nbin && ctr_.err == 0 && ctr_.sort_qoverflow == 0, "fused per-bin launch");
+    }
 }
 
 
