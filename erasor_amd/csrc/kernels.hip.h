@@ -2635,6 +2635,24 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {  // inverse of esort
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
+// ---- the level-synchronous sort of the per-bin stages, OUT OF LINE (round 3) ----
+// Inlined into the per-bin kernels (four copies: one and two keys per thread, two stages) the sort shared a register allocation with
+// everything around it, and these kernels are capped at 128 VGPRs by their 1024 threads: values that are live across the sort were
+// spilled and RELOADED INSIDE ITS LEVEL LOOP (16 / 13 scratch loads per level, each a memory round trip on a chain that is nothing but
+// round trips).  As a function of its own the sort has the allocation it has in k_esort_final -- no scratch at all -- and what is live
+// around the call is saved once per call.  The pool is file-scope LDS so that the function sees LDS arrays, not generic pointers
+// (ds_* instead of flat_* instructions); the caller leaves the (key, index) pairs in the pool's first 2 * n words, the sorted keys /
+// indices come back in words [2 * RG_LMAX, ...) / [3 * RG_LMAX, ...) (the callers' sL / sR).
+__shared__ uint32_t g_rev_pool[4 * RG_LMAX];
+__shared__ uint32_t g_sync_stab[68];
+static_assert(4 * RG_LMAX == 8 * ESYNC_MAX, "the per-bin pool is exactly lds_esort_sync_kv's layout");
+__device__ __attribute__((noinline)) void lds_esort_sync_call(uint32_t n, uint32_t *n_fallback, unsigned long long *tstamp) {
+    uint32_t *pool = g_rev_pool;
+    const uint2 *sKV = reinterpret_cast<const uint2 *>(pool);
+    lds_esort_sync_kv(n, [&](uint32_t i) { return sKV[i].x; }, [&](uint32_t i) { return sKV[i].y; }, pool, g_sync_stab, pool + 2 * RG_LMAX,
+                      pool + 3 * RG_LMAX, n_fallback, tstamp);
+}
+
 // The workgroup's two large LDS buffers come from the caller: `pool` (4 * RG_LMAX words: sort phase K | V | posL | posR or
 // lds_esort_sync's layout; fit phase glist | X | Y | Z) and `sProd` (9 * RG_RS floats, 16-byte aligned), so that the fused kernel
 // (k_revert_bins) can hand the same storage to the per-bin voxelisation afterwards.  Bins rk0, rk0 + rk_step, ... of the list.
@@ -2652,7 +2670,6 @@ __device__ __forceinline__ void rgpf_bins(const DP &P, uint32_t rk0, uint32_t rk
     __shared__ double s_th, s_lpr;
     __shared__ uint32_t s_carry;
     __shared__ uint32_t s_tab[64];
-    __shared__ uint32_t s_stab[68];
     __shared__ unsigned long long s_t[12];
     __shared__ unsigned long long s_es[24];  // diagnostics: block_esort's own stamps (shader clock)
 #define RG_STAMP(i) do { if (dbg && tid == 0) s_t[i] = wall_clock64(); } while (0)
@@ -2685,8 +2702,11 @@ __device__ __forceinline__ void rgpf_bins(const DP &P, uint32_t rk0, uint32_t rk
         if (M <= ESYNC_MAX && M <= 2 * bs) {  // level-synchronous over the whole workgroup (the common case)
             RG_STAMP(0);
             if (dbg && tid < 24) s_es[tid] = 0;
-            lds_esort_sync(M, [&](uint32_t i) { return esort::float_key(__float_as_uint(pts[i].z)); }, pool, s_stab, sL, sR, &ctr->n_sort_fallback,
-                           dbg ? s_es : nullptr);
+            {   // (key, bin-local index) pairs into the pool, then the out-of-line sort (each thread reads back what it wrote)
+                uint2 *sKV = reinterpret_cast<uint2 *>(pool);
+                for (uint32_t i = tid; i < M; i += bs) sKV[i] = make_uint2(esort::float_key(__float_as_uint(pts[i].z)), i);
+                lds_esort_sync_call(M, &ctr->n_sort_fallback, dbg ? s_es : nullptr);
+            }
         } else {
             for (uint32_t i = tid; i < M; i += bs) {
                 sK[i] = esort::float_key(__float_as_uint(pts[i].z));
@@ -2892,10 +2912,9 @@ __global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict
                                                 uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
                                                 uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
                                                 Counters *ctr, unsigned long long *dbg) {
-    __shared__ uint32_t pool[4 * RG_LMAX];
     __shared__ __attribute__((aligned(16))) float sProd[9 * RG_RS];
     rgpf_bins(P, blockIdx.x, gridDim.x, rev_list, st, moff, spts, gsK, gsV, gsL, gsR, gsH, gsK2, gsV2, gflag, grank, glist_out, ng_out, plane_n,
-              plane_d, ctr, dbg, pool, sProd);
+              plane_d, ctr, dbg, g_rev_pool, sProd);
 }
 
 // ================================================================================================
@@ -3061,7 +3080,6 @@ __device__ __forceinline__ void binvox_bins(const DP &P, uint32_t rk0, uint32_t 
     __shared__ uint32_t sbb[6];
     __shared__ uint32_t s_carry;
     __shared__ uint32_t s_tab[64];
-    __shared__ uint32_t s_stab[68];
     uint32_t *sK = pool, *sV = pool + BV2_LMAX, *sL = pool + 2 * BV2_LMAX, *sR = pool + 3 * BV2_LMAX;
     const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = bs >> 6;
     const uint32_t n_rev = st->n_rev;
@@ -3140,7 +3158,14 @@ __device__ __forceinline__ void binvox_bins(const DP &P, uint32_t rk0, uint32_t 
             continue;
         }
         if (m <= ESYNC_MAX && m <= 2 * bs) {  // level-synchronous over the whole workgroup (the common case)
-            lds_esort_sync(m, [&](uint32_t j) { const float4 p = sC[j]; return vox_index(g, p.x, p.y, p.z); }, pool, s_stab, sL, sR, &ctr->n_sort_fallback);
+            {
+                uint2 *sKV = reinterpret_cast<uint2 *>(pool);
+                for (uint32_t j = tid; j < m; j += bs) {
+                    const float4 p = sC[j];
+                    sKV[j] = make_uint2(vox_index(g, p.x, p.y, p.z), j);
+                }
+                lds_esort_sync_call(m, &ctr->n_sort_fallback, nullptr);
+            }
         } else {
             for (uint32_t j = tid; j < m; j += bs) {
                 const float4 p = sC[j];
@@ -3335,10 +3360,9 @@ __global__ __launch_bounds__(1024) void k_binvox2(DP P, const uint32_t *__restri
                                                   uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
                                                   float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr,
                                                   unsigned long long *dbg) {
-    __shared__ uint32_t pool[4 * BV2_LMAX];
     __shared__ float4 sC[BV2_LMAX];
     binvox_bins(P, blockIdx.x, gridDim.x, rev_list, st, moff, spts, qoff, sq, glist, ng_arr, vox_off, gsK, gsV, gsL, gsR, gsH, gsK2, gsV2, gsC, vox_out,
-                nvox_out, ctr, dbg, pool, sC);
+                nvox_out, ctr, dbg, g_rev_pool, sC);
 }
 
 // v3's two per-bin stages in ONE launch (erasor.cpp:521-528: extract_ground, then voxelize_preserving_labels of curr + ground): a
@@ -3358,8 +3382,8 @@ __global__ __launch_bounds__(1024) void k_revert_bins(DP P, const uint32_t *__re
                                                       // different workgroups the voxelisation works `vox_base` entries (`h_base` flag words) further up
                                                       uint32_t vox_base, uint32_t h_base) {
     static_assert(RG_LMAX == BV2_LMAX && 9 * RG_RS * sizeof(float) <= BV2_LMAX * sizeof(float4), "the two stages share their LDS");
-    __shared__ uint32_t pool[4 * RG_LMAX];
     __shared__ float4 big[BV2_LMAX];
+    uint32_t *pool = g_rev_pool;
     const uint32_t n_rev = st->n_rev;
     for (uint32_t rk = blockIdx.x; rk < n_rev; rk += gridDim.x) {
         rgpf_bins(P, rk, 0x7FFFFFFFu, rev_list, st, moff, spts, gsK, gsV, gsL, gsR, gsH, gsK2, gsV2, gflag, grank, glist, ng_arr, plane_n, plane_d, ctr,
