@@ -69,7 +69,7 @@ def parse_args():
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="stop the CPU leg after this much CPU work")
     ap.add_argument("--profile-all", action="store_true", help="second pass with per-kernel HIP events (breakdown on stderr)")
-    ap.add_argument("--lookahead", type=int, default=2, choices=[1, 2], help="scans announced ahead (erasor_hip_prefetch_scan)")
+    ap.add_argument("--lookahead", type=int, default=2, choices=[1, 2, 3], help="scans announced ahead (erasor_hip_prefetch_scan)")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not announce the next scan (erasor_hip_prefetch_scan): every step runs its own query chain first")
     ap.add_argument("--seqs", type=int, default=len(SEQS), help="seq-per-gpu: use only the first N of the five sequences (e.g. 2: what one GPU of config 3's four gets)")
@@ -719,6 +719,8 @@ def main():
         for wname, label in (("large_scale_05", "config 4"), ("seq05_yaml", "config 2, config/seq_05.yaml verbatim"), ("ouster128", "config 5 shape, 1 GPU")):
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", wname, "--steps", "12", "--warmup", "3", "--no-cpu-baseline",
                    "--no-extra-workloads"]
+            if wname == "ouster128":  # 233 k-point scans: the query chain is the longer one, a third node ahead pays (gpurun_out/r03ah)
+                cmd += ["--lookahead", "3"]
             t_sub = time.time()
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
@@ -727,6 +729,7 @@ def main():
                 extra.append({"workload": wname, "baseline_config": label, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                               "ms_per_step_without_lookahead": d["ms_per_step_without_lookahead"], "steps": d["steps"], "warmup": d["warmup"],
                               "map_points": d["config"]["map_points"], "scan_points": d["config"]["scan_points"],
+                              "lookahead_scans": d["config"].get("lookahead_scans"),
                               "roofline": {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "avg_launch_us",
                                                              "launches", "step_alg_bytes", "step_achieved", "step_frac")},
                               "wall_s": round(time.time() - t_sub, 1)})

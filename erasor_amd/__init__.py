@@ -187,7 +187,7 @@ class Erasor:
     def prefetch(self, scan, T_l2b, T_b2o=None):
         """announce the next scan (host array): its query chain starts now, beside the step in flight"""
         scan = _f32(scan).reshape(-1, 4)
-        # every announced buffer stays alive until a step has consumed it (up to three scans can be announced ahead; a freed
+        # every announced buffer stays alive until a step has consumed it (up to four scans can be outstanding; a freed
         # buffer's address could be handed to the next np.ascontiguousarray)
         self._keep = (getattr(self, "_keep", []) + [scan])[-4:]
         if T_b2o is None:

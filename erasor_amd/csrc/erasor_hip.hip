@@ -98,7 +98,8 @@ static void graph_release(GSeg &seg) {
 }
 
 // The query side of a step (see erasor_hip_handle::q)
-static constexpr int NSIDE = 3;  // the scan being stepped + two announced ahead
+static constexpr int NSIDE = 4;  // the scan being stepped + up to three announced ahead
+static constexpr int MAX_AHEAD = NSIDE - 1;
 struct QSide {
     uint32_t capS = 0;
     DBuf<float4> scan, cent, query, sq;
@@ -151,7 +152,7 @@ struct erasor_hip_handle {
     hipStream_t cur = nullptr;      // stream LAUNCH() currently targets
     std::vector<GNode> *rec = nullptr;  // non-null: LAUNCH() records instead of launching (the query chain as a graph)
     bool use_graph = false;
-    int pend[2] = {0, 0};           // query sides with a prefetched chain in flight, oldest first
+    int pend[MAX_AHEAD] = {0, 0, 0};  // query sides with a prefetched chain in flight, oldest first
     int npend = 0;
     // a scan announced by erasor_hip_prefetch_scan whose chain is not enqueued yet (the step in flight goes first)
     struct {
@@ -1307,7 +1308,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             if (!prevox && c.src == scan_src && c.src_n == n_scan && c.src_dev == src_is_device && (src_is_device || c.fp == fp_now) &&
                 memcmp(c.Tl, T_l2b, sizeof(c.Tl)) == 0) {
                 side = h->pend[0];
-                h->pend[0] = h->pend[1];
+                for (int j = 1; j < h->npend; ++j) h->pend[j - 1] = h->pend[j];
                 --h->npend;
             } else {
                 // not the scan that was announced: the prefetched chains are dropped.  Let them run out before going on, so
@@ -1753,8 +1754,8 @@ static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n
     NOFLY(h);
     if (!h || !T_l2b || (!scan_xyzi && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
-    if (h->ann.valid && h->npend >= 2) {
-        h->err = "erasor_hip_prefetch_scan: three scans are already announced";
+    if (h->ann.valid && h->npend >= MAX_AHEAD) {
+        h->err = "erasor_hip_prefetch_scan: as many scans as there are query sides to hold them are already announced";
         return ERASOR_E_STATE;
     }
     int rc = flush_announced(h);  // an earlier announcement nobody stepped on yet: its chain starts now
@@ -1807,7 +1808,7 @@ int erasor_hip_step_wait(erasor_hip_handle *h, erasor_step_result *res) { return
 int erasor_hip_run_nodes(erasor_hip_handle *h, const void *const *scans, const size_t *n_pts, size_t n_total, int src_is_device,
                          const float T_lidar2body[16], const float *T_body2origin /* n_total x 16 */, const float *T_origin2body /* n_total x 16 */,
                          size_t first, size_t count, int lookahead, size_t *announced, erasor_step_result *res) {
-    if (!h || !scans || !n_pts || !T_lidar2body || !T_body2origin || !T_origin2body || !announced || first + count > n_total || lookahead < 0 || lookahead > 2)
+    if (!h || !scans || !n_pts || !T_lidar2body || !T_body2origin || !T_origin2body || !announced || first + count > n_total || lookahead < 0 || lookahead > MAX_AHEAD)
         return ERASOR_E_INVALID;
     NOFLY(h);
     for (size_t i = first; i < first + count; ++i) {

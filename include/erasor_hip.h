@@ -140,8 +140,8 @@ int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n
  * recognises its scan by pointer, size, T_lidar2body and a fingerprint of ~258 sampled points -- a buffer refilled at the same
  * address that differs only in unsampled points would be taken for the announced scan and the step would run on the copy
  * (hashing all 2 MB would cost more than the step's own enqueue).  A device scan (src_is_device != 0) is read in place and must stay valid until the step that
- * consumes it has returned.  Up to three scans can be announced ahead of a step (three query sides); the chains of
- * different scans run on their own streams.  When every side is taken, a new announcement re-uses the side of the last
+ * consumes it has returned.  Up to four scans can be outstanding between two steps (four query sides: a step can have its own scan
+ * and three more announced ahead of it); the chains of consecutive scans alternate between two streams.  When every side is taken, a new announcement re-uses the side of the last
  * finished step: its query-derived outputs (erasor_hip_get_cloud / _get_bins) are gone from then on. */
 int erasor_hip_prefetch_scan(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device,
                              const float T_lidar2body[16]);
@@ -182,7 +182,7 @@ int erasor_hip_step_wait(erasor_hip_handle *h, erasor_step_result *res);
 int erasor_hip_step_done(erasor_hip_handle *h);
 
 /* replaces: the node loop of the offline driver (main_in_your_env.cpp:92-123): nodes [first, first + count) of a sequence of n_total,
- * every node announced `lookahead` (0..2) nodes ahead with its pose, stepped one after the other -- the very calls a host loop would
+ * every node announced `lookahead` (0..3) nodes ahead with its pose, stepped one after the other -- the very calls a host loop would
  * make (erasor_hip_prefetch_node, erasor_hip_step[_device]), minus the caller's own time between two steps.  *announced (in / out):
  * nodes [0, *announced) are announced already, so a sequence can be split over several calls.  T_body2origin / T_origin2body: n_total
  * row-major 4x4 matrices each; res: `count` result blocks (may be NULL). */

@@ -657,7 +657,7 @@ def test_mapgen_accumulation_matches_oracle(gpu_mod, large):
         assert len(o.cloud_maps) == 1  # the first accumulated scan closes a submap (cnt_voxel == 0)
 
 
-@pytest.mark.parametrize("version,ahead", [(3, 1), (2, 1), (3, 2)])
+@pytest.mark.parametrize("version,ahead", [(3, 1), (2, 1), (3, 2), (3, 3)])
 def test_prefetched_scans_give_the_same_results(gpu_mod, version, ahead):
     """erasor_hip_prefetch_scan: the query chain of scan k+1 runs beside step k's map-side stages (second query side).
     Every output of every step must be what the oracle's plain sequence gives; a prefetch that is not followed by
@@ -676,10 +676,11 @@ def test_prefetched_scans_give_the_same_results(gpu_mod, version, ahead):
         rg = g.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         ro = o.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         compare_step(g, o, rg, ro, full=True)
-    with pytest.raises(gpu_mod.ErasorError):  # nothing consumed in between: the fourth announcement has no side left
-        for j in range(4):
+    with pytest.raises(gpu_mod.ErasorError):  # nothing consumed in between: the fifth announcement has no side left
+        for j in range(5):
             g.prefetch(scans[j], sc["T_l2b"])
-    g.voxelize_preserving_labels(sc["scans"][0][:100], 0.3)  # (standalone call: drops the three announcements)
+        raise AssertionError("five announcements were accepted")
+    g.voxelize_preserving_labels(sc["scans"][0][:100], 0.3)  # (standalone call: drops the four announcements)
     # a prefetch that is not honoured: the announced scan is dropped, the step's own scan is processed
     g.prefetch(scans[0], sc["T_l2b"])
     k = n
@@ -734,7 +735,7 @@ def test_api_error_two_handles_interleaved_with_step_async(gpu_mod):
         compare_step(gb, ob, rgb, rob, full=(k % 2 == 1))
 
 
-@pytest.mark.parametrize("version,ahead", [(3, 1), (3, 2), (2, 2)])
+@pytest.mark.parametrize("version,ahead", [(3, 1), (3, 2), (2, 2), (3, 3)])
 def test_nodes_announced_with_their_pose_split_ahead(gpu_mod, version, ahead):
     """erasor_hip_prefetch_node: with the next node's pose known, the step in flight launches the next step's VoI split
     behind its own last kernel (it reads the store that step has just written and the extents it commits on the device).
