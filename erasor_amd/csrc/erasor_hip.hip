@@ -873,9 +873,10 @@ int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n
 
 // exact std::sort of (qk_a, qv_a)[0..n) -> (qk_b, qv_b): global levels (one workgroup per big segment, one partition per
 // launch), then every remaining segment is completed inside LDS by one workgroup.
-static void run_exact_sort(erasor_hip_handle *h, uint32_t n) {
+static void run_exact_sort(erasor_hip_handle *h, uint32_t n, bool queues_open = false) {
     Counters *dc = Q(h).d_qctr.p;
-    LAUNCH(h, "q_esort", k_esort_init, 1, 1, Q(h).qk_a.p, Q(h).qv_a.p, Q(h).esq0.p, Q(h).essmall.p, Q(h).esqs.p, Q(h).wseg0.p, Q(h).wstate.p, n);
+    if (!queues_open)  // (the scan's voxelisation opens them in its key kernel: k_voxel_keys_es)
+        LAUNCH(h, "q_esort", k_esort_init, 1, 1, Q(h).qk_a.p, Q(h).qv_a.p, Q(h).esq0.p, Q(h).essmall.p, Q(h).esqs.p, Q(h).wseg0.p, Q(h).wstate.p, n);
     int nlev = 0;
     if (n >= WIDE_MIN && (n - 1 + WTILE - 1) / WTILE <= WTILES_MAX) {
         // wide levels: segments >= WIDE_MIN keys, many workgroups each.  A segment halves (roughly) per level, so
@@ -928,11 +929,19 @@ static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf, co
     Counters *dc = Q(h).d_qctr.p;
     // (the bounding box was reset by k_query_begin)
     if (n) LAUNCH(h, "q_bbox", k_bbox, bbox_grid(n), 256, Q(h).scan_in, n, Q(h).bb.p);
-    LAUNCH(h, "q_keys", k_voxel_keys, std::max(1u, cdiv(n, 256)), 256, Q(h).scan_in, n, (const uint32_t *)Q(h).bb.p, leaf, Q(h).qk_a.p,
-           Q(h).qv_a.p, Q(h).qgrid.p, dc, Q(h).hkey.p, 1u << Q(h).hbits);
+    {
+        EsInit es;
+        es.q0 = Q(h).esq0.p;
+        es.smallq = Q(h).essmall.p;
+        es.qs = Q(h).esqs.p;
+        es.w0 = Q(h).wseg0.p;
+        es.ws = Q(h).wstate.p;
+        LAUNCH(h, "q_keys", k_voxel_keys_es, std::max(1u, cdiv(n, 256)), 256, Q(h).scan_in, n, (const uint32_t *)Q(h).bb.p, leaf, Q(h).qk_a.p,
+               Q(h).qv_a.p, Q(h).qgrid.p, dc, Q(h).hkey.p, 1u << Q(h).hbits, es);
+    }
     after_keys();  // ctr->err (VoxelGrid overflow) is final from here on: the caller may fork work that depends on it
     // exact std::sort: a few global levels (one workgroup per big segment), then per-segment completion in LDS
-    run_exact_sort(h, n);
+    run_exact_sort(h, n, true);
     // runs
     const uint32_t ntile = std::max(1u, cdiv(n, 1024));
     if (ntile <= 1024) {  // (a scan: ~120 tiles) two launches: tile totals, then heads -> run_begin with the tile's offset summed in place

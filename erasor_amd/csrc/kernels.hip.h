@@ -145,6 +145,26 @@ __device__ __forceinline__ float wave_min_f(float x) {
     return __int_as_float((int)__builtin_amdgcn_readlane((uint32_t)__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max_f(float x) { return -wave_min_f(-x); }
+// the same for unsigned keys (fkey_ord: the bounding boxes of k_bbox and of the per-bin voxelisation); IDENT: what a lane without a source
+// contributes (~0u for a minimum, 0u for a maximum)
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_minmax_u(uint32_t x) {
+    const int id = MAX ? 0 : -1;
+    uint32_t v = x;
+#define ERASOR_DPP_MMSTEP(ctrl, rmask)                                                                   \
+    do {                                                                                                 \
+        const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, ctrl, rmask, 0xf, false);  \
+        v = MAX ? (o_ > v ? o_ : v) : (o_ < v ? o_ : v);                                                 \
+    } while (0)
+    ERASOR_DPP_MMSTEP(0x111, 0xf);
+    ERASOR_DPP_MMSTEP(0x112, 0xf);
+    ERASOR_DPP_MMSTEP(0x114, 0xf);
+    ERASOR_DPP_MMSTEP(0x118, 0xf);
+    ERASOR_DPP_MMSTEP(0x142, 0xa);
+    ERASOR_DPP_MMSTEP(0x143, 0xc);
+#undef ERASOR_DPP_MMSTEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
 
 // ================================================================================================
 // (1) voi_split — THE HBM-bound kernel.  fetch_VoI's membership test (OMU.cpp:391-395) over every
@@ -798,6 +818,14 @@ __global__ __launch_bounds__(1024) void k_qb_scatter(const uint32_t *__restrict_
     if (valid) dst[pre + r] = src[i];
 }
 
+__device__ __forceinline__ uint32_t fkey_ord(float f) {  // total-order key for float min/max atomics
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+    const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(b);
+}
 // ---- the same one-digit counting sort for the (much longer) VoI list of the map: tiles of 4096 keys keep the
 // [tile][bucket] table short (~200 rows for a 0.8 M-point VoI), the per-tile start of a bucket becomes a table look-up
 // through a column scan (one wavefront per bucket over the tiles), and the scatter carries the point, its pre-step
@@ -1052,14 +1080,6 @@ __global__ __launch_bounds__(256) void k_bin_stats(const float4 *__restrict__ sp
 // ================================================================================================
 // query-scan voxelisation: PCL 1.8 VoxelGrid + label-preserving 1-NN (utils.cpp:80-114; OMU.cpp:238)
 // ================================================================================================
-__device__ __forceinline__ uint32_t fkey_ord(float f) {  // total-order key for float min/max atomics
-    const uint32_t b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float fkey_inv(uint32_t k) {
-    const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-    return __uint_as_float(b);
-}
 
 // getMinMax3D (dense): plain min/max; -0.0/+0.0 order is irrelevant downstream (only products/floors of it)
 __global__ __launch_bounds__(256) void k_bbox(const float4 *__restrict__ pts, uint32_t n, uint32_t *bb) {
@@ -1079,11 +1099,8 @@ __global__ __launch_bounds__(256) void k_bbox(const float4 *__restrict__ pts, ui
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t t0 = __shfl_down(mn[a], o, 64), t1 = __shfl_down(mx[a], o, 64);
-            mn[a] = t0 < mn[a] ? t0 : mn[a];
-            mx[a] = t1 > mx[a] ? t1 : mx[a];
-        }
+        mn[a] = wave_minmax_u<false>(mn[a]);  // (DPP row shifts: a shuffle ladder is six dependent LDS-crossbar round trips per value)
+        mx[a] = wave_minmax_u<true>(mx[a]);
         if ((threadIdx.x & 63u) == 0) {
             atomicMin(&sm[a], mn[a]);
             atomicMax(&sm[3 + a], mx[a]);
@@ -1134,9 +1151,9 @@ __device__ __forceinline__ uint32_t vox_index(const VoxGrid &g, float x, float y
     return (uint32_t)(i0 + i1 * g.div_b[0] + i2 * (g.div_b[0] * g.div_b[1]));
 }
 
-__global__ __launch_bounds__(256) void k_voxel_keys(const float4 *__restrict__ pts, uint32_t n, const uint32_t *__restrict__ bb,
-                                                     float leaf, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                     VoxGrid *gout, Counters *ctr, uint32_t *__restrict__ hkey, uint32_t hsize) {
+__device__ __forceinline__ void voxel_keys_body(const float4 *__restrict__ pts, uint32_t n, const uint32_t *__restrict__ bb,
+                                                float leaf, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                VoxGrid *gout, Counters *ctr, uint32_t *__restrict__ hkey, uint32_t hsize) {
     // (side job) empty the voxel hash table that k_centroids fills and k_query_nn probes
     for (uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x; sl < hsize; sl += gridDim.x * blockDim.x) hkey[sl] = 0xFFFFFFFFu;
     const float mn[3] = {fkey_inv(bb[0]), fkey_inv(bb[1]), fkey_inv(bb[2])};
@@ -1161,6 +1178,11 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4 *__restrict__ p
     const float4 p = pts[i];
     keys[i] = g.overflow ? 0u : vox_index(g, p.x, p.y, p.z);
     vals[i] = i;
+}
+__global__ __launch_bounds__(256) void k_voxel_keys(const float4 *__restrict__ pts, uint32_t n, const uint32_t *__restrict__ bb,
+                                                     float leaf, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                     VoxGrid *gout, Counters *ctr, uint32_t *__restrict__ hkey, uint32_t hsize) {
+    voxel_keys_body(pts, n, bb, leaf, keys, vals, gout, ctr, hkey, hsize);
 }
 
 // ---- VoxelGrid index overflow: PCL warns and returns the input cloud unchanged (utils.cpp:88-91), after which the label
@@ -1302,8 +1324,14 @@ struct WideState {
     uint32_t ntiles[2];
 };
 
-__global__ void k_esort_init(uint32_t *K, uint32_t *V, esort::Seg *q0, esort::Seg *smallq, EsQueues *qs, WideSeg *w0, WideState *ws,
-                             uint32_t n) {
+// (the queues of the exact scan sort: also opened by thread 0 of k_voxel_keys -- one launch less on the query chain)
+struct EsInit {
+    esort::Seg *q0, *smallq;
+    EsQueues *qs;
+    WideSeg *w0;
+    WideState *ws;
+};
+__device__ __forceinline__ void esort_init(esort::Seg *q0, esort::Seg *smallq, EsQueues *qs, WideSeg *w0, WideState *ws, uint32_t n) {
     qs->cnt[0] = qs->cnt[1] = qs->cnt[2] = 0;
     qs->small_cnt = 0;
     ws->nseg[0] = ws->nseg[1] = 0;
@@ -1329,6 +1357,17 @@ __global__ void k_esort_init(uint32_t *K, uint32_t *V, esort::Seg *q0, esort::Se
         smallq[0] = s;
         qs->small_cnt = 1;
     }
+}
+__global__ void k_esort_init(uint32_t *K, uint32_t *V, esort::Seg *q0, esort::Seg *smallq, EsQueues *qs, WideSeg *w0, WideState *ws,
+                             uint32_t n) {
+    esort_init(q0, smallq, qs, w0, ws, n);
+}
+// the scan's voxel keys AND the opening of the sort's queues (thread 0 of workgroup 0: the queues do not depend on the keys)
+__global__ __launch_bounds__(256) void k_voxel_keys_es(const float4 *__restrict__ pts, uint32_t n, const uint32_t *__restrict__ bb,
+                                                        float leaf, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                        VoxGrid *gout, Counters *ctr, uint32_t *__restrict__ hkey, uint32_t hsize, EsInit es) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) esort_init(es.q0, es.smallq, es.qs, es.w0, es.ws, n);
+    voxel_keys_body(pts, n, bb, leaf, keys, vals, gout, ctr, hkey, hsize);
 }
 
 __global__ __launch_bounds__(256) void k_esort_wide_mark(const uint32_t *__restrict__ K, const uint32_t *__restrict__ V, uint32_t *__restrict__ posL,
@@ -2340,12 +2379,14 @@ __device__ __forceinline__ Rot make_jacobi(float x, float y, float z) {  // Eige
     } else {
         const float tau = (x - z) / deno;
         const float w = sqrtf(tau * tau + 1.0f);
-        float t;
-        if (tau > 0.f) t = 1.0f / (tau + w);
-        else t = 1.0f / (tau - w);
+        // (round 3: ONE division for t -- the denominator is selected first, the quotient is the same either way -- and none for
+        // y / |y|, which is copysign(1, y) for every finite y that gets here (|y| >= 2^-127: no zero, no denormal quotient) and NaN
+        // for an infinite or NaN y like the quotient: an IEEE division is ~12 dependent instructions of the one lane that runs this)
+        const float t = 1.0f / (tau > 0.f ? tau + w : tau - w);
         const float sign_t = t > 0.f ? 1.0f : -1.0f;
         const float n = 1.0f / sqrtf(t * t + 1.0f);
-        r.s = -sign_t * (y / fabsf(y)) * fabsf(t) * n;
+        const float unit_y = (fabsf(y) < __int_as_float(0x7F800000)) ? copysignf(1.0f, y) : __int_as_float(0x7FC00000);
+        r.s = -sign_t * unit_y * fabsf(t) * n;
         r.c = n;
     }
     return r;
@@ -2857,11 +2898,7 @@ __device__ __forceinline__ void rgpf_bins(const DP &P, uint32_t rk0, uint32_t rk
             __syncthreads();
             if (wave == 0) {  // exclusive scan of the 64 (e-major, wave-minor) counts
                 const uint32_t v = s_tab[lane];
-                uint32_t inc = v;
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t t = __shfl_up(inc, off, 64);
-                    if ((int)lane >= off) inc += t;
-                }
+                const uint32_t inc = esort::wave_incl_scan(v);  // (DPP row shifts)
                 s_tab[lane] = inc - v;
                 if (lane == 63) s_carry = inc;
             }
@@ -3122,11 +3159,8 @@ __device__ __forceinline__ void binvox_bins(const DP &P, uint32_t rk0, uint32_t 
             }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                for (int o = 32; o > 0; o >>= 1) {
-                    const uint32_t t0 = __shfl_down(mn[a], o, 64), t1 = __shfl_down(mx[a], o, 64);
-                    mn[a] = t0 < mn[a] ? t0 : mn[a];
-                    mx[a] = t1 > mx[a] ? t1 : mx[a];
-                }
+                mn[a] = wave_minmax_u<false>(mn[a]);
+                mx[a] = wave_minmax_u<true>(mx[a]);
                 if (lane == 0) {
                     atomicMin(&sbb[a], mn[a]);
                     atomicMax(&sbb[3 + a], mx[a]);
@@ -3190,11 +3224,7 @@ __device__ __forceinline__ void binvox_bins(const DP &P, uint32_t rk0, uint32_t 
         __syncthreads();
         if (wave == 0) {
             const uint32_t v = s_tab[lane];
-            uint32_t inc = v;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t t = __shfl_up(inc, off, 64);
-                if ((int)lane >= off) inc += t;
-            }
+            const uint32_t inc = esort::wave_incl_scan(v);  // (DPP row shifts)
             s_tab[lane] = inc - v;
             if (lane == 63) s_carry = inc;
         }

@@ -51,7 +51,7 @@ o2 = orc.Oracle(sc["params"])
 g2.set_map(sc["map"])
 o2.set_map(sc["map"])
 ptr = [s.ctypes.data for s in scans]
-n3 = n_steps + 1
+n3 = n_steps + 3  # (long enough for the chains announced after the first finished step: they take the one-launch query bucketing)
 for j in range(2):
     g2.prefetch_device(ptr[j], len(scans[j]), sc["T_l2b"], sc["T_b2o"][j])
 for k in range(n3):
