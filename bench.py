@@ -34,6 +34,11 @@ import time
 
 import numpy as np
 
+# (several handles in one process -- seq-per-gpu mode -- need more hardware queues than HIP's default of 4, or a handle's two query streams can
+# share one and its chains serialise: gpurun_out/r03ap.  Read when the HIP runtime starts, i.e. before torch or the library touch the device;
+# liberasor_hip.so sets the same default when it is loaded)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -742,6 +742,14 @@ static bool create_sides(erasor_hip_handle *h, int prio) {
     return hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) == hipSuccess;
 }
 
+// A handle runs its chains on four streams, and HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4):
+// with several handles in one process -- one per sequence, or the shim's updaters -- the two query streams of a handle can land on ONE
+// queue, its two chains in flight then run one after the other and the step waits for them (measured, gpurun_out/r03ap: five sequences in
+// one process 2777 scans/s with the default, 4180 with 8 or 16 queues; the C++ bench's third handle 0.22 or 0.65 ms per step depending on
+// where its streams landed).  The variable is read when the HIP runtime starts: this runs when the library is loaded, does not override a
+// value the user has set, and is a no-op if the process initialised HIP earlier (then export GPU_MAX_HW_QUEUES=16 yourself).
+__attribute__((constructor)) static void erasor_hip_more_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **out) {
     if (!p || !out) return ERASOR_E_INVALID;
     *out = nullptr;
@@ -761,10 +769,14 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
     memset(&h->st, 0, sizeof(h->st));
     memset(&h->ctr, 0, sizeof(h->ctr));
     memset(&h->last_res, 0, sizeof(h->last_res));
-    // with look-ahead the main stream (map chain, SRT .. write-back) is the critical path of a sequence: highest priority;
-    // the query chains of the scans ahead get the lowest
+    // Every stream at the DEFAULT priority.  Rounds 1-2 gave the main stream the highest and the query streams the lowest: on a single
+    // handle that measures nothing (0.2363 vs 0.2363 ms per scan), but priorities are strict between hardware queues that share a pipe --
+    // with several handles in one process (a handle per sequence, the shim's updaters) a handle's query queues sometimes land beside its
+    // always-busy main queue and starve: its chains then run only while the main stream waits for them, the look-ahead is gone, and the
+    // step takes 0.64 ms instead of 0.22 -- for the whole life of the handle (gpurun_out/r03as-r03av: 10 of 17 runs of the C++ bench's
+    // third handle; 0 of 6 without priorities).  ERASOR_HIP_STREAM_PRIORITIES=1 restores them.
     int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (getenv("ERASOR_HIP_STREAM_PRIORITIES")) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         !create_sides(h, prio_lo) ||
         hipHostMalloc((void **)&h->pin, sizeof(HostOut), hipHostMallocDefault) != hipSuccess) {
