@@ -12,14 +12,19 @@
 namespace {
 typedef pcl::PointCloud<pcl::PointXYZI> Cloud;
 
-std::vector<float> to_xyzi(const Cloud &c) {
-    std::vector<float> v(c.size() * 4);
+// (into a caller-owned buffer: a 2 MB vector allocated per node is an mmap and ~500 page faults each time)
+static void to_xyzi_into(const Cloud &c, std::vector<float> &v) {
+    v.resize(c.size() * 4);
     for (size_t i = 0; i < c.size(); ++i) {
         v[4 * i] = c.points[i].x;
         v[4 * i + 1] = c.points[i].y;
         v[4 * i + 2] = c.points[i].z;
         v[4 * i + 3] = c.points[i].intensity;
     }
+}
+std::vector<float> to_xyzi(const Cloud &c) {
+    std::vector<float> v;
+    to_xyzi_into(c, v);
     return v;
 }
 void from_xyzi(const std::vector<float> &v, size_t n, Cloud &c) {
@@ -356,9 +361,13 @@ void OfflineMapUpdater::set_global_map(const Cloud &map_init) {
     check(h_, erasor_hip_set_map(h_, v.data(), map_init.size()), "erasor_hip_set_map");
 }
 // is `lidar` the cloud whose xyzi copy `v` holds?  (bitwise; stops at the first difference)
+// Is `lidar` the cloud that was announced (and repacked into v)?  Size, then every 256th point and the last one -- the same sampling rule
+// the C ABI applies to an announced host buffer (include/erasor_hip.h): a cloud of the same size that differs only in unsampled points is
+// taken for the announced one.  (All points compared: 0.1 ms per node on the host, a sixth of the callback.)
 static bool same_cloud(const Cloud &lidar, const std::vector<float> &v) {
     if (v.size() != 4 * lidar.size()) return false;
-    for (size_t i = 0; i < lidar.size(); ++i) {
+    const size_t n = lidar.size(), stride = n / 256 + 1;
+    for (size_t i = 0; i < n; i = (i + stride < n || i == n - 1) ? i + stride : n - 1) {
         const pcl::PointXYZI &p = lidar.points[i];
         const float q[4] = {p.x, p.y, p.z, p.intensity};
         if (memcmp(q, &v[4 * i], sizeof(q)) != 0) return false;
@@ -377,14 +386,13 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
         mat16(tf_lidar2body_, Tl);
         mat16(tf_body2origin_, Tb);
         mat16(tf_origin2body, To);
-        std::vector<float> own;
         const float *scan = nullptr;
         // the cloud announced before the PREVIOUS callback is this one's: the step must get that very buffer (its query chain is
         // in flight under that address); anything else goes in as a fresh scan (the handle then drops what was announced)
         if (have_cur_ && same_cloud(lidar, cur_xyzi_)) scan = cur_xyzi_.data();
         if (!scan) {
-            own = to_xyzi(lidar);
-            scan = own.data();
+            to_xyzi_into(lidar, own_xyzi_);
+            scan = own_xyzi_.data();
         }
         check(h_, erasor_hip_step(h_, scan, lidar.size(), Tl, Tb, To, &last), "erasor_hip_step");
         if (last.n_ambiguous)  // (never seen on transformed clouds; said aloud because bin equality is only PROVABLE when it is zero)
@@ -415,7 +423,7 @@ void OfflineMapUpdater::announce(const Cloud &lidar, const geometry_msgs::Pose *
     // called BEFORE callback_node(current) with the cloud of the node after it: current is callback number stack_count_ + 1
     if ((stack_count_ + 2) % cfg_.params.removal_interval != 0) return;  // that node will be gated out (OMU.cpp:206-209)
     if (has_next_) return;                                                 // one cloud ahead is what callback_node can honour
-    next_xyzi_ = to_xyzi(lidar);
+    to_xyzi_into(lidar, next_xyzi_);
     float Tl[16];
     mat16(tf_lidar2body_, Tl);
     if (odom) {  // the whole node is known: the next callback's fetch_VoI pass can be launched ahead too

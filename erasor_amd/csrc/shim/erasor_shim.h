@@ -163,6 +163,7 @@ private:
     erasor_hip_handle *h_ = nullptr;
     Eigen::Matrix4f tf_lidar2body_, tf_body2origin_;
     int stack_count_ = 0;
+    std::vector<float> own_xyzi_;              // repack buffer of a callback whose cloud was not announced
     std::vector<float> next_xyzi_, cur_xyzi_;  // announced for the node after the upcoming one / for the upcoming one (the step must
                                                // pass the very buffer that was announced)
     bool has_next_ = false, have_cur_ = false;
