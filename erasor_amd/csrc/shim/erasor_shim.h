@@ -146,6 +146,8 @@ public:
     // Offline look-ahead (no counterpart in the reference, which learns about a node when its message arrives): called BEFORE
     // callback_node(k) with the cloud of node k + 1 -- tell the updater which cloud the callback after the upcoming one brings.  Its voxelisation / binning then overlap the current node's
     // map-side stages (erasor_hip_prefetch_scan); results are unchanged.  Ignored for nodes the removal_interval gate skips.
+    // The callback recognises the announced cloud by its size and a sample of its points (every 256th and the last: the C ABI's rule for
+    // announced host buffers, include/erasor_hip.h) -- do not modify a cloud between its announcement and its callback.
     void announce_next(const pcl::PointCloud<pcl::PointXYZI> &lidar);
     // ... and its odometry, when the whole next node is known (erasor_hip_prefetch_node: the VoI pass of the next callback is
     // launched ahead as well)
