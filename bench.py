@@ -644,8 +644,14 @@ def main():
                 "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": traffic,
                 "traffic_source": src_note, "dominant_kernel": cp["dominant"],
                 "bytes_per_launch": int(alg_bytes),
-                "bytes_note": "this layout streams {x,y} pairs (8 B) of the outskirts + float4 of the VoI-resident part + masks; "
-                              "SURVEY §8(d)'s 16 B/pt assumed an AoS map (aos16_equiv_GBps is the rate in that currency)",
+                "bytes_note": "what a launch has to READ: float4 of the VoI-resident part + {x,y} pairs (8 B) of the outskirts chunks whose bounding "
+                              "box meets the VoI circle + a 32-byte record per outskirts chunk + masks; chunks outside the circle are skipped by "
+                              "their record (round 3) -- full_stream_bytes is what the same pass streamed before, full_stream_equiv_GBps that figure "
+                              "over this launch's time (NOT an HBM rate: most of those bytes are never touched); SURVEY §8(d)'s 16 B/pt assumed "
+                              "an AoS map (aos16_equiv_GBps is the rate in that currency)",
+                "full_stream_bytes": int(8 * (N_map - int(last.n_voi)) + 16 * int(last.n_voi)),
+                "full_stream_equiv_GBps": round((8 * (N_map - int(last.n_voi)) + 16 * int(last.n_voi)) / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
+                "bound_after_skipping": "latency: per wavefront a record load, the decision, then 16 loads -- 10 k wavefronts, ~12 us for ~15 MB",
                 "entries_per_launch": int(entries), "avg_launch_us": round(avg_ms * 1e3, 2),
                 "rocprofv3_kernel_avg_us": rocprof_avg, "rocprofv3_source": src_note,
                 "launches": int(vs_n), "launches_note": "every fourth k_voi_split launch of the timed region carries the start / stop events",

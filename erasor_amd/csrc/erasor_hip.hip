@@ -224,7 +224,9 @@ struct erasor_hip_handle {
     uint64_t o_valid = 0;          // live outskirts entries
     // ---- VoI split ----
     DBuf<unsigned long long> vmask, hmask;
-    DBuf<uint32_t> cinfo, pvl, phl, topv, toph;
+    DBuf<uint32_t> cinfo, pvl, phl, topv, toph, topr;
+    DBuf<OMeta> ometa;  // one record per outskirts chunk (bounding box, valid count): chunks outside the VoI circle are not read
+    bool use_ometa = true;
     // ---- VoI-order arrays ----
     DBuf<float4> voi_ego, spts, rejected;
     DBuf<uint32_t> voi_key, voi_src, ssrc, rejected_src, grank, glist;
@@ -554,6 +556,18 @@ int alloc_step(erasor_hip_handle *h, uint32_t n_voi, uint32_t nq) {
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
 
+// Everything that rewrites the outskirts other than a step voids the chunk records (OMeta: bounding box + valid count per chunk); the
+// next VoI pass reads every chunk and rebuilds them.  ERASOR_HIP_NO_OMETA=1: no records, every pass reads everything (A/B).
+static int ometa_reset(erasor_hip_handle *h) {
+    static const bool off = getenv("ERASOR_HIP_NO_OMETA") != nullptr;
+    h->use_ometa = !off;
+    if (off) return ERASOR_OK;
+    const size_t nrec = (size_t)h->capO / CHUNK + 8;
+    if (ensure(h, h->ometa, nrec)) return ERASOR_E_NO_DEVICE;
+    HIPC(h, hipMemsetAsync(h->ometa.p, 0, nrec * sizeof(OMeta), h->stream));
+    return ERASOR_OK;
+}
+
 // rebuild the outskirts region without tombstones at the end of the buffer (stable)
 int rebuild_outskirts(erasor_hip_handle *h, uint32_t min_front_room) {
     ++h->store_epoch;
@@ -582,6 +596,10 @@ int rebuild_outskirts(erasor_hip_handle *h, uint32_t min_front_room) {
     }
     h->o_begin = h->capO - nvalid;
     if (nvalid) LAUNCH(h, "o_rebuild", k_store_outskirts, cdiv(nvalid, 256), 256, (const float4 *)tmp.p, nvalid, h->Oxy.p, h->Ozi.p, h->o_begin);
+    {
+        const int rc_m = ometa_reset(h);
+        if (rc_m) return rc_m;
+    }
     HIPC(h, hipStreamSynchronize(h->stream));
     h->o_valid = nvalid;
     release(flag);
@@ -645,6 +663,10 @@ int split_submap(erasor_hip_handle *h, double x, double y) {
     if (total)
         LAUNCH(h, "submap", k_box_partition, cdiv(total, 256), 256, (const float4 *)G.p, total, (const uint32_t *)flag.p, (const uint32_t *)pl.p,
                (const uint32_t *)tops.p, h->Oxy.p, h->Ozi.p, dst0, newC.p);
+    {
+        const int rc_m = ometa_reset(h);
+        if (rc_m) return rc_m;
+    }
     h->nF = 0;
     h->o_begin = dst0;
     h->o_valid = n_sub;
@@ -813,7 +835,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     }
     h->qi = 0;
     release(h->Cbuf); release(h->F[0]); release(h->F[1]); release(h->Oxy); release(h->Ozi);
-    release(h->vmask); release(h->hmask); release(h->cinfo); release(h->pvl); release(h->phl); release(h->topv); release(h->toph);
+    release(h->vmask); release(h->hmask); release(h->cinfo); release(h->pvl); release(h->phl); release(h->topv); release(h->toph); release(h->topr); release(h->ometa);
     release(h->voi_ego); release(h->spts); release(h->rejected); release(h->voi_key); release(h->voi_src); release(h->ssrc);
     release(h->rejected_src); release(h->grank); release(h->glist); release(h->gflag);
     release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->lab_slots); release(h->mb_hist); release(h->mb_tot); release(h->mg_curr); release(h->mg_map); release(h->mg_done); release(h->mg_tmp);
@@ -863,6 +885,8 @@ static int set_map_common(erasor_hip_handle *h, const void *src, size_t n, bool 
     h->nC = 0;
     h->submap_not_initialized = true;
     if (n) LAUNCH(h, "set_map", k_store_outskirts, cdiv(n, 256), 256, (const float4 *)h->voi_ego.p, (uint32_t)n, h->Oxy.p, h->Ozi.p, h->o_begin);
+    rc = ometa_reset(h);
+    if (rc) return rc;
     memset(&h->st, 0, sizeof(h->st));
     rc = push_state(h);
     if (rc) return rc;
@@ -1277,13 +1301,14 @@ static void launch_voi_split(erasor_hip_handle *h, const float4 *F, uint32_t nF,
         ke.a = get_evt(h);
         ke.b = get_evt(h);
         hipExtLaunchKernelGGL(k_voi_split, dim3(grid), dim3(256), 0, h->stream, ke.a, ke.b, 0, F, nF, nFchunks, (const float2 *)h->Oxy.p, o_begin,
-                              o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks);
+                              o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks,
+                              h->use_ometa ? h->ometa.p : (OMeta *)nullptr);
         h->pending.push_back(ke);
     } else {
         hipStream_t keep = h->cur;
         h->cur = h->stream;
         LAUNCH(h, "voi_split", k_voi_split, grid, 256, F, nF, nFchunks, (const float2 *)h->Oxy.p, o_begin, o_chunk0, nOchunks, xc, yc, voi_r2,
-               h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks);
+               h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks, h->use_ometa ? h->ometa.p : (OMeta *)nullptr);
         h->cur = keep;
     }
 }
@@ -1390,7 +1415,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         h->spec.valid = false;  // (re-allocated below: a pass launched ahead wrote into the old buffers)
     if (ensure(h, h->vmask, chunks_room * CHUNK_TILES + 8) || ensure(h, h->hmask, chunks_room * CHUNK_TILES + 8) ||
         ensure(h, h->cinfo, chunks_room + 8) || ensure(h, h->pvl, nchunks + 8) || ensure(h, h->phl, nchunks + 8) ||
-        ensure(h, h->topv, nchunks / 1024 + 8) || ensure(h, h->toph, nchunks / 1024 + 8))
+        ensure(h, h->topv, nchunks / 1024 + 8) || ensure(h, h->toph, nchunks / 1024 + 8) || ensure(h, h->topr, nchunks / 1024 + 8))
         return ERASOR_E_NO_DEVICE;
     // No mid-step read-back: everything is launched on upper-bound grids and reads the actual counts
     // (st->voi_total, st->q_nvox) from device memory.  n_voi <= logical map size, nq <= n_scan.
@@ -1429,11 +1454,14 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));
             if (nchunks <= 16384) {
                 LAUNCH(h, "chunk_scan", k_chunk_scan_one, 1, 1024, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, ntop,
-                       nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u);
+                       nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u,
+                       h->use_ometa ? h->ometa.p : (OMeta *)nullptr);
             } else {
-                LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p);
+                LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p,
+                       h->topr.p);
                 LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
-                       nchunks, nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u);
+                       nchunks, nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u,
+                       (const uint32_t *)h->topr.p, h->use_ometa ? h->ometa.p : (OMeta *)nullptr);
             }
         }
         (void)hipStreamWaitEvent(h->stream, Q(h).ev_keys, 0);  // k_voi_gather must see the query side's error flag
@@ -1443,7 +1471,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             LAUNCH(h, "voi_gather", k_voi_gather, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, h->Oxy.p, h->Ozi.p, o_chunk0,
                    nOchunks, (const unsigned long long *)h->vmask.p, (const unsigned long long *)h->hmask.p, (const uint32_t *)h->cinfo.p,
                    (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p, (const uint32_t *)h->topv.p, (const uint32_t *)h->toph.p, h->To2b, P, ds,
-                   dc, (const Counters *)Q(h).d_qctr.p, h->voi_ego.p, h->voi_key.p, h->voi_src.p);
+                   dc, (const Counters *)Q(h).d_qctr.p, h->voi_ego.p, h->voi_key.p, h->voi_src.p, h->use_ometa ? h->ometa.p : (OMeta *)nullptr);
         }
         if (mb_count) {
             // the table is sized for the whole map (n_voi is an upper bound), the GRIDS for 1.5 x the previous step's VoI: the
@@ -2331,6 +2359,14 @@ int erasor_hip_voi_split_bytes(erasor_hip_handle *h, uint64_t *algorithmic_bytes
     const uint64_t oe = (uint64_t)h->capO - h->o_begin;
     if (physical_entries) *physical_entries = (uint64_t)h->nF + oe;
     // F region streams 16 B/entry (float4), the outskirts region 8 B/entry ({x,y} only); + 16 B of masks per 64 entries
+    // (outskirts chunks whose bounding box lies outside the VoI circle are not read: what a launch must stream is the chunks the last
+    // step's pass DID read -- counted on the device, DevState::n_o_read -- plus one 32-byte record per chunk)
+    if (h->use_ometa && h->have_step) {
+        const uint64_t rd = (uint64_t)h->st.n_o_read * CHUNK, nrec = ((uint64_t)h->capO - h->o_begin + CHUNK - 1) / CHUNK;
+        if (physical_entries) *physical_entries = (uint64_t)h->nF + rd;
+        if (algorithmic_bytes) *algorithmic_bytes = 16ull * h->nF + 8ull * rd + ((uint64_t)h->nF + rd) / 4 + 32ull * nrec;
+        return ERASOR_OK;
+    }
     if (algorithmic_bytes) *algorithmic_bytes = 16ull * h->nF + 8ull * oe + ((uint64_t)h->nF + oe) / 4;
     return ERASOR_OK;
 }

@@ -53,7 +53,7 @@ struct DevState {
     // VoI split products
     uint32_t voi_total, voiF, valid_total, validF, n_leaving, o_new_begin;
     // query
-    uint32_t q_nvox, q_overflow, q_nbinned, pad0;
+    uint32_t q_nvox, q_overflow, q_nbinned, n_o_read;  // n_o_read: outskirts chunks the VoI split had to READ this step (the others: skipped by bounding box)
     int32_t q_min_b[3], q_div_b[3];
     // SRT / R-GPF
     uint32_t n_rev, vox_scratch_total;
@@ -173,12 +173,27 @@ __device__ __forceinline__ uint32_t wave_minmax_u(uint32_t x) {
 //   O region: outskirts, split SoA-of-pairs layout {x,y} | {z,intensity}; only {x,y} is streamed.
 // Outputs: per 64-point tile an in-VoI mask and a valid mask, per chunk (voi | valid<<16).
 // ================================================================================================
+// Round 3: every outskirts chunk carries the bounding box of its valid entries and their number (OMeta, 32 B per 8 KB of {x,y}).  A chunk
+// whose box lies outside the VoI circle is NOT READ: its counts come from the record.  The outskirts are written in runs that are close
+// in space (set_map keeps the input order -- a voxelised map is sorted by voxel index --, later the points that leave the VoI, step by
+// step), and a VoI is a few per cent of a map: most of the pass's bytes go.  The test is conservative -- distance from the centre to the
+// box in float64, skipped only beyond r^2 * (1 + 1e-9) -- so no entry that could pass `d^2 < r^2` (OMU.cpp:394) is ever skipped, and the
+// masks of the chunks that are read are what they were.  A record is (re)built by the pass itself whenever it reads the chunk
+// (known = 1); it is dropped (known = 0) for the chunks a step prepends leaving points to (k_chunk_scan_*), its count is corrected when
+// entering points are tombstoned (k_voi_gather), and the host clears all records whenever something else rewrites the store.
+struct OMeta {
+    float xmin, xmax, ymin, ymax;
+    uint32_t valid, known, pad0, pad1;
+};
+static constexpr uint32_t CINFO_READ = 0x80000000u;  // cinfo: voi count | valid count << 16 | "the chunk was read"
+static constexpr uint32_t CINFO_HMASK = 0x7FFFu;
 __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F, uint32_t nF, uint32_t nFchunks,
                                                     const float2 *__restrict__ Oxy, uint32_t o_begin, uint32_t o_chunk0,
                                                     uint32_t nOchunks, double xc, double yc, double r2,
                                                     unsigned long long *__restrict__ vmask,
                                                     unsigned long long *__restrict__ hmask, uint32_t *__restrict__ cinfo,
-                                                    const DevState *__restrict__ dev, uint32_t capO_chunks, uint32_t cap_chunks) {
+                                                    const DevState *__restrict__ dev, uint32_t capO_chunks, uint32_t cap_chunks,
+                                                    OMeta *__restrict__ ometa) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -195,11 +210,26 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
     const uint32_t nchunks = nFchunks + nOchunks;
     for (uint32_t c = wid; c < nchunks; c += nwaves) {
         unsigned long long myv = 0, myh = 0;
-        uint32_t cv = 0, ch = 0;
+        uint32_t cv = 0, ch = 0, read_flag = 0;
+        float bxmin = __int_as_float(0x7F800000), bxmax = __int_as_float(0xFF800000), bymin = bxmin, bymax = bxmax;
         if (c >= nFchunks) {
+            const uint32_t a = c - nFchunks + o_chunk0;  // the chunk's number in the store
+            if (ometa) {  // can the chunk be skipped?  (the record is the same for every lane: scalar branch)
+                const OMeta m = ometa[a];
+                if (__builtin_amdgcn_readfirstlane(m.known)) {
+                    const double bx = fmax(fmax((double)m.xmin - xc, xc - (double)m.xmax), 0.0);
+                    const double by = fmax(fmax((double)m.ymin - yc, yc - (double)m.ymax), 0.0);
+                    const bool out = bx * bx + by * by > r2 * (1.0 + 1e-9);  // (an empty chunk has an inverted box: infinitely far)
+                    if (__builtin_amdgcn_readfirstlane((uint32_t)out)) {
+                        if (lane == 0) cinfo[c] = m.valid << 16;  // (no VoI entry: k_voi_gather never looks at its masks)
+                        esort::wave_sync();  // (the wavefront goes on together: the next chunk's ballots want every lane)
+                        continue;
+                    }
+                }
+            }
             // ---- outskirts: stream {x,y} only; all 16 loads of the chunk are issued before the first use.  Unconditional
             // loads matter: predicating them (even wave-uniformly) serialises the batch (measured 2.9 vs 5.5 TB/s).
-            const uint32_t base = (c - nFchunks + o_chunk0) * CHUNK + lane;
+            const uint32_t base = a * CHUNK + lane;
             float2 p[CHUNK_TILES];
 #pragma unroll
             for (int t = 0; t < CHUNK_TILES; ++t) p[t] = Oxy[base + t * TILE];  // the buffer covers whole chunks: no bounds test
@@ -218,7 +248,31 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
                 }
                 cv += __popcll(vm);
                 ch += __popcll(hm);
+                if (valid) {
+                    bxmin = fminf(bxmin, p[t].x);
+                    bxmax = fmaxf(bxmax, p[t].x);
+                    bymin = fminf(bymin, p[t].y);
+                    bymax = fmaxf(bymax, p[t].y);
+                }
             }
+            if (ometa) {  // the chunk's record, from what was just read
+                bxmin = wave_min_f(bxmin);
+                bxmax = wave_max_f(bxmax);
+                bymin = wave_min_f(bymin);
+                bymax = wave_max_f(bymax);
+                if (lane == 0) {
+                    OMeta m;
+                    m.xmin = bxmin;
+                    m.xmax = bxmax;
+                    m.ymin = bymin;
+                    m.ymax = bymax;
+                    m.valid = ch;
+                    m.known = 1u;
+                    m.pad0 = m.pad1 = 0u;
+                    ometa[a] = m;
+                }
+            }
+            read_flag = CINFO_READ;
         } else {
             // ---- F region: dense float4, two half-chunks to bound the registers ----
             const uint32_t base = c * CHUNK + lane;
@@ -252,7 +306,7 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
             vmask[(size_t)c * CHUNK_TILES + lane] = myv;
             hmask[(size_t)c * CHUNK_TILES + lane] = myh;
         }
-        if (lane == 0) cinfo[c] = cv | (ch << 16);
+        if (lane == 0) cinfo[c] = cv | (ch << 16) | read_flag;
     }
 }
 
@@ -264,22 +318,25 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
 // level 1 of the chunk-count scan: 1024 chunks per workgroup, local prefixes + workgroup totals
 __global__ __launch_bounds__(256) void k_chunk_scan_local(const uint32_t *__restrict__ cinfo, uint32_t nchunks,
                                                            uint32_t *__restrict__ pvl, uint32_t *__restrict__ phl,
-                                                           uint32_t *__restrict__ topv, uint32_t *__restrict__ toph) {
+                                                           uint32_t *__restrict__ topv, uint32_t *__restrict__ toph, uint32_t *__restrict__ topr) {
     __shared__ uint32_t sm[40];
     const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
     uint32_t v[4], h[4];
-    uint32_t sv = 0, sh = 0;
+    uint32_t sv = 0, sh = 0, sr = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t ci = (base + j < nchunks) ? cinfo[base + j] : 0u;
         v[j] = ci & 0xFFFFu;
-        h[j] = ci >> 16;
+        h[j] = (ci >> 16) & CINFO_HMASK;
         sv += v[j];
         sh += h[j];
+        sr += ci >> 31;
     }
-    uint32_t tv, th;
+    uint32_t tv, th, tr;
     uint32_t pv = block_excl_scan(sv, sm, tv);
     uint32_t ph = block_excl_scan(sh, sm, th);
+    (void)block_excl_scan(sr, sm, tr);
+    if (threadIdx.x == 0 && topr) topr[blockIdx.x] = tr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (base + j < nchunks) {
@@ -301,9 +358,18 @@ __global__ __launch_bounds__(256) void k_chunk_scan_local(const uint32_t *__rest
 __global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ topv, uint32_t *__restrict__ toph, uint32_t ntop,
                                                           const uint32_t *__restrict__ pvl, const uint32_t *__restrict__ phl,
                                                           uint32_t nchunks, uint32_t nFchunks, DevState *st, Counters *ctr, DevState init,
-                                                          unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n) {
+                                                          unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n,
+                                                          const uint32_t *__restrict__ topr, OMeta *__restrict__ ometa) {
     __shared__ uint32_t sm[40];
     __shared__ uint32_t carry[2];
+    uint32_t n_read = 0;
+    if (topr)
+        for (uint32_t i = threadIdx.x; i < ntop; i += blockDim.x) n_read += topr[i];
+    {
+        uint32_t tr;
+        (void)block_excl_scan(n_read, sm, tr);
+        n_read = tr;
+    }
     if (lab_slots && threadIdx.x < 128) lab_slots[threadIdx.x] = 0;
     for (uint32_t b = threadIdx.x; b < mb_n; b += blockDim.x) mb_tot[b] = 0;
     if (threadIdx.x == 0) {
@@ -346,7 +412,11 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ 
         s.validF = validF;
         s.n_leaving = validF - voiF;
         s.o_new_begin = s.o_begin - (validF - voiF);
+        s.n_o_read = n_read;
         *st = s;
+        // the chunks that receive this step's leaving points (k_voi_gather prepends them to the outskirts): their records are void
+        if (ometa && s.o_new_begin < s.o_begin)
+            for (uint32_t a = s.o_new_begin / CHUNK; a <= (s.o_begin - 1u) / CHUNK; ++a) ometa[a].known = 0u;
     }
 }
 
@@ -359,7 +429,7 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ 
 __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restrict__ cinfo, uint32_t nchunks, uint32_t *__restrict__ pvl,
                                                           uint32_t *__restrict__ phl, uint32_t *__restrict__ topv, uint32_t *__restrict__ toph,
                                                           uint32_t ntop, uint32_t nFchunks, DevState *st, Counters *ctr, DevState init,
-                                                          unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n) {
+                                                          unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n, OMeta *__restrict__ ometa) {
     __shared__ uint32_t sm[40];
     __shared__ uint32_t s_voiF, s_validF;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -390,18 +460,23 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restr
         ctr->n_neg_sector = ctr->n_ambiguous = ctr->n_degenerate = ctr->n_voxel_overflow = ctr->n_sort_fallback = 0;
         ctr->sort_qoverflow = ctr->err = 0;
     }
-    uint32_t sv = 0, sh = 0;
+    uint32_t sv = 0, sh = 0, sr = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
+        sr += ci[j] >> 31;  // (the "chunk was read" flag of the VoI split: counted, then dropped)
+        ci[j] &= ~CINFO_READ;
         sv += ci[j] & 0xFFFFu;
         sh += ci[j] >> 16;
     }
+    sr = wave_sum(sr);
     const uint32_t iv = esort::wave_incl_scan(sv), ih = esort::wave_incl_scan(sh);
     if (lane == 63) {
         sm[wave] = iv;
         sm[16 + wave] = ih;
+        sm[32 + (wave & 7u)] = 0u;
     }
     __syncthreads();
+    if (lane == 0) atomicAdd(&sm[32], sr);
     const uint32_t nw = blockDim.x >> 6;
     const uint32_t wv = lane < nw ? sm[lane] : 0u, wh = lane < nw ? sm[16 + lane] : 0u;
     const uint32_t wiv = esort::wave_incl_scan(wv), wih = esort::wave_incl_scan(wh);
@@ -460,7 +535,11 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restr
         s.validF = validF;
         s.n_leaving = validF - voiF;
         s.o_new_begin = s.o_begin - (validF - voiF);
+        s.n_o_read = sm[32];
         *st = s;
+        // the chunks that receive this step's leaving points (k_voi_gather prepends them to the outskirts): their records are void
+        if (ometa && s.o_new_begin < s.o_begin)
+            for (uint32_t a = s.o_new_begin / CHUNK; a <= (s.o_begin - 1u) / CHUNK; ++a) ometa[a].known = 0u;
     }
 }
 
@@ -477,7 +556,7 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
                                                      const uint32_t *__restrict__ phl, const uint32_t *__restrict__ topv,
                                                      const uint32_t *__restrict__ toph, Xf To2b, DP P, DevState *st,
                                                      Counters *ctr, const Counters *qctr, float4 *__restrict__ voi_ego,
-                                                     uint32_t *__restrict__ voi_key, uint32_t *__restrict__ voi_src) {
+                                                     uint32_t *__restrict__ voi_key, uint32_t *__restrict__ voi_src, OMeta *__restrict__ ometa) {
     if (ctr->err || qctr->err) return;  // the voxelisation of this step's scan failed: do not touch the map store
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -496,7 +575,7 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
         const int t_lo = isF ? (int)(w % GATHER_SUB) * (CHUNK_TILES / (int)GATHER_SUB) : 0;
         const int t_hi = isF ? t_lo + CHUNK_TILES / (int)GATHER_SUB : CHUNK_TILES;
         const uint32_t ci = cinfo[c];
-        const uint32_t cv = ci & 0xFFFFu, ch = ci >> 16;
+        const uint32_t cv = ci & 0xFFFFu, ch = (ci >> 16) & CINFO_HMASK;
         if (cv == 0 && !(isF && ch > cv)) continue;
         uint32_t pv = pvl[c] + topv[c >> 10];
         uint32_t ph = phl[c] + toph[c >> 10];
@@ -549,6 +628,8 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
             pv += __popcll(vm);
             ph += __popcll(hm);
         }
+        // (the chunk's entering entries are tombstones now: its record counts the valid ones)
+        if (!isF && ometa && lane == 0) ometa[c - nFchunks + o_chunk0].valid = ch - cv;
     }
     (void)voiF;
     // outskirts label counters (parse_dynamic_obj is maintained incrementally, OMU.cpp:294)

@@ -277,7 +277,9 @@ static void test_map_store(std::mt19937 &rng) {
     for (uint32_t i = 0; i < nF; ++i) F[i] = make_float4(u(rng) * 0.6f, u(rng) * 0.6f, uz(rng), (rng() % 6 == 0) ? 252.f : 40.f);
     uint32_t o_valid = 0;
     for (uint32_t i = 0; i < capO; ++i) {
-        Oxy[i] = make_float2(u(rng), u(rng));
+        // (the outskirts are written in runs that are close in space: chunk j sits around x = (j % 8 - 4) * 20 m -- some chunks are far from
+        // the VoI circle and can be skipped by their bounding box, some straddle it)
+        Oxy[i] = make_float2(u(rng) * 0.25f + ((float)((i / CHUNK) % 8) - 4.f) * 20.f, u(rng));
         Ozi[i] = make_float2(uz(rng), (rng() % 6 == 0) ? 253.f : 44.f);
         if (i >= o_begin) {
             if (rng() % 9 == 0) reinterpret_cast<uint32_t *>(&Oxy[i])[0] = HOLE_BITS;  // tombstones of earlier steps
@@ -315,8 +317,11 @@ static void test_map_store(std::mt19937 &rng) {
         }
         ++validO;
     }
-    for (int ahead = 0; ahead < 2; ++ahead) {
+    for (int variant = 0; variant < 4; ++variant) {
+        const int ahead = variant & 1, warm = variant >> 1;  // warm: the chunk records exist already (built by an earlier pass): chunks get skipped
         std::vector<float2> oxy(Oxy), ozi(Ozi);
+        std::vector<OMeta> ometa(capO / CHUNK + 8);
+        memset(ometa.data(), 0, ometa.size() * sizeof(OMeta));
         const uint32_t nFchunks = (nF + CHUNK - 1) / CHUNK, o_chunk0 = o_begin / CHUNK, nOchunks = capO / CHUNK - o_chunk0, nchunks = nFchunks + nOchunks;
         std::vector<unsigned long long> vmask((size_t)(nchunks + 4) * CHUNK_TILES, 0), hmask((size_t)(nchunks + 4) * CHUNK_TILES, 0), lab(128, 1);
         std::vector<uint32_t> cinfo(nchunks + 8, 0), pvl(nchunks + 8, 0), phl(nchunks + 8, 0), topv(8, 9), toph(8, 9), mb_tot(64, 5);
@@ -330,17 +335,33 @@ static void test_map_store(std::mt19937 &rng) {
         Counters ctr, qctr;
         memset(&ctr, 0, sizeof(ctr));
         memset(&qctr, 0, sizeof(qctr));
-        if (ahead)  // extents from the committed device state, upper-bound grid
-            simt::run_grid(3, 256, [&] {
-                k_voi_split(F.data(), 0u, 0u, oxy.data(), 0u, 0u, 0u, xc, yc, P.voi_r2, vmask.data(), hmask.data(), cinfo.data(), &st, capO / CHUNK, nchunks + 2);
-            });
-        else
-            simt::run_grid((nchunks + 3) / 4, 256, [&] {
-                k_voi_split(F.data(), nF, nFchunks, oxy.data(), o_begin, o_chunk0, nOchunks, xc, yc, P.voi_r2, vmask.data(), hmask.data(), cinfo.data(), nullptr, 0u, 0u);
-            });
+        for (int pass = warm ? 0 : 1; pass < 2; ++pass) {  // (warm: a first pass around a far-away centre builds the records)
+            const double px = pass ? xc : xc + 500.0;
+            if (pass) {
+                std::fill(cinfo.begin(), cinfo.end(), 0xDEADBEEFu);
+                std::fill(vmask.begin(), vmask.end(), ~0ull);
+                std::fill(hmask.begin(), hmask.end(), ~0ull);
+            }
+            if (ahead)  // extents from the committed device state, upper-bound grid
+                simt::run_grid(3, 256, [&] {
+                    k_voi_split(F.data(), 0u, 0u, oxy.data(), 0u, 0u, 0u, px, yc, P.voi_r2, vmask.data(), hmask.data(), cinfo.data(), &st, capO / CHUNK, nchunks + 2,
+                                ometa.data());
+                });
+            else
+                simt::run_grid((nchunks + 3) / 4, 256, [&] {
+                    k_voi_split(F.data(), nF, nFchunks, oxy.data(), o_begin, o_chunk0, nOchunks, px, yc, P.voi_r2, vmask.data(), hmask.data(), cinfo.data(), nullptr, 0u,
+                                0u, ometa.data());
+                });
+        }
+        uint32_t n_read = 0;
+        for (uint32_t c = nFchunks; c < nchunks; ++c) n_read += cinfo[c] >> 31;
+        if (getenv("DBG_CINFO")) { printf("   [dbg] variant %d cinfo:", variant); for (uint32_t c = 0; c < nchunks; ++c) printf(" %08x", cinfo[c]); printf("\n"); }
+        CHECK(warm ? (n_read > 0 && n_read + 3 <= nOchunks) : n_read == nOchunks, "outskirts chunks read: %u of %u (warm=%d)", n_read, nOchunks, warm);
         simt::run_grid(1, 1024, [&] {
-            k_chunk_scan_one(cinfo.data(), nchunks, pvl.data(), phl.data(), topv.data(), toph.data(), 1u, nFchunks, &st, &ctr, init, lab.data(), mb_tot.data(), 64u);
+            k_chunk_scan_one(cinfo.data(), nchunks, pvl.data(), phl.data(), topv.data(), toph.data(), 1u, nFchunks, &st, &ctr, init, lab.data(), mb_tot.data(), 64u,
+                             ometa.data());
         });
+        CHECK(st.n_o_read == n_read, "n_o_read %u vs %u", st.n_o_read, n_read);
         {   // the two-level scan (maps beyond 16384 chunks) opens the step with the same state and the same prefixes
             std::vector<uint32_t> pvl2(nchunks + 8, 0), phl2(nchunks + 8, 0), topv2(8, 0), toph2(8, 0), mb2(64, 5);
             std::vector<unsigned long long> lab2(128, 1);
@@ -348,10 +369,14 @@ static void test_map_store(std::mt19937 &rng) {
             Counters ctr2;
             memset(&ctr2, 0, sizeof(ctr2));
             const uint32_t ntop = (nchunks + 1023) / 1024;
-            simt::run_grid(ntop, 256, [&] { k_chunk_scan_local(cinfo.data(), nchunks, pvl2.data(), phl2.data(), topv2.data(), toph2.data()); });
+            std::vector<uint32_t> topr2(8, 77);
+            std::vector<OMeta> ometa2(ometa);
+            simt::run_grid(ntop, 256, [&] { k_chunk_scan_local(cinfo.data(), nchunks, pvl2.data(), phl2.data(), topv2.data(), toph2.data(), topr2.data()); });
             simt::run_grid(1, 1024, [&] {
-                k_chunk_scan_top(topv2.data(), toph2.data(), ntop, pvl2.data(), phl2.data(), nchunks, nFchunks, &st2, &ctr2, init, lab2.data(), mb2.data(), 64u);
+                k_chunk_scan_top(topv2.data(), toph2.data(), ntop, pvl2.data(), phl2.data(), nchunks, nFchunks, &st2, &ctr2, init, lab2.data(), mb2.data(), 64u,
+                                 topr2.data(), ometa2.data());
             });
+            CHECK(memcmp(ometa2.data(), ometa.data(), ometa.size() * sizeof(OMeta)) == 0, "both scans void the same chunk records");
             bool same = memcmp(&st2, &st, sizeof(st)) == 0;
             for (uint32_t c = 0; same && c < nchunks; ++c)
                 same = pvl2[c] + topv2[c >> 10] == pvl[c] + topv[c >> 10] && phl2[c] + toph2[c >> 10] == phl[c] + toph[c >> 10];
@@ -363,8 +388,27 @@ static void test_map_store(std::mt19937 &rng) {
         std::vector<uint32_t> key(want.size() + 8), src(want.size() + 8);
         simt::run_grid(5, 256, [&] {
             k_voi_gather(F.data(), nF, nFchunks, oxy.data(), ozi.data(), o_chunk0, nOchunks, vmask.data(), hmask.data(), cinfo.data(), pvl.data(),
-                         phl.data(), topv.data(), toph.data(), To2b, P, &st, &ctr, &qctr, ego.data(), key.data(), src.data());
+                         phl.data(), topv.data(), toph.data(), To2b, P, &st, &ctr, &qctr, ego.data(), key.data(), src.data(), ometa.data());
         });
+        {   // the chunk records afterwards: void where leaving points arrived, counts corrected where entries were tombstoned, and every
+            // known record describes its chunk (box covers the valid entries, count exact)
+            bool rec = true;
+            for (uint32_t a = o_chunk0; rec && a < capO / CHUNK; ++a) {
+                const bool recv = st.o_new_begin < o_begin && a >= st.o_new_begin / CHUNK && a <= (o_begin - 1) / CHUNK;
+                if (recv) { rec = ometa[a].known == 0; continue; }
+                if (!ometa[a].known) continue;
+                uint32_t cnt = 0;
+                for (uint32_t i = a * CHUNK; rec && i < (a + 1) * CHUNK; ++i) {
+                    if (i < o_begin || __float_as_uint(oxy[i].x) == HOLE_BITS) continue;
+                    ++cnt;
+                    rec = oxy[i].x >= ometa[a].xmin && oxy[i].x <= ometa[a].xmax && oxy[i].y >= ometa[a].ymin && oxy[i].y <= ometa[a].ymax;
+                }
+                rec = rec && cnt == ometa[a].valid;
+            }
+            for (uint32_t a = st.o_new_begin / CHUNK; rec && a < o_chunk0; ++a) rec = ometa[a].known == 0;
+            CHECK(rec, "chunk records after the step (variant %d)", variant);
+        }
+        if (!ok) printf("   [dbg] state mismatch: voi_total %u (want %zu) voiF %u (%u) validF %u (%u) valid_total %u (%u) n_leaving %u (%zu)\n", st.voi_total, want.size(), st.voiF, voiF, st.validF, nF, st.valid_total, nF + validO, st.n_leaving, leaving.size());
         for (size_t i = 0; ok && i < want.size(); ++i) ok = memcmp(&ego[i], &want[i].ego, 16) == 0 && key[i] == want[i].key && src[i] == want[i].src;
         for (size_t i = 0; ok && i < leaving.size(); ++i) {  // [leaving (F order) | old outskirts]
             const uint32_t d = st.o_new_begin + (uint32_t)i;
@@ -375,9 +419,10 @@ static void test_map_store(std::mt19937 &rng) {
         for (auto &q : leaving) (is_dynamic_label(q.w) ? dyn : stat) += 1;
         for (uint32_t i : tomb) (is_dynamic_label(Ozi[i].y) ? dyn : stat) -= 1;
         ok = ok && (long long)st.O_dynamic == 1000000 + dyn && (long long)st.O_static == 1000000 + stat;
-        printf("map store: split%s / chunk scan / gather     VoI %zu (%u resident), %zu leaving, %zu entering  %s\n",
-               ahead ? " (launched ahead)" : "                 ", want.size(), voiF, leaving.size(), tomb.size(), ok ? "ok" : "MISMATCH");
-        CHECK(ok, "map store ahead=%d", ahead);
+        printf("map store: split%s%s / chunk scan / gather     VoI %zu (%u resident), %zu leaving, %zu entering, %u of %u outskirts chunks read  %s\n",
+               ahead ? " (launched ahead)" : "                 ", warm ? ", records known" : "               ", want.size(), voiF, leaving.size(), tomb.size(),
+               n_read, nOchunks, ok ? "ok" : "MISMATCH");
+        CHECK(ok, "map store variant=%d", variant);
     }
 }
 
