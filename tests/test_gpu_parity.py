@@ -830,12 +830,14 @@ print("ALT-PATH-OK")
 """
 
 
-@pytest.mark.parametrize("env", [{"ERASOR_HIP_GRAPH": "1"}, {"ERASOR_HIP_NO_FUSE": "1", "ERASOR_HIP_NO_FOLD": "1", "ERASOR_HIP_NO_SRT_AHEAD": "1"}],
-                         ids=["query_chain_as_hipgraphs", "separate_rgpf_binvox_layout_srt_launches"])
+@pytest.mark.parametrize("env", [{"ERASOR_HIP_GRAPH": "1"}, {"ERASOR_HIP_NO_FUSE": "1", "ERASOR_HIP_NO_FOLD": "1", "ERASOR_HIP_NO_SRT_AHEAD": "1"},
+                                 {"ERASOR_HIP_NO_OMETA": "1", "ERASOR_HIP_STREAM_PRIORITIES": "1"}],
+                         ids=["query_chain_as_hipgraphs", "separate_rgpf_binvox_layout_srt_launches", "no_chunk_records_stream_priorities"])
 def test_alternative_launch_paths_keep_parity(gpu_mod, tmp_path, env):
     """The paths behind the library's A/B switches are product code too: the query chain replayed as two hipGraphs per side
     (ERASOR_HIP_GRAPH=1: measured, no gain, opt-in) and the unfused launches (R-GPF and per-bin voxelisation apart, k_layout4,
-    the Scan Ratio Test's first pass inside k_srt4) -- five look-ahead steps of a v3 and a v2 sequence each, in a process of its
+    the Scan Ratio Test's first pass inside k_srt4), the VoI pass without the outskirts' chunk records and rounds 1-2's stream priorities
+    -- five look-ahead steps of a v3 and a v2 sequence each, in a process of its
     own (the switches are read once), every step against the oracle."""
     import subprocess
     import sys
