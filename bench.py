@@ -635,10 +635,13 @@ def main():
     src_note = ("STALE: the device sources changed since profiles/ was collected (tools/collect_profiles.sh) -> null" if cp["stale"]
                 else "from_profiles (separate rocprofv3 passes of this very build, profiles/*_latest%s.*)" % prof_tag)
     roofline = {"bound": "l3+hbm" if in_l3 else "hbm", "kernel": "k_voi_split",
-                "kernel_role": "hbm_kernel: the step's one pass over the whole map store (fetch_VoI membership) -- NOT the kernel that "
-                               "dominates GPU time, see dominant_kernel and step_frac",
-                "bound_note": ("the %.0f MB this launch streams fit the 256 MiB Infinity Cache: the rate is an L3+HBM figure; "
-                               "--workload large_scale_05 (378 MB per launch) is the HBM-only measurement" % (alg_bytes / 1e6)) if in_l3
+                "kernel_role": "hbm_kernel: the step's one pass over the map store (fetch_VoI membership) -- NOT the kernel that dominates GPU "
+                               "time, see dominant_kernel and step_frac.  Since round 3 the pass skips the outskirts chunks whose bounding box "
+                               "lies outside the VoI circle (see bytes_note): it reads a sixth of what it streamed and is latency-bound as a "
+                               "launch; no kernel of the step is HBM-bound any more (largest consumers by PMC traffic: profiles/pmc_latest*.json)",
+                "bound_note": ("the %.0f MB this launch reads fit the 256 MiB Infinity Cache: the rate is an L3+HBM figure; "
+                               "ERASOR_HIP_NO_OMETA=1 --workload large_scale_05 (378 MB per launch, every chunk read) is the HBM-only streaming "
+                               "measurement" % (alg_bytes / 1e6)) if in_l3
                               else "%.0f MB per launch, beyond the 256 MiB Infinity Cache: HBM-bound" % (alg_bytes / 1e6),
                 "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": traffic,
