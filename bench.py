@@ -117,7 +117,7 @@ def device_source_hash():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "erasor_amd", "csrc")
-    for f in ("erasor_hip.hip", "kernels.hip.h", "exact_sort.hip.h", "exact_sort_core.h"):
+    for f in ("erasor_hip.hip", "kernels.hip.h", "revert_bins.hip.h", "exact_sort.hip.h", "exact_sort_core.h"):
         with open(os.path.join(d, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -59,7 +59,7 @@ class ErasorError(RuntimeError):
 
 def build(force=False):
     """hipcc --offload-arch=gfx950 … -shared -> erasor_amd/liberasor_hip.so (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_SRC_DIR, f) for f in ("erasor_hip.hip", "kernels.hip.h", "exact_sort.hip.h", "exact_sort_core.h")]
+    srcs = [os.path.join(_SRC_DIR, f) for f in ("erasor_hip.hip", "kernels.hip.h", "revert_bins.hip.h", "exact_sort.hip.h", "exact_sort_core.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "erasor_hip.h"))
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _SRC_DIR, "-s"])

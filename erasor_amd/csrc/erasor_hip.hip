@@ -1285,10 +1285,15 @@ static void q_drain(erasor_hip_handle *h) {
 // The VoI split on the main stream.  dev == nullptr: a step's own pass (extents from the host mirror).  dev != nullptr: the
 // pass of the NEXT step, launched ahead; the kernel takes the extents the step in flight commits on the device.
 static void launch_voi_split(erasor_hip_handle *h, const float4 *F, uint32_t nF, uint32_t nFchunks, uint32_t o_begin, uint32_t o_chunk0,
-                             uint32_t nOchunks, uint32_t nchunks_grid, double xc, double yc, double voi_r2, const DevState *dev, uint32_t cap_chunks) {
+                             uint32_t nOchunks, uint32_t nchunks_grid, double xc, double yc, double voi_r2, const DevState *dev, uint32_t cap_chunks,
+                             const StepEnd *step_end = nullptr) {
     // one chunk per wave while that needs <= 16 workgroups per CU: the hardware back-fills workgroups as they finish,
     // which balances better than a grid-stride tail (measured, tools/bw_probe.hip)
-    const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nchunks_grid, 4), 256 * 16));
+    // (step_end: the launch's LAST workgroup ends the step in flight -- round 4, see StepEnd in kernels.hip.h)
+    StepEnd se;
+    memset(&se, 0, sizeof(se));
+    if (step_end) se = *step_end;
+    const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nchunks_grid, 4), 256 * 16)) + (step_end ? 1u : 0u);
     const uint32_t capO_chunks = h->capO / CHUNK;
     // (prof 3: the same on every FOURTH launch -- the bracket costs the step it observes ~9 us (gpurun_out/r03k: 0.276 vs 0.267 ms
     // per scan with / without), a sample of the timed region's launches costs a quarter of that)
@@ -1302,13 +1307,13 @@ static void launch_voi_split(erasor_hip_handle *h, const float4 *F, uint32_t nF,
         ke.b = get_evt(h);
         hipExtLaunchKernelGGL(k_voi_split, dim3(grid), dim3(256), 0, h->stream, ke.a, ke.b, 0, F, nF, nFchunks, (const float2 *)h->Oxy.p, o_begin,
                               o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks,
-                              h->use_ometa ? h->ometa.p : (OMeta *)nullptr);
+                              h->use_ometa ? h->ometa.p : (OMeta *)nullptr, se);
         h->pending.push_back(ke);
     } else {
         hipStream_t keep = h->cur;
         h->cur = h->stream;
         LAUNCH(h, "voi_split", k_voi_split, grid, 256, F, nF, nFchunks, (const float2 *)h->Oxy.p, o_begin, o_chunk0, nOchunks, xc, yc, voi_r2,
-               h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks, h->use_ometa ? h->ometa.p : (OMeta *)nullptr);
+               h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks, h->use_ometa ? h->ometa.p : (OMeta *)nullptr, se);
         h->cur = keep;
     }
 }
@@ -1518,7 +1523,14 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     // the write-back finishes it (ERASOR_HIP_NO_FOLD=1: the separate k_layout4 launch, for A/B)
     static const bool no_fold = getenv("ERASOR_HIP_NO_FOLD") != nullptr;
     const bool fold = B <= 1024 * SRT_KPT && !no_fold && n_voi > 0;
-    if (B <= 1024 * SRT_KPT)
+    // round 4: v3's second pass is the LAST WORKGROUP of the per-bin launch (k_revert_bins_srt): the revert decision is local to a bin, so
+    // the per-bin workgroups find their bins themselves and nothing on the chain waits for k_srt4 (ERASOR_HIP_NO_SRT_FOLD=1: as before)
+    static const bool no_fuse = getenv("ERASOR_HIP_NO_FUSE") != nullptr;
+    static const bool no_srt_fold = getenv("ERASOR_HIP_NO_SRT_FOLD") != nullptr;
+    const bool srt_in_revert = st1_ahead && P.version == 3 && !no_fuse && !no_srt_fold && h->prof != 1;
+    if (srt_in_revert) {
+        // (no launch)
+    } else if (B <= 1024 * SRT_KPT)
         LAUNCH(h, "srt", k_srt4, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
            (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds,
            fold ? h->out_off0.p : (uint32_t *)nullptr, fold ? h->rev_before.p : (uint32_t *)nullptr, fold ? h->crej_off.p : (uint32_t *)nullptr,
@@ -1529,22 +1541,65 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     // R-GPF and the per-bin voxelisation walk the reverted-bin LIST on a small fixed grid (n_rev is on the device)
     static const uint32_t rev_grid = getenv("ERASOR_HIP_REV_GRID") ? (uint32_t)atoi(getenv("ERASOR_HIP_REV_GRID")) : 128u;
     // v3: R-GPF and the per-bin voxelisation of a reverted bin in ONE launch (k_revert_bins); ERASOR_HIP_NO_FUSE=1: two launches (A/B)
-    static const bool no_fuse = getenv("ERASOR_HIP_NO_FUSE") != nullptr;
-    if (P.version == 3 && !no_fuse && h->prof != 1) {
+    RevArgs ra;
+    ra.moff = h->moff.p;
+    ra.spts = h->spts.p;
+    ra.qoff = Q(h).qoff.p;
+    ra.sq = Q(h).sq.p;
+    ra.gsK = h->gsK.p;
+    ra.gsV = h->gsV.p;
+    ra.gsL = h->gsL.p;
+    ra.gsR = h->gsR.p;
+    ra.gsH = h->gsH.p;
+    ra.gsK2 = h->gsK2.p;
+    ra.gsV2 = h->gsV2.p;
+    ra.gsC = h->gsC.p;
+    ra.gflag = h->gflag.p;
+    ra.grank = h->grank.p;
+    ra.glist = h->glist.p;
+    ra.ng_arr = h->ng.p;
+    ra.plane_n = h->plane_n.p;
+    ra.plane_d = h->plane_d.p;
+    ra.vox_out = h->vox_out.p;
+    ra.nvox_out = h->nvox.p;
+    ra.ctr = dc;
+    ra.dbg = h->dbg_stamps.p;
+    // (fused launch: the voxelisation's global-memory path works in the upper half of the shared scratch arrays)
+    ra.vox_base = (uint32_t)((size_t)n_voi + nq + 8);
+    ra.h_base = (uint32_t)(((size_t)n_voi + nq + 8) / 32 + 2 * (size_t)B + 16);
+    if (srt_in_revert) {
+        SrtArgs sa;
+        sa.mcnt = h->mcnt.p;
+        sa.mmin = h->mmin.p;
+        sa.mmax = h->mmax.p;
+        sa.ccnt = Q(h).ccnt.p;
+        sa.cmin = Q(h).cmin.p;
+        sa.cmax = Q(h).cmax.p;
+        sa.st1 = h->st1.p;
+        sa.status = h->status.p;
+        sa.action = h->action.p;
+        sa.rev_idx = h->rev_idx.p;
+        sa.rev_list = h->rev_list.p;
+        sa.vox_off = h->vox_off.p;
+        sa.st = ds;
+        sa.out_off0 = fold ? h->out_off0.p : (uint32_t *)nullptr;
+        sa.rev_before = fold ? h->rev_before.p : (uint32_t *)nullptr;
+        sa.crej_off = fold ? h->crej_off.p : (uint32_t *)nullptr;
+        sa.st1_in = h->st1b.p;
+        sa.moff = h->moff.p;
+        sa.qoff = Q(h).qoff.p;
+        LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins_srt, std::min<uint32_t>(rev_grid, B) + 1u, 1024, P, sa, ra);
+    } else if (P.version == 3 && !no_fuse && h->prof != 1) {
         LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds,
-               (const uint32_t *)h->moff.p, (const float4 *)h->spts.p, (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p, h->gsK.p, h->gsV.p,
-               h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p, h->gsC.p, h->gflag.p, h->grank.p, h->glist.p, h->ng.p, h->plane_n.p, h->plane_d.p,
-               (const uint32_t *)h->vox_off.p, h->vox_out.p, h->nvox.p, dc, h->dbg_stamps.p, (uint32_t)((size_t)n_voi + nq + 8),
-               (uint32_t)(((size_t)n_voi + nq + 8) / 32 + 2 * (size_t)B + 16));
+               (const uint32_t *)h->vox_off.p, ra);
     } else {
-    LAUNCH(h, "rgpf", k_rgpf2, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds, (const uint32_t *)h->moff.p,
-           (const float4 *)h->spts.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p, h->gsH.p, h->gsK2.p, h->gsV2.p, h->gflag.p, h->grank.p, h->glist.p,
-           h->ng.p, h->plane_n.p, h->plane_d.p, dc, h->dbg_stamps.p);
-    if (P.version == 3)
-        LAUNCH(h, "bin_voxelize", k_binvox2, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds,
-               (const uint32_t *)h->moff.p, (const float4 *)h->spts.p, (const uint32_t *)Q(h).qoff.p, (const float4 *)Q(h).sq.p,
-               (const uint32_t *)h->glist.p, (const uint32_t *)h->ng.p, (const uint32_t *)h->vox_off.p, h->gsK.p, h->gsV.p, h->gsL.p, h->gsR.p,
-               h->gsH.p, h->gsK2.p, h->gsV2.p, h->gsC.p, h->vox_out.p, h->nvox.p, dc, h->dbg_stamps.p);
+        // (two launches: the stages' global-memory paths do not overlap in time and share the scratch arrays from their start)
+        ra.vox_base = 0u;
+        ra.h_base = 0u;
+        LAUNCH(h, "rgpf", k_rgpf2, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds, ra);
+        if (P.version == 3)
+            LAUNCH(h, "bin_voxelize", k_binvox2, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds,
+                   (const uint32_t *)h->vox_off.p, ra);
     }
     if (fold) {
         // (no launch)
@@ -1579,13 +1634,13 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     }
     // (label counters of the new VoI-resident region are accumulated by the two assemble kernels)
     const unsigned long long step_seq = ++h->step_seq;
-    LAUNCH(h, "step_end", k_step_end, 1, 1, ds, dc, h->pin, (const unsigned long long *)h->lab_slots.p, (const Counters *)Q(h).d_qctr.p,
-           (const uint32_t *)Q(h).d_nvox.p, step_seq);
-    {   // the NEXT step's VoI split goes right behind k_step_end when its pose is known (erasor_hip_prefetch_node): the main
+    {   // the NEXT step's VoI split goes right behind the step when its pose is known (erasor_hip_prefetch_node): the main
         // stream runs it while the host collects this step's results and the caller comes back with the next scan -- the pass
-        // reads the store this step has just written and the extents k_step_end commits; a step that finds anything else than
-        // what was assumed here (pose, store, buffers) simply runs its own pass
+        // reads the store this step has just written and the extents the step's end commits; a step that finds anything else than
+        // what was assumed here (pose, store, buffers) simply runs its own pass.
+        // Round 4: that launch also ENDS this step (its last workgroup does k_step_end's work, ERASOR_HIP_NO_END_FOLD=1: a launch of its own)
         static const bool no_spec = getenv("ERASOR_HIP_NO_AHEAD_SPLIT") != nullptr;
+        static const bool no_end_fold = getenv("ERASOR_HIP_NO_END_FOLD") != nullptr;
         bool have_pose = false;
         double nx = 0, ny = 0;
         if (h->npend > 0) {
@@ -1598,9 +1653,22 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             nx = h->ann.pose_x;
             ny = h->ann.pose_y;
         }
-        if (have_pose && !no_spec && !flags && !h->P.is_large_scale) {
+        const bool spec = have_pose && !no_spec && !flags && !h->P.is_large_scale;
+        StepEnd se;
+        se.st = ds;
+        se.ctr = dc;
+        se.out = h->pin;
+        se.lab_slots = (const unsigned long long *)h->lab_slots.p;
+        se.qctr = (const Counters *)Q(h).d_qctr.p;
+        se.q_nvox = (const uint32_t *)Q(h).d_nvox.p;
+        se.seq = step_seq;
+        const bool end_in_split = spec && !no_end_fold && h->prof != 1;
+        if (!end_in_split)
+            LAUNCH(h, "step_end", k_step_end, 1, 1, se.st, se.ctr, se.out, se.lab_slots, se.qctr, se.q_nvox, se.seq);
+        if (spec) {
             const size_t cap_chunks = std::min(std::min(h->vmask.cap, h->hmask.cap) / CHUNK_TILES, h->cinfo.cap) - 8;
-            launch_voi_split(h, (const float4 *)Fnew, 0u, 0u, 0u, 0u, 0u, nchunks + 64, nx, ny, P.voi_r2, (const DevState *)ds, (uint32_t)cap_chunks);
+            launch_voi_split(h, (const float4 *)Fnew, 0u, 0u, 0u, 0u, 0u, nchunks + 64, nx, ny, P.voi_r2, (const DevState *)ds, (uint32_t)cap_chunks,
+                             end_in_split ? &se : (const StepEnd *)nullptr);
             h->spec.valid = true;
             h->spec.x = nx;
             h->spec.y = ny;

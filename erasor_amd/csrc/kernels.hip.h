@@ -173,6 +173,78 @@ __device__ __forceinline__ uint32_t wave_minmax_u(uint32_t x) {
 //   O region: outskirts, split SoA-of-pairs layout {x,y} | {z,intensity}; only {x,y} is streamed.
 // Outputs: per 64-point tile an in-VoI mask and a valid mask, per chunk (voi | valid<<16).
 // ================================================================================================
+// result block in pinned host memory: k_step_end stores the step's state and counters there, so the host needs no D2H copies
+struct HostOut {
+    DevState st;
+    Counters ctr;
+    unsigned long long seq;  // number of the step these results belong to: written last, the host polls it
+};
+
+// end of a step: fold in the query side's counters and voxel count, commit the map sizes, report to the pinned host block
+__device__ __forceinline__ void step_end_body(DevState *st, Counters *ctr, HostOut *out, const unsigned long long *lab_slots, const Counters *qctr,
+                                              const uint32_t *q_nvox, unsigned long long seq) {
+    // round 3: everything is READ first (one memory round trip: the loads are independent and nothing is stored in between), then
+    // computed, then written -- interleaved read-modify-writes of st / ctr cost a round trip each (6 us for this one-thread kernel)
+    DevState s = *st;
+    Counters c = *ctr;
+    const Counters q = *qctr;
+    const uint32_t nv = *q_nvox;
+    unsigned long long ns = 0, nd = 0;
+    if (lab_slots) {
+        unsigned long long a[16], b[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            a[i] = lab_slots[i * 8];
+            b[i] = lab_slots[i * 8 + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ns += a[i];
+            nd += b[i];
+        }
+        s.F_static = ns;
+        s.F_dynamic = nd;
+    }
+    c.n_neg_sector += q.n_neg_sector;
+    c.n_ambiguous += q.n_ambiguous;
+    c.n_degenerate += q.n_degenerate;
+    c.n_voxel_overflow += q.n_voxel_overflow;
+    c.n_sort_fallback += q.n_sort_fallback;
+    if (q.sort_qoverflow) c.sort_qoverflow = q.sort_qoverflow;
+    if (q.err) c.err = q.err;
+    s.q_nvox = nv;
+    if (!(c.err || c.sort_qoverflow)) {
+        s.nF = s.nF_new;
+        s.o_begin = s.o_new_begin;
+    }
+    *st = s;
+    *ctr = c;
+    if (out) {
+        out->st = s;
+        out->ctr = c;
+        __threadfence_system();
+        *(volatile unsigned long long *)&out->seq = seq;
+    }
+}
+
+__global__ void k_step_end(DevState *st, Counters *ctr, HostOut *out, const unsigned long long *lab_slots, const Counters *qctr,
+                           const uint32_t *q_nvox, unsigned long long seq) {
+    step_end_body(st, ctr, out, lab_slots, qctr, q_nvox, seq);
+}
+// Round 4: the step's end as a passenger of the NEXT step's VoI split.  When the next node's pose is known the split is launched right
+// behind the step anyway (dev != nullptr below); one extra workgroup of that launch then does k_step_end's work -- everything the step
+// wrote is visible at the kernel boundary either way -- and the launch of its own (5 us of dependent loads on one thread + a boundary)
+// leaves the main stream's chain.  The other workgroups cannot wait for that commit: they derive the two extents themselves.
+struct StepEnd {
+    DevState *st;
+    Counters *ctr;
+    HostOut *out;
+    const unsigned long long *lab_slots;
+    const Counters *qctr;
+    const uint32_t *q_nvox;
+    unsigned long long seq;
+};
+
 // Round 3: every outskirts chunk carries the bounding box of its valid entries and their number (OMeta, 32 B per 8 KB of {x,y}).  A chunk
 // whose box lies outside the VoI circle is NOT READ: its counts come from the record.  The outskirts are written in runs that are close
 // in space (set_map keeps the input order -- a voxelised map is sorted by voxel index --, later the points that leave the VoI, step by
@@ -193,11 +265,28 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
                                                     unsigned long long *__restrict__ vmask,
                                                     unsigned long long *__restrict__ hmask, uint32_t *__restrict__ cinfo,
                                                     const DevState *__restrict__ dev, uint32_t capO_chunks, uint32_t cap_chunks,
-                                                    OMeta *__restrict__ ometa) {
+                                                    OMeta *__restrict__ ometa, StepEnd se) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    if (dev) {
+    uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    if (dev && se.st) {
+        // the launch also ENDS the previous step (se): its last workgroup is k_step_end; the others take the extents that commit will
+        // publish straight from what the step left (the same decision, the same values whichever comes first)
+        if (blockIdx.x == gridDim.x - 1) {
+            if (threadIdx.x == 0) step_end_body(se.st, se.ctr, se.out, se.lab_slots, se.qctr, se.q_nvox, se.seq);
+            return;
+        }
+        nwaves -= blockDim.x >> 6;
+        const uint32_t e0 = se.ctr->err, e1 = se.ctr->sort_qoverflow, e2 = se.qctr->err, e3 = se.qctr->sort_qoverflow;
+        const uint32_t nF_old = dev->nF, nF_new = dev->nF_new, ob_old = dev->o_begin, ob_new = dev->o_new_begin;
+        const bool ok = !(e0 | e1 | e2 | e3);
+        nF = ok ? nF_new : nF_old;
+        nFchunks = (nF + CHUNK - 1) / CHUNK;
+        o_begin = ok ? ob_new : ob_old;
+        o_chunk0 = o_begin / CHUNK;
+        nOchunks = capO_chunks - o_chunk0;
+        if (nFchunks + nOchunks > cap_chunks) return;
+    } else if (dev) {
         // launched AHEAD of its step (right behind the previous step's k_step_end, while the host is still collecting that
         // step's results): the extent of the two regions is what that step has just committed on the device
         nF = dev->nF;
@@ -1338,11 +1427,13 @@ __global__ __launch_bounds__(256) void k_dup_label_passthrough(const float4 *__r
 // produced into registers by key_of(i); scratch = 16384 words of LDS (pool) laid out as pairs[2048] | left stops[2048] | right
 // stops[2048] | counts[2048] | cuts[2048]; sorted keys -> K2, their indices -> V2 (LDS; both may lie in pool beyond its first 4096 words).
 static constexpr uint32_t ESYNC_MAX = 2048;
-template <class KeyFn, class ValFn, class K2P, class V2P>
+// (`cap` >= n lays out the scratch: 8 * cap words of `pool`)
+template <bool BIG = false, class KeyFn, class ValFn, class K2P, class V2P>
 __device__ __forceinline__ void lds_esort_sync_kv(uint32_t n, KeyFn key_of, ValFn val_of, uint32_t *pool, uint32_t *stab, K2P K2, V2P V2,
-                                                  uint32_t *n_fallback, unsigned long long *tstamp = nullptr, int32_t depth_budget = -1) {
-    uint2 *sKV = reinterpret_cast<uint2 *>(pool), *sLL = reinterpret_cast<uint2 *>(pool + 2 * ESYNC_MAX), *sRR = reinterpret_cast<uint2 *>(pool + 4 * ESYNC_MAX);
-    uint32_t *sPS = pool + 6 * ESYNC_MAX, *sCut = pool + 7 * ESYNC_MAX;
+                                                  uint32_t *n_fallback, unsigned long long *tstamp = nullptr, int32_t depth_budget = -1,
+                                                  uint32_t cap = ESYNC_MAX) {
+    uint2 *sKV = reinterpret_cast<uint2 *>(pool), *sLL = reinterpret_cast<uint2 *>(pool + 2 * cap), *sRR = reinterpret_cast<uint2 *>(pool + 4 * cap);
+    uint32_t *sPS = pool + 6 * cap, *sCut = pool + 7 * cap;
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
     if (n <= bs) {
         uint32_t k[1], v[1];
@@ -1363,7 +1454,7 @@ __device__ __forceinline__ void lds_esort_sync_kv(uint32_t n, KeyFn key_of, ValF
 template <class KeyFn>
 __device__ __forceinline__ void lds_esort_sync(uint32_t n, KeyFn key_of, uint32_t *pool, uint32_t *stab, uint32_t *K2, uint32_t *V2,
                                                uint32_t *n_fallback, unsigned long long *tstamp = nullptr) {
-    lds_esort_sync_kv(n, key_of, [](uint32_t i) { return i; }, pool, stab, K2, V2, n_fallback, tstamp);
+    lds_esort_sync_kv<false>(n, key_of, [](uint32_t i) { return i; }, pool, stab, K2, V2, n_fallback, tstamp);
 }
 
 static constexpr uint32_t ES_LMAX = 2048;   // segments up to this size are finished inside LDS
@@ -1817,7 +1908,7 @@ __global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, 
             const unsigned long long t_a = clock64();
             const uint32_t *Kg = K + sg.first, *Vg = V + sg.first;
             __syncthreads();  // (the previous segment's ranking may still be reading the pool)
-            lds_esort_sync_kv(len, [&](uint32_t i) { return Kg[i]; }, [&](uint32_t i) { return Vg[i]; }, pool, s_stab, K2 + sg.first, V2 + sg.first,
+            lds_esort_sync_kv<false>(len, [&](uint32_t i) { return Kg[i]; }, [&](uint32_t i) { return Vg[i]; }, pool, s_stab, K2 + sg.first, V2 + sg.first,
                               &ctr->n_sort_fallback, dbg ? s_stamps : nullptr, sg.depth);
             if (dbg && threadIdx.x == 0) {  // diagnostics: keep the stamps of the slowest segment
                 const unsigned long long dur = clock64() - t_a;
@@ -2327,7 +2418,8 @@ __global__ __launch_bounds__(1024) void k_srt(DP P, const uint32_t *__restrict__
 // together), the first-pass status lives in LDS, and the reverted list needs two block scans in all.  This kernel sits on
 // the main stream's dependency chain, where the general variant's nine dependent rounds of global accesses cost 20 us.
 static constexpr int SRT_KPT = 4;
-__global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict__ mcnt, const float *__restrict__ mmin,
+template <class S1P>
+__device__ __forceinline__ void srt4_body(const DP &P, uint32_t *sm, S1P s_st1, const uint32_t *__restrict__ mcnt, const float *__restrict__ mmin,
                                                 const float *__restrict__ mmax, const uint32_t *__restrict__ ccnt,
                                                 const float *__restrict__ cmin, const float *__restrict__ cmax, uint8_t *__restrict__ st1,
                                                 uint8_t *__restrict__ status, uint8_t *__restrict__ action, uint32_t *__restrict__ rev_idx,
@@ -2339,9 +2431,11 @@ __global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict_
                                                 uint32_t *__restrict__ crej_off,
                                                 // v3: the first pass has been done bin by bin in k_bin_stats_srt (status | 0x80 if the map bin is taller
                                                 // than 0.5 m); nullptr: done here
-                                                const uint8_t *__restrict__ st1_in) {
-    __shared__ uint32_t sm[40];
-    __shared__ uint8_t s_st1[1024 * SRT_KPT];
+                                                const uint8_t *__restrict__ st1_in,
+                                                // fused launch (k_revert_bins_srt): a reverted bin's share of the voxel scratch begins at
+                                                // moff[key] + qoff[key] (disjoint ranges of mc + cc entries, like the prefix of capacities, but
+                                                // a per-bin workgroup knows it without a scan); nullptr: the prefix
+                                                const uint32_t *__restrict__ moff_pos = nullptr, const uint32_t *__restrict__ qoff_pos = nullptr) {
     const int B = P.B;
     const int k0 = threadIdx.x * SRT_KPT;
     BinStat bs[SRT_KPT];
@@ -2377,7 +2471,7 @@ __global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict_
         act[j] = 0;
         if (k0 + j < B) {
             uint8_t fs;
-            srt_second(P, k0 + j, bs[j], s_st1[k0 + j], (const uint8_t *)s_st1, fs, act[j]);
+            srt_second(P, k0 + j, bs[j], s_st1[k0 + j], s_st1, fs, act[j]);
             status[k0 + j] = fs;
             action[k0 + j] = act[j];
             if (act[j] == 1) {
@@ -2396,7 +2490,7 @@ __global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict_
             rev_idx[k0 + j] = rv ? p0 : 0xFFFFFFFFu;
             if (rv) {
                 rev_list[p0] = (uint32_t)(k0 + j);
-                vox_off[p0] = p1;
+                vox_off[p0] = moff_pos ? moff_pos[k0 + j] + qoff_pos[k0 + j] : p1;
                 ++p0;
                 p1 += bs[j].mc + bs[j].cc;
             }
@@ -2442,6 +2536,57 @@ __global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict_
             st->n_curr_rejected = t3;
         }
     }
+}
+__global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict__ mcnt, const float *__restrict__ mmin,
+                                                const float *__restrict__ mmax, const uint32_t *__restrict__ ccnt,
+                                                const float *__restrict__ cmin, const float *__restrict__ cmax, uint8_t *__restrict__ st1,
+                                                uint8_t *__restrict__ status, uint8_t *__restrict__ action, uint32_t *__restrict__ rev_idx,
+                                                uint32_t *__restrict__ rev_list, uint32_t *__restrict__ vox_off, DevState *st,
+                                                uint32_t *__restrict__ out_off0, uint32_t *__restrict__ rev_before,
+                                                uint32_t *__restrict__ crej_off, const uint8_t *__restrict__ st1_in) {
+    __shared__ uint32_t sm[40];
+    __shared__ uint8_t s_st1[1024 * SRT_KPT];
+    srt4_body(P, sm, s_st1, mcnt, mmin, mmax, ccnt, cmin, cmax, st1, status, action, rev_idx, rev_list, vox_off, st, out_off0, rev_before, crej_off,
+              st1_in);
+}
+
+// Round 4: which bin is entry `rk` of the reverted list -- WITHOUT the list.  In v3 a bin is reverted iff its first-pass status
+// (k_bin_stats_srt: st1b) is MAP_IS_HIGHER and the map bin is taller than 0.5 m (erasor.cpp:510-511): a decision local to the bin.  Every
+// workgroup of the fused per-bin launch therefore finds its own bin from the 2160 status bytes (every thread owns SRT_KPT consecutive
+// bins, two block scans) while ONE extra workgroup of the same launch does k_srt4's work for the kernels behind it (status / action /
+// layout prefixes): the Scan Ratio Test's second pass leaves the main stream's dependency chain (14 us + a kernel boundary).
+// sel[0] = bin key, sel[2] = number of reverted bins (the bin's share of the voxel scratch begins at moff[key] + qoff[key]).
+__shared__ uint32_t g_sel[4];
+__shared__ uint32_t g_selsm[40];
+// (out of line, like the sort: a register allocation of its own instead of a share of the per-bin kernel's 128 VGPRs)
+__device__ __attribute__((noinline)) void rev_select_call(int B, const uint8_t *__restrict__ st1b, uint32_t rk) {
+    uint32_t *sm = g_selsm, *sel = g_sel;
+    const int k0 = threadIdx.x * SRT_KPT;
+    uint32_t rvm = 0;
+    if (k0 < B) {
+        uint32_t w = 0;
+        if (k0 + SRT_KPT <= B) w = *reinterpret_cast<const uint32_t *>(st1b + k0);  // (k0 is a multiple of four: one aligned load)
+        else
+            for (int j = 0; k0 + j < B; ++j) w |= (uint32_t)st1b[k0 + j] << (8 * j);
+#pragma unroll
+        for (int j = 0; j < SRT_KPT; ++j) {
+            const uint32_t v = (w >> (8 * j)) & 0xFFu;
+            if (k0 + j < B && (v & 0x7Fu) == ST_MAP && (v & 0x80u)) rvm |= 1u << j;
+        }
+    }
+    const uint32_t nrv = (uint32_t)__popc(rvm);
+    uint32_t t0;
+    uint32_t p0 = block_excl_scan(nrv, sm, t0);
+    if (threadIdx.x == 0) sel[2] = t0;
+    if (rk >= p0 && rk < p0 + nrv) {
+#pragma unroll
+        for (int j = 0; j < SRT_KPT; ++j)
+            if ((rvm >> j) & 1u) {
+                if (p0 == rk) sel[0] = (uint32_t)(k0 + j);
+                ++p0;
+            }
+    }
+    __syncthreads();
 }
 
 // ================================================================================================
@@ -2740,301 +2885,6 @@ __device__ __forceinline__ void rgpf_after_sort(const DP &P, const float4 *__res
     if (tid == 0) ng_out[rk] = ng;
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_rgpf2: R-GPF over the reverted-bin LIST (a small fixed grid; bin r of the list is handled by workgroup r mod grid),
-// bins of <= RG_LMAX points entirely in LDS:
-//   * z-sort: the reference's std::sort (erasor.cpp:240) is unstable and float32 z values of a bin DO collide (a few
-//     ties per thousand points), so the tie order matters for the float32 covariance sums: the exact introsort
-//     emulation (esort::block_esort) cannot be replaced by a plain parallel sort;
-//   * the bin's x / y / z are staged in LDS once; plane-fit products go to LDS rows padded to 1028 floats (nine lanes read
-//     nine different banks with 128-bit loads) and are added strictly in list order by lane a of wave 0;
-//   * classification: every thread owns strided points, ONE table scan per iteration instead of one block scan per 1024.
-// Larger bins take the global-memory path (rgpf_after_sort on global scratch, same arithmetic).
-// ------------------------------------------------------------------------------------------------
-static constexpr uint32_t RG_RS = RG_CH + 4;  // padded row stride of the product rows (floats)
-
-__device__ __forceinline__ float key_to_float(uint32_t k) {  // inverse of esort::float_key (-0 comes back as +0)
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
-}
-
-// ---- the level-synchronous sort of the per-bin stages, OUT OF LINE (round 3) ----
-// Inlined into the per-bin kernels (four copies: one and two keys per thread, two stages) the sort shared a register allocation with
-// everything around it, and these kernels are capped at 128 VGPRs by their 1024 threads: values that are live across the sort were
-// spilled and RELOADED INSIDE ITS LEVEL LOOP (16 / 13 scratch loads per level, each a memory round trip on a chain that is nothing but
-// round trips).  As a function of its own the sort has the allocation it has in k_esort_final -- no scratch at all -- and what is live
-// around the call is saved once per call.  The pool is file-scope LDS so that the function sees LDS arrays, not generic pointers
-// (ds_* instead of flat_* instructions); the caller leaves the (key, index) pairs in the pool's first 2 * n words, the sorted keys /
-// indices come back in words [2 * RG_LMAX, ...) / [3 * RG_LMAX, ...) (the callers' sL / sR).
-__shared__ uint32_t g_rev_pool[4 * RG_LMAX];
-__shared__ uint32_t g_sync_stab[68];
-static_assert(4 * RG_LMAX == 8 * ESYNC_MAX, "the per-bin pool is exactly lds_esort_sync_kv's layout");
-__device__ __attribute__((noinline)) void lds_esort_sync_call(uint32_t n, uint32_t *n_fallback, unsigned long long *tstamp) {
-    uint32_t *pool = g_rev_pool;
-    const uint2 *sKV = reinterpret_cast<const uint2 *>(pool);
-    lds_esort_sync_kv(n, [&](uint32_t i) { return sKV[i].x; }, [&](uint32_t i) { return sKV[i].y; }, pool, g_sync_stab, pool + 2 * RG_LMAX,
-                      pool + 3 * RG_LMAX, n_fallback, tstamp);
-}
-
-// The workgroup's two large LDS buffers come from the caller: `pool` (4 * RG_LMAX words: sort phase K | V | posL | posR or
-// lds_esort_sync's layout; fit phase glist | X | Y | Z) and `sProd` (9 * RG_RS floats, 16-byte aligned), so that the fused kernel
-// (k_revert_bins) can hand the same storage to the per-bin voxelisation afterwards.  Bins rk0, rk0 + rk_step, ... of the list.
-__device__ __forceinline__ void rgpf_bins(const DP &P, uint32_t rk0, uint32_t rk_step, const uint32_t *__restrict__ rev_list,
-                                          const DevState *__restrict__ st, const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
-                                          uint32_t *gsK, uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
-                                          uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
-                                          uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d, Counters *ctr,
-                                          unsigned long long *dbg, uint32_t *pool, float *sProd) {
-    __shared__ uint32_t sH[RG_LMAX / 32 + 2];
-    __shared__ esort::Seg qa[RG_LMAX / 16 + 2], qb[RG_LMAX / 16 + 2];
-    __shared__ uint32_t qcnt[2];
-    __shared__ uint32_t sm[40];
-    __shared__ float s_n[3];
-    __shared__ double s_th, s_lpr;
-    __shared__ uint32_t s_carry;
-    __shared__ uint32_t s_tab[64];
-    __shared__ unsigned long long s_t[12];
-    __shared__ unsigned long long s_es[24];  // diagnostics: block_esort's own stamps (shader clock)
-#define RG_STAMP(i) do { if (dbg && tid == 0) s_t[i] = wall_clock64(); } while (0)
-    uint32_t *sK = pool, *sV = pool + RG_LMAX, *sL = pool + 2 * RG_LMAX, *sR = pool + 3 * RG_LMAX;
-    const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = bs >> 6;
-    const uint32_t n_rev = st->n_rev;
-    for (uint32_t rk = rk0; rk < n_rev; rk += rk_step) {
-        const uint32_t key = rev_list[rk];
-        const uint32_t o0 = moff[key], M = moff[key + 1] - o0;
-        const float4 *pts = spts + o0;
-        __syncthreads();  // LDS of the previous bin is dead
-        if (M > RG_LMAX) {  // rare: the bin does not fit LDS -> global scratch, same arithmetic (rgpf_after_sort)
-            uint32_t *K = gsK + o0, *V = gsV + o0;
-            for (uint32_t i = tid; i < M; i += bs) {
-                K[i] = esort::float_key(__float_as_uint(pts[i].z));
-                V[i] = i;
-            }
-            __threadfence_block();
-            __syncthreads();
-            esort::block_esort(K, V, gsL + o0, gsR + o0, gsH + (o0 >> 5) + 2 * key, gsK2 + o0, gsV2 + o0, 0u, M, 2 * esort::lg2_floor(M), qa, qb,
-                               qcnt, (uint32_t)(RG_LMAX / 16 + 2), &ctr->n_sort_fallback, &ctr->sort_qoverflow);
-            __threadfence_block();
-            __syncthreads();
-            rgpf_after_sort(P, pts, M, o0, rk, gsV2 + o0, K, sm, sProd, s_n, &s_th, &s_lpr, &s_carry, gflag, grank, glist_out, ng_out, plane_n,
-                            plane_d, ctr);
-            continue;
-        }
-        const unsigned long long t_a = dbg ? wall_clock64() : 0ull;
-        // ---- (1) std::sort(src_copy, point_cmp), erasor.cpp:239-240: exact introsort emulation in LDS ----
-        if (M <= ESYNC_MAX && M <= 2 * bs) {  // level-synchronous over the whole workgroup (the common case)
-            RG_STAMP(0);
-            if (dbg && tid < 24) s_es[tid] = 0;
-            {   // (key, bin-local index) pairs into the pool, then the out-of-line sort (each thread reads back what it wrote)
-                uint2 *sKV = reinterpret_cast<uint2 *>(pool);
-                for (uint32_t i = tid; i < M; i += bs) sKV[i] = make_uint2(esort::float_key(__float_as_uint(pts[i].z)), i);
-                lds_esort_sync_call(M, &ctr->n_sort_fallback, dbg ? s_es : nullptr);
-            }
-        } else {
-            for (uint32_t i = tid; i < M; i += bs) {
-                sK[i] = esort::float_key(__float_as_uint(pts[i].z));
-                sV[i] = i;
-            }
-            __syncthreads();
-            RG_STAMP(0);
-            if (dbg && tid < 24) s_es[tid] = 0;
-            esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, M, 2 * esort::lg2_floor(M), qa, qb, qcnt, (uint32_t)(RG_LMAX / 16 + 2),
-                               &ctr->n_sort_fallback, &ctr->sort_qoverflow, dbg ? s_es : nullptr);
-        }
-        RG_STAMP(1);
-        // sorted keys in sL, sorted bin-local indices in sR
-        uint32_t drop = 0, ng = 0;
-        {
-            // --- drop leading z < min_h (erasor.cpp:242-251); monotone in sorted order ---
-            uint32_t cnt = 0;
-            for (uint32_t k = tid; k < M; k += bs) cnt += ((double)key_to_float(sL[k]) < P.min_h) ? 1u : 0u;
-            uint32_t tot;
-            block_excl_scan(cnt, sm, tot);
-            drop = tot;
-            const uint32_t Ms = M - drop;
-            // --- extract_initial_seeds_ (erasor.cpp:204-231) ---
-            if (tid == 0) {
-                uint32_t cl = 0;
-                if (P.num_lowest >= 0 && Ms > (uint32_t)P.num_lowest && P.gf_lpr > 0) cl = min((uint32_t)P.gf_lpr, Ms - (uint32_t)P.num_lowest);
-                double sum = 0;
-                for (uint32_t t = 0; t < cl; ++t) sum += (double)key_to_float(sL[drop + (uint32_t)P.num_lowest + t]);
-                s_lpr = cl != 0 ? sum / (int)cl : 0;
-            }
-            __syncthreads();
-            const double seed_thr = s_lpr + P.gf_seeds_h;
-            cnt = 0;
-            for (uint32_t k = tid; k < Ms; k += bs) cnt += ((double)key_to_float(sL[drop + k]) < seed_thr) ? 1u : 0u;
-            block_excl_scan(cnt, sm, tot);
-            ng = tot;  // seeds = the first ng of the sorted points (the predicate is monotone in z)
-        }
-        const unsigned long long t_b = dbg ? wall_clock64() : 0ull;
-        // ---- (2) ground list <- seeds; stage the bin's coordinates in LDS ----
-        uint32_t *glist = sK;
-        for (uint32_t k = tid; k < ng; k += bs) glist[k] = sR[drop + k];
-        __syncthreads();  // sV / sL / sR are dead from here on
-        float *X = reinterpret_cast<float *>(sV), *Y = reinterpret_cast<float *>(sL), *Z = reinterpret_cast<float *>(sR);
-        for (uint32_t i = tid; i < M; i += bs) {
-            const float4 q = pts[i];
-            X[i] = q.x;
-            Y[i] = q.y;
-            Z[i] = q.z;
-        }
-        __syncthreads();
-        RG_STAMP(2);
-        const uint32_t E = (M + bs - 1) / bs;  // points per thread in the classification (<= 4)
-        for (int it = 0; it < P.gf_iter; ++it) {
-            // --- estimate_plane_: pcl::computeMeanAndCovarianceMatrix, nine float32 accumulators in list order ---
-            float acc = 0.f;
-            for (uint32_t cb = 0; cb < ng; cb += RG_CH) {
-                const uint32_t cn = min(RG_CH, ng - cb);
-                for (uint32_t t = tid; t < cn; t += bs) {
-                    const uint32_t gi = glist[cb + t];
-                    const float x = X[gi], y = Y[gi], z = Z[gi];
-                    sProd[0 * RG_RS + t] = x * x;
-                    sProd[1 * RG_RS + t] = x * y;
-                    sProd[2 * RG_RS + t] = x * z;
-                    sProd[3 * RG_RS + t] = y * y;
-                    sProd[4 * RG_RS + t] = y * z;
-                    sProd[5 * RG_RS + t] = z * z;
-                    sProd[6 * RG_RS + t] = x;
-                    sProd[7 * RG_RS + t] = y;
-                    sProd[8 * RG_RS + t] = z;
-                }
-                __syncthreads();
-                if (wave == 0 && lane < 9) {
-                    const float4 *row4 = reinterpret_cast<const float4 *>(sProd + lane * RG_RS);
-                    const uint32_t c4 = cn >> 2;
-#pragma unroll 4
-                    for (uint32_t k = 0; k < c4; ++k) {
-                        const float4 v = row4[k];
-                        acc += v.x;
-                        acc += v.y;
-                        acc += v.z;
-                        acc += v.w;
-                    }
-                    const float *row = sProd + lane * RG_RS;
-                    for (uint32_t k = c4 << 2; k < cn; ++k) acc += row[k];
-                }
-                __syncthreads();
-            }
-            if (it == 0) RG_STAMP(3);
-            if (wave == 0) {
-                float a[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) a[k] = __shfl(acc, k, 64);
-                if (lane == 0) {
-                    float cov[9], mean[3], U[9], sv[3];
-                    if (ng == 0) {
-                        for (int k = 0; k < 9; ++k) cov[k] = 0.f;
-                        mean[0] = mean[1] = mean[2] = 0.f;
-                        atomicAdd(&ctr->n_degenerate, 1u);
-                    } else {
-                        const float fn = (float)ng;
-                        for (int k = 0; k < 9; ++k) a[k] /= fn;
-                        mean[0] = a[6];
-                        mean[1] = a[7];
-                        mean[2] = a[8];
-                        cov[0] = a[0] - a[6] * a[6];
-                        cov[1] = a[1] - a[6] * a[7];
-                        cov[2] = a[2] - a[6] * a[8];
-                        cov[4] = a[3] - a[7] * a[7];
-                        cov[5] = a[4] - a[7] * a[8];
-                        cov[8] = a[5] - a[8] * a[8];
-                        cov[3] = cov[1];
-                        cov[6] = cov[2];
-                        cov[7] = cov[5];
-                    }
-                    jacobi_svd3(cov, U, sv);
-                    const float n0 = U[2], n1 = U[5], n2_ = U[8];
-                    const float dot = (n0 * mean[0] + n1 * mean[1]) + n2_ * mean[2];
-                    const double d = -dot;
-                    s_n[0] = n0;
-                    s_n[1] = n1;
-                    s_n[2] = n2_;
-                    s_th = P.gf_dist - d;
-                    plane_n[((size_t)rk * P.gf_iter + it) * 3 + 0] = n0;
-                    plane_n[((size_t)rk * P.gf_iter + it) * 3 + 1] = n1;
-                    plane_n[((size_t)rk * P.gf_iter + it) * 3 + 2] = n2_;
-                    plane_d[(size_t)rk * P.gf_iter + it] = d;
-                }
-            }
-            __syncthreads();
-            if (it == 0) RG_STAMP(4);
-            // --- points * normal_ < th_dist_d_ in source order (erasor.cpp:265-281) ---
-            const float n0 = s_n[0], n1 = s_n[1], n2_ = s_n[2];
-            const double th = s_th;
-            const bool last = it == P.gf_iter - 1;
-            // point i = e * bs + tid; per (e, wave) ground counts -> one 64-entry table scan gives every wave its offset
-            uint64_t bal[4];
-#pragma unroll
-            for (uint32_t e = 0; e < 4; ++e) {
-                bool g = false;
-                const uint32_t i = e * bs + tid;
-                if (e < E && i < M) {
-                    const float res = (X[i] * n0 + Y[i] * n1) + Z[i] * n2_;
-                    g = (double)res < th;
-                }
-                bal[e] = __ballot(g);
-                if (lane == 0) s_tab[e * 16 + wave] = (e < E && wave < nw) ? (uint32_t)__popcll(bal[e]) : 0u;
-            }
-            __syncthreads();
-            if (wave == 0) {  // exclusive scan of the 64 (e-major, wave-minor) counts
-                const uint32_t v = s_tab[lane];
-                const uint32_t inc = esort::wave_incl_scan(v);  // (DPP row shifts)
-                s_tab[lane] = inc - v;
-                if (lane == 63) s_carry = inc;
-            }
-            __syncthreads();
-            const uint64_t lt = lanemask_lt();
-#pragma unroll
-            for (uint32_t e = 0; e < 4; ++e) {
-                const uint32_t i = e * bs + tid;
-                if (e < E && i < M) {
-                    const bool g = (bal[e] >> lane) & 1ull;
-                    const uint32_t gr = s_tab[e * 16 + wave] + (uint32_t)__popcll(bal[e] & lt);  // rank among the ground points
-                    if (g) glist[gr] = i;
-                    if (last) {
-                        gflag[o0 + i] = g ? 1 : 0;
-                        grank[o0 + i] = g ? gr : (i - gr);  // rank among ground / among rejected
-                    }
-                }
-            }
-            ng = s_carry;
-            __syncthreads();
-            if (it == 0) RG_STAMP(5);
-        }
-        for (uint32_t k = tid; k < ng; k += bs) glist_out[o0 + k] = glist[k];
-        if (tid == 0) ng_out[rk] = ng;
-        if (dbg && tid == 0) {  // diagnostics (ERASOR_HIP_SORT_STAMPS): the slowest bin's split between the z-sort and the rest, 10 ns ticks
-            const unsigned long long t_c = wall_clock64();
-            if (atomicMax(&dbg[16], t_c - t_a) < t_c - t_a) {
-                dbg[17] = t_b - t_a;
-                dbg[18] = t_c - t_b;
-                dbg[19] = M;
-                dbg[32] = s_t[0] - t_a;   // key load
-                dbg[33] = s_t[1] - s_t[0];  // exact sort
-                dbg[34] = t_b - s_t[1];   // seeds
-                dbg[35] = s_t[2] - t_b;   // staging
-                dbg[36] = s_t[3] - s_t[2];  // covariance sums (iteration 0)
-                dbg[37] = s_t[4] - s_t[3];  // SVD
-                dbg[38] = s_t[5] - s_t[4];  // classification
-                dbg[39] = ng;
-                for (int i = 0; i < 24; ++i) dbg[40 + i] = s_es[i];
-            }
-        }
-    }
-#undef RG_STAMP
-}
-__global__ __launch_bounds__(1024) void k_rgpf2(DP P, const uint32_t *__restrict__ rev_list, const DevState *__restrict__ st,
-                                                const uint32_t *__restrict__ moff, const float4 *__restrict__ spts, uint32_t *gsK,
-                                                uint32_t *gsV, uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2,
-                                                uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *__restrict__ glist_out,
-                                                uint32_t *__restrict__ ng_out, float *__restrict__ plane_n, double *__restrict__ plane_d,
-                                                Counters *ctr, unsigned long long *dbg) {
-    __shared__ __attribute__((aligned(16))) float sProd[9 * RG_RS];
-    rgpf_bins(P, blockIdx.x, gridDim.x, rev_list, st, moff, spts, gsK, gsV, gsL, gsR, gsH, gsK2, gsV2, gflag, grank, glist_out, ng_out, plane_n,
-              plane_d, ctr, dbg, g_rev_pool, sProd);
-}
-
 // ================================================================================================
 // per-bin voxelize_preserving_labels(curr points + reverted ground, /erasor/map_voxel_size) —
 // erasor.cpp:523-528.  One workgroup per reverted bin.
@@ -3172,340 +3022,7 @@ __device__ __forceinline__ void binvox_core(const DP &P, uint32_t m, uint32_t nc
     if (tid == 0) *nvox_slot = nv;
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_binvox2: per-bin voxelisation over the reverted-bin LIST, clouds of <= BV2_LMAX points entirely in LDS.
-// VoxelGrid's std::sort has equal keys by construction (the points of a voxel), so the exact introsort emulation stays;
-// what changed against round 1 (one workgroup of a num_bins-sized grid per bin, 2048 points in LDS, every centroid x every point): (i) twice the LDS-resident size, (ii) run heads through one table scan, (iii) the exact
-// 1-NN label search walks the voxel grid (own cell, then shells of neighbour cells found by binary search in the sorted
-// unique keys, pruned by conservative cell bounds) instead of testing every centroid against every input point —
-// the result is the same minimum over (distance, index) pairs.
-// ------------------------------------------------------------------------------------------------
-static constexpr uint32_t BV2_LMAX = 4096;
-
-// (`pool`: 4 * BV2_LMAX words -- K | V | posL (-> sorted keys) | posR (-> sorted indices); after the sort K -> unique keys, V -> run
-// begins -- and `sC`: BV2_LMAX points, both from the caller, see rgpf_bins)
-__device__ __forceinline__ void binvox_bins(const DP &P, uint32_t rk0, uint32_t rk_step, const uint32_t *__restrict__ rev_list,
-                                            const DevState *__restrict__ st, const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
-                                            const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq, const uint32_t *__restrict__ glist,
-                                            const uint32_t *__restrict__ ng_arr, const uint32_t *__restrict__ vox_off, uint32_t *gsK, uint32_t *gsV,
-                                            uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
-                                            float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr, unsigned long long *dbg,
-                                            uint32_t *pool, float4 *sC) {
-    __shared__ uint32_t sH[BV2_LMAX / 32 + 2];
-    __shared__ esort::Seg qa2[BV2_LMAX / 16 + 2], qb2[BV2_LMAX / 16 + 2];
-    __shared__ uint32_t qcnt[2];
-    __shared__ uint32_t sm[40];
-    __shared__ uint32_t sbb[6];
-    __shared__ uint32_t s_carry;
-    __shared__ uint32_t s_tab[64];
-    uint32_t *sK = pool, *sV = pool + BV2_LMAX, *sL = pool + 2 * BV2_LMAX, *sR = pool + 3 * BV2_LMAX;
-    const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = bs >> 6;
-    const uint32_t n_rev = st->n_rev;
-    for (uint32_t rk = rk0; rk < n_rev; rk += rk_step) {
-        const uint32_t key = rev_list[rk];
-        const uint32_t mo = moff[key], qo = qoff[key];
-        const uint32_t nc = qoff[key + 1] - qo, ngr = ng_arr[rk];
-        const uint32_t m = nc + ngr;
-        __syncthreads();  // LDS of the previous bin is dead
-        if (nc == 0) {  // selected = bin_curr with is_occupied == false: r_pod2pc skips the bin
-            if (tid == 0) nvox_out[rk] = 0;
-            continue;
-        }
-        const uint32_t vo = vox_off[rk];
-        const unsigned long long t_a = dbg ? wall_clock64() : 0ull;
-        if (m > BV2_LMAX) {  // rare: global scratch, brute-force search (binvox_core)
-            esort::Seg *qa = qa2, *qb = qb2;
-            binvox_core(P, m, nc, sq + qo, spts + mo, glist + mo, gsK + vo, gsV + vo, gsK2 + vo, gsV2 + vo, gsC + vo, gsL + vo, gsR + vo,
-                        gsH + (vo >> 5) + 2 * rk, qa, qb, qcnt, sm, sbb, &s_carry, vox_out + vo, nvox_out + rk, ctr);
-            continue;
-        }
-        const float4 *sqb = sq + qo, *sptb = spts + mo;
-        const uint32_t *glb = glist + mo;
-        float4 *vout = vox_out + vo;
-        // input cloud of this call: curr bin points (scan order) then the reverted ground (source order)
-        for (uint32_t j = tid; j < m; j += bs) sC[j] = j < nc ? sqb[j] : sptb[glb[j - nc]];
-        if (tid < 3) sbb[tid] = 0xFFFFFFFFu;
-        if (tid >= 3 && tid < 6) sbb[tid] = 0u;
-        __syncthreads();
-        {
-            uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
-            for (uint32_t j = tid; j < m; j += bs) {
-                const float4 p = sC[j];
-                const uint32_t k3[3] = {fkey_ord(p.x), fkey_ord(p.y), fkey_ord(p.z)};
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    mn[a] = k3[a] < mn[a] ? k3[a] : mn[a];
-                    mx[a] = k3[a] > mx[a] ? k3[a] : mx[a];
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                mn[a] = wave_minmax_u<false>(mn[a]);
-                mx[a] = wave_minmax_u<true>(mx[a]);
-                if (lane == 0) {
-                    atomicMin(&sbb[a], mn[a]);
-                    atomicMax(&sbb[3 + a], mx[a]);
-                }
-            }
-        }
-        __syncthreads();
-        const float mnf[3] = {fkey_inv(sbb[0]), fkey_inv(sbb[1]), fkey_inv(sbb[2])};
-        const float mxf[3] = {fkey_inv(sbb[3]), fkey_inv(sbb[4]), fkey_inv(sbb[5])};
-        const VoxGrid g = vox_grid_from_bbox(mnf, mxf, P.leaf_map);
-        if (g.overflow) {  // VoxelGrid returns the input unchanged (utils.cpp:88-91); the label search then finds the point itself or
-            // its first exact duplicate (distance 0, lowest index)
-            for (uint32_t j = tid; j < m; j += bs) {
-                const float4 p = sC[j];
-                float label = p.w;
-                for (uint32_t i = 0; i < j; ++i) {
-                    const float4 q = sC[i];
-                    if (q.x == p.x && q.y == p.y && q.z == p.z) {
-                        label = q.w;
-                        break;
-                    }
-                }
-                vout[j] = make_float4(p.x, p.y, p.z, label);
-            }
-            if (tid == 0) {
-                atomicAdd(&ctr->n_voxel_overflow, 1u);
-                nvox_out[rk] = m;
-            }
-            continue;
-        }
-        if (m <= ESYNC_MAX && m <= 2 * bs) {  // level-synchronous over the whole workgroup (the common case)
-            {
-                uint2 *sKV = reinterpret_cast<uint2 *>(pool);
-                for (uint32_t j = tid; j < m; j += bs) {
-                    const float4 p = sC[j];
-                    sKV[j] = make_uint2(vox_index(g, p.x, p.y, p.z), j);
-                }
-                lds_esort_sync_call(m, &ctr->n_sort_fallback, nullptr);
-            }
-        } else {
-            for (uint32_t j = tid; j < m; j += bs) {
-                const float4 p = sC[j];
-                sK[j] = vox_index(g, p.x, p.y, p.z);
-                sV[j] = j;
-            }
-            __syncthreads();
-            esort::block_esort(sK, sV, sL, sR, sH, sL, sR, 0u, m, 2 * esort::lg2_floor(m), qa2, qb2, qcnt, (uint32_t)(BV2_LMAX / 16 + 2),
-                               &ctr->n_sort_fallback, &ctr->sort_qoverflow);
-        }
-        __syncthreads();
-        // ---- run heads: unique keys (ascending) -> sK, run begins -> sV ----
-        const uint32_t E = (m + bs - 1) / bs;
-        uint64_t bal[4];
-#pragma unroll
-        for (uint32_t e = 0; e < 4; ++e) {
-            const uint32_t i = e * bs + tid;
-            const bool hd = e < E && i < m && (i == 0 || sL[i] != sL[i - 1]);
-            bal[e] = __ballot(hd);
-            if (lane == 0) s_tab[e * 16 + wave] = (wave < nw) ? (uint32_t)__popcll(bal[e]) : 0u;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            const uint32_t v = s_tab[lane];
-            const uint32_t inc = esort::wave_incl_scan(v);  // (DPP row shifts)
-            s_tab[lane] = inc - v;
-            if (lane == 63) s_carry = inc;
-        }
-        __syncthreads();
-        {
-            const uint64_t lt = lanemask_lt();
-#pragma unroll
-            for (uint32_t e = 0; e < 4; ++e) {
-                const uint32_t i = e * bs + tid;
-                if ((bal[e] >> lane) & 1ull) {
-                    const uint32_t v = s_tab[e * 16 + wave] + (uint32_t)__popcll(bal[e] & lt);
-                    sK[v] = sL[i];
-                    sV[v] = i;
-                }
-            }
-        }
-        const uint32_t nv = s_carry;
-        __syncthreads();
-        // ---- per voxel: CentroidPoint float sums in sorted order, then the exact 1-NN label (utils.cpp:94-112) ----
-        const int dx = g.div_b[0], dy = g.div_b[1], dz = g.div_b[2];
-        const double L = 1.0 / (double)g.inv_leaf;
-        const int maxrho = max(dx, max(dy, dz));
-        for (uint32_t v0 = 0; v0 < nv; v0 += bs / NN_SUB) {
-            const uint32_t v = v0 + tid / NN_SUB, sub = tid & (NN_SUB - 1);
-            if (v >= nv) continue;  // (the eight lanes of a voxel take the same branch; no barrier inside this loop)
-            const uint32_t rs = sV[v], re = (v + 1 < nv) ? sV[v + 1] : m;
-            float sx = 0.f, sy = 0.f, sz = 0.f;
-            uint32_t li = rs;
-            for (; li + 3 < re; li += 4) {  // four points' two dependent LDS reads in flight at a time; the additions keep their order
-                const uint32_t i0 = sR[li], i1 = sR[li + 1], i2 = sR[li + 2], i3 = sR[li + 3];
-                const float4 p0 = sC[i0], p1 = sC[i1], p2 = sC[i2], p3 = sC[i3];
-                sx += p0.x; sy += p0.y; sz += p0.z;
-                sx += p1.x; sy += p1.y; sz += p1.z;
-                sx += p2.x; sy += p2.y; sz += p2.z;
-                sx += p3.x; sy += p3.y; sz += p3.z;
-            }
-            for (; li < re; ++li) {  // (the averaged intensity is overwritten by the nearest input point's label)
-                const float4 p = sC[sR[li]];
-                sx += p.x;
-                sy += p.y;
-                sz += p.z;
-            }
-            const float fc = (float)(re - rs);
-            const float cx = sx / fc, cy = sy / fc, cz = sz / fc;
-            const uint32_t vkey = sK[v];
-            const int ci = (int)(vkey % (uint32_t)dx), cj = (int)((vkey / (uint32_t)dx) % (uint32_t)dy), ck = (int)(vkey / ((uint32_t)dx * (uint32_t)dy));
-            const double cc[3] = {(double)cx, (double)cy, (double)cz};
-            const int cidx[3] = {ci, cj, ck};
-            float best = __int_as_float(0x7F800000);
-            uint32_t best_i = 0xFFFFFFFFu;
-            for (uint32_t li = rs + sub; li < re; li += NN_SUB) {  // stage 0: the voxel's own points
-                const uint32_t pi = sR[li];
-                const float4 p = sC[pi];
-                nn_take(l2_simple(cx, cy, cz, p.x, p.y, p.z), pi, best, best_i);
-            }
-            nn_merge(best, best_i);
-            bool done = false;
-            {
-                double gmin = 1e300;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const double lo = (double)(g.min_b[a] + cidx[a]) * L;
-                    const double hi = (double)(g.min_b[a] + cidx[a] + 1) * L;
-                    const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
-                    gmin = fmin(gmin, fmin(cc[a] - lo, hi - cc[a]) - margin);
-                }
-                done = (gmin > 0.0 && (double)best <= gmin * gmin);
-            }
-            // one cell of a shell: pruned by its squared distance d2c from the centroid, found by binary search in the ascending
-            // unique keys, its points taken
-            auto visit = [&](int ii, int jj, int kk, double d2c, float shell_best) {
-                if (d2c > (double)shell_best) return;
-                const uint32_t q = (uint32_t)ii + (uint32_t)jj * (uint32_t)dx + (uint32_t)kk * (uint32_t)dx * (uint32_t)dy;
-                uint32_t lo = 0, hi = nv;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (sK[mid] < q) lo = mid + 1;
-                    else hi = mid;
-                }
-                if (lo >= nv || sK[lo] != q) return;  // empty cell
-                const uint32_t ws = sV[lo], we = (lo + 1 < nv) ? sV[lo + 1] : m;
-                for (uint32_t li = ws; li < we; ++li) {
-                    const uint32_t pi = sR[li];
-                    const float4 p = sC[pi];
-                    nn_take(l2_simple(cx, cy, cz, p.x, p.y, p.z), pi, best, best_i);
-                }
-            };
-            auto slab_d2 = [&](int a, int cell_a) -> double {
-                const double lo_a = (double)(g.min_b[a] + cell_a) * L, hi_a = (double)(g.min_b[a] + cell_a + 1) * L;
-                const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
-                const double da = fmax(0.0, fmax(lo_a - cc[a], cc[a] - hi_a) - margin);
-                return da * da;
-            };
-            for (int rho = 1; !done; ++rho) {
-                const float shell_best = best;
-                if (rho == 1) {  // (the first shell by cell number, slab distances from a 3 x 3 table: see k_query_nn)
-                    double tab[3][3];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a)
-#pragma unroll
-                        for (int o = 0; o < 3; ++o) tab[a][o] = slab_d2(a, cidx[a] + o - 1);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = (int)sub + 8 * r;
-                        const int oi = n % 3, oj = (n / 3) % 3, ok = n / 9;
-                        const int ii = ci + oi - 1, jj = cj + oj - 1, kk = ck + ok - 1;
-                        if (n >= 27 || n == 13 || ii < 0 || ii >= dx || jj < 0 || jj >= dy || kk < 0 || kk >= dz) continue;
-                        double d2c = 0.0;
-                        d2c += oi == 0 ? tab[0][0] : (oi == 1 ? tab[0][1] : tab[0][2]);
-                        d2c += oj == 0 ? tab[1][0] : (oj == 1 ? tab[1][1] : tab[1][2]);
-                        d2c += ok == 0 ? tab[2][0] : (ok == 1 ? tab[2][1] : tab[2][2]);
-                        visit(ii, jj, kk, d2c, shell_best);
-                    }
-                } else {
-                    uint32_t turn = 0;
-                    for (int kk = ck - rho; kk <= ck + rho; ++kk) {
-                        if (kk < 0 || kk >= dz) continue;
-                        for (int jj = cj - rho; jj <= cj + rho; ++jj) {
-                            if (jj < 0 || jj >= dy) continue;
-                            const bool shell_jk = (abs(jj - cj) == rho) || (abs(kk - ck) == rho);
-                            for (int ii = ci - rho; ii <= ci + rho; ++ii) {
-                                if (ii < 0 || ii >= dx) continue;
-                                if (!shell_jk && abs(ii - ci) < rho) continue;
-                                if ((turn++ & (NN_SUB - 1)) != sub) continue;
-                                double d2c = 0.0;
-                                d2c += slab_d2(0, ii);
-                                d2c += slab_d2(1, jj);
-                                d2c += slab_d2(2, kk);
-                                visit(ii, jj, kk, d2c, shell_best);
-                            }
-                        }
-                    }
-                }
-                nn_merge(best, best_i);
-                if (rho >= maxrho) break;
-                double gmin = 1e300;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const double lo = (double)(g.min_b[a] + cidx[a] - rho) * L;
-                    const double hi = (double)(g.min_b[a] + cidx[a] + rho + 1) * L;
-                    const double margin = 1e-3 * L + 1e-6 * fabs(cc[a]);
-                    gmin = fmin(gmin, fmin(cc[a] - lo, hi - cc[a]) - margin);
-                }
-                if (best_i != 0xFFFFFFFFu && gmin > 0.0 && (double)best <= gmin * gmin) break;
-            }
-            if (sub == 0) vout[v] = make_float4(cx, cy, cz, sC[best_i < m ? best_i : 0u].w);
-        }
-        if (tid == 0) nvox_out[rk] = nv;
-        if (dbg && tid == 0) {
-            const unsigned long long t_c = wall_clock64();
-            if (atomicMax(&dbg[20], t_c - t_a) < t_c - t_a) {
-                dbg[21] = m;
-                dbg[22] = nv;
-            }
-        }
-    }
-}
-__global__ __launch_bounds__(1024) void k_binvox2(DP P, const uint32_t *__restrict__ rev_list, const DevState *__restrict__ st,
-                                                  const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
-                                                  const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq,
-                                                  const uint32_t *__restrict__ glist, const uint32_t *__restrict__ ng_arr,
-                                                  const uint32_t *__restrict__ vox_off, uint32_t *gsK, uint32_t *gsV, uint32_t *gsL,
-                                                  uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
-                                                  float4 *__restrict__ vox_out, uint32_t *__restrict__ nvox_out, Counters *ctr,
-                                                  unsigned long long *dbg) {
-    __shared__ float4 sC[BV2_LMAX];
-    binvox_bins(P, blockIdx.x, gridDim.x, rev_list, st, moff, spts, qoff, sq, glist, ng_arr, vox_off, gsK, gsV, gsL, gsR, gsH, gsK2, gsV2, gsC, vox_out,
-                nvox_out, ctr, dbg, g_rev_pool, sC);
-}
-
-// v3's two per-bin stages in ONE launch (erasor.cpp:521-528: extract_ground, then voxelize_preserving_labels of curr + ground): a
-// workgroup runs R-GPF on its bin and voxelises it right away -- the ground list it has just written is its own, so no kernel boundary
-// is needed in between, and a small bin is through both stages while the largest one is still fitting planes.  The two stages share the
-// workgroup's LDS (64 KB pool + 64 KB for the covariance products / the cloud).
-__global__ __launch_bounds__(1024) void k_revert_bins(DP P, const uint32_t *__restrict__ rev_list, const DevState *__restrict__ st,
-                                                      const uint32_t *__restrict__ moff, const float4 *__restrict__ spts,
-                                                      const uint32_t *__restrict__ qoff, const float4 *__restrict__ sq, uint32_t *gsK, uint32_t *gsV,
-                                                      uint32_t *gsL, uint32_t *gsR, uint32_t *gsH, uint32_t *gsK2, uint32_t *gsV2, float4 *gsC,
-                                                      uint8_t *__restrict__ gflag, uint32_t *__restrict__ grank, uint32_t *glist,
-                                                      uint32_t *ng_arr, float *__restrict__ plane_n, double *__restrict__ plane_d,
-                                                      const uint32_t *__restrict__ vox_off, float4 *__restrict__ vox_out,
-                                                      uint32_t *__restrict__ nvox_out, Counters *ctr, unsigned long long *dbg,
-                                                      // the global-memory paths of the two stages (bins beyond the LDS-resident sizes) index the same
-                                                      // scratch arrays, R-GPF by map offsets, the voxelisation by its own: with both stages in flight in
-                                                      // different workgroups the voxelisation works `vox_base` entries (`h_base` flag words) further up
-                                                      uint32_t vox_base, uint32_t h_base) {
-    static_assert(RG_LMAX == BV2_LMAX && 9 * RG_RS * sizeof(float) <= BV2_LMAX * sizeof(float4), "the two stages share their LDS");
-    __shared__ float4 big[BV2_LMAX];
-    uint32_t *pool = g_rev_pool;
-    const uint32_t n_rev = st->n_rev;
-    for (uint32_t rk = blockIdx.x; rk < n_rev; rk += gridDim.x) {
-        rgpf_bins(P, rk, 0x7FFFFFFFu, rev_list, st, moff, spts, gsK, gsV, gsL, gsR, gsH, gsK2, gsV2, gflag, grank, glist, ng_arr, plane_n, plane_d, ctr,
-                  dbg, pool, reinterpret_cast<float *>(big));
-        __threadfence_block();
-        __syncthreads();  // the bin's ground list and count (global memory, written by this workgroup) are read below
-        binvox_bins(P, rk, 0x7FFFFFFFu, rev_list, st, moff, spts, qoff, sq, glist, ng_arr, vox_off, gsK + vox_base, gsV + vox_base, gsL + vox_base,
-                    gsR + vox_base, gsH + h_base, gsK2 + vox_base, gsV2 + vox_base, gsC, vox_out, nvox_out, ctr, dbg, pool, big);
-        __syncthreads();
-    }
-}
+#include "revert_bins.hip.h"
 
 // ================================================================================================
 // output layout of the new F region (get_static_estimate erasor.cpp:612-626; OMU.cpp:281-290):
@@ -3936,13 +3453,6 @@ __global__ __launch_bounds__(256) void k_count_labels4(const float4 *__restrict_
 // empty kernel: bracketed by HIP events exactly like k_voi_split to measure the bracket's own overhead
 __global__ void k_null() {}
 
-// result block in pinned host memory: k_step_end stores the step's state and counters there, so the host needs no D2H copies
-struct HostOut {
-    DevState st;
-    Counters ctr;
-    unsigned long long seq;  // number of the step these results belong to: written last, the host polls it
-};
-
 // start of a scan's query chain (its own stream): counters, bounding box, bucket totals, voxel count of this query side
 __global__ void k_query_begin(Counters *qctr, uint32_t *bb, uint32_t *qb_tot, uint32_t qb_n, uint32_t *nvox, uint32_t nvox_init) {
     for (uint32_t b = threadIdx.x; b < qb_n; b += blockDim.x) qb_tot[b] = 0;  // bucket totals of the query counting sort
@@ -3954,53 +3464,6 @@ __global__ void k_query_begin(Counters *qctr, uint32_t *bb, uint32_t *qb_tot, ui
     if (threadIdx.x < 3) bb[threadIdx.x] = 0xFFFFFFFFu;
     if (threadIdx.x >= 3 && threadIdx.x < 6) bb[threadIdx.x] = 0u;
 }
-// end of a step: fold in the query side's counters and voxel count, commit the map sizes, report to the pinned host block
-__global__ void k_step_end(DevState *st, Counters *ctr, HostOut *out, const unsigned long long *lab_slots, const Counters *qctr,
-                           const uint32_t *q_nvox, unsigned long long seq) {
-    // round 3: everything is READ first (one memory round trip: the loads are independent and nothing is stored in between), then
-    // computed, then written -- interleaved read-modify-writes of st / ctr cost a round trip each (6 us for this one-thread kernel)
-    DevState s = *st;
-    Counters c = *ctr;
-    const Counters q = *qctr;
-    const uint32_t nv = *q_nvox;
-    unsigned long long ns = 0, nd = 0;
-    if (lab_slots) {
-        unsigned long long a[16], b[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            a[i] = lab_slots[i * 8];
-            b[i] = lab_slots[i * 8 + 1];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            ns += a[i];
-            nd += b[i];
-        }
-        s.F_static = ns;
-        s.F_dynamic = nd;
-    }
-    c.n_neg_sector += q.n_neg_sector;
-    c.n_ambiguous += q.n_ambiguous;
-    c.n_degenerate += q.n_degenerate;
-    c.n_voxel_overflow += q.n_voxel_overflow;
-    c.n_sort_fallback += q.n_sort_fallback;
-    if (q.sort_qoverflow) c.sort_qoverflow = q.sort_qoverflow;
-    if (q.err) c.err = q.err;
-    s.q_nvox = nv;
-    if (!(c.err || c.sort_qoverflow)) {
-        s.nF = s.nF_new;
-        s.o_begin = s.o_new_begin;
-    }
-    *st = s;
-    *ctr = c;
-    if (out) {
-        out->st = s;
-        out->ctr = c;
-        __threadfence_system();
-        *(volatile unsigned long long *)&out->seq = seq;
-    }
-}
-
 // ---- mapgen (src/mapgen/mapgen.hpp:198-257): per-scan preparation ----------------------------------------------
 // keep flag of the self-filter (mapgen.hpp:219-228): a point is dropped when pow(x,2) + pow(y,2) (double) is below
 // max_dist_square, a FLOAT holding pow(CAR_BODY_SIZE, 2)

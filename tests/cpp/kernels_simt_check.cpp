@@ -146,7 +146,9 @@ static void test_per_bin(std::mt19937 &rng) {
     const uint32_t B = (uint32_t)P.B;
     std::uniform_real_distribution<float> u01(0.f, 1.f);
     // a few reverted bins of different sizes: sloped ground quantised to 1 cm (ties in z), clutter above, something below min_h
-    const uint32_t sizes[] = {12, 40, 300, 900, 1700, 2300};  // <= 1024: one key per thread; <= 2048: two; beyond: one wavefront per segment (block_esort)
+    // <= 1024: one key per thread of the level-synchronous sort; <= 2048: two; <= 4096: four (3000: its cloud of curr + ground points is
+    // beyond 2048 as well -- staged twice); beyond 4096: the global-memory paths of both stages (block_esort, binvox_core)
+    const uint32_t sizes[] = {12, 40, 300, 900, 1700, 2300, 3000, 4500};
     const uint32_t nbin = sizeof(sizes) / sizeof(sizes[0]);
     std::vector<uint32_t> moff(B + 3, 0), qoff(B + 3, 0), rev_list, rev_key;
     std::vector<float4> spts, sq;
@@ -190,10 +192,34 @@ static void test_per_bin(std::mt19937 &rng) {
     std::vector<uint8_t> gflag(G, 9);
     std::vector<float> plane_n((size_t)nbin * P.gf_iter * 3 + 8, 0.f);
     std::vector<double> plane_d((size_t)nbin * P.gf_iter + 8, 0.0);
-    simt::run_grid(2, 1024, [&] {
-        k_rgpf2(P, rev_list.data(), &st, moff.data(), spts.data(), gsK.data(), gsV.data(), gsL.data(), gsR.data(), gsH.data(), gsK2.data(),
-                       gsV2.data(), gflag.data(), grank.data(), glist.data(), ng.data(), plane_n.data(), plane_d.data(), &ctr, nullptr);
-    });
+    std::vector<uint32_t> vox_off(nbin + 1, 0), nvox(nbin + 1, 0);
+    for (uint32_t b = 0; b < nbin; ++b) vox_off[b + 1] = vox_off[b] + (uint32_t)(cur_bin[b].size() + sizes[b]);
+    std::vector<float4> gsC(G), vox_out(vox_off[nbin] + 8);
+    RevArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.moff = moff.data();
+    ra.spts = spts.data();
+    ra.qoff = qoff.data();
+    ra.sq = sq.data();
+    ra.gsK = gsK.data();
+    ra.gsV = gsV.data();
+    ra.gsL = gsL.data();
+    ra.gsR = gsR.data();
+    ra.gsH = gsH.data();
+    ra.gsK2 = gsK2.data();
+    ra.gsV2 = gsV2.data();
+    ra.gsC = gsC.data();
+    ra.gflag = gflag.data();
+    ra.grank = grank.data();
+    ra.glist = glist.data();
+    ra.ng_arr = ng.data();
+    ra.plane_n = plane_n.data();
+    ra.plane_d = plane_d.data();
+    ra.vox_out = vox_out.data();
+    ra.nvox_out = nvox.data();
+    ra.ctr = &ctr;
+    ra.dbg = nullptr;
+    simt::run_grid(2, 1024, [&] { k_rgpf2(P, rev_list.data(), &st, ra); });
     for (uint32_t b = 0; b < nbin; ++b) {
         const uint32_t M = sizes[b], o0 = moff[rev_list[b]];
         std::vector<uint8_t> mask(M);
@@ -214,13 +240,7 @@ static void test_per_bin(std::mt19937 &rng) {
         CHECK(ok, "rgpf bin %u", b);
     }
     // per-bin voxelisation of [curr bin | ground of the map bin] (erasor.cpp:512-528)
-    std::vector<uint32_t> vox_off(nbin + 1, 0), nvox(nbin + 1, 0);
-    for (uint32_t b = 0; b < nbin; ++b) vox_off[b + 1] = vox_off[b] + (uint32_t)(cur_bin[b].size() + sizes[b]);
-    std::vector<float4> gsC(G), vox_out(vox_off[nbin] + 8);
-    simt::run_grid(2, 1024, [&] {
-        k_binvox2(P, rev_list.data(), &st, moff.data(), spts.data(), qoff.data(), sq.data(), glist.data(), ng.data(), vox_off.data(), gsK.data(),
-                  gsV.data(), gsL.data(), gsR.data(), gsH.data(), gsK2.data(), gsV2.data(), gsC.data(), vox_out.data(), nvox.data(), &ctr, nullptr);
-    });
+    simt::run_grid(2, 1024, [&] { k_binvox2(P, rev_list.data(), &st, vox_off.data(), ra); });
     for (uint32_t b = 0; b < nbin; ++b) {
         const uint32_t o0 = moff[rev_list[b]];
         std::vector<float4> in(cur_bin[b]);
@@ -246,12 +266,28 @@ static void test_per_bin(std::mt19937 &rng) {
         Counters ctr_;
         memset(&ctr_, 0, sizeof(ctr_));
         uint32_t n_rare = 0;
-        for (uint32_t b = 0; b < nbin; ++b) n_rare += (sizes[b] > ESYNC_MAX || sizes[b] + cur_bin[b].size() > ESYNC_MAX) ? 1u : 0u;
-        simt::run_grid(3, 1024, [&] {
-            k_revert_bins(P, rev_list.data(), &st, moff.data(), spts.data(), qoff.data(), sq.data(), gsK_.data(), gsV_.data(), gsL_.data(), gsR_.data(), gsH_.data(),
-                          gsK2_.data(), gsV2_.data(), gsC_.data(), gflag_.data(), grank_.data(), glist_.data(), ng_.data(), plane_n_.data(), plane_d_.data(),
-                          vox_off.data(), vox_out_.data(), nvox_.data(), &ctr_, nullptr, (uint32_t)G, (uint32_t)(G / 32 + 2 * B + 16));
-        });
+        for (uint32_t b = 0; b < nbin; ++b) n_rare += (sizes[b] > PB_CAP || sizes[b] + cur_bin[b].size() > PB_CAP) ? 1u : 0u;
+        RevArgs rb = ra;
+        rb.gsK = gsK_.data();
+        rb.gsV = gsV_.data();
+        rb.gsL = gsL_.data();
+        rb.gsR = gsR_.data();
+        rb.gsH = gsH_.data();
+        rb.gsK2 = gsK2_.data();
+        rb.gsV2 = gsV2_.data();
+        rb.gsC = gsC_.data();
+        rb.gflag = gflag_.data();
+        rb.grank = grank_.data();
+        rb.glist = glist_.data();
+        rb.ng_arr = ng_.data();
+        rb.plane_n = plane_n_.data();
+        rb.plane_d = plane_d_.data();
+        rb.vox_out = vox_out_.data();
+        rb.nvox_out = nvox_.data();
+        rb.ctr = &ctr_;
+        rb.vox_base = (uint32_t)G;
+        rb.h_base = (uint32_t)(G / 32 + 2 * B + 16);
+        simt::run_grid(3, 1024, [&] { k_revert_bins(P, rev_list.data(), &st, vox_off.data(), rb); });
         bool same = ng_ == ng && nvox_ == nvox && memcmp(plane_n_.data(), plane_n.data(), plane_n.size() * 4) == 0 &&
                     memcmp(plane_d_.data(), plane_d.data(), plane_d.size() * 8) == 0;
         for (uint32_t b = 0; same && b < nbin; ++b) {
@@ -259,7 +295,7 @@ static void test_per_bin(std::mt19937 &rng) {
             same = memcmp(&gflag_[o0], &gflag[o0], sizes[b]) == 0 && memcmp(&grank_[o0], &grank[o0], sizes[b] * 4) == 0 &&
                    memcmp(&glist_[o0], &glist[o0], ng[b] * 4) == 0 && memcmp(&vox_out_[vox_off[b]], &vox_out[vox_off[b]], (size_t)nvox[b] * 16) == 0;
         }
-        printf("k_revert_bins (%u of %u bins beyond the level-synchronous sort's size) == k_rgpf2 + k_binvox2  %s\n", n_rare, nbin, same ? "ok" : "MISMATCH");
+        printf("k_revert_bins (%u of %u bins beyond the LDS-resident size) == k_rgpf2 + k_binvox2  %s\n", n_rare, nbin, same ? "ok" : "MISMATCH");
         CHECK(same && n_rare > 0 && n_rare < nbin && ctr_.err == 0 && ctr_.sort_qoverflow == 0, "fused per-bin launch");
     }
 }
@@ -345,12 +381,12 @@ static void test_map_store(std::mt19937 &rng) {
             if (ahead)  // extents from the committed device state, upper-bound grid
                 simt::run_grid(3, 256, [&] {
                     k_voi_split(F.data(), 0u, 0u, oxy.data(), 0u, 0u, 0u, px, yc, P.voi_r2, vmask.data(), hmask.data(), cinfo.data(), &st, capO / CHUNK, nchunks + 2,
-                                ometa.data());
+                                ometa.data(), StepEnd{});
                 });
             else
                 simt::run_grid((nchunks + 3) / 4, 256, [&] {
                     k_voi_split(F.data(), nF, nFchunks, oxy.data(), o_begin, o_chunk0, nOchunks, px, yc, P.voi_r2, vmask.data(), hmask.data(), cinfo.data(), nullptr, 0u,
-                                0u, ometa.data());
+                                0u, ometa.data(), StepEnd{});
                 });
         }
         uint32_t n_read = 0;

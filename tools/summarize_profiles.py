@@ -62,7 +62,7 @@ if fs:
 import hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 hh = hashlib.sha256()
-for f in ("erasor_hip.hip", "kernels.hip.h", "exact_sort.hip.h", "exact_sort_core.h"):
+for f in ("erasor_hip.hip", "kernels.hip.h", "revert_bins.hip.h", "exact_sort.hip.h", "exact_sort_core.h"):
     hh.update(open(os.path.join(root, "erasor_amd", "csrc", f), "rb").read())
 json.dump({"device_source_sha16": hh.hexdigest()[:16]}, open(os.path.join(out, "latest_meta.json"), "w"))
 print(json.dumps({"kernel_stats": ks, "voi_split_fetch": fs, "voi_split_write": ws}))
