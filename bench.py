@@ -465,6 +465,7 @@ def main():
     first = seqs[0][1] if seqs else None
     if first is not None:
         first.g.profile_reset()
+        first.g.chain_timing(reset=True)
         if not os.environ.get("ERASOR_BENCH_NO_SPLIT_EVENTS"):  # (A/B switch: what the roofline's own measurement costs the step)
             # start / stop HIP events attached to every FOURTH k_voi_split launch of the timed region, on the handle's stream (the
             # bracket costs the step it observes ~9 us: measured 0.276 vs 0.267 ms per scan with every launch bracketed / none)
@@ -555,6 +556,7 @@ def main():
     if world_size == 1 and not args.no_cpu_baseline and args.mode == "replicas" and first is not None:
         gpu_final = (first.g.get_map(), first.g.get_rejected_indices())  # (after the clock has stopped; compared with the oracle's below)
     prof = first.g.profile_get() if first is not None else {}
+    chain_us = first.g.chain_timing() if first is not None else (0.0, 0.0, 0)
     if first is not None:
         first.g.profiling(0)
     elapsed = ed.max_over_ranks(dist, elapsed_local, dev)
@@ -711,6 +713,9 @@ def main():
                    "node_loop": "native (erasor_hip_run_nodes: one call for the timed nodes)" if native_loop else "python (prefetch + step per node)"},
         "map_points_x_scans_per_sec": round(value * N_map, 1),
         "ms_per_step_without_lookahead": None if sync_ms is None else round(sync_ms, 4),
+        # the main stream's dependency chain in the timed pass, on the device's own clock (chunk scan .. the step's end), and the time
+        # the stream spends between two steps (host turnaround; the next step's VoI split, launched ahead, runs in there)
+        "main_chain_us": round(chain_us[0], 1), "between_steps_us": round(chain_us[1], 1),
         "roofline": roofline, "cpu_baseline": cpu, "cpu_port": cpu_port, "host": host_identity(),
         "parity_checked_steps": parity["parity_checked_steps"], "parity": parity.get("parity"), "final_map_checked": parity.get("final_map_checked", False),
         "rccl_ranks": rccl_ranks, "backend": backend if dist is not None else None,

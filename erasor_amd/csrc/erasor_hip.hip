@@ -146,7 +146,9 @@ struct erasor_hip_handle {
     hipStream_t stream = nullptr;   // main stream: step begin, SRT .. write-back
     // query chains alternate between two streams, so that two consecutive scans' chains overlap (three streams in all; the
     // runtime multiplexes streams onto 4 hardware queues by default -- a fifth stream shares one and serialises behind it)
-    hipStream_t qstream[2] = {nullptr, nullptr};
+    static constexpr int NQS_MAX = 4;
+    hipStream_t qstream[NQS_MAX] = {nullptr, nullptr, nullptr, nullptr};
+    int nqs = 2;  // query streams in use (ERASOR_HIP_QSTREAMS, 1..4)
     hipStream_t cstream = nullptr;  // host scans on their way into a query side (staged, asynchronous)
     unsigned n_chain = 0;
     hipStream_t cur = nullptr;      // stream LAUNCH() currently targets
@@ -186,6 +188,9 @@ struct erasor_hip_handle {
     uint64_t mg_cnt_voxel = 0, mg_accum = 0;
     DBuf<uint32_t> mb_hist, mb_tot;   // the map's bucketing as a counting sort: [tiles][B + 1] table, [B + 1] totals
     DBuf<unsigned long long> lab_slots;  // [16][8] label tallies of the assemble kernels (one cache line per slot)
+    double tm_span = 0, tm_gap = 0;  // erasor_hip_chain_timing: sums in microseconds
+    uint64_t tm_n = 0, tm_ngap = 0;
+    unsigned long long tm_last_end = 0, tm_last_seq = 0;
     unsigned long long step_seq = 0;  // steps issued so far (k_step_end echoes it into the pinned block)
     // a step that has been enqueued (erasor_hip_step_async) and not collected yet (erasor_hip_step_wait)
     struct {
@@ -754,7 +759,8 @@ int erasor_hip_params_default(erasor_params *p) {
 }
 
 static bool create_sides(erasor_hip_handle *h, int prio) {
-    for (int k = 0; k < 2; ++k)
+    if (const char *e = getenv("ERASOR_HIP_QSTREAMS")) h->nqs = std::max(1, std::min((int)erasor_hip_handle::NQS_MAX, atoi(e)));
+    for (int k = 0; k < h->nqs; ++k)
         if (hipStreamCreateWithPriority(&h->qstream[k], hipStreamNonBlocking, prio) != hipSuccess) return false;
     for (int k = 0; k < NSIDE; ++k)
         if (hipEventCreateWithFlags(&h->q[k].ev_keys, hipEventDisableTiming) != hipSuccess ||
@@ -824,7 +830,7 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
 void erasor_hip_destroy(erasor_hip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < erasor_hip_handle::NQS_MAX; ++k)
         if (h->qstream[k]) (void)hipStreamSynchronize(h->qstream[k]);
     if (h->cstream) (void)hipStreamSynchronize(h->cstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -855,7 +861,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
         graph_release(h->q[k].gseg[0]);
         graph_release(h->q[k].gseg[1]);
     }
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < erasor_hip_handle::NQS_MAX; ++k)
         if (h->qstream[k]) (void)hipStreamDestroy(h->qstream[k]);
     if (h->cstream) (void)hipStreamDestroy(h->cstream);
     if (h->pin) (void)hipHostFree(h->pin);
@@ -1157,7 +1163,7 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     h->qi = side;
     // (the radix fallback for very fine R-POD grids -- and the pass-through chain's radix sort -- share their scratch bank
     // between the sides: one stream for all of them then)
-    hipStream_t qstream = (h->B + 1 <= QB_NB_MAX && !passthrough) ? h->qstream[h->n_chain++ & 1u] : h->qstream[0];
+    hipStream_t qstream = (h->B + 1 <= QB_NB_MAX && !passthrough) ? h->qstream[h->n_chain++ % (unsigned)h->nqs] : h->qstream[0];
     h->cur = qstream;
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
@@ -1195,6 +1201,10 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
 #ifndef ERASOR_NO_HIPGRAPH
     if (h->use_graph && h->prof != 1 && !g_debug_sync && !passthrough && !prevox && B + 1 <= QB_NB_MAX && ns) h->rec = &recorded;
 #endif
+    {
+        static const int qpad = getenv("ERASOR_HIP_QPAD_US") ? atoi(getenv("ERASOR_HIP_QPAD_US")) : 0;
+        if (qpad > 0) LAUNCH(h, "q_pad", k_pad, 1, 64, (unsigned long long)qpad * 100ull);
+    }
     LAUNCH(h, "q_begin", k_query_begin, 1, 256, qc, q.bb.p, B + 1 <= QB_NB_MAX ? q.qb_tot.p : (uint32_t *)nullptr, B + 1 <= QB_NB_MAX ? B + 1 : 0u,
            q.d_nvox.p, (prevox || passthrough) ? ns : 0u);
     // ---- part 1: bounding box, voxel keys, exact std::sort, runs ----
@@ -1278,7 +1288,7 @@ static int flush_announced(erasor_hip_handle *h) {
 static void q_drain(erasor_hip_handle *h) {
     h->npend = 0;
     h->ann.valid = false;
-    for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(h->qstream[k]);
+    for (int k = 0; k < h->nqs; ++k) (void)hipStreamSynchronize(h->qstream[k]);
 }
 
 
@@ -1430,7 +1440,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     if (rc) return rc;
     const int bits = key_bits(B + 1);
     if (B + 1 <= QB_NB_MAX) {  // [tiles][B + 1] table of the map's counting sort
-        if (ensure(h, h->mb_hist, (size_t)(B + 1) * std::max(1u, cdiv(n_voi, MB_TILE)) + 8)) return ERASOR_E_NO_DEVICE;
+        if (ensure(h, h->mb_hist, (size_t)mb_row_stride(B + 1) * std::max(1u, cdiv(n_voi, MB_TILE)) + 8)) return ERASOR_E_NO_DEVICE;
     } else {  // the map chain's scratch bank of the radix bucket sort
         const uint32_t nb_m = 256u * std::max(1u, cdiv(n_voi, RTILE));
         if (ensure(h, h->hist2, nb_m) || ensure(h, h->hist2_l, nb_m) || ensure(h, h->hist2_t, cdiv(nb_m, 1024) + 2)) return ERASOR_E_NO_DEVICE;
@@ -1457,6 +1467,10 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                 launch_voi_split(h, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, h->o_begin, o_chunk0, nOchunks, nchunks, xc, yc, voi_r2,
                                  (const DevState *)nullptr, 0u);
             const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));
+            {
+                static const int mpad = getenv("ERASOR_HIP_MPAD_US") ? atoi(getenv("ERASOR_HIP_MPAD_US")) : 0;
+                if (mpad > 0) LAUNCH(h, "m_pad", k_pad, 1, 64, (unsigned long long)mpad * 100ull);
+            }
             if (nchunks <= 16384) {
                 LAUNCH(h, "chunk_scan", k_chunk_scan_one, 1, 1024, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, ntop,
                        nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u,
@@ -1484,7 +1498,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             const uint32_t ntile_tab = std::max(1u, cdiv(n_voi, MB_TILE));
             const uint32_t ntile_ub = h->last_n_voi ? std::min(ntile_tab, std::max(64u, cdiv((uint64_t)h->last_n_voi * 3 / 2, MB_TILE))) : ntile_tab;
             LAUNCH(h, "voi_bucket", k_mb_hist, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, n_voi, nvoi_dev, B + 1, h->mb_hist.p, h->mb_tot.p);
-            LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv((uint64_t)(B + 1) * 64, 256), 256, h->mb_hist.p, n_voi, nvoi_dev, B + 1, (const uint32_t *)h->mb_tot.p,
+            LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv(B + 1, MB_PAD), 256, h->mb_hist.p, n_voi, nvoi_dev, B + 1, (const uint32_t *)h->mb_tot.p,
                    h->moff.p);
             if (B + 1 <= MBW_NB_MAX)
                 LAUNCH(h, "voi_bucket", k_mb_scatter_w, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
@@ -1745,6 +1759,20 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
     }
     h->st = h->pin->st;
     h->ctr = h->pin->ctr;
+    {   // measurement (erasor_hip_chain_timing): the main chain's span on the device's own clock, and how long the stream sat between the
+        // previous step's end and this step's chunk scan
+        const unsigned long long t_open = h->st.t_open, t_end = h->pin->t_end;
+        if (t_end > t_open) {
+            h->tm_span += (double)(t_end - t_open) * 0.01;
+            if (h->tm_last_end && t_open > h->tm_last_end && h->tm_last_seq + 1 == step_seq) {
+                h->tm_gap += (double)(t_open - h->tm_last_end) * 0.01;
+                ++h->tm_ngap;
+            }
+            ++h->tm_n;
+        }
+        h->tm_last_end = t_end;
+        h->tm_last_seq = step_seq;
+    }
     if (host_timing)
         fprintf(stderr, "[step host] wait %.1f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host1).count());
     if (h->dbg_stamps.p) {
@@ -1764,6 +1792,7 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
                 (double)(t[26] - t[28]) / 100.0, (double)(t[27] - t[28]) / 100.0, t[25], t[24]);
         fprintf(stderr, "[slowest reverted bin] R-GPF: %llu points, z-sort %.1f us + rest %.1f us; per-bin voxelisation: %llu points -> %llu voxels, %.1f us\n",
                 t[19], (double)t[17] / 100.0, (double)t[18] / 100.0, t[21], t[22], (double)t[20] / 100.0);
+        fprintf(stderr, "[reverted bins] %llu, %llu of them beyond the LDS pool, %llu points in all\n", t[23] & 0xFFFFFFFFull, t[23] >> 32, t[63]);
         memset(t, 0, sizeof(t));
         t[28] = ~0ull;
         (void)hipMemcpy(h->dbg_stamps.p, t, sizeof(t), hipMemcpyHostToDevice);
@@ -2399,10 +2428,22 @@ int erasor_hip_profiling(erasor_hip_handle *h, int enable) {
     h->prof = enable;
     return ERASOR_OK;
 }
+int erasor_hip_chain_timing(erasor_hip_handle *h, double *main_chain_us, double *between_steps_us, uint64_t *steps, int reset) {
+    if (!h) return ERASOR_E_INVALID;
+    if (main_chain_us) *main_chain_us = h->tm_n ? h->tm_span / (double)h->tm_n : 0.0;
+    if (between_steps_us) *between_steps_us = h->tm_ngap ? h->tm_gap / (double)h->tm_ngap : 0.0;
+    if (steps) *steps = h->tm_n;
+    if (reset) {
+        h->tm_span = h->tm_gap = 0;
+        h->tm_n = h->tm_ngap = 0;
+        h->tm_last_end = 0;
+    }
+    return ERASOR_OK;
+}
 int erasor_hip_profile_reset(erasor_hip_handle *h) {
     if (!h) return ERASOR_E_INVALID;
     (void)hipStreamSynchronize(h->stream);
-    for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(h->qstream[k]);
+    for (int k = 0; k < h->nqs; ++k) (void)hipStreamSynchronize(h->qstream[k]);
     prof_collect(h, true);
     for (auto &e : h->prof_tab) e = ProfEntry();
     return ERASOR_OK;
@@ -2410,7 +2451,7 @@ int erasor_hip_profile_reset(erasor_hip_handle *h) {
 int erasor_hip_profile_get(erasor_hip_handle *h, const char **names, double *total_ms, uint64_t *launches, size_t cap, size_t *n) {
     if (!h) return ERASOR_E_INVALID;
     (void)hipStreamSynchronize(h->stream);
-    for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(h->qstream[k]);
+    for (int k = 0; k < h->nqs; ++k) (void)hipStreamSynchronize(h->qstream[k]);
     prof_collect(h, true);
     const size_t cnt = h->prof_names.size();
     if (n) *n = cnt;

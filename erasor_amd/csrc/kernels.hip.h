@@ -62,6 +62,8 @@ struct DevState {
     uint32_t total_bins0;  // k_srt4: size of the bin part of the output WITHOUT the reverted bins (k_assemble_map<., true> adds them)
     // label counters
     unsigned long long F_static, F_dynamic, O_static, O_dynamic;
+    // measurement: the constant-rate counter (100 MHz) when the step's chunk scan began
+    unsigned long long t_open;
 };
 
 __device__ __forceinline__ uint64_t lanemask_lt() { return esort::lanemask_lt(); }
@@ -177,7 +179,8 @@ __device__ __forceinline__ uint32_t wave_minmax_u(uint32_t x) {
 struct HostOut {
     DevState st;
     Counters ctr;
-    unsigned long long seq;  // number of the step these results belong to: written last, the host polls it
+    unsigned long long t_end;  // measurement: the constant-rate counter when the step's end ran (with st.t_open: the main chain's span)
+    unsigned long long seq;    // number of the step these results belong to: written last, the host polls it
 };
 
 // end of a step: fold in the query side's counters and voxel count, commit the map sizes, report to the pinned host block
@@ -222,6 +225,7 @@ __device__ __forceinline__ void step_end_body(DevState *st, Counters *ctr, HostO
     if (out) {
         out->st = s;
         out->ctr = c;
+        out->t_end = wall_clock64();
         __threadfence_system();
         *(volatile unsigned long long *)&out->seq = seq;
     }
@@ -502,6 +506,7 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ 
         s.n_leaving = validF - voiF;
         s.o_new_begin = s.o_begin - (validF - voiF);
         s.n_o_read = n_read;
+        s.t_open = wall_clock64();  // (the two-launch scan: stamped here, one launch late)
         *st = s;
         // the chunks that receive this step's leaving points (k_voi_gather prepends them to the outskirts): their records are void
         if (ometa && s.o_new_begin < s.o_begin)
@@ -521,6 +526,7 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restr
                                                           unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n, OMeta *__restrict__ ometa) {
     __shared__ uint32_t sm[40];
     __shared__ uint32_t s_voiF, s_validF;
+    const unsigned long long t_open = wall_clock64();
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t base = tid * 16;
     uint32_t ci[16];
@@ -625,6 +631,7 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restr
         s.n_leaving = validF - voiF;
         s.o_new_begin = s.o_begin - (validF - voiF);
         s.n_o_read = sm[32];
+        s.t_open = t_open;
         *st = s;
         // the chunks that receive this step's leaving points (k_voi_gather prepends them to the outskirts): their records are void
         if (ometa && s.o_new_begin < s.o_begin)
@@ -1004,8 +1011,13 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
 #define ERASOR_MB_TILE 4096
 #endif
 static constexpr uint32_t MB_TILE = ERASOR_MB_TILE;
+// (round 4: the table's rows are padded to MB_PAD buckets -- `nbs` words per tile -- so that the column scan can take 16 consecutive buckets
+// of a tile as ONE fully used 64-byte line)
+static constexpr uint32_t MB_PAD = 16;
+__host__ __device__ __forceinline__ uint32_t mb_row_stride(uint32_t nb) { return (nb + MB_PAD - 1) / MB_PAD * MB_PAD; }
 __global__ __launch_bounds__(1024) void k_mb_hist(const uint32_t *__restrict__ keys, uint32_t n_host, const uint32_t *n_dev, uint32_t nb,
-                                                   uint32_t *__restrict__ hist /* [tile][nb] */, uint32_t *__restrict__ tot /* [nb] */) {
+                                                   uint32_t *__restrict__ hist /* [tile][nbs] */, uint32_t *__restrict__ tot /* [nb] */) {
+    const uint32_t nbs = mb_row_stride(nb);
     __shared__ uint32_t cnt[QB_NB_MAX];
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
@@ -1023,56 +1035,78 @@ __global__ __launch_bounds__(1024) void k_mb_hist(const uint32_t *__restrict__ k
         __syncthreads();
         for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
             const uint32_t c = cnt[b];
-            hist[(size_t)tile * nb + b] = c;
+            hist[(size_t)tile * nbs + b] = c;
             if (c) atomicAdd(&tot[b], c);
         }
         __syncthreads();
     }
 }
 
-// (the bucket offsets -- exclusive scan of the bucket totals -- are recomputed by every workgroup for its own four
-// buckets: cheaper than a launch of its own on the main stream's dependency chain; workgroup 0 publishes them)
-__global__ __launch_bounds__(256) void k_mb_colscan(uint32_t *__restrict__ hist /* [tile][nb] -> start of (bucket, tile) */, uint32_t n_host,
+// (the bucket offsets -- exclusive scan of the bucket totals -- are recomputed by every workgroup for its own buckets: cheaper than a
+// launch of its own on the main stream's dependency chain; workgroup 0 publishes them)
+// Round 4: a workgroup takes MB_PAD = 16 CONSECUTIVE buckets of every tile: a wavefront's load covers four tiles x one 64-byte line each,
+// every fetched byte is used (round 3 walked a column with one 4-byte word per cache line: 18.5 MB of traffic for a 1.7 MB table on
+// config 2, 88.7 MB on config 4).  The 256 x 16 block is scanned down its columns in LDS (rows padded to 17 words: conflict-free), four
+// columns per wavefront, 64 tiles per DPP scan, and goes back the way it came.
+__global__ __launch_bounds__(256) void k_mb_colscan(uint32_t *__restrict__ hist /* [tile][nbs] -> start of (bucket, tile) */, uint32_t n_host,
                                                      const uint32_t *n_dev, uint32_t nb, const uint32_t *__restrict__ tot,
                                                      uint32_t *__restrict__ off_out) {
     __shared__ uint32_t sm[40];
-    __shared__ uint32_t s_off[4];
-    const uint32_t b0 = (blockIdx.x * blockDim.x) >> 6;  // first of this workgroup's four buckets
+    __shared__ uint32_t s_off[MB_PAD];
+    __shared__ uint32_t s_blk[256][MB_PAD + 1];
+    const uint32_t nbs = mb_row_stride(nb);
+    const uint32_t b0 = blockIdx.x * MB_PAD;  // first of this workgroup's buckets
     {
         const uint32_t per = (nb + blockDim.x - 1) / blockDim.x;
         const uint32_t lo = min(threadIdx.x * per, nb), hi = min(lo + per, nb);
-        uint32_t s = 0;
-        for (uint32_t i = lo; i < hi; ++i) s += tot[i];
+        uint32_t s_ = 0;
+        for (uint32_t i = lo; i < hi; ++i) s_ += tot[i];
         uint32_t t;
-        uint32_t run = block_excl_scan(s, sm, t);
+        uint32_t run = block_excl_scan(s_, sm, t);
         for (uint32_t i = lo; i < hi; ++i) {
             if (blockIdx.x == 0) off_out[i] = run;
-            if (i >= b0 && i < b0 + 4) s_off[i - b0] = run;
+            if (i >= b0 && i < b0 + MB_PAD) s_off[i - b0] = run;
             run += tot[i];
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) off_out[nb] = t;
         __syncthreads();
     }
-    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-    if (b >= nb) return;
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
-    uint32_t run = s_off[b - b0];
-    // (a column is walked with a stride of nb words -- one cache line per lane: four rounds of loads are issued together)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t r0 = threadIdx.x >> 4, c = threadIdx.x & 15u;  // this thread's rows r0, r0 + 16, ... of the block, column c
+    uint32_t run[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) run[j] = (b0 + wave * 4 + j < nb) ? s_off[wave * 4 + j] : 0u;
     for (uint32_t t0 = 0; t0 < ntile; t0 += 256) {
-        uint32_t c[4];
+        uint32_t v[16];
 #pragma unroll
-        for (uint32_t r = 0; r < 4; ++r) {
-            const uint32_t t = t0 + r * 64 + lane;
-            c[r] = t < ntile ? hist[(size_t)t * nb + b] : 0u;
+        for (uint32_t k = 0; k < 16; ++k) {  // (all sixteen loads in flight)
+            const uint32_t t = t0 + r0 + 16 * k;
+            v[k] = t < ntile ? hist[(size_t)t * nbs + b0 + c] : 0u;
         }
 #pragma unroll
-        for (uint32_t r = 0; r < 4; ++r) {
-            const uint32_t t = t0 + r * 64 + lane;
-            const uint32_t inc = esort::wave_incl_scan(c[r]);  // (DPP row shifts: no LDS crossbar round trips)
-            if (t < ntile) hist[(size_t)t * nb + b] = run + inc - c[r];
-            run += __builtin_amdgcn_readlane(inc, 63);
+        for (uint32_t k = 0; k < 16; ++k) s_blk[r0 + 16 * k][c] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t col = wave * 4 + j;
+#pragma unroll
+            for (uint32_t rr = 0; rr < 4; ++rr) {
+                const uint32_t row = rr * 64 + lane;
+                const uint32_t x = s_blk[row][col];
+                const uint32_t inc = esort::wave_incl_scan(x);  // (DPP row shifts)
+                s_blk[row][col] = run[j] + inc - x;
+                run[j] += __builtin_amdgcn_readlane(inc, 63);
+            }
         }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t t = t0 + r0 + 16 * k;
+            if (t < ntile && b0 + c < nb) hist[(size_t)t * nbs + b0 + c] = s_blk[r0 + 16 * k][c];
+        }
+        __syncthreads();
     }
 }
 
@@ -1088,7 +1122,7 @@ __global__ __launch_bounds__(1024) void k_mb_scatter(const uint32_t *__restrict_
     for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     __syncthreads();
     // cnt[k] starts at the tile's first slot of bucket k and advances as the tile's keys are placed, in index order
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = base[(size_t)tile * nb + b];
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = base[(size_t)tile * mb_row_stride(nb) + b];
     __syncthreads();
     for (uint32_t r = 0; r < MB_TILE / 1024; ++r) {
         const uint32_t i = tile * MB_TILE + r * 1024 + threadIdx.x;
@@ -1141,7 +1175,7 @@ __global__ __launch_bounds__(1024) void k_mb_scatter_w(const uint32_t *__restric
     constexpr uint32_t R = MB_TILE / 16 / 64;  // 64-key strips per wavefront
     for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) sbase[b] = base[(size_t)tile * nb + b];
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) sbase[b] = base[(size_t)tile * mb_row_stride(nb) + b];
     for (uint32_t i = threadIdx.x; i < 16 * MBW_NB_MAX / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(&wcnt[0][0])[i] = 0u;
     __syncthreads();
     const uint32_t i0 = tile * MB_TILE + wave * (MB_TILE / 16) + lane;
@@ -3452,6 +3486,11 @@ __global__ __launch_bounds__(256) void k_count_labels4(const float4 *__restrict_
 
 // empty kernel: bracketed by HIP events exactly like k_voi_split to measure the bracket's own overhead
 __global__ void k_null() {}
+// ALU-only delay (measurement aid: ERASOR_HIP_QPAD_US / ERASOR_HIP_MPAD_US lengthen a chain by a known amount to see which one bounds the step)
+__global__ void k_pad(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+}
 
 // start of a scan's query chain (its own stream): counters, bounding box, bucket totals, voxel count of this query side
 __global__ void k_query_begin(Counters *qctr, uint32_t *bb, uint32_t *qb_tot, uint32_t qb_n, uint32_t *nvox, uint32_t nvox_init) {

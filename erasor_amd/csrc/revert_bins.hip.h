@@ -348,6 +348,10 @@ __device__ __attribute__((noinline)) void rg_fit_call() {
 __device__ __forceinline__ void rgpf_stage() {
     const uint32_t key = g_rb.key;
     const uint32_t M = g_ra.moff[key + 1] - g_ra.moff[key];
+    if (g_ra.dbg && threadIdx.x == 0) {  // diagnostics: reverted bins, those beyond the pool, points
+        atomicAdd(&g_ra.dbg[23], 1ull + (M > PB_CAP ? (1ull << 32) : 0ull));
+        atomicAdd(&g_ra.dbg[63], (unsigned long long)M);
+    }
     if (M > PB_CAP) {
         rg_rare_call();
     } else {

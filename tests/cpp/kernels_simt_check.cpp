@@ -92,12 +92,12 @@ static void test_map_bucketing(std::mt19937 &rng) {
             pts[i] = make_float4((float)i, 0.5f, -1.f, 40.f);
         }
         const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
-        std::vector<uint32_t> hist((size_t)ntile * nb + 8, 0xDEADu), tot(nb + 2, 0), off(nb + 2, 0), dsrc(n), dkeys(n), nd(1, n);
+        std::vector<uint32_t> hist((size_t)ntile * mb_row_stride(nb) + 8, 0xDEADu), tot(nb + 2, 0), off(nb + 2, 0), dsrc(n), dkeys(n), nd(1, n);
         std::vector<float4> dpts(n);
         int bits = 1;
         while ((1u << bits) < nb) ++bits;
         simt::run_grid(std::max(1u, ntile / 2), 1024, [&] { k_mb_hist(keys.data(), n + 100, nd.data(), nb, hist.data(), tot.data()); });
-        simt::run_grid((nb * 64 + 255) / 256, 256, [&] { k_mb_colscan(hist.data(), n + 100, nd.data(), nb, tot.data(), off.data()); });
+        simt::run_grid((nb + MB_PAD - 1) / MB_PAD, 256, [&] { k_mb_colscan(hist.data(), n + 100, nd.data(), nb, tot.data(), off.data()); });
         simt::run_grid(std::max(1u, ntile / 2), 1024, [&] {
             k_mb_scatter_w(keys.data(), pts.data(), src.data(), n + 100, nd.data(), nb, bits, hist.data(), dpts.data(), dsrc.data(), dkeys.data());
         });
