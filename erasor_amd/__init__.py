@@ -147,6 +147,7 @@ class Erasor:
         self.B = params.num_rings * params.num_sectors
         self._h = C.c_void_p()
         rc = lib().erasor_hip_create(C.byref(params), C.c_int(device), C.byref(self._h))
+        self._last_res = None
         if rc != 0:
             self._h = C.c_void_p()
             raise ErasorError(rc, "erasor_hip_create failed (no GPU / invalid parameters)")
@@ -208,11 +209,44 @@ class Erasor:
         res = StepResult()
         self._check(lib().erasor_hip_step(self._h, _p(scan), C.c_size_t(len(scan)), _p(_f32(T_l2b).reshape(16)),
                                           _p(_f32(T_b2o).reshape(16)), _p(_f32(T_o2b).reshape(16)), C.byref(res)))
+        self._last_res = res
         return res
 
     def step_device(self, dptr, n, T_l2b, T_b2o, T_o2b):
         res = StepResult()
         self._check(lib().erasor_hip_step_device(self._h, C.c_void_p(dptr), C.c_size_t(n), _m(T_l2b), _m(T_b2o), _m(T_o2b), C.byref(res)))
+        self._last_res = res
+        return res
+
+    # -- host records in the caller's layout, announcements by ticket (erasor_hip_step_rows / _prefetch_node_rows / _step_ticket) --
+    @staticmethod
+    def _rows(rows):
+        """rows: a C-contiguous 2-D array of 4-byte items, one record per row: x, y, z first; returns (array, stride in bytes)"""
+        rows = np.ascontiguousarray(rows)
+        assert rows.ndim == 2 and rows.itemsize == 4 and rows.shape[1] >= 4
+        return rows, rows.shape[1] * 4
+
+    def step_rows(self, rows, intensity_col, T_l2b, T_b2o, T_o2b):
+        """a step on host records laid out like the caller has them (pcl::PointXYZI: 8 floats per row, intensity in column 4)"""
+        rows, stride = self._rows(rows)
+        res = StepResult()
+        self._check(lib().erasor_hip_step_rows(self._h, _p(rows), C.c_size_t(len(rows)), C.c_size_t(stride), C.c_size_t(4 * intensity_col),
+                                               _m(T_l2b), _m(T_b2o), _m(T_o2b), C.byref(res)))
+        self._last_res = res
+        return res
+
+    def prefetch_node_rows(self, rows, intensity_col, T_l2b, T_b2o=None):
+        """announce the next node (host records); returns its ticket.  The buffer is the caller's again on return."""
+        rows, stride = self._rows(rows)
+        t = C.c_uint64(0)
+        self._check(lib().erasor_hip_prefetch_node_rows(self._h, _p(rows), C.c_size_t(len(rows)), C.c_size_t(stride), C.c_size_t(4 * intensity_col),
+                                                        _m(T_l2b), None if T_b2o is None else _m(T_b2o), C.byref(t)))
+        return t.value
+
+    def step_ticket(self, ticket, T_b2o, T_o2b):
+        res = StepResult()
+        self._check(lib().erasor_hip_step_ticket(self._h, C.c_uint64(ticket), _m(T_b2o), _m(T_o2b), C.byref(res)))
+        self._last_res = res
         return res
 
     def step_async(self, scan, n=None, T_l2b=None, T_b2o=None, T_o2b=None, device=False):
@@ -386,28 +420,3 @@ class Erasor:
 
     def device_free(self, ptr):
         self._check(lib().erasor_hip_device_free(self._h, C.c_void_p(ptr)))
-
-    # -- test hooks --
-    def probe_math(self, x, y):
-        x = np.ascontiguousarray(x, np.float64)
-        y = np.ascontiguousarray(y, np.float64)
-        o = [np.zeros_like(x) for _ in range(3)]
-        self._check(lib().erasor_hip_probe_math(self._h, _p(x), _p(y), C.c_size_t(len(x)), _p(o[0]), _p(o[1]), _p(o[2])))
-        return o
-
-    def exact_sort_u32(self, keys, vals):
-        keys = np.ascontiguousarray(keys, np.uint32).copy()
-        vals = np.ascontiguousarray(vals, np.uint32).copy()
-        nf = C.c_uint32(0)
-        self._check(lib().erasor_hip_exact_sort_u32(self._h, _p(keys), _p(vals), C.c_size_t(len(keys)), C.byref(nf)))
-        return keys, vals, int(nf.value)
-
-    def radix_sort_u32(self, keys, bits):
-        keys = np.ascontiguousarray(keys, np.uint32)
-        ko = np.zeros_like(keys)
-        po = np.zeros_like(keys)
-        self._check(lib().erasor_hip_radix_sort_u32(self._h, _p(keys), C.c_size_t(len(keys)), C.c_int(bits), _p(ko), _p(po)))
-        return ko, po
-
-    def debug_rebuild_outskirts(self):
-        self._check(lib().erasor_hip_debug_rebuild_outskirts(self._h))

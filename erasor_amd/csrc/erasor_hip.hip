@@ -98,6 +98,11 @@ static void graph_release(GSeg &seg) {
 }
 
 // The query side of a step (see erasor_hip_handle::q)
+// layout of a HOST scan's records: float x, y, z at byte 0, float intensity at byte `ioff`, one record every `stride` bytes
+// (the library's own XYZI rows: 16 / 12; pcl::PointXYZI, what OMU.cpp:237 pcl::fromROSMsg leaves: 32 / 16)
+struct RowFmt {
+    uint32_t stride = 16, ioff = 12;
+};
 static constexpr int NSIDE = 4;  // the scan being stepped + up to three announced ahead
 static constexpr int MAX_AHEAD = NSIDE - 1;
 struct QSide {
@@ -132,7 +137,9 @@ struct QSide {
     float Tl[16] = {0};
     uint32_t ns = 0;
     bool src_dev = false;             // src is a device pointer (read in place; not fingerprinted)
-    uint64_t fp = 0;                  // host scans are copied when they are announced: fingerprint of that copy
+    uint64_t fp = 0;                  // host scans are copied when they are announced: hash of EVERY record of that copy
+    uint64_t ticket = 0;              // the announcement's ticket (erasor_hip_prefetch_node_rows -> erasor_hip_step_ticket)
+    RowFmt fmt;                       // record layout of src (host scans)
     bool used = false;                // ev_done has been recorded at least once
     bool pose_valid = false;          // the scan was announced together with its pose (erasor_hip_prefetch_node)
     double pose_x = 0, pose_y = 0;    // T_body2origin translation (OMU.cpp:246-247): all fetch_VoI needs
@@ -164,9 +171,12 @@ struct erasor_hip_handle {
         float Tl[16] = {0};
         int side = 0;
         uint64_t fp = 0;
+        uint64_t ticket = 0;
+        RowFmt fmt;
         bool pose_valid = false;
         double pose_x = 0, pose_y = 0;
     } ann;
+    uint64_t next_ticket = 1;
     // the NEXT step's VoI split, launched ahead (behind this step's k_step_end) when the next scan was announced with its pose
     struct {
         bool valid = false;
@@ -204,6 +214,8 @@ struct erasor_hip_handle {
         size_t n_scan = 0;
         bool src_is_device = false;
         float Tl[16], Tb[16], To[16];
+        uint32_t nchunks = 0;     // chunk count of the step's own VoI pass (grid hint of a split launched ahead later)
+        bool spec_launched = false;
     } fly;
     HostOut *pin = nullptr;         // pinned host block k_step_end reports into
     int bank = 0;                   // scratch bank of scan/radix helpers (0: query chains, 1: map chain)
@@ -542,7 +554,7 @@ int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
     Q(h).hbits = 10;  // voxel hash table: >= 2 slots per possible voxel
     while ((1ull << Q(h).hbits) < 2ull * S) ++Q(h).hbits;
     rc |= ensure(h, Q(h).hkey, (size_t)1 << Q(h).hbits) | ensure(h, Q(h).hval, (size_t)1 << Q(h).hbits);
-    if (getenv("ERASOR_HIP_SORT_STAMPS")) rc |= ensure(h, h->dbg_stamps, 64);
+    if (getenv("ERASOR_HIP_SORT_STAMPS")) rc |= ensure(h, h->dbg_stamps, 96);
     rc |= ensure(h, Q(h).wseg0, WSEG_MAX) | ensure(h, Q(h).wseg1, WSEG_MAX) | ensure(h, Q(h).wstate, 1) | ensure(h, Q(h).wtileL, WTILES_MAX) | ensure(h, Q(h).wtileR, WTILES_MAX);
     rc |= ensure(h, Q(h).esq0, 65536) | ensure(h, Q(h).esq1, 65536) | ensure(h, Q(h).esq2, 65536) | ensure(h, Q(h).essmall, 65536);
     return rc ? ERASOR_E_NO_DEVICE : 0;
@@ -772,11 +784,21 @@ static bool create_sides(erasor_hip_handle *h, int prio) {
 
 // A handle runs its chains on four streams, and HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4):
 // with several handles in one process -- one per sequence, or the shim's updaters -- the two query streams of a handle can land on ONE
-// queue, its two chains in flight then run one after the other and the step waits for them (measured, gpurun_out/r03ap: five sequences in
-// one process 2777 scans/s with the default, 4180 with 8 or 16 queues; the C++ bench's third handle 0.22 or 0.65 ms per step depending on
-// where its streams landed).  The variable is read when the HIP runtime starts: this runs when the library is loaded, does not override a
-// value the user has set, and is a no-op if the process initialised HIP earlier (then export GPU_MAX_HW_QUEUES=16 yourself).
-__attribute__((constructor)) static void erasor_hip_more_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// queue, its two chains in flight then run one after the other and the step waits for them (measured, round 3: five sequences in one
+// process 2777 scans/s with the default, 4180 with 8 or 16 queues; the C++ bench's third handle 0.22 or 0.65 ms per step depending on
+// where its streams landed).  The variable is read when the HIP runtime starts, so it is the PROCESS's business: rounds 2-3 set it from a
+// load-time constructor of this library, which changed the environment of whoever loaded it.  Now: a documented requirement
+// (include/erasor_hip.h; bench.py and the offline driver export it themselves) and ONE warning when a process creates
+// its second handle without it.
+static std::atomic<int> g_handles_created{0};
+static void warn_hw_queues_once() {
+    static std::atomic<bool> warned{false};
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    if ((e && atoi(e) >= 8) || warned.exchange(true)) return;
+    fprintf(stderr, "[erasor_hip] several handles in one process and GPU_MAX_HW_QUEUES is %s: their streams share %s hardware queues and "
+                    "look-ahead chains of one handle may run one after the other (export GPU_MAX_HW_QUEUES=16 before the process starts HIP)\n",
+            e ? e : "unset", e ? e : "the default 4");
+}
 
 int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **out) {
     if (!p || !out) return ERASOR_E_INVALID;
@@ -823,6 +845,7 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
         erasor_hip_destroy(h);
         return ERASOR_E_NO_DEVICE;
     }
+    if (g_handles_created.fetch_add(1) >= 1) warn_hw_queues_once();
     *out = h;
     return ERASOR_OK;
 }
@@ -1001,19 +1024,65 @@ static int voxelize_query_part1(erasor_hip_handle *h, uint32_t n, float leaf, co
 
 enum { STEP_QUERY_PREVOXELIZED = 1, STEP_VOI_EVERYTHING = 2, STEP_RETRIED = 4 };
 
-// A HOST scan on its way into query side Q(h): copied into the side's pinned staging buffer NOW (the caller's buffer is free again
-// when this returns), from there asynchronously into q.scan on `stream`.  The side's previous chain must be through with q.scan and
-// the staging buffer (the caller has waited for q.ev_done).
-static int stage_host_scan(erasor_hip_handle *h, const void *scan_src, uint32_t ns, hipStream_t stream) {
+// Hash of EVERY record of a host scan (the 16 bytes a record contributes: x, y, z, intensity).  Round 3 sampled ~258 records: a
+// buffer refilled in place that differed only in unsampled points was taken for the announced scan and the step ran on the stale copy
+// (ADVICE r02 / VERDICT r03).  Four independent multiply-xor lanes, one per field; ~0.1 ms for a 2 MB scan on one host core -- which is
+// why the drop-in path hands over a TICKET instead (erasor_hip_step_ticket: nothing is guessed, nothing is read twice).
+struct RowHash {
+    uint64_t a = 0x9E3779B97F4A7C15ull, b = 0xC2B2AE3D27D4EB4Full, c = 0x165667B19E3779F9ull, d = 0x27D4EB2F165667C5ull;
+    inline void add(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+        a = (a ^ x) * 0x100000001B3ull;
+        b = (b ^ y) * 0x100000001B3ull;
+        c = (c ^ z) * 0x100000001B3ull;
+        d = (d ^ w) * 0x100000001B3ull;
+    }
+    inline uint64_t done(size_t n) const {
+        uint64_t h = a ^ (b << 1 | b >> 63) ^ (c << 2 | c >> 62) ^ (d << 3 | d >> 61) ^ (uint64_t)n * 0x9FB21C651E98DF25ull;
+        h ^= h >> 32;
+        h *= 0xD6E8FEB86659FD93ull;
+        h ^= h >> 32;
+        return h;
+    }
+};
+static uint64_t scan_fingerprint(const void *host_rows, size_t n, RowFmt fmt) {
+    RowHash rh;
+    const unsigned char *p = static_cast<const unsigned char *>(host_rows);
+    for (size_t i = 0; i < n; ++i, p += fmt.stride) {
+        uint32_t w[4];
+        memcpy(w, p, 12);
+        memcpy(w + 3, p + fmt.ioff, 4);
+        rh.add(w[0], w[1], w[2], w[3]);
+    }
+    return rh.done(n);
+}
+
+// A HOST scan on its way into query side Q(h): REPACKED into the side's pinned staging buffer NOW -- one pass that also hashes every
+// record (the caller's buffer is free again when this returns) --, from there asynchronously into q.scan on `stream`.  The side's
+// previous chain must be through with q.scan and the staging buffer (the caller has waited for q.ev_done).
+static int stage_host_scan(erasor_hip_handle *h, const void *scan_src, uint32_t ns, hipStream_t stream, RowFmt fmt, uint64_t *fp_out) {
     QSide &q = Q(h);
     if (q.h2d_pending) HIPC(h, hipEventSynchronize(q.ev_h2d));  // (an announcement that was dropped: its copy may still read the staging buffer)
-    if (q.stage_cap < ns) {
+    if (scan_src != (const void *)q.stage && q.stage_cap < ns) {
         if (q.stage) (void)hipHostFree(q.stage);
         q.stage = nullptr;
         q.stage_cap = (size_t)ns + ns / 4 + 1024;
         HIPC(h, hipHostMalloc((void **)&q.stage, q.stage_cap * sizeof(float4), hipHostMallocDefault));
     }
-    memcpy(q.stage, scan_src, (size_t)ns * sizeof(float4));
+    RowHash rh;
+    const unsigned char *p = static_cast<const unsigned char *>(scan_src);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(q.stage);
+    if (scan_src == (const void *)q.stage) {  // (a step run again from its own staged copy: already in place)
+        for (uint32_t i = 0; i < ns; ++i) rh.add(dst[4 * i], dst[4 * i + 1], dst[4 * i + 2], dst[4 * i + 3]);
+    } else {
+        for (uint32_t i = 0; i < ns; ++i, p += fmt.stride) {
+            uint32_t w[4];
+            memcpy(w, p, 12);
+            memcpy(w + 3, p + fmt.ioff, 4);
+            memcpy(dst + 4 * (size_t)i, w, 16);
+            rh.add(w[0], w[1], w[2], w[3]);
+        }
+    }
+    if (fp_out) *fp_out = rh.done(ns);
     HIPC(h, hipMemcpyAsync(q.scan.p, q.stage, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, stream));
     return ERASOR_OK;
 }
@@ -1053,7 +1122,7 @@ static int graph_flush(erasor_hip_handle *h, GSeg &seg, std::vector<GNode> &rec,
             prev = gn;
         }
         ok = ok && hipGraphInstantiate(&seg.exec, seg.graph, nullptr, nullptr, 0) == hipSuccess;
-        if (ok) seg.nodes = std::move(rec);
+        if (ok) seg.nodes = rec;  // (a copy: `rec` stays whole until the launch has succeeded -- the fallback below replays it)
         ++seg.n_rebuild;
     } else {
         for (size_t i = 0; ok && i < rec.size(); ++i) {
@@ -1061,7 +1130,7 @@ static int graph_flush(erasor_hip_handle *h, GSeg &seg, std::vector<GNode> &rec,
             if (o.grid.x == n.grid.x && o.grid.y == n.grid.y && o.grid.z == n.grid.z && o.block.x == n.block.x && o.blob == n.blob) continue;
             hipKernelNodeParams p = params(n);
             ok = hipGraphExecKernelNodeSetParams(seg.exec, seg.gnodes[i], &p) == hipSuccess;
-            o = std::move(n);
+            if (ok) o = n;  // (copied, not moved: see the fallback)
             ++seg.n_patch;
         }
     }
@@ -1072,8 +1141,9 @@ static int graph_flush(erasor_hip_handle *h, GSeg &seg, std::vector<GNode> &rec,
         return ERASOR_OK;
     }
     (void)hipGetLastError();
-    std::vector<GNode> &src = rec.empty() ? seg.nodes : rec;  // (after a failed patch / launch the recorded arguments are in seg.nodes)
-    for (GNode &n : src) {
+    // a graph call failed: this recording -- still complete, nothing was moved out of it -- is launched kernel by kernel, and the
+    // handle stops using graphs (the fallback used to replay entries whose argument blobs had been moved away)
+    for (GNode &n : rec) {
         hipKernelNodeParams p = params(n);
         if (hipLaunchKernel(p.func, p.gridDim, p.blockDim, p.kernelParams, 0, stream) != hipSuccess) {
             h->err = "kernel launch failed (graph fallback)";
@@ -1124,21 +1194,6 @@ struct SideGuard {
 // chain recognises "the same scan" by (pointer, size, T_lidar2body) -- and by this fingerprint of the contents, so that a
 // buffer that was refilled (or freed and re-used at the same address) in between is not mistaken for the announced one.
 // FNV-1a over at most 256 evenly spaced points plus the first and the last: microseconds, not a checksum of 2 MB.
-static uint64_t scan_fingerprint(const void *host_xyzi, size_t n) {
-    uint64_t hsh = 1469598103934665603ull ^ (uint64_t)n;
-    if (!host_xyzi || !n) return hsh;
-    const uint32_t *w = static_cast<const uint32_t *>(host_xyzi);
-    const size_t step = n > 256 ? n / 256 : 1;
-    auto mix = [&](size_t i) {
-        for (int k = 0; k < 4; ++k) {
-            hsh ^= w[4 * i + k];
-            hsh *= 1099511628211ull;
-        }
-    };
-    for (size_t i = 0; i < n; i += step) mix(i);
-    mix(n - 1);
-    return hsh;
-}
 
 // VoxelGrid pass-through (see k_dup_label_passthrough): out[0..ns) = T * (point with the label of its first exact duplicate),
 // on the current stream.  Scratch: the current query side's sort buffers.
@@ -1158,7 +1213,7 @@ static int enqueue_passthrough(erasor_hip_handle *h, const float4 *d_src, uint32
 }
 
 static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_src, uint32_t ns, bool src_is_device, const float T_l2b[16],
-                               bool prevox, bool staged = false, bool passthrough = false) {
+                               bool prevox, bool staged = false, bool passthrough = false, RowFmt fmt = RowFmt()) {
     SideGuard guard(h);
     h->qi = side;
     // (the radix fallback for very fine R-POD grids -- and the pass-through chain's radix sort -- share their scratch bank
@@ -1183,9 +1238,11 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
         // the side may still be executing a chain that was dropped (a prefetch that no step claimed): its kernels read
         // q.scan, and a scan that changes between the bounding-box pass and the voxel keys sends them astray
         if (q.used) HIPC(h, hipEventSynchronize(q.ev_done));
-        rc = stage_host_scan(h, scan_src, ns, qstream);  // (on the chain's own stream: ordered before its first kernel)
+        uint64_t fp_staged = 0;
+        rc = stage_host_scan(h, scan_src, ns, qstream, fmt, &fp_staged);  // (on the chain's own stream: ordered before its first kernel)
         if (rc) return rc;
         q.h2d_pending = false;
+        q.fp = fp_staged;
     }
     if (q.h2d_pending) {  // announced earlier (erasor_hip_prefetch_*): the copy runs on the copy stream
         (void)hipStreamWaitEvent(qstream, q.ev_h2d, 0);
@@ -1264,7 +1321,9 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     q.ns = ns;
     q.src_dev = src_is_device;
     q.pose_valid = false;  // (flush_announced adds the pose of an announced node)
-    if (!src_is_device) q.fp = staged ? h->ann.fp : scan_fingerprint(scan_src, ns);
+    if (!src_is_device && staged) q.fp = h->ann.fp;  // (not staged: the hash the staging pass has just taken)
+    q.fmt = fmt;
+    q.ticket = staged ? h->ann.ticket : 0ull;
     memcpy(q.Tl, T_l2b, sizeof(q.Tl));
     return ERASOR_OK;
 }
@@ -1274,7 +1333,7 @@ static int flush_announced(erasor_hip_handle *h) {
     if (!h->ann.valid) return ERASOR_OK;
     h->ann.valid = false;
     const int rc = enqueue_query_chain(h, h->ann.side, h->ann.src, (uint32_t)h->ann.n, h->ann.is_device, h->ann.Tl, false, /*staged=*/true,
-                                       h->q_passthrough);
+                                       h->q_passthrough, h->ann.fmt);
     if (rc) return rc;
     h->q[h->ann.side].pose_valid = h->ann.pose_valid;
     h->q[h->ann.side].pose_x = h->ann.pose_x;
@@ -1289,6 +1348,10 @@ static void q_drain(erasor_hip_handle *h) {
     h->npend = 0;
     h->ann.valid = false;
     for (int k = 0; k < h->nqs; ++k) (void)hipStreamSynchronize(h->qstream[k]);
+    // a dropped announcement's host scan may still be on its way from pinned staging into its side (copy stream): whoever uses the
+    // sides as scratch next must not race with that copy
+    if (h->cstream) (void)hipStreamSynchronize(h->cstream);
+    for (int k = 0; k < NSIDE; ++k) h->q[k].h2d_pending = false;
 }
 
 
@@ -1328,11 +1391,33 @@ static void launch_voi_split(erasor_hip_handle *h, const float4 *F, uint32_t nF,
     }
 }
 
+// The NEXT step's VoI split behind the step in flight (its pose is known: erasor_hip_prefetch_node): reads the store that step writes
+// and the extents its end commits; `step_end`: the launch also ends the step in flight (see StepEnd).
+static void launch_split_ahead(erasor_hip_handle *h, double nx, double ny, uint32_t nchunks_hint, const StepEnd *step_end) {
+    const size_t cap_chunks = std::min(std::min(h->vmask.cap, h->hmask.cap) / CHUNK_TILES, h->cinfo.cap) - 8;
+    launch_voi_split(h, (const float4 *)h->F[h->curF ^ 1].p, 0u, 0u, 0u, 0u, 0u, nchunks_hint + 64, nx, ny, h->dp.voi_r2, (const DevState *)h->d_st.p,
+                     (uint32_t)cap_chunks, step_end);
+    h->spec.valid = true;
+    h->spec.x = nx;
+    h->spec.y = ny;
+    h->spec.seq = h->step_seq;
+    h->spec.epoch = h->store_epoch;
+    h->spec.curF = h->curF ^ 1;
+    h->spec.cap_chunks = (uint32_t)cap_chunks;
+    h->spec.vmask = h->vmask.p;
+    h->spec.hmask = h->hmask.p;
+    h->spec.cinfo = h->cinfo.p;
+    h->fly.spec_launched = true;
+    ++h->n_spec_launched;
+}
+
 static int step_collect(erasor_hip_handle *h, erasor_step_result *res);
 // First half of a step: everything is ENQUEUED (this scan's query chain unless it is in flight already, the map chain, Scan Ratio
 // Test .. write-back, k_step_end, the next step's VoI split and the next announced scan's query chain); nothing is waited for.
+// ticket != 0: the scan is the OLDEST announced one and must carry that ticket (erasor_hip_step_ticket): nothing is compared, the
+// caller's buffer is not read again; scan_src / n_scan / T_l2b are ignored.
 static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_scan, bool src_is_device, const float T_l2b[16],
-                        const float T_b2o[16], const float T_o2b[16], int flags = 0) {
+                        const float T_b2o[16], const float T_o2b[16], int flags = 0, RowFmt fmt = RowFmt(), uint64_t ticket = 0) {
     if (!h) return ERASOR_E_INVALID;
     if (h->fly.active) {
         h->err = "erasor_hip_step_async: the previous step has not been collected (erasor_hip_step_wait)";
@@ -1343,9 +1428,31 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                              : "erasor_hip_step before erasor_hip_set_map";
         return ERASOR_E_STATE;
     }
-    if (!T_l2b || !T_b2o || !T_o2b || (!scan_src && n_scan) || n_scan > 0x3FFFFFFFull) return ERASOR_E_INVALID;
+    if (!ticket && (!T_l2b || (!scan_src && n_scan) || n_scan > 0x3FFFFFFFull)) return ERASOR_E_INVALID;
+    if (!T_b2o || !T_o2b || (src_is_device && (fmt.stride != 16 || fmt.ioff != 12)) || fmt.stride < 16 || fmt.ioff < 12 || fmt.ioff + 4 > fmt.stride)
+        return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
     prof_collect(h);
+    float Tl_ticket[16];
+    if (ticket) {
+        // the announced scan, by ticket: still only announced (the first node of a sequence) -> its chain starts now
+        if (h->npend == 0 && h->ann.valid && h->ann.ticket == ticket) {
+            const int rc_f = flush_announced(h);
+            if (rc_f) return rc_f;
+        }
+        if (h->npend == 0 || h->q[h->pend[0]].ticket != ticket) {
+            h->err = "erasor_hip_step_ticket: not the ticket of the oldest announced scan (announcements are consumed in order)";
+            return ERASOR_E_STATE;
+        }
+        const QSide &c = h->q[h->pend[0]];
+        memcpy(Tl_ticket, c.Tl, sizeof(Tl_ticket));
+        T_l2b = Tl_ticket;
+        n_scan = c.src_n;
+        src_is_device = c.src_dev;
+        // (a host scan lives on in the side's pinned staging copy: that is what a step that has to run again reads)
+        scan_src = c.src_dev ? c.src : (const void *)c.stage;
+        fmt = RowFmt();
+    }
     const auto t_host0 = std::chrono::steady_clock::now();
     static const bool host_timing = getenv("ERASOR_HIP_HOST_TIMING") != nullptr;
     std::vector<std::pair<const char *, double>> marks;
@@ -1358,16 +1465,23 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     // ---- this scan's query chain: already in flight (erasor_hip_prefetch_scan), or enqueued now -- first, it is the long one ----
     {
         int side = -1;
-        const uint64_t fp_now = src_is_device ? 0ull : scan_fingerprint(scan_src, n_scan);
-        if (h->npend == 0 && h->ann.valid && !prevox && h->ann.src == scan_src && h->ann.n == n_scan && h->ann.is_device == src_is_device &&
-            (src_is_device || h->ann.fp == fp_now) && memcmp(h->ann.Tl, T_l2b, sizeof(h->ann.Tl)) == 0) {
+        // (recognition WITHOUT a ticket: pointer, size, T_lidar2body -- and, for a host scan, the hash of every record of the caller's
+        // buffer against the hash of the copy that was staged: only taken when the cheap tests have passed)
+        const bool ann_cand = !ticket && h->npend == 0 && h->ann.valid && !prevox && h->ann.src == scan_src && h->ann.n == n_scan &&
+                              h->ann.is_device == src_is_device && memcmp(h->ann.Tl, T_l2b, sizeof(h->ann.Tl)) == 0 &&
+                              h->ann.fmt.stride == fmt.stride && h->ann.fmt.ioff == fmt.ioff;
+        const bool pend_cand = !ticket && h->npend > 0 && !prevox && h->q[h->pend[0]].src == scan_src && h->q[h->pend[0]].src_n == n_scan &&
+                               h->q[h->pend[0]].src_dev == src_is_device && memcmp(h->q[h->pend[0]].Tl, T_l2b, sizeof(h->q[0].Tl)) == 0 &&
+                               h->q[h->pend[0]].fmt.stride == fmt.stride && h->q[h->pend[0]].fmt.ioff == fmt.ioff;
+        const uint64_t fp_now = (!src_is_device && (ann_cand || pend_cand)) ? scan_fingerprint(scan_src, n_scan, fmt) : 0ull;
+        if (ann_cand && (src_is_device || h->ann.fp == fp_now)) {
             rc = flush_announced(h);  // announced, not yet started (first scan of a sequence): start it now, it is ours
             if (rc) return rc;
         }
         if (h->npend > 0) {
             const QSide &c = h->q[h->pend[0]];
-            if (!prevox && c.src == scan_src && c.src_n == n_scan && c.src_dev == src_is_device && (src_is_device || c.fp == fp_now) &&
-                memcmp(c.Tl, T_l2b, sizeof(c.Tl)) == 0) {
+            if (ticket || (!prevox && c.src == scan_src && c.src_n == n_scan && c.src_dev == src_is_device && (src_is_device || c.fp == fp_now) &&
+                           memcmp(c.Tl, T_l2b, sizeof(c.Tl)) == 0 && c.fmt.stride == fmt.stride && c.fmt.ioff == fmt.ioff)) {
                 side = h->pend[0];
                 for (int j = 1; j < h->npend; ++j) h->pend[j - 1] = h->pend[j];
                 --h->npend;
@@ -1380,7 +1494,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         if (side < 0) {
             // (an announcement that is not this scan is the NEXT scan: it keeps the side it was staged into)
             side = pick_side(h);
-            rc = enqueue_query_chain(h, side, scan_src, ns, src_is_device, T_l2b, prevox, false, h->q_passthrough && !prevox);
+            rc = enqueue_query_chain(h, side, scan_src, ns, src_is_device, T_l2b, prevox, false, h->q_passthrough && !prevox, fmt);
             if (rc) return rc;
         }
         h->qi = side;
@@ -1679,22 +1793,9 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         const bool end_in_split = spec && !no_end_fold && h->prof != 1;
         if (!end_in_split)
             LAUNCH(h, "step_end", k_step_end, 1, 1, se.st, se.ctr, se.out, se.lab_slots, se.qctr, se.q_nvox, se.seq);
-        if (spec) {
-            const size_t cap_chunks = std::min(std::min(h->vmask.cap, h->hmask.cap) / CHUNK_TILES, h->cinfo.cap) - 8;
-            launch_voi_split(h, (const float4 *)Fnew, 0u, 0u, 0u, 0u, 0u, nchunks + 64, nx, ny, P.voi_r2, (const DevState *)ds, (uint32_t)cap_chunks,
-                             end_in_split ? &se : (const StepEnd *)nullptr);
-            h->spec.valid = true;
-            h->spec.x = nx;
-            h->spec.y = ny;
-            h->spec.seq = h->step_seq;
-            h->spec.epoch = h->store_epoch;
-            h->spec.curF = h->curF ^ 1;
-            h->spec.cap_chunks = (uint32_t)cap_chunks;
-            h->spec.vmask = h->vmask.p;
-            h->spec.hmask = h->hmask.p;
-            h->spec.cinfo = h->cinfo.p;
-            ++h->n_spec_launched;
-        }
+        h->fly.nchunks = nchunks;
+        h->fly.spec_launched = false;
+        if (spec) launch_split_ahead(h, nx, ny, nchunks, end_in_split ? &se : (const StepEnd *)nullptr);
     }
     {   // the NEXT scan's query chain goes into its queue now, behind this step's own launches; it runs while we wait
         const int keep_side = h->qi;
@@ -1712,7 +1813,9 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     h->fly.ns = ns;
     h->fly.sm_keys = sm_keys;
     h->fly.flags = flags;
-    h->fly.scan_src = scan_src;
+    // (what a step that has to run again reads: a host scan's staged copy -- float4 rows in the side's pinned buffer --, never the
+    // caller's buffer, which is the caller's again once this call has returned)
+    h->fly.scan_src = (src_is_device || !n_scan) ? scan_src : (const void *)Q(h).stage;
     h->fly.n_scan = n_scan;
     h->fly.src_is_device = src_is_device;
     memcpy(h->fly.Tl, T_l2b, sizeof(h->fly.Tl));
@@ -1776,7 +1879,7 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
     if (host_timing)
         fprintf(stderr, "[step host] wait %.1f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host1).count());
     if (h->dbg_stamps.p) {
-        unsigned long long t[64];
+        unsigned long long t[96];
         (void)hipMemcpy(t, h->dbg_stamps.p, sizeof(t), hipMemcpyDeviceToHost);
         fprintf(stderr, "[slowest R-GPF bin, 10 ns ticks] key load %llu, exact sort %llu, seeds %llu, staging %llu, it0: cov %llu svd %llu classify %llu (final ground %llu)\n",
                 t[32], t[33], t[34], t[35], t[36], t[37], t[38], t[39]);
@@ -1792,6 +1895,8 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
                 (double)(t[26] - t[28]) / 100.0, (double)(t[27] - t[28]) / 100.0, t[25], t[24]);
         fprintf(stderr, "[slowest reverted bin] R-GPF: %llu points, z-sort %.1f us + rest %.1f us; per-bin voxelisation: %llu points -> %llu voxels, %.1f us\n",
                 t[19], (double)t[17] / 100.0, (double)t[18] / 100.0, t[21], t[22], (double)t[20] / 100.0);
+        fprintf(stderr, "[last per-bin workgroup] %.1f us: open %.1f, select %.1f, R-GPF %.1f (%llu points), voxelisation %.1f (%llu points)\n", (double)t[64] / 100.0,
+                (double)t[65] / 100.0, (double)t[66] / 100.0, (double)t[67] / 100.0, t[69], (double)t[68] / 100.0, t[70]);
         fprintf(stderr, "[reverted bins] %llu, %llu of them beyond the LDS pool, %llu points in all\n", t[23] & 0xFFFFFFFFull, t[23] >> 32, t[63]);
         memset(t, 0, sizeof(t));
         t[28] = ~0ull;
@@ -1816,7 +1921,11 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
             h->q_passthrough = h->ctr.err == 2;
             if (!(flags & STEP_RETRIED)) {
                 q_drain(h);  // chains announced ahead were enqueued in the other mode: dropped, their steps enqueue their own
-                const int rc_again = step_enqueue(h, h->fly.scan_src, h->fly.n_scan, h->fly.src_is_device, h->fly.Tl, h->fly.Tb, h->fly.To, flags | STEP_RETRIED);
+                float Tl[16], Tb[16], To[16];  // (step_enqueue stores its arguments into h->fly: no aliasing copies)
+                memcpy(Tl, h->fly.Tl, sizeof(Tl));
+                memcpy(Tb, h->fly.Tb, sizeof(Tb));
+                memcpy(To, h->fly.To, sizeof(To));
+                const int rc_again = step_enqueue(h, h->fly.scan_src, h->fly.n_scan, h->fly.src_is_device, Tl, Tb, To, flags | STEP_RETRIED);
                 return rc_again ? rc_again : step_collect(h, res);
             }
             h->err = "VoxelGrid pass-through decision did not settle";
@@ -1877,15 +1986,17 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
 }
 
 static int step_common(erasor_hip_handle *h, const void *scan_src, size_t n_scan, bool src_is_device, const float T_l2b[16],
-                       const float T_b2o[16], const float T_o2b[16], erasor_step_result *res, int flags = 0) {
-    const int rc = step_enqueue(h, scan_src, n_scan, src_is_device, T_l2b, T_b2o, T_o2b, flags);
+                       const float T_b2o[16], const float T_o2b[16], erasor_step_result *res, int flags = 0, RowFmt fmt = RowFmt(),
+                       uint64_t ticket = 0) {
+    const int rc = step_enqueue(h, scan_src, n_scan, src_is_device, T_l2b, T_b2o, T_o2b, flags, fmt, ticket);
     return rc ? rc : step_collect(h, res);
 }
 
 // Announce the NEXT scan: its query chain (voxelisation, label search, bucketing -- everything that does not depend on the
 // map) is enqueued now and runs beside the map-side stages of the step in flight.  The step call that follows must pass the
 // same (pointer, size, T_lidar2body); anything else simply drops the prefetch.
-static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device, const float T_l2b[16], const float *T_b2o);
+static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device, const float T_l2b[16], const float *T_b2o,
+                           RowFmt fmt = RowFmt(), uint64_t *ticket = nullptr);
 int erasor_hip_prefetch_scan(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device, const float T_l2b[16]) {
     return prefetch_common(h, scan_xyzi, n, src_is_device, T_l2b, nullptr);
 }
@@ -1896,9 +2007,12 @@ int erasor_hip_prefetch_node(erasor_hip_handle *h, const void *scan_xyzi, size_t
     if (!T_body2origin) return ERASOR_E_INVALID;
     return prefetch_common(h, scan_xyzi, n, src_is_device, T_l2b, T_body2origin);
 }
-static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device, const float T_l2b[16], const float *T_b2o) {
-    NOFLY(h);
+static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n, int src_is_device, const float T_l2b[16], const float *T_b2o,
+                           RowFmt fmt, uint64_t *ticket) {
+    // (round 4: allowed while a step is in flight -- between erasor_hip_step_async / _step_ticket_async and erasor_hip_step_wait: the
+    // host then stages the next node's cloud while the GPU is busy with the current one; see the end of this function)
     if (!h || !T_l2b || (!scan_xyzi && n) || n > 0x3FFFFFFFull) return ERASOR_E_INVALID;
+    if ((src_is_device && (fmt.stride != 16 || fmt.ioff != 12)) || fmt.stride < 16 || fmt.ioff < 12 || fmt.ioff + 4 > fmt.stride) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
     if (h->ann.valid && h->npend >= MAX_AHEAD) {
         h->err = "erasor_hip_prefetch_scan: as many scans as there are query sides to hold them are already announced";
@@ -1913,21 +2027,40 @@ static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n
         rc = alloc_scan(h, (uint32_t)n);
         if (rc) return rc;
         if (Q(h).used) HIPC(h, hipEventSynchronize(Q(h).ev_done));  // (a dropped chain may still be reading this side's scan)
-        rc = stage_host_scan(h, scan_xyzi, (uint32_t)n, h->cstream);
+        rc = stage_host_scan(h, scan_xyzi, (uint32_t)n, h->cstream, fmt, &h->ann.fp);
         if (rc) return rc;
         HIPC(h, hipEventRecord(Q(h).ev_h2d, h->cstream));
         Q(h).h2d_pending = true;
-    }
+    } else
+        h->ann.fp = 0ull;
     h->ann.valid = true;
     h->ann.is_device = src_is_device != 0;
     h->ann.src = scan_xyzi;
     h->ann.n = n;
-    h->ann.fp = src_is_device ? 0ull : scan_fingerprint(scan_xyzi, n);
+    h->ann.fmt = fmt;
+    h->ann.ticket = h->next_ticket++;
+    if (ticket) *ticket = h->ann.ticket;
     h->ann.side = side;
     memcpy(h->ann.Tl, T_l2b, sizeof(h->ann.Tl));
     h->ann.pose_valid = T_b2o != nullptr;
     h->ann.pose_x = T_b2o ? (double)T_b2o[3] : 0.0;  // OMU.cpp:246-247
     h->ann.pose_y = T_b2o ? (double)T_b2o[7] : 0.0;
+    if (h->fly.active) {
+        // the step in flight has enqueued everything of its own already: the announced chain starts NOW (nothing to go first), and if
+        // this is the node right behind that step and its pose is known, its VoI split goes behind the step as well
+        static const bool no_spec = getenv("ERASOR_HIP_NO_AHEAD_SPLIT") != nullptr;
+        const bool next_in_line = h->npend == 0;
+        const bool pose = h->ann.pose_valid;
+        const double nx = h->ann.pose_x, ny = h->ann.pose_y;
+        rc = flush_announced(h);
+        if (rc) return rc;
+        if (next_in_line && pose && !no_spec && !h->fly.flags && !h->P.is_large_scale && !h->fly.spec_launched) {
+            hipStream_t keep = h->cur;
+            h->cur = h->stream;
+            launch_split_ahead(h, nx, ny, h->fly.nchunks, nullptr);
+            h->cur = keep;
+        }
+    }
     return ERASOR_OK;
 }
 
@@ -1938,6 +2071,33 @@ int erasor_hip_step(erasor_hip_handle *h, const float *scan_xyzi, size_t n_scan,
 int erasor_hip_step_device(erasor_hip_handle *h, const void *d_scan_xyzi, size_t n_scan, const float T_lidar2body[16],
                            const float T_body2origin[16], const float T_origin2body[16], erasor_step_result *res) {
     return step_common(h, d_scan_xyzi, n_scan, true, T_lidar2body, T_body2origin, T_origin2body, res);
+}
+// Host records in the caller's own layout (pcl::PointXYZI: stride 32, intensity at byte 16 -- what pcl::fromROSMsg leaves, OMU.cpp:237):
+// the one pass that stages the scan in pinned memory repacks it, so a caller no longer rewrites 4 MB per node into XYZI rows first.
+static RowFmt row_fmt(size_t stride, size_t ioff) {
+    RowFmt f;
+    f.stride = stride > 0xFFFFFFFFull ? 0u : (uint32_t)stride;  // (0: rejected as invalid further down)
+    f.ioff = ioff > 0xFFFFFFFFull ? 0u : (uint32_t)ioff;
+    return f;
+}
+int erasor_hip_step_rows(erasor_hip_handle *h, const void *rows, size_t n, size_t stride_bytes, size_t intensity_offset_bytes,
+                         const float T_lidar2body[16], const float T_body2origin[16], const float T_origin2body[16], erasor_step_result *res) {
+    return step_common(h, rows, n, false, T_lidar2body, T_body2origin, T_origin2body, res, 0, row_fmt(stride_bytes, intensity_offset_bytes));
+}
+int erasor_hip_prefetch_node_rows(erasor_hip_handle *h, const void *rows, size_t n, size_t stride_bytes, size_t intensity_offset_bytes,
+                                  const float T_lidar2body[16], const float *T_body2origin, uint64_t *ticket) {
+    return prefetch_common(h, rows, n, 0, T_lidar2body, T_body2origin, row_fmt(stride_bytes, intensity_offset_bytes), ticket);
+}
+// The step of an ANNOUNCED node by the ticket its announcement returned: nothing is recognised by pointer or content, the caller's
+// buffer is not touched again (it was the caller's again when the announcement returned).  Tickets are consumed in announcement order.
+int erasor_hip_step_ticket(erasor_hip_handle *h, uint64_t ticket, const float T_body2origin[16], const float T_origin2body[16],
+                           erasor_step_result *res) {
+    if (!ticket) return ERASOR_E_INVALID;
+    return step_common(h, nullptr, 0, false, nullptr, T_body2origin, T_origin2body, res, 0, RowFmt(), ticket);
+}
+int erasor_hip_step_ticket_async(erasor_hip_handle *h, uint64_t ticket, const float T_body2origin[16], const float T_origin2body[16]) {
+    if (!ticket) return ERASOR_E_INVALID;
+    return step_enqueue(h, nullptr, 0, false, nullptr, T_body2origin, T_origin2body, 0, RowFmt(), ticket);
 }
 // SURVEY 8(b), threading row: the step in two halves, so that ONE host thread can keep several handles (independent sequences,
 // OMU.cpp:203 is one callback per node per updater) busy: async enqueues everything and returns, wait collects.
@@ -2509,6 +2669,18 @@ int erasor_hip_device_free(erasor_hip_handle *h, void *d_ptr) {
     return ERASOR_OK;
 }
 
+
+int erasor_hip_erasor_run(erasor_hip_handle *h, const float *map_voi_xyzi, size_t n_map, const float *query_voi_xyzi, size_t n_query,
+                          erasor_step_result *res) {
+    NOFLY(h);
+    int rc = set_map_common(h, map_voi_xyzi, n_map, false);
+    if (rc) return rc;
+    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    return step_common(h, query_voi_xyzi, n_query, false, I, I, I, res, STEP_QUERY_PREVOXELIZED | STEP_VOI_EVERYTHING);
+}
+#ifdef ERASOR_HIP_TEST_HOOKS
+// ---- test hooks: NOT part of the product library (round 4).  The test suite builds its own copy of this file with
+// -DERASOR_HIP_TEST_HOOKS (erasor_amd/csrc/Makefile: tests/_build/liberasor_hip_hooks.so) and declares them itself. ----
 // test hook: device libm probe (sqrt / div / atan2 in double)
 int erasor_hip_probe_math(erasor_hip_handle *h, const double *x, const double *y, size_t n, double *o_sqrt, double *o_div, double *o_atan2) {
     NOFLY(h);
@@ -2571,15 +2743,6 @@ int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *va
     return ERASOR_OK;
 }
 
-int erasor_hip_erasor_run(erasor_hip_handle *h, const float *map_voi_xyzi, size_t n_map, const float *query_voi_xyzi, size_t n_query,
-                          erasor_step_result *res) {
-    NOFLY(h);
-    int rc = set_map_common(h, map_voi_xyzi, n_map, false);
-    if (rc) return rc;
-    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    return step_common(h, query_voi_xyzi, n_query, false, I, I, I, res, STEP_QUERY_PREVOXELIZED | STEP_VOI_EVERYTHING);
-}
-
 // test hook: force the tombstone-free rebuild of the outskirts region (normally triggered by hole / room heuristics)
 int erasor_hip_debug_rebuild_outskirts(erasor_hip_handle *h) {
     NOFLY(h);
@@ -2610,5 +2773,6 @@ int erasor_hip_radix_sort_u32(erasor_hip_handle *h, const uint32_t *keys, size_t
     }
     return ERASOR_OK;
 }
+#endif  // ERASOR_HIP_TEST_HOOKS
 
 }  // extern "C"

@@ -670,13 +670,16 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
         const uint32_t c = isF ? w / GATHER_SUB : w - nFchunks * (GATHER_SUB - 1);
         const int t_lo = isF ? (int)(w % GATHER_SUB) * (CHUNK_TILES / (int)GATHER_SUB) : 0;
         const int t_hi = isF ? t_lo + CHUNK_TILES / (int)GATHER_SUB : CHUNK_TILES;
+        // (round 4: everything the item needs is fetched TOGETHER -- the loads only depend on c; behind the early exit they were three
+        // dependent round trips at the head of every wavefront's life.  A skipped outskirts chunk wastes five small loads.)
         const uint32_t ci = cinfo[c];
-        const uint32_t cv = ci & 0xFFFFu, ch = (ci >> 16) & CINFO_HMASK;
-        if (cv == 0 && !(isF && ch > cv)) continue;
-        uint32_t pv = pvl[c] + topv[c >> 10];
-        uint32_t ph = phl[c] + toph[c >> 10];
+        const uint32_t pvl_c = pvl[c], phl_c = phl[c], topv_c = topv[c >> 10], toph_c = toph[c >> 10];
         const unsigned long long mv = lane < CHUNK_TILES ? vmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
         const unsigned long long mh = lane < CHUNK_TILES ? hmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
+        const uint32_t cv = ci & 0xFFFFu, ch = (ci >> 16) & CINFO_HMASK;
+        if (cv == 0 && !(isF && ch > cv)) continue;
+        uint32_t pv = pvl_c + topv_c;
+        uint32_t ph = phl_c + toph_c;
         if (t_lo > 0) {  // entries of the chunk's tiles before this piece
             // (lanes >= CHUNK_TILES hold empty masks; both counts are < 2^16: one packed DPP reduction)
             const uint32_t a2 = wave_sum(((int)lane < t_lo) ? ((uint32_t)__popcll(mv) | ((uint32_t)__popcll(mh) << 16)) : 0u);

@@ -761,17 +761,32 @@ __global__ __launch_bounds__(1024) void k_revert_bins_srt(DP P, SrtArgs sa, RevA
         srt4_call();
         return;
     }
+    const unsigned long long w0 = ra.dbg ? wall_clock64() : 0ull;
     rev_open(P, ra);
     for (uint32_t rk = blockIdx.x;; rk += gridDim.x - 1) {
         __syncthreads();  // (g_sel of the previous round has been read)
+        const unsigned long long w1 = ra.dbg ? wall_clock64() : 0ull;
         rev_select_call(P.B, sa.st1_in, rk);
         const uint32_t key = g_sel[0], n_rev = g_sel[2];
         if (rk >= n_rev) break;
         rev_set_bin(rk, key, ra.moff[key] + ra.qoff[key]);
+        const unsigned long long w2 = ra.dbg ? wall_clock64() : 0ull;
         rgpf_stage();
         __threadfence_block();
         __syncthreads();  // the bin's ground list and count (global memory, written by this workgroup) are read below
+        const unsigned long long w3 = ra.dbg ? wall_clock64() : 0ull;
         binvox_stage();
+        if (ra.dbg && threadIdx.x == 0) {  // diagnostics: the workgroup that finishes last, 10 ns ticks since its start
+            const unsigned long long w4 = wall_clock64();
+            if (atomicMax(&ra.dbg[64], w4 - w0) < w4 - w0) {
+                ra.dbg[65] = w1 - w0;
+                ra.dbg[66] = w2 - w1;
+                ra.dbg[67] = w3 - w2;
+                ra.dbg[68] = w4 - w3;
+                ra.dbg[69] = ra.moff[key + 1] - ra.moff[key];
+                ra.dbg[70] = g_rb.m;
+            }
+        }
     }
 }
 

@@ -360,24 +360,38 @@ void OfflineMapUpdater::set_global_map(const Cloud &map_init) {
     const std::vector<float> v = to_xyzi(map_init);
     check(h_, erasor_hip_set_map(h_, v.data(), map_init.size()), "erasor_hip_set_map");
 }
-// is `lidar` the cloud whose xyzi copy `v` holds?  (bitwise; stops at the first difference)
-// Is `lidar` the cloud that was announced (and repacked into v)?  Size, then every 256th point and the last one -- the same sampling rule
-// the C ABI applies to an announced host buffer (include/erasor_hip.h): a cloud of the same size that differs only in unsampled points is
-// taken for the announced one.  (All points compared: 0.1 ms per node on the host, a sixth of the callback.)
-static bool same_cloud(const Cloud &lidar, const std::vector<float> &v) {
-    if (v.size() != 4 * lidar.size()) return false;
-    const size_t n = lidar.size(), stride = n / 256 + 1;
-    for (size_t i = 0; i < n; i = (i + stride < n || i == n - 1) ? i + stride : n - 1) {
-        const pcl::PointXYZI &p = lidar.points[i];
-        const float q[4] = {p.x, p.y, p.z, p.intensity};
-        if (memcmp(q, &v[4 * i], sizeof(q)) != 0) return false;
-    }
-    return true;
+// pcl::PointXYZI records go to the library as they lie (erasor_hip_step_rows / _prefetch_node_rows): x, y, z at byte 0, intensity at
+// its own offset; the pass that stages a host scan in pinned memory repacks them (rounds 2-3 rewrote 4 MB per node into XYZI rows first)
+static constexpr size_t kRowStride = sizeof(pcl::PointXYZI);
+static const size_t kRowIntensity = offsetof(pcl::PointXYZI, intensity);
+void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, const Cloud &lidar) { callback_node(seq, odom, lidar, 0); }
+void OfflineMapUpdater::announce_next_deferred(int seq, const Cloud &lidar, const geometry_msgs::Pose &odom) {
+    def_cloud_ = &lidar;
+    def_odom_ = odom;
+    def_seq_ = seq;
 }
-void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, const Cloud &lidar) {
+// the deferred announcement, made now (by the callback in front of the announced node: stack_count_ counts that callback already)
+void OfflineMapUpdater::stage_deferred() {
+    if (!def_cloud_) return;
+    const Cloud &lidar = *def_cloud_;
+    def_cloud_ = nullptr;
+    if ((stack_count_ + 1) % cfg_.params.removal_interval != 0 || has_next_) return;  // gated out (OMU.cpp:206-209) / one ahead already
+    float Tl[16], Tb[16];
+    mat16(tf_lidar2body_, Tl);
+    mat16(erasor_utils::geoPose2eigen(def_odom_), Tb);
+    uint64_t t = 0;
+    check(h_, erasor_hip_prefetch_node_rows(h_, lidar.points.data(), lidar.size(), kRowStride, kRowIntensity, Tl, Tb, &t), "erasor_hip_prefetch_node_rows");
+    has_next_ = true;
+    auto_ticket_ = t;
+    auto_seq_ = def_seq_;
+}
+void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, const Cloud &lidar, uint64_t ticket) {
     stack_count_++;
+    if (!ticket && auto_ticket_ && auto_seq_ == seq) ticket = auto_ticket_;  // announced through announce_next_deferred
+    auto_ticket_ = 0;
     if (stack_count_ % cfg_.params.removal_interval != 0) {  // OMU.cpp:206-209,327-329 "PASS!"
         if (cfg_.verbose) printf(" PASS! \n");
+        stage_deferred();
     } else {
         if (cfg_.environment != "outdoor") throw std::invalid_argument("Other modes are not supported");  // OMU.cpp:312
         tf_body2origin_ = erasor_utils::geoPose2eigen(odom);  // OMU.cpp:219
@@ -386,15 +400,20 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
         mat16(tf_lidar2body_, Tl);
         mat16(tf_body2origin_, Tb);
         mat16(tf_origin2body, To);
-        const float *scan = nullptr;
-        // the cloud announced before the PREVIOUS callback is this one's: the step must get that very buffer (its query chain is
-        // in flight under that address); anything else goes in as a fresh scan (the handle then drops what was announced)
-        if (have_cur_ && same_cloud(lidar, cur_xyzi_)) scan = cur_xyzi_.data();
-        if (!scan) {
-            to_xyzi_into(lidar, own_xyzi_);
-            scan = own_xyzi_.data();
+        // an announced node, by ticket: the step runs on the copy that was staged when it was announced.  Otherwise the records go in as
+        // they lie; if this very cloud was announced the library recognises it (pointer, size, a hash of every record) and anything
+        // else is a fresh scan (the handle then drops what was announced)
+        if (ticket) {
+            // (in two halves: a deferred announcement of the node behind this one is staged while this step runs on the GPU)
+            check(h_, erasor_hip_step_ticket_async(h_, ticket, Tb, To), "erasor_hip_step_ticket_async");
+            has_next_ = false;
+            stage_deferred();
+            check(h_, erasor_hip_step_wait(h_, &last), "erasor_hip_step_wait");
+        } else {
+            check(h_, erasor_hip_step_rows(h_, lidar.points.data(), lidar.size(), kRowStride, kRowIntensity, Tl, Tb, To, &last), "erasor_hip_step_rows");
+            has_next_ = false;  // (whatever was announced has been consumed or dropped by this step)
+            stage_deferred();
         }
-        check(h_, erasor_hip_step(h_, scan, lidar.size(), Tl, Tb, To, &last), "erasor_hip_step");
         if (last.n_ambiguous)  // (never seen on transformed clouds; said aloud because bin equality is only PROVABLE when it is zero)
             fprintf(stderr, "[erasor shim] node %d: %u point(s) within 1e-11 of a sector boundary: their bin is not provably the reference's (device atan2 vs glibc)\n",
                     seq, last.n_ambiguous);
@@ -408,31 +427,21 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
                    (unsigned long long)last.n_static);
         }
     }
-    // what announce_next brought for the node AFTER this one is the next callback's cloud (the two buffers swap roles: the
-    // address the handle knows stays valid)
-    have_cur_ = false;
-    if (has_next_) {
-        cur_xyzi_.swap(next_xyzi_);
-        have_cur_ = true;
-        has_next_ = false;
-    }
 }
-void OfflineMapUpdater::announce_next(const Cloud &lidar) { announce(lidar, nullptr); }
-void OfflineMapUpdater::announce_next(const Cloud &lidar, const geometry_msgs::Pose &odom) { announce(lidar, &odom); }
-void OfflineMapUpdater::announce(const Cloud &lidar, const geometry_msgs::Pose *odom) {
+uint64_t OfflineMapUpdater::announce_next(const Cloud &lidar) { return announce(lidar, nullptr); }
+uint64_t OfflineMapUpdater::announce_next(const Cloud &lidar, const geometry_msgs::Pose &odom) { return announce(lidar, &odom); }
+uint64_t OfflineMapUpdater::announce(const Cloud &lidar, const geometry_msgs::Pose *odom) {
     // called BEFORE callback_node(current) with the cloud of the node after it: current is callback number stack_count_ + 1
-    if ((stack_count_ + 2) % cfg_.params.removal_interval != 0) return;  // that node will be gated out (OMU.cpp:206-209)
-    if (has_next_) return;                                                 // one cloud ahead is what callback_node can honour
-    to_xyzi_into(lidar, next_xyzi_);
-    float Tl[16];
+    if ((stack_count_ + 2) % cfg_.params.removal_interval != 0) return 0;  // that node will be gated out (OMU.cpp:206-209)
+    if (has_next_) return 0;                                                 // one cloud ahead is what callback_node can honour
+    float Tl[16], Tb[16];
     mat16(tf_lidar2body_, Tl);
-    if (odom) {  // the whole node is known: the next callback's fetch_VoI pass can be launched ahead too
-        float Tb[16];
-        mat16(erasor_utils::geoPose2eigen(*odom), Tb);  // OMU.cpp:219
-        check(h_, erasor_hip_prefetch_node(h_, next_xyzi_.data(), lidar.size(), 0, Tl, Tb), "erasor_hip_prefetch_node");
-    } else
-        check(h_, erasor_hip_prefetch_scan(h_, next_xyzi_.data(), lidar.size(), 0, Tl), "erasor_hip_prefetch_scan");
+    if (odom) mat16(erasor_utils::geoPose2eigen(*odom), Tb);  // OMU.cpp:219: the whole node is known, the next fetch_VoI pass goes ahead too
+    uint64_t ticket = 0;
+    check(h_, erasor_hip_prefetch_node_rows(h_, lidar.points.data(), lidar.size(), kRowStride, kRowIntensity, Tl, odom ? Tb : nullptr, &ticket),
+          "erasor_hip_prefetch_node_rows");
     has_next_ = true;
+    return ticket;
 }
 void OfflineMapUpdater::get_map(Cloud &dst) {
     size_t n = 0;

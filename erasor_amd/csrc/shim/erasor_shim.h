@@ -144,14 +144,25 @@ public:
     // one erasor::node message: header.seq, odom, lidar (msg/node.msg:1-4) — OMU.cpp:203-330
     void callback_node(int seq, const geometry_msgs::Pose &odom, const pcl::PointCloud<pcl::PointXYZI> &lidar);
     // Offline look-ahead (no counterpart in the reference, which learns about a node when its message arrives): called BEFORE
-    // callback_node(k) with the cloud of node k + 1 -- tell the updater which cloud the callback after the upcoming one brings.  Its voxelisation / binning then overlap the current node's
-    // map-side stages (erasor_hip_prefetch_scan); results are unchanged.  Ignored for nodes the removal_interval gate skips.
-    // The callback recognises the announced cloud by its size and a sample of its points (every 256th and the last: the C ABI's rule for
-    // announced host buffers, include/erasor_hip.h) -- do not modify a cloud between its announcement and its callback.
-    void announce_next(const pcl::PointCloud<pcl::PointXYZI> &lidar);
+    // callback_node(k) with the cloud of node k + 1 -- tell the updater which cloud the callback after the upcoming one brings.  Its
+    // voxelisation / binning then overlap the current node's map-side stages; results are unchanged.  Ignored (returns 0) for nodes
+    // the removal_interval gate skips.  The cloud is copied at once: it is the caller's again when the call returns.
+    // Round 4: the call returns a TICKET.  Hand it to the callback of that node (callback_node(seq, odom, lidar, ticket)) and nothing
+    // has to be recognised: the step runs on the announced copy, the cloud is not read again.  Without a ticket the callback's cloud
+    // is compared with the announced copy record by record (a hash of every point, ~0.1 ms): a cloud that differs anywhere is
+    // processed as the new cloud it is -- rounds 2-3 sampled 257 points and could run on a stale copy.
+    uint64_t announce_next(const pcl::PointCloud<pcl::PointXYZI> &lidar);
     // ... and its odometry, when the whole next node is known (erasor_hip_prefetch_node: the VoI pass of the next callback is
     // launched ahead as well)
-    void announce_next(const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose &odom);
+    uint64_t announce_next(const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose &odom);
+    // the callback of an announced node, by ticket (0: like the three-argument form)
+    void callback_node(int seq, const geometry_msgs::Pose &odom, const pcl::PointCloud<pcl::PointXYZI> &lidar, uint64_t ticket);
+    // The same announcement WITHOUT the copy on the caller's time: the cloud is staged by the UPCOMING callback_node while that node's
+    // own step runs on the GPU (0.1 ms of host work per 125 k-point cloud that no longer precedes the step).  `lidar` must stay alive
+    // and unchanged until that callback has returned; the callback of node `seq` then finds its ticket by itself.
+    void announce_next_deferred(int seq, const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose &odom);
+    // is node `seq` staged (its callback will not look at the cloud it is handed)?
+    bool staged(int seq) const { return auto_ticket_ != 0 && auto_seq_ == seq; }
     void save_static_map(float voxel_size);                    // OMU.cpp:174-196
     void get_map(pcl::PointCloud<pcl::PointXYZI> &dst);        // *map_arranged_
     erasor_hip_handle *handle() { return h_; }                 // for adapters that read more of the last step (ros1_adapter.cpp)
@@ -165,11 +176,13 @@ private:
     erasor_hip_handle *h_ = nullptr;
     Eigen::Matrix4f tf_lidar2body_, tf_body2origin_;
     int stack_count_ = 0;
-    std::vector<float> own_xyzi_;              // repack buffer of a callback whose cloud was not announced
-    std::vector<float> next_xyzi_, cur_xyzi_;  // announced for the node after the upcoming one / for the upcoming one (the step must
-                                               // pass the very buffer that was announced)
-    bool has_next_ = false, have_cur_ = false;
-    void announce(const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose *odom);
+    bool has_next_ = false;  // a node is announced and not yet consumed (one cloud ahead is what callback_node can honour)
+    const pcl::PointCloud<pcl::PointXYZI> *def_cloud_ = nullptr;  // announce_next_deferred: staged by the upcoming callback
+    geometry_msgs::Pose def_odom_;
+    int def_seq_ = 0, auto_seq_ = 0;
+    uint64_t auto_ticket_ = 0;  // ticket of the node announced that way (its callback takes it when the sequence number matches)
+    void stage_deferred();
+    uint64_t announce(const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose *odom);
 };
 // main_in_your_env.cpp:66-70: the driver's own rosparams
 struct DriverConfig {

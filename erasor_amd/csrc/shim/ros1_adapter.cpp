@@ -127,20 +127,26 @@ private:
         if (held_) {
             pcl::PointCloud<pcl::PointXYZI> next;
             pcl::fromROSMsg(msg->lidar, next);
-            updater_->announce_next(next, msg->odom);
-            process(*held_);
+            // announced WITHOUT a copy on this thread's time: the held node's callback stages `next` (alive until process() returns)
+            // while its own step runs on the GPU, and the callback of header.seq finds its ticket by itself
+            updater_->announce_next_deferred((int)msg->header.seq, next, msg->odom);
+            process(*held_, held_announced_);
+            held_announced_ = true;
         }
         held_ = msg;
     }
     void flush_held() {
-        if (held_) process(*held_);
+        if (held_) process(*held_, held_announced_);
         held_.reset();
+        held_announced_ = false;
     }
 
-    void process(const erasor::node &node) {
+    void process(const erasor::node &node, bool announced = false) {
         const erasor::node *msg = &node;
         pcl::PointCloud<pcl::PointXYZI> query;
-        pcl::fromROSMsg(msg->lidar, query);  // OMU.cpp:237
+        // OMU.cpp:237 -- unless the node was announced and will be processed: its cloud is on the device already (the gate is the
+        // updater's: a node the removal interval skips was not staged, and its callback does not look at the cloud either)
+        if (!announced || !updater_->staged((int)msg->header.seq)) pcl::fromROSMsg(msg->lidar, query);
         const size_t before = updater_->num_processed;
         updater_->callback_node((int)msg->header.seq, msg->odom, query);  // gate, voxelise, fetch_VoI, ERASOR, write-back on the GPU
         if (updater_->num_processed == before) {
@@ -255,6 +261,7 @@ private:
     nav_msgs::Path path_;
     bool hold_ = false;
     erasor::node::ConstPtr held_;
+    bool held_announced_ = false;  // the held message was announced (announce_next_deferred) when it arrived
 };
 
 }  // namespace erasor

@@ -136,10 +136,13 @@ int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n
  *   for k: erasor_hip_prefetch_scan(h, scan[k+2]);  erasor_hip_step*(h, scan[k], ...);      (or one ahead: k+1)
  * The following step must pass the same pointer, size and T_lidar2body (otherwise every announcement is dropped;
  * their chains have run out when that step returns).  A host
- * scan is copied at once, so the buffer MUST NOT CHANGE between the announcement and the step that consumes it: the step
- * recognises its scan by pointer, size, T_lidar2body and a fingerprint of ~258 sampled points -- a buffer refilled at the same
- * address that differs only in unsampled points would be taken for the announced scan and the step would run on the copy
- * (hashing all 2 MB would cost more than the step's own enqueue).  A device scan (src_is_device != 0) is read in place and must stay valid until the step that
+ * scan is copied at once (the buffer is the caller's again when the announcement returns).  The step that follows recognises its
+ * scan by pointer, size, T_lidar2body AND a hash of EVERY record of the buffer it is handed against the hash of the copy that was
+ * staged (round 4; rounds 2-3 sampled ~258 records, so a buffer refilled in place could be mistaken for the announced scan): a buffer
+ * that has changed in any record is a different scan -- the announcements are dropped and the step runs on what it was given.  That
+ * second pass over the caller's buffer costs ~0.1 ms of host time per 2 MB scan; a caller that knows which announcement its step
+ * belongs to should say so instead -- erasor_hip_prefetch_node_rows returns a TICKET, erasor_hip_step_ticket takes it, nothing is
+ * compared and the buffer is not read again.  A device scan (src_is_device != 0) is read in place and must stay valid until the step that
  * consumes it has returned.  Up to four scans can be outstanding between two steps (four query sides: a step can have its own scan
  * and three more announced ahead of it); the chains of consecutive scans alternate between two streams.  When every side is taken, a new announcement re-uses the side of the last
  * finished step: its query-derived outputs (erasor_hip_get_cloud / _get_bins) are gone from then on. */
@@ -262,6 +265,24 @@ int erasor_hip_mapgen_save(erasor_hip_handle *h, float *dst_xyzi, size_t cap_poi
 
 /* replaces: erasor_utils::parse_dynamic_obj as counters (utils.cpp:57-78) over the current map */
 int erasor_hip_count_static_dynamic(erasor_hip_handle *h, uint64_t *n_static, uint64_t *n_dynamic);
+
+/* ---- host records in the caller's layout, and announcements by ticket (round 4) ------------------------------------------
+ * replaces: pcl::fromROSMsg(msg->lidar, *ptr_query) (OMU.cpp:237) handing a pcl::PointCloud<pcl::PointXYZI> to the per-scan path.
+ * `rows`: n records of `stride_bytes` bytes, float x, y, z at byte 0, float intensity at byte `intensity_offset_bytes`
+ * (XYZI rows: 16 / 12; pcl::PointXYZI: 32 / 16).  The pass that stages a host scan in pinned memory repacks it, so the caller does
+ * not rewrite the cloud into XYZI rows first.  Host memory only. */
+int erasor_hip_step_rows(erasor_hip_handle *h, const void *rows, size_t n, size_t stride_bytes, size_t intensity_offset_bytes,
+                         const float T_lidar2body[16], const float T_body2origin[16], const float T_origin2body[16],
+                         erasor_step_result *res);
+/* Announce the NEXT node (like erasor_hip_prefetch_node; T_body2origin may be NULL = erasor_hip_prefetch_scan) and get its ticket
+ * (never 0).  The buffer is the caller's again when this returns. */
+int erasor_hip_prefetch_node_rows(erasor_hip_handle *h, const void *rows, size_t n, size_t stride_bytes, size_t intensity_offset_bytes,
+                                  const float T_lidar2body[16], const float *T_body2origin, uint64_t *ticket);
+/* The step of the announced node that holds `ticket` (tickets are consumed in the order of the announcements; anything else is
+ * ERASOR_E_STATE).  T_lidar2body is the announcement's.  _async: first half only, collect with erasor_hip_step_wait. */
+int erasor_hip_step_ticket(erasor_hip_handle *h, uint64_t ticket, const float T_body2origin[16], const float T_origin2body[16],
+                           erasor_step_result *res);
+int erasor_hip_step_ticket_async(erasor_hip_handle *h, uint64_t ticket, const float T_body2origin[16], const float T_origin2body[16]);
 
 /* ---- measurement hooks (no reference counterpart) ------------------------ */
 /* When enabled, every kernel launch of a step is bracketed by HIP events on the

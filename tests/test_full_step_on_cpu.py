@@ -28,7 +28,7 @@ pytestmark = pytest.mark.timeout(7200)  # (pytest.ini's 300 s is for the device;
 @pytest.fixture(scope="module")
 def simt_lib(tmp_path_factory):
     lib = str(tmp_path_factory.mktemp("simt") / "liberasor_hip_simt.so")
-    subprocess.check_call(["g++", "-x", "c++", "-O1", "-std=c++20", "-pthread", "-ffp-contract=off", "-fPIC", "-shared",
+    subprocess.check_call(["g++", "-x", "c++", "-O1", "-std=c++20", "-pthread", "-ffp-contract=off", "-fPIC", "-shared", "-DERASOR_HIP_TEST_HOOKS",
                            "-I" + os.path.join(HERE, "cpp", "simt_emu"), "-o", lib, os.path.join(ROOT, "erasor_amd", "csrc", "erasor_hip.hip")])
     sys.path.insert(0, ROOT)
     from oracle import orc
@@ -50,7 +50,8 @@ def test_part_of_the_gpu_parity_suite_passes_on_the_cpu_stand_in(simt_lib):
     if os.environ.get("ERASOR_SIMT_ALL"):  # everything but the full-size cases: 49 tests, ~40 minutes on 8 cores
         expr = "not (full_size or config4 or whole_map or long_segments or map_grows)"
     env = dict(os.environ, ERASOR_TEST_SIMT_LIB=simt_lib)
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k", expr,
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_gpu_hooks.py"), "-m", "gpu",
+                          "-q", "-x", "-k", expr,
                           "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=7200 if os.environ.get("ERASOR_SIMT_ALL") else 2400, cwd=ROOT, env=env)
     tail = out.stdout[-1500:]
     sys.stdout.write(tail)

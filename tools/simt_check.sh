@@ -18,17 +18,17 @@ case $MODE in
 quick)
   $CXX -o $OUT/esort_simt_check tests/cpp/esort_simt_check.cpp && $OUT/esort_simt_check | tail -1
   $CXX -o $OUT/kernels_simt_check tests/cpp/kernels_simt_check.cpp -Loracle -lerasor_oracle -Wl,-rpath,$ROOT/oracle && $OUT/kernels_simt_check | tail -1
-  $CXX -x c++ -fPIC -shared -o $OUT/liberasor_hip_simt.so erasor_amd/csrc/erasor_hip.hip
+  $CXX -x c++ -fPIC -shared -DERASOR_HIP_TEST_HOOKS -o $OUT/liberasor_hip_simt.so erasor_amd/csrc/erasor_hip.hip
   python tests/simt_full_step.py $OUT/liberasor_hip_simt.so $ROOT 2 | tail -3
   ;;
 suite)
-  $CXX -x c++ -fPIC -shared -o $OUT/liberasor_hip_simt.so erasor_amd/csrc/erasor_hip.hip
-  ERASOR_TEST_SIMT_LIB=$OUT/liberasor_hip_simt.so python -m pytest tests/test_gpu_parity.py tests/test_golden.py -m gpu -q -p no:cacheprovider -k "$EXPR"
+  $CXX -x c++ -fPIC -shared -DERASOR_HIP_TEST_HOOKS -o $OUT/liberasor_hip_simt.so erasor_amd/csrc/erasor_hip.hip
+  ERASOR_TEST_SIMT_LIB=$OUT/liberasor_hip_simt.so python -m pytest tests/test_gpu_parity.py tests/test_gpu_hooks.py tests/test_golden.py -m gpu -q -p no:cacheprovider -k "$EXPR"
   ;;
 asan)
-  $CXX -g -fsanitize=address -fno-omit-frame-pointer -x c++ -fPIC -shared -o $OUT/liberasor_hip_asan.so erasor_amd/csrc/erasor_hip.hip
+  $CXX -g -fsanitize=address -fno-omit-frame-pointer -x c++ -fPIC -shared -DERASOR_HIP_TEST_HOOKS -o $OUT/liberasor_hip_asan.so erasor_amd/csrc/erasor_hip.hip
   LD_PRELOAD=$(g++ -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1 \
-    ERASOR_TEST_SIMT_LIB=$OUT/liberasor_hip_asan.so python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider -k "$EXPR"
+    ERASOR_TEST_SIMT_LIB=$OUT/liberasor_hip_asan.so python -m pytest tests/test_gpu_parity.py tests/test_gpu_hooks.py -m gpu -q -x -p no:cacheprovider -k "$EXPR"
   ;;
 *) echo "usage: $0 quick | suite [-k expr] | asan [-k expr]"; exit 2;;
 esac
