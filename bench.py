@@ -86,6 +86,8 @@ def parse_args():
     ap.add_argument("--python-loop", action="store_true",
                     help="drive the timed steps from a Python loop (prefetch + step per node) instead of ONE erasor_hip_run_nodes call "
                          "(the offline driver's node loop in native code: the same calls, without ~20 us of interpreter time between two steps)")
+    ap.add_argument("--no-pr-rr", action="store_true", help="skip PR / RR of the final map (erasor_amd.evalmap; ~10-20 s of host time for a 10 M-point map)")
+    ap.add_argument("--no-callback-bench", action="store_true", help="skip the C++ drop-in path benchmark (erasor_offline_demo --bench)")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="default run (1 GPU, seq05, replicas) only: do not append the short passes over BASELINE configs 4 / 2-yaml / 5")
     ap.add_argument("--union-eval", type=int, default=0, metavar="N",
@@ -553,7 +555,7 @@ def main():
         dist.barrier()
     elapsed_local = time.perf_counter() - t_start
     gpu_final = None
-    if world_size == 1 and not args.no_cpu_baseline and args.mode == "replicas" and first is not None:
+    if world_size == 1 and (not args.no_cpu_baseline or not args.no_pr_rr) and args.mode == "replicas" and first is not None:
         gpu_final = (first.g.get_map(), first.g.get_rejected_indices())  # (after the clock has stopped; compared with the oracle's below)
     prof = first.g.profile_get() if first is not None else {}
     chain_us = first.g.chain_timing() if first is not None else (0.0, 0.0, 0)
@@ -663,7 +665,19 @@ def main():
                 "aos16_equiv_GBps": round(16.0 * entries / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
                 "working_set_vs_L3": "%.0f MB streamed per launch vs 256 MiB Infinity Cache" % (alg_bytes / 1e6),
                 "step_alg_bytes": int(step_alg), "step_achieved": round(step_gbps, 1), "step_frac": round(step_gbps / PEAK_HBM_GBPS, 4),
-                "step_note": "SURVEY §8(d): (16*N_map + 16*n_scan + 16*N_voi_out) / ms_per_step — the whole step against the HBM peak"}
+                "step_note": "SURVEY §8(d): (16*N_map + 16*n_scan + 16*N_voi_out) / ms_per_step — the whole step against the HBM peak.  CAVEAT "
+                             "(VERDICT r03): 16*N_map is NOT read any more (the VoI pass skips the outskirts chunks whose bounding box lies outside "
+                             "the circle), so this fraction flatters a step that is bound by latency, not bandwidth: read needed_bytes / "
+                             "time_target_us and main_chain_us instead",
+                # what the step has to move WITH the chunk records: the VoI pass as it is, the scan, the VoI-resident region read once and
+                # written back once -- and the time 60 % of the HBM peak would need for that, beside north_star's own target (the §8(d) bytes)
+                "needed_bytes": int(alg_bytes + 16.0 * n_scan + 16.0 * int(last.n_voi) + 16.0 * n_voi_out),
+                "time_target_us": round((alg_bytes + 16.0 * n_scan + 16.0 * int(last.n_voi) + 16.0 * n_voi_out) / (0.6 * PEAK_HBM_GBPS * 1e9) * 1e6, 2),
+                "north_star_time_target_us": round(step_alg / (0.6 * PEAK_HBM_GBPS * 1e9) * 1e6, 1),
+                "time_note": "time_target_us = needed_bytes at 60 % of the HBM peak; north_star_time_target_us = SURVEY §8(d)'s bytes at the same "
+                             "rate (what north_star asks of a step); the step takes ms_per_step: a dependency chain of ~10 launches "
+                             "(main_chain_us on the device's clock), every one bound by latency -- exact std::sort emulation, sequential "
+                             "float32 sums, a single-lane SVD"}
 
     # ---- optional per-kernel breakdown (extra K steps, all kernels bracketed) ----
     if args.profile_all:
@@ -698,6 +712,46 @@ def main():
     elif world_size == 1 and not args.no_cpu_baseline:
         cpu = cpu_sequence_parallel(args, seqs, maps, l2b7)
 
+    # ---- PR / RR of the map the timed pass has left (BASELINE.json: "PR/RR vs ref"): the reference's protocol (scripts/analysis_runner.py
+    # :74-105 restated in erasor_amd/evalmap.py, pinned to the original's outputs by tests/test_evalmap.py) against the initial map as
+    # labelled ground truth.  The oracle's map is bit-identical (final_map_checked), so its PR / RR are these very numbers.
+    pr_rr = None
+    if world_size == 1 and args.mode == "replicas" and not args.no_pr_rr and m is not None and gpu_final is not None:
+        from erasor_amd import evalmap
+        t_ev = time.time()
+        est = g.voxelize_preserving_labels(gpu_final[0], 0.2)
+        gt = g.voxelize_preserving_labels(m, 0.2)
+        ev = evalmap.evaluate_clouds(gt, est, 0.2)
+        pr_rr = {"PR": round(ev["PR"], 3), "RR": round(ev["RR"], 3), "F1": round(ev["F1"], 4), "gt_static": ev["gt_static"], "gt_dynamic": ev["gt_dynamic"],
+                 "protocol": "scripts/analysis_runner.py:74-105 (1-NN within voxel*sqrt(3)/2 of every ground-truth point), both maps voxelised at 0.2 m "
+                             "by voxelize_preserving_labels (save_static_map, OfflineMapUpdater.cpp:174-196); ground truth = the labelled initial map",
+                 "vs_reference": ("identical: the %d-point map compared here is bit-identical to the CPU path's (final_map_checked)" % len(gpu_final[0]))
+                 if parity.get("final_map_checked") else "the CPU path's map was not compared in this run",
+                 "steps": int(K + W), "wall_s": round(time.time() - t_ev, 1)}
+
+    # ---- the drop-in path in C++: erasor::OfflineMapUpdater::callback_node with host pcl::PointXYZI clouds in and the
+    # rejected clouds out, timed by erasor_offline_demo --bench on an export of this very workload (no Python in its loop)
+    callback = None
+    demo = os.path.join(ROOT, "erasor_amd", "erasor_offline_demo")
+    if (world_size == 1 and args.mode == "replicas" and args.workload == "seq05" and not args.no_callback_bench and not args.no_cpu_baseline
+            and os.path.exists(demo)):
+        import subprocess
+        import tempfile
+        t_cb = time.time()
+        try:
+            with tempfile.TemporaryDirectory(prefix="erasor_cppbench_") as d:
+                subprocess.run([sys.executable, os.path.join(ROOT, "tools", "export_cpp_bench.py"), d, str(K + W + 2)], check=True, capture_output=True, timeout=300)
+                r = subprocess.run([demo, "--bench", d, str(K), str(W)], capture_output=True, text=True, timeout=300)
+                j = json.loads(r.stdout.strip().split("\n")[-1])
+            callback = {"callback_ms": j["ms_per_callback"], "callback_next_announced_ms": j["ms_per_callback_next_node_announced"],
+                        "of_which_announce_next_ms": j["of_which_announce_next"],
+                        "callback_next_announced_deferred_ms": j.get("ms_per_callback_next_node_announced_deferred"),
+                        "c_abi_device_resident_two_ahead_ms": j["ms_per_step_device_resident_two_ahead"], "passes_agree": j.get("four_passes_agree"),
+                        "note": j["callback_note"] + "; one node ahead is all a callback can know, so the query chain of the next node (~0.25 ms alone) "
+                                "bounds this path, not the main chain", "wall_s": round(time.time() - t_cb, 1)}
+        except Exception as e:  # (never takes the headline down)
+            callback = {"error": str(e)[:300]}
+
     out = {
         "metric": "scans_per_sec", "value": round(value, 2), "unit": "scans/s", "n_gpus": world_size, "steps": K, "warmup": W,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -716,6 +770,11 @@ def main():
         # the main stream's dependency chain in the timed pass, on the device's own clock (chunk scan .. the step's end), and the time
         # the stream spends between two steps (host turnaround; the next step's VoI split, launched ahead, runs in there)
         "main_chain_us": round(chain_us[0], 1), "between_steps_us": round(chain_us[1], 1),
+        "steady_state_ms_per_step": round((chain_us[0] + chain_us[1]) / 1e3, 4),
+        "steady_state_note": "main_chain_us + between_steps_us: the period of the main stream in the timed pass.  ms_per_step (the contract's figure: "
+                             "K steps between two device synchronisations) also pays for draining the query chains of the nodes announced beyond "
+                             "the last timed step, once per pass",
+        "pr_rr": pr_rr, "callback_path": callback,
         "roofline": roofline, "cpu_baseline": cpu, "cpu_port": cpu_port, "host": host_identity(),
         "parity_checked_steps": parity["parity_checked_steps"], "parity": parity.get("parity"), "final_map_checked": parity.get("final_map_checked", False),
         "rccl_ranks": rccl_ranks, "backend": backend if dist is not None else None,
@@ -728,32 +787,46 @@ def main():
     if union_eval is not None:
         out["union_exchange"] = union_eval
     if evals is not None:
-        out["pr_rr"] = [{"seq": "%02d" % e[0], "PR": e[1] / 1e2, "RR": e[2] / 1e2} for e in sorted(evals)]
+        out["pr_rr"] = [{"seq": "%02d" % e[0], "PR": e[1] / 1e2, "RR": e[2] / 1e2} for e in sorted(evals)]  # (seq-per-gpu --eval: one entry per sequence)
     # ---- the other single-GPU BASELINE configs, measured in the same run (short passes, each its own process: a clean device state
     # and exactly the code path above).  config 4 is the only workload whose VoI pass streams more than the 256 MiB Infinity Cache.
     if (world_size == 1 and args.workload == "seq05" and args.mode == "replicas" and not args.no_extra_workloads and not args.no_cpu_baseline
             and not args.profile_all):
         import subprocess
         extra = []
-        for wname, label in (("large_scale_05", "config 4"), ("seq05_yaml", "config 2, config/seq_05.yaml verbatim"), ("ouster128", "config 5 shape, 1 GPU")):
-            cmd = [sys.executable, os.path.abspath(__file__), "--workload", wname, "--steps", "12", "--warmup", "3", "--no-cpu-baseline",
-                   "--no-extra-workloads"]
-            if wname == "ouster128":  # 233 k-point scans: the query chain is the longer one, a third node ahead pays (gpurun_out/r03ah)
-                cmd += ["--lookahead", "3"]
+        passes = (
+            # (workload, label, extra arguments, environment, verified against the oracle?)
+            ("large_scale_05", "config 4 (39 M-point dense map), is_large_scale off", ["--cpu-seconds", "24", "--cpu-steps", "1"], {}, True),
+            ("large_scale_05", "config 4, --large-scale-mode on (submap 160, OfflineMapUpdater.cpp:332-379)", ["--large-scale-mode", "on"], {}, False),
+            ("large_scale_05", "config 4 with the chunk records OFF (ERASOR_HIP_NO_OMETA=1): the VoI pass streams the whole map store -- "
+                               "the HBM-bound measurement of k_voi_split", [], {"ERASOR_HIP_NO_OMETA": "1"}, False),
+            ("seq05_yaml", "config 2, config/seq_05.yaml verbatim", [], {}, False),
+            ("ouster128", "config 5 shape, 1 GPU", ["--lookahead", "3"], {"ERASOR_HIP_QSTREAMS": "3"}, False),
+        )
+        for wname, label, xargs, xenv, verified in passes:
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", wname, "--steps", "12", "--warmup", "3", "--no-extra-workloads",
+                   "--no-pr-rr", "--no-callback-bench"] + xargs
+            if not verified:
+                cmd.append("--no-cpu-baseline")
             t_sub = time.time()
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=dict(os.environ, **xenv))
                 d = json.loads(r.stdout.strip().split("\n")[-1])
                 rf = d["roofline"]
                 extra.append({"workload": wname, "baseline_config": label, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                              "ms_per_step_without_lookahead": d["ms_per_step_without_lookahead"], "steps": d["steps"], "warmup": d["warmup"],
+                              "ms_per_step_without_lookahead": d["ms_per_step_without_lookahead"], "main_chain_us": d.get("main_chain_us"),
+                              "between_steps_us": d.get("between_steps_us"), "steps": d["steps"], "warmup": d["warmup"],
                               "map_points": d["config"]["map_points"], "scan_points": d["config"]["scan_points"],
-                              "lookahead_scans": d["config"].get("lookahead_scans"),
-                              "roofline": {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "avg_launch_us",
-                                                             "launches", "step_alg_bytes", "step_achieved", "step_frac")},
+                              "is_large_scale": d["config"].get("is_large_scale"), "lookahead_scans": d["config"].get("lookahead_scans"),
+                              "environment": xenv,
+                              "parity_checked_steps": d.get("parity_checked_steps"), "final_map_checked": d.get("final_map_checked"),
+                              "cpu_baseline": d.get("cpu_baseline"), "cpu_port": d.get("cpu_port"),
+                              "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "avg_launch_us",
+                                                                  "launches", "step_alg_bytes", "step_achieved", "step_frac", "needed_bytes",
+                                                                  "time_target_us")},
                               "wall_s": round(time.time() - t_sub, 1)})
             except Exception as e:  # (an extra pass must never take the headline line down with it)
-                extra.append({"workload": wname, "baseline_config": label, "error": str(e)[:200]})
+                extra.append({"workload": wname, "baseline_config": label, "error": (str(e) + " | " + (r.stderr[-300:] if "r" in dir() else ""))[:500]})
         out["other_workloads"] = extra
     print(json.dumps(out))
     if dist is not None:
