@@ -78,6 +78,10 @@ def parse_args():
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not announce the next scan (erasor_hip_prefetch_scan): every step runs its own query chain first")
     ap.add_argument("--seqs", type=int, default=len(SEQS), help="seq-per-gpu: use only the first N of the five sequences (e.g. 2: what one GPU of config 3's four gets)")
+    ap.add_argument("--placement", choices=["queue", "static"], default="queue",
+                    help="seq-per-gpu: which rank runs which sequence -- 'queue': the next sequence goes to whichever rank is idle (BASELINE config 3: "
+                         "the fifth sequence onto the first free GPU; every rank prepares all sequences, a shared counter hands them out); "
+                         "'static': dealt round-robin in advance")
     ap.add_argument("--interleave", choices=["async", "threads", "off"], default="off",
                     help="seq-per-gpu with several sequences on one rank: off = one sequence after the other (default: measured fastest on one "
                          "MI355X -- the chains of two sequences slow each other down more than the overlap gains: 2 sequences 3864 scans/s one "
@@ -441,7 +445,9 @@ def main():
         maps = {"replica%d" % rank: m}
     else:
         maps = {}
-        for i in ed.deal_round_robin(min(max(args.seqs, 1), len(SEQS)), rank, world_size):
+        n_seqs = min(max(args.seqs, 1), len(SEQS))
+        queued = args.placement == "queue" and world_size > 1 and args.interleave == "off"
+        for i in (range(n_seqs) if queued else ed.deal_round_robin(n_seqs, rank, world_size)):
             sid = SEQS[i]
             world = synth.World(seed=20210305 + int(sid), length=args.street_length, n_streets=args.streets, street_gap=50.0,
                                 n_moving=10, n_peds=6)
@@ -537,7 +543,17 @@ def main():
             totals += t
             last = r_
     else:
-        for si, (_, s) in enumerate(seqs):
+        # seq-per-gpu with --placement queue and several ranks: every rank has prepared ALL sequences; a shared counter (ed.JobQueue) hands
+        # the next one to whichever rank is idle.  Otherwise: the sequences this rank owns, one after the other.
+        jq = ed.JobQueue(dist, len(seqs)) if (args.mode == "seq-per-gpu" and args.placement == "queue" and world_size > 1) else None
+        order = iter(range(len(seqs)))
+        ran = []
+        while True:
+            si = jq.next() if jq is not None else next(order, None)
+            if si is None:
+                break
+            s = seqs[si][1]
+            ran.append(seqs[si][0])
             for k in range(W, W + K):
                 if si == 0:
                     split_bytes.append(s.g.voi_split_bytes())
@@ -550,6 +566,8 @@ def main():
             totals[3] += last.n_map_out
             totals[4] += last.n_static
             totals[5] += last.n_dynamic
+        if jq is not None:
+            seqs = [sq for sq in seqs if sq[0] in ran] or seqs[:1]  # (what this rank ran: the evaluation / reporting below is about those)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -139,6 +139,17 @@ def invert_rigid(T):
     return np.linalg.inv(T).astype(np.float32).reshape(16)
 
 
+def replicate_map(handles, root=0):
+    """erasor_hip_replicate_map: the map of handles[root] to every other handle (one per device) -- single-process RCCL broadcast over
+    xGMI, or peer copies.  Returns the transport used (1 RCCL, 2 peer copies, 0 empty map)."""
+    arr = (C.c_void_p * len(handles))(*[h._h for h in handles])
+    t = C.c_int(0)
+    rc = lib().erasor_hip_replicate_map(arr, C.c_int(len(handles)), C.c_int(root), C.byref(t))
+    if rc != 0:
+        raise ErasorError(rc, (lib().erasor_hip_last_error(handles[root]._h) or b"").decode())
+    return t.value
+
+
 class Erasor:
     """Handle of the HIP hot path (one GPU, one stream)."""
 

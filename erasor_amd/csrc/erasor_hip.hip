@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -2132,6 +2133,165 @@ int erasor_hip_run_nodes(erasor_hip_handle *h, const void *const *scans, const s
     }
     return ERASOR_OK;
 }
+// ---- one host process, several devices (north_star: "RCCL broadcast of the global map over xGMI") --------------
+// The map of handles[root] is assembled into one dense XYZI array on its device and sent to every other handle's device:
+//   * RCCL, single process: ncclCommInitAll over the handles' devices + ONE ncclBroadcast per rank inside a group (float32, 4 n values) --
+//     the library is loaded lazily (dlopen librccl.so: a process that never replicates never pays for it);
+//   * otherwise (RCCL missing, two handles on one device -- which ncclCommInitAll refuses --, ERASOR_HIP_NO_RCCL=1): hipMemcpyPeerAsync.
+// Every receiver then takes the copy with erasor_hip_set_map_device's code.  *transport: 1 RCCL, 2 peer copies, 0 nothing to send.
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+Rccl &rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    if (getenv("ERASOR_HIP_NO_RCCL")) return r;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return r;
+    r.CommInitAll = (int (*)(void **, int, const int *))dlsym(r.lib, "ncclCommInitAll");
+    r.CommDestroy = (int (*)(void *))dlsym(r.lib, "ncclCommDestroy");
+    r.Broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(r.lib, "ncclBroadcast");
+    r.GroupStart = (int (*)())dlsym(r.lib, "ncclGroupStart");
+    r.GroupEnd = (int (*)())dlsym(r.lib, "ncclGroupEnd");
+    r.GetErrorString = (const char *(*)(int))dlsym(r.lib, "ncclGetErrorString");
+    r.ok = r.CommInitAll && r.CommDestroy && r.Broadcast && r.GroupStart && r.GroupEnd;
+    return r;
+}
+// the handle's whole map as ONE dense device array, in the reference's order: [VoI-resident part | outskirts | submap complement]
+int map_to_device(erasor_hip_handle *h, DBuf<float4> &dense, size_t *n_out) {
+    const size_t total = (size_t)h->nF + (size_t)h->o_valid + (size_t)h->nC;
+    *n_out = total;
+    if (ensure(h, dense, total + 8)) return ERASOR_E_NO_DEVICE;
+    hipStream_t keep = h->cur;
+    h->cur = h->stream;
+    if (h->nF) HIPC(h, hipMemcpyAsync(dense.p, h->F[h->curF].p, (size_t)h->nF * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    const uint32_t span = h->capO - h->o_begin;
+    if (span && h->o_valid) {
+        DBuf<uint32_t> flag, pl, tops;
+        if (ensure(h, flag, span + 1) || ensure(h, pl, span + 1) || ensure(h, tops, span / 1024 + 4)) return ERASOR_E_NO_DEVICE;
+        LAUNCH(h, "replicate", k_o_valid, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, h->o_begin, h->capO, flag.p);
+        scan_u32(h, flag.p, pl.p, tops.p, span, span, nullptr, nullptr, "replicate");
+        LAUNCH(h, "replicate", k_o_compact, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, (const float2 *)h->Ozi.p, h->o_begin, h->capO,
+               (const uint32_t *)flag.p, (const uint32_t *)pl.p, (const uint32_t *)tops.p, dense.p + h->nF);
+        HIPC(h, hipStreamSynchronize(h->stream));
+        release(flag);
+        release(pl);
+        release(tops);
+    }
+    if (h->nC)
+        HIPC(h, hipMemcpyAsync(dense.p + (size_t)h->nF + h->o_valid, h->Cbuf.p, (size_t)h->nC * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    h->cur = keep;
+    return ERASOR_OK;
+}
+}  // namespace
+int erasor_hip_replicate_map(erasor_hip_handle *const *handles, int n, int root, int *transport) {
+    if (transport) *transport = 0;
+    if (!handles || n < 1 || root < 0 || root >= n) return ERASOR_E_INVALID;
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i]) return ERASOR_E_INVALID;
+        NOFLY(handles[i]);
+    }
+    erasor_hip_handle *hr = handles[root];
+    if (!hr->have_map) {
+        hr->err = "erasor_hip_replicate_map: the root handle has no map (erasor_hip_set_map first)";
+        return ERASOR_E_STATE;
+    }
+    HIPC(hr, hipSetDevice(hr->device));
+    DBuf<float4> dense;
+    size_t total = 0;
+    int rc = map_to_device(hr, dense, &total);
+    if (rc) return rc;
+    // receive buffers, one per other handle, on its device
+    std::vector<float4 *> recv(n, nullptr);
+    bool distinct = true;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) distinct = distinct && handles[i]->device != handles[j]->device;
+    auto cleanup = [&]() {
+        for (int i = 0; i < n; ++i)
+            if (recv[i]) {
+                (void)hipSetDevice(handles[i]->device);
+                (void)hipFree(recv[i]);
+            }
+        (void)hipSetDevice(hr->device);
+        release(dense);
+    };
+    for (int i = 0; i < n; ++i) {
+        if (i == root) continue;
+        if (hipSetDevice(handles[i]->device) != hipSuccess || hipMalloc((void **)&recv[i], (total + 8) * sizeof(float4)) != hipSuccess) {
+            hr->err = "erasor_hip_replicate_map: no memory for the copy on device " + std::to_string(handles[i]->device);
+            cleanup();
+            return ERASOR_E_NO_DEVICE;
+        }
+    }
+    int used = 0;
+    Rccl &R = rccl();
+    if (R.ok && distinct && total) {
+        // single-process RCCL: one communicator per device, the broadcasts of all ranks in ONE group
+        std::vector<void *> comms(n, nullptr);
+        std::vector<int> devs(n);
+        for (int i = 0; i < n; ++i) devs[i] = handles[i]->device;
+        int e = R.CommInitAll(comms.data(), n, devs.data());
+        if (e == 0) {
+            e = R.GroupStart();
+            for (int i = 0; e == 0 && i < n; ++i) {
+                (void)hipSetDevice(handles[i]->device);
+                void *buf = i == root ? (void *)dense.p : (void *)recv[i];
+                e = R.Broadcast(buf, buf, total * 4, /*ncclFloat*/ 7, root, comms[i], handles[i]->stream);
+            }
+            const int e2 = R.GroupEnd();
+            if (e == 0) e = e2;
+            for (int i = 0; i < n; ++i) {
+                (void)hipSetDevice(handles[i]->device);
+                (void)hipStreamSynchronize(handles[i]->stream);
+            }
+            for (int i = 0; i < n; ++i)
+                if (comms[i]) (void)R.CommDestroy(comms[i]);
+            if (e == 0) used = 1;
+        }
+        if (e != 0) fprintf(stderr, "[erasor_hip] RCCL broadcast failed (%s): falling back to peer copies\n", R.GetErrorString ? R.GetErrorString(e) : "?");
+    }
+    if (!used && total) {
+        for (int i = 0; i < n; ++i) {
+            if (i == root) continue;
+            (void)hipSetDevice(hr->device);
+            if (handles[i]->device != hr->device) {
+                int can = 0;
+                (void)hipDeviceCanAccessPeer(&can, hr->device, handles[i]->device);
+                if (can) (void)hipDeviceEnablePeerAccess(handles[i]->device, 0);  // (already enabled: an error we ignore)
+                (void)hipGetLastError();
+            }
+            if (hipMemcpyPeerAsync(recv[i], handles[i]->device, dense.p, hr->device, total * sizeof(float4), hr->stream) != hipSuccess) {
+                hr->err = "erasor_hip_replicate_map: hipMemcpyPeerAsync failed";
+                cleanup();
+                return ERASOR_E_NO_DEVICE;
+            }
+        }
+        (void)hipStreamSynchronize(hr->stream);
+        used = 2;
+    }
+    for (int i = 0; i < n && rc == ERASOR_OK; ++i) {
+        if (i == root) continue;
+        rc = set_map_common(handles[i], recv[i], total, true);
+    }
+    cleanup();
+    if (transport) *transport = total ? used : 0;
+    return rc;
+}
+
 int erasor_hip_step_done(erasor_hip_handle *h) {
     if (!h || !h->fly.active) return 1;
     return *(volatile unsigned long long *)&h->pin->seq == h->fly.seq ? 1 : 0;

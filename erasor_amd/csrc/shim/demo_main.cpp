@@ -2,11 +2,16 @@
 //   <dir>/map.pcd, <dir>/pcds/%06d.pcd, <dir>/poses.csv (header line; idx,?,x,y,z,qx,qy,qz,qw per line, cols 2..8)
 // processes every node through erasor::OfflineMapUpdater and writes <dir>/<data_name>_result.pcd and map_final.pcd.
 #include <array>
+#include <chrono>
 #include <cstdio>
 #include <fstream>
+#include <memory>
 #include <sstream>
+#include <thread>
 
 #include "erasor_shim.h"
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static bool read_bin(const std::string &path, pcl::PointCloud<pcl::PointXYZI> &c) {
     std::ifstream f(path, std::ios::binary | std::ios::ate);
@@ -79,19 +84,18 @@ static int erasor_class_mode(int argc, char **argv) {
 //   <data_dir>/poses_lidar2body.csv, <data_dir>/pcds/%06d.pcd from init_idx on, every node through
 //   OfflineMapUpdater::callback_node (pose -> eigen2geoPose -> node.odom), then save_static_map(0.2).
 // The initial map is /MapUpdater/initial_map_path, or <data_dir>/dense_global_map.pcd when that key is absent.
-static int config_mode(int argc, char **argv) {
-    if (argc < 3) return 2;
+static int run_config(const std::string &yaml, int max_frames, int device, bool verbose, int *nodes_done = nullptr) {
     erasor::OfflineMapUpdater::Config cfg;
     erasor_hip_params_default(&cfg.params);
     cfg.params.query_voxel_size = 0.05;  // OMU.cpp:66
     cfg.params.removal_interval = 2;     // OMU.cpp:69
-    cfg.verbose = true;                  // OMU.cpp:83
+    cfg.verbose = verbose;               // OMU.cpp:83
+    cfg.device = device;
     erasor::DriverConfig drv;
-    if (!erasor::load_config_yaml(argv[2], cfg, &drv)) {
-        fprintf(stderr, "cannot read %s\n", argv[2]);
+    if (!erasor::load_config_yaml(yaml, cfg, &drv)) {
+        fprintf(stderr, "cannot read %s\n", yaml.c_str());
         return 3;
     }
-    const int max_frames = argc > 3 ? atoi(argv[3]) : 1 << 30;
     if (cfg.initial_map_path.empty() || cfg.initial_map_path == "/") cfg.initial_map_path = drv.data_dir + "/dense_global_map.pcd";
     if (cfg.save_path == "/" || cfg.save_path == ".") cfg.save_path = drv.data_dir;
     erasor::OfflineMapUpdater updater(cfg);
@@ -119,9 +123,129 @@ static int config_mode(int argc, char **argv) {
         ticket = next_ticket;
         have = have_next;
     }
+    if (nodes_done) *nodes_done = done;
     if (done == 0 && !have) return 3;
     updater.save_static_map(0.2f);  // main_in_your_env.cpp:123
-    printf("Static map building complete!\n");
+    if (verbose) printf("Static map building complete!\n");
+    return 0;
+}
+static int config_mode(int argc, char **argv) {
+    if (argc < 3) return 2;
+    return run_config(argv[2], argc > 3 ? atoi(argv[3]) : 1 << 30, 0, true);
+}
+
+// --queue <n_workers> <max_frames> <a.yaml> <b.yaml> ...: independent sequences (one rosparam file each) over n_workers devices
+// (worker w drives device w mod the visible devices): every worker is a thread with its own updater per job, and takes the NEXT sequence
+// of the list whenever it is idle (erasor::WorkQueue) -- BASELINE config 3 on a node with fewer GPUs than sequences.
+static int queue_mode(int argc, char **argv) {
+    if (argc < 5) return 2;
+    const int n_workers = std::max(1, atoi(argv[2])), max_frames = atoi(argv[3]);
+    std::vector<std::string> jobs(argv + 4, argv + argc);
+    int ndev = 1;
+    {   // (the C ABI answers with ERASOR_E_NO_DEVICE for a device that does not exist: probe upwards)
+        erasor_params p;
+        erasor_hip_params_default(&p);
+        for (ndev = 0; ndev < 64; ++ndev) {
+            erasor_hip_handle *h = nullptr;
+            if (erasor_hip_create(&p, ndev, &h) != ERASOR_OK) break;
+            erasor_hip_destroy(h);
+        }
+        if (ndev == 0) return 4;
+    }
+    erasor::WorkQueue q(jobs.size());
+    std::vector<int> rc(jobs.size(), -1), nodes(jobs.size(), 0);
+    std::vector<double> t_begin(jobs.size(), 0), t_end(jobs.size(), 0);
+    const double t0 = now_ms();
+    std::vector<std::thread> th;
+    for (int w = 0; w < n_workers; ++w)
+        th.emplace_back([&, w] {
+            for (long j; (j = q.next(w)) >= 0;) {
+                t_begin[j] = now_ms() - t0;
+                try {
+                    rc[j] = run_config(jobs[j], max_frames, w % ndev, false, &nodes[j]);
+                } catch (const std::exception &e) {
+                    fprintf(stderr, "job %ld (%s): %s\n", j, jobs[j].c_str(), e.what());
+                    rc[j] = 1;
+                }
+                t_end[j] = now_ms() - t0;
+            }
+        });
+    for (auto &t : th) t.join();
+    int bad = 0;
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        printf("job %zu %s: worker %d (device %d), %d nodes, %.1f .. %.1f ms, rc %d\n", j, jobs[j].c_str(), q.taken_by(j), q.taken_by(j) % ndev, nodes[j],
+               t_begin[j], t_end[j], rc[j]);
+        bad += rc[j] != 0;
+    }
+    printf("{\"mode\": \"queue\", \"workers\": %d, \"devices\": %d, \"jobs\": %zu, \"failed\": %d, \"wall_ms\": %.1f}\n", n_workers, ndev, jobs.size(), bad,
+           now_ms() - t0);
+    return bad ? 5 : 0;
+}
+
+// --replicas <n> <rosparam.yaml> [n_frames]: ONE process, n updaters (device r mod the visible devices), the global map loaded ONCE and
+// replicated with erasor_hip_replicate_map (RCCL broadcast over xGMI / peer copies), then replica r works through nodes r, r + n, ... of the
+// sequence on its own thread -- scan-parallel replicas (every replica folds ITS scans into ITS copy; a deviation from
+// the reference's single sequential fold, which is why nothing is saved here: it reports what each replica removed).
+static int replicas_mode(int argc, char **argv) {
+    if (argc < 4) return 2;
+    const int n = std::max(1, atoi(argv[2]));
+    const int max_frames = argc > 4 ? atoi(argv[4]) : 1 << 30;
+    erasor::OfflineMapUpdater::Config cfg;
+    erasor_hip_params_default(&cfg.params);
+    cfg.params.query_voxel_size = 0.05;
+    cfg.params.removal_interval = 2;
+    erasor::DriverConfig drv;
+    if (!erasor::load_config_yaml(argv[3], cfg, &drv)) return 3;
+    if (cfg.initial_map_path.empty() || cfg.initial_map_path == "/") cfg.initial_map_path = drv.data_dir + "/dense_global_map.pcd";
+    const std::string map_path = cfg.initial_map_path;
+    cfg.params.removal_interval = 1;  // (the interval is what spreads the nodes over the replicas here)
+    int ndev = 0;
+    for (; ndev < 64; ++ndev) {
+        erasor_hip_handle *h = nullptr;
+        if (erasor_hip_create(&cfg.params, ndev, &h) != ERASOR_OK) break;
+        erasor_hip_destroy(h);
+    }
+    if (ndev == 0) return 4;
+    std::vector<std::unique_ptr<erasor::OfflineMapUpdater>> up;
+    for (int r = 0; r < n; ++r) {
+        erasor::OfflineMapUpdater::Config c = cfg;
+        c.device = r % ndev;
+        c.initial_map_path = r == 0 ? map_path : std::string();  // only the root reads the file
+        up.emplace_back(new erasor::OfflineMapUpdater(c));
+    }
+    std::vector<erasor_hip_handle *> hs;
+    for (auto &u : up) hs.push_back(u->handle());
+    int transport = 0;
+    const double tb = now_ms();
+    if (erasor_hip_replicate_map(hs.data(), n, 0, &transport) != ERASOR_OK) {
+        fprintf(stderr, "erasor_hip_replicate_map: %s\n", erasor_hip_last_error(hs[0]));
+        return 4;
+    }
+    const double ms_bcast = now_ms() - tb;
+    std::vector<Eigen::Matrix4f> poses;
+    if (!erasor::load_all_poses(drv.data_dir + "/poses_lidar2body.csv", poses)) return 3;
+    const int last = std::min<int>((int)poses.size(), drv.init_idx + max_frames);
+    std::vector<unsigned long long> rejected(n, 0), map_out(n, 0);
+    std::vector<int> done(n, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < n; ++r)
+        th.emplace_back([&, r] {
+            for (int i = drv.init_idx + r; i < last; i += n) {
+                char name[64];
+                snprintf(name, sizeof(name), "/pcds/%06d.pcd", i);
+                pcl::PointCloud<pcl::PointXYZI> scan;
+                if (erasor_utils::load_pcd(drv.data_dir + name, scan) == -1) break;
+                up[r]->callback_node(i, erasor_utils::eigen2geoPose(poses[i]), scan);
+                rejected[r] += up[r]->last.n_map_rejected;
+                map_out[r] = up[r]->last.n_map_out;
+                ++done[r];
+            }
+        });
+    for (auto &t : th) t.join();
+    for (int r = 0; r < n; ++r)
+        printf("replica %d (device %d): %d nodes, %llu map points rejected, map %llu\n", r, r % ndev, done[r], rejected[r], map_out[r]);
+    printf("{\"mode\": \"replicas\", \"replicas\": %d, \"devices\": %d, \"transport\": \"%s\", \"replicate_ms\": %.2f}\n", n, ndev,
+           transport == 1 ? "rccl" : (transport == 2 ? "peer copies" : "none"), ms_bcast);
     return 0;
 }
 
@@ -171,8 +295,6 @@ static int voxelize_mode(int argc, char **argv) {
 //   2. the same with the next node announced (announce_next: what an offline driver or a node holding one message back can do);
 //   3. the C ABI itself with the scans resident in HBM and nodes announced two ahead (bench.py's loop, minus Python).
 // Prints ONE JSON line.
-#include <chrono>
-static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int bench_mode(int argc, char **argv) {
     if (argc < 5) return 2;
     const std::string dir = argv[2];
@@ -292,6 +414,14 @@ int main(int argc, char **argv) {
     if (argc >= 2 && std::string(argv[1]) == "--bench") {
         try {
             return bench_mode(argc, argv);
+        } catch (const std::exception &e) {
+            fprintf(stderr, "error: %s\n", e.what());
+            return 1;
+        }
+    }
+    if (argc >= 2 && (std::string(argv[1]) == "--queue" || std::string(argv[1]) == "--replicas")) {
+        try {
+            return std::string(argv[1]) == "--queue" ? queue_mode(argc, argv) : replicas_mode(argc, argv);
         } catch (const std::exception &e) {
             fprintf(stderr, "error: %s\n", e.what());
             return 1;

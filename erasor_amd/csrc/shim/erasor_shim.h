@@ -9,6 +9,7 @@
 #ifndef ERASOR_SHIM_H
 #define ERASOR_SHIM_H
 
+#include "erasor_shim_queue.h"
 #include <memory>
 #include <stdexcept>
 #include <string>

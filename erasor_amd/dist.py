@@ -63,6 +63,32 @@ def deal_round_robin(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
+class JobQueue:
+    """Independent jobs (sequences) handed out in order to whichever RANK asks next -- BASELINE config 3's "the fifth sequence onto
+    the first free GPU"  instead of a static deal.  One shared counter in the process group's key-value store (an atomic
+    add at rank 0's TCPStore: a few bytes per job, no collective, no data-path traffic); a single process counts locally.
+    next() -> job index, or None when the jobs are gone.  Every rank must create its queues in the same order (the n-th queue of every
+    rank is the same queue)."""
+    _serial = 0
+
+    def __init__(self, dist, n_jobs, store=None):
+        self.n, self.dist, self._local = int(n_jobs), dist, 0
+        JobQueue._serial += 1
+        self.key = "erasor_job_queue_%d" % JobQueue._serial
+        self.store = store
+        if dist is not None and store is None:
+            from torch.distributed import distributed_c10d
+            self.store = distributed_c10d._get_default_store()
+
+    def next(self):
+        if self.dist is None:
+            j = self._local
+            self._local += 1
+        else:
+            j = int(self.store.add(self.key, 1)) - 1
+        return j if j < self.n else None
+
+
 def max_over_ranks(dist, value, device):
     import torch
     if dist is None:

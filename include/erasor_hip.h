@@ -284,6 +284,15 @@ int erasor_hip_step_ticket(erasor_hip_handle *h, uint64_t ticket, const float T_
                            erasor_step_result *res);
 int erasor_hip_step_ticket_async(erasor_hip_handle *h, uint64_t ticket, const float T_body2origin[16], const float T_origin2body[16]);
 
+/* ---- one host process, several devices (round 4) --------------------------------------------------------------------------
+ * replaces: one OfflineMapUpdater per process, each loading the global map itself (main_kitti.cpp:4-11, main_in_your_env.cpp:92-123,
+ * OfflineMapUpdater::load_global_map OMU.cpp:107-135) when ONE process drives several GPUs: the map of handles[root] is sent to every
+ * other handle (one per device, erasor_hip_create(.., device, ..)) -- single-process RCCL (ncclCommInitAll + ncclBroadcast of the
+ * XYZI rows over xGMI; librccl is loaded on first use), hipMemcpyPeerAsync where RCCL is not available or two handles share a device.
+ * The receivers end up as after erasor_hip_set_map.  *transport (may be NULL): 1 RCCL, 2 peer copies, 0 empty map.
+ * Replicas then run independently (scans are a sequential fold over ONE map): no per-scan communication. */
+int erasor_hip_replicate_map(erasor_hip_handle *const *handles, int n, int root, int *transport);
+
 /* ---- measurement hooks (no reference counterpart) ------------------------ */
 /* When enabled, every kernel launch of a step is bracketed by HIP events on the
  * handle's stream; totals are accumulated per kernel name. */

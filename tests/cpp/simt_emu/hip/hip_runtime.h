@@ -536,6 +536,15 @@ inline hipError_t hipMemset(void *d, int v, size_t n) {
 }
 inline hipError_t hipMemcpyAsync(void *d, const void *s_, size_t n, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy(d, s_, n, k); }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { return hipMemset(d, v, n); }
+inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s_, int, size_t n, hipStream_t = nullptr) {  // (one address space here)
+    memcpy(d, s_, n);
+    return hipSuccess;
+}
+inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) {
+    *can = 1;
+    return hipSuccess;
+}
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t *s_, unsigned, int) {
     *s_ = new simt_stream_t{0};
     return hipSuccess;

@@ -30,6 +30,19 @@ WORKER = textwrap.dedent('''
     assert sorted(v for per in dealt for v in per if v >= 0) == [0, 1, 2, 3, 4]
     tmax = ed.max_over_ranks(dist, 1.0 + rank, dev)
     assert tmax == 2.0
+    # config 3 with a QUEUE instead of a deal (round 4): jobs go to whichever rank asks next; rank 1 is slow, rank 0 takes most of them
+    import time
+    q = ed.JobQueue(dist, 5)
+    took = []
+    while True:
+        j = q.next()
+        if j is None:
+            break
+        took.append(j)
+        time.sleep(0.02 if rank == 0 else 0.5)
+    got = ed.gather_counts(dist, world, took + [-1] * (5 - len(took)), dev)
+    assert sorted(v for per in got for v in per if v >= 0) == [0, 1, 2, 3, 4], got     # every job exactly once
+    assert len([v for v in got[0] if v >= 0]) > len([v for v in got[1] if v >= 0]), got  # the idle rank took the next job
     dist.barrier()
     dist.destroy_process_group()
     sys.stdout.write("rank" + str(rank) + "-ok" + chr(10))
@@ -110,6 +123,21 @@ def test_two_ranks_run_real_steps_and_exchange_the_union_of_their_removals(tmp_p
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "rank0-union-ok" in out.stdout and "rank1-union-ok" in out.stdout
+
+
+def test_job_queue_in_a_single_process():
+    sys.path.insert(0, ROOT)
+    from erasor_amd import dist as ed
+    q = ed.JobQueue(None, 3)
+    assert [q.next(), q.next(), q.next(), q.next(), q.next()] == [0, 1, 2, None, None]
+
+
+def test_work_queue_of_the_cpp_driver(tmp_path):
+    """erasor::WorkQueue (erasor_amd/csrc/shim/erasor_shim_queue.h), what erasor_offline_demo --queue hands sequences out with"""
+    exe = str(tmp_path / "wq")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "cpp", "work_queue_check.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "WORK-QUEUE-OK" in out.stdout, out.stdout + out.stderr
 
 
 def test_single_process_path_needs_no_process_group():

@@ -604,6 +604,33 @@ def test_prefetched_scans_give_the_same_results(gpu_mod, version, ahead):
     compare_step(g, o, rg, ro, full=True)
 
 
+def test_replicate_map_to_other_handles(gpu_mod):
+    """erasor_hip_replicate_map (round 4): one host process, several handles.  On this one-GPU box: a communicator of ONE through RCCL
+    (transport 1), and two handles on the same device through peer copies (transport 2; ncclCommInitAll refuses duplicate devices).
+    The replica must be the root's map -- AFTER steps have re-arranged it (VoI-resident part, tombstones) -- and then behave like it."""
+    sc = scenarios.small()
+    g, o = make_pair(gpu_mod, sc["params"])
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    for k in range(3):
+        rg = g.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        ro = o.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+    assert gpu_mod.replicate_map([g], 0) in (1, 2)  # (1 where librccl is present)
+    same(g.get_map(), o.get_map(), "root after a one-rank broadcast")
+    r = gpu_mod.Erasor(scenarios.to_product_params(sc["params"]))
+    assert gpu_mod.replicate_map([g, r], 0) == 2
+    same(r.get_map(), o.get_map(), "replica == the root's map")
+    for k in range(3, 5):  # root and replica go on independently: identical results
+        rr = r.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        rg = g.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        ro = o.step(sc["scans"][k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
+        compare_step(g, o, rg, ro, full=False)
+        compare_step(r, o, rr, ro, full=False)
+    same(r.get_map(), o.get_map(), "replica after its own steps")
+    with pytest.raises(gpu_mod.ErasorError):
+        gpu_mod.replicate_map([gpu_mod.Erasor(scenarios.to_product_params(sc["params"])), r], 0)  # a root without a map
+
+
 def _pcl_rows(scan):
     """the scan as pcl::PointXYZI records: 8 floats per point, x y z pad | intensity pad pad pad (what pcl::fromROSMsg leaves)"""
     rows = np.full((len(scan), 8), 7.25, np.float32)  # (padding is garbage on purpose)

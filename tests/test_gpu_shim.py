@@ -279,6 +279,68 @@ def test_config_driver_like_main_in_your_env(tmp_path):
     assert np.allclose(saved[:, :3], ref[:, :3], rtol=2e-7, atol=1e-7) and np.array_equal(saved[:, 3], ref[:, 3].astype(np.float64))
 
 
+def _write_sequence_dir(d, sc, n, init_idx, data_name):
+    """<d>/dense_global_map.pcd, pcds/, poses_lidar2body.csv, cfg.yaml in the reference's layout; returns the yaml's path"""
+    from erasor_amd import synth
+    os.makedirs(os.path.join(d, "pcds"))
+    os.makedirs(os.path.join(d, "out"))
+    write_pcd_binary(os.path.join(d, "dense_global_map.pcd"), sc["map"])
+    with open(os.path.join(d, "poses_lidar2body.csv"), "w") as f:
+        f.write("index, timestamp, x, y, z, qx, qy, qz, qw\n")
+        for k in range(n):
+            write_pcd_binary(os.path.join(d, "pcds", "%06d.pcd" % k), sc["scans"][k])
+            f.write("%d, %.2f, %s\n" % (k, 0.1 * k, ", ".join("%.9f" % v for v in sc["poses"][k])))
+    sp = synth.SEQ_PARAMS["05"]
+    with open(os.path.join(d, "cfg.yaml"), "w") as f:
+        f.write("erasor:\n")
+        for key in ("max_range", "num_rings", "num_sectors", "min_h", "max_h", "th_bin_max_h", "scan_ratio_threshold", "minimum_num_pts",
+                    "gf_dist_thr", "gf_iter", "gf_num_lpr", "gf_th_seeds_height"):
+            f.write("    %s: %s\n" % (key, sp[key]))
+        f.write("    rejection_ratio: 0\n    version: 3\n\nMapUpdater:\n    data_name: \"%s\"\n    env: \"outdoor\"\n" % data_name)
+        f.write("    save_path: \"%s\"\n    query_voxel_size: 0.2\n    map_voxel_size: 0.05\n    removal_interval: 1\n\n" % os.path.join(d, "out"))
+        f.write("data_dir: \"%s\"\ninit_idx: %d\ninterval: 2\nvoxel_size: 0.075\n" % (d, init_idx))
+        f.write("tf:\n     lidar2body: [0.0, 0.0, %s, 0, 0.0, 0.0, 1.0]\n\nverbose: false\n" % synth.LIDAR_HEIGHT)
+    return os.path.join(d, "cfg.yaml")
+
+
+def test_sequences_from_a_queue_and_replicas_in_one_process(tmp_path):
+    """round 4, BASELINE config 3 / VERDICT r03 item 5 in the C++ driver: (a) --queue: three sequences over two workers, the next sequence
+    goes to whichever worker is idle (erasor::WorkQueue); every saved map equals what --config saves for that sequence alone.  (b)
+    --replicas 2: ONE map file read, erasor_hip_replicate_map (two handles on this box's one device: peer copies), the nodes dealt
+    over the replicas."""
+    import json
+    ensure_demo()
+    sc = scenarios.small()
+    cfgs = []
+    for j in range(3):
+        d = str(tmp_path / ("seq%d" % j))
+        os.makedirs(d)
+        cfgs.append(_write_sequence_dir(d, sc, 4 + j, 0, "0%d" % j))
+    out = subprocess.run([DEMO, "--queue", "2", "100"] + cfgs, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    j = json.loads(out.stdout.strip().split("\n")[-1])
+    assert j["jobs"] == 3 and j["failed"] == 0 and j["workers"] == 2
+    lines = [l for l in out.stdout.split("\n") if l.startswith("job ")]
+    assert len(lines) == 3 and {int(l.split("worker ")[1].split()[0]) for l in lines} <= {0, 1}
+    assert ["%d nodes" % (4 + k) in lines[k] for k in range(3)] == [True] * 3
+    # each sequence alone, into another directory: the same saved map
+    for k in range(3):
+        d2 = str(tmp_path / ("alone%d" % k))
+        os.makedirs(d2)
+        cfg2 = _write_sequence_dir(d2, sc, 4 + k, 0, "0%d" % k)
+        o2 = subprocess.run([DEMO, "--config", cfg2], capture_output=True, text=True, timeout=600)
+        assert o2.returncode == 0, o2.stdout + o2.stderr
+        a = open(os.path.join(str(tmp_path / ("seq%d" % k)), "out", "0%d_result.pcd" % k)).read()
+        b = open(os.path.join(d2, "out", "0%d_result.pcd" % k)).read()
+        assert a == b, "sequence %d: the queue's saved map differs from the stand-alone run's" % k
+    out = subprocess.run([DEMO, "--replicas", "2", cfgs[2], "6"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    j = json.loads(out.stdout.strip().split("\n")[-1])
+    assert j["replicas"] == 2 and j["transport"] in ("peer copies", "rccl")
+    reps = [l for l in out.stdout.split("\n") if l.startswith("replica ")]
+    assert len(reps) == 2 and "3 nodes" in reps[0] and "3 nodes" in reps[1]
+
+
 @pytest.mark.parametrize("large", [0, 1])
 def test_mapgen_class_and_driver(tmp_path, large):
     """class mapgen of the shim (setValue / accumPointCloud / getPointClouds / saveNaiveMap, mapgen.hpp:182-303) driven
