@@ -1615,9 +1615,14 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             LAUNCH(h, "voi_bucket", k_mb_hist, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, n_voi, nvoi_dev, B + 1, h->mb_hist.p, h->mb_tot.p);
             LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv(B + 1, MB_PAD), 256, h->mb_hist.p, n_voi, nvoi_dev, B + 1, (const uint32_t *)h->mb_tot.p,
                    h->moff.p);
-            if (B + 1 <= MBW_NB_MAX)
-                LAUNCH(h, "voi_bucket", k_mb_scatter_w, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
-                       (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, B + 1, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p);
+            if (B + 1 <= MBW_NB_SMALL)
+                LAUNCH(h, "voi_bucket", k_mb_scatter_w<MBW_NB_SMALL>, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
+                       (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, B + 1, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p,
+                       h->dbg_stamps.p);
+            else if (B + 1 <= MBW_NB_MAX)
+                LAUNCH(h, "voi_bucket", k_mb_scatter_w<MBW_NB_MAX>, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
+                       (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, B + 1, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p,
+                       h->dbg_stamps.p);
             else
                 LAUNCH(h, "voi_bucket", k_mb_scatter, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
                        (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, B + 1, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p);
@@ -1898,6 +1903,8 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
                 t[19], (double)t[17] / 100.0, (double)t[18] / 100.0, t[21], t[22], (double)t[20] / 100.0);
         fprintf(stderr, "[last per-bin workgroup] %.1f us: open %.1f, select %.1f, R-GPF %.1f (%llu points), voxelisation %.1f (%llu points)\n", (double)t[64] / 100.0,
                 (double)t[65] / 100.0, (double)t[66] / 100.0, (double)t[67] / 100.0, t[69], (double)t[68] / 100.0, t[70]);
+        fprintf(stderr, "[map scatter, workgroup 3, 10 ns ticks] table + zero %llu, count %llu, prefix %llu, place %llu\n", t[73] - t[72], t[74] - t[73], t[75] - t[74],
+                t[76] - t[75]);
         fprintf(stderr, "[reverted bins] %llu, %llu of them beyond the LDS pool, %llu points in all\n", t[23] & 0xFFFFFFFFull, t[23] >> 32, t[63]);
         memset(t, 0, sizeof(t));
         t[28] = ~0ull;
@@ -2150,17 +2157,17 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
-Rccl &rccl() {
+Rccl *rccl_api() {
     static Rccl r;
     static bool tried = false;
-    if (tried) return r;
+    if (tried) return &r;
     tried = true;
-    if (getenv("ERASOR_HIP_NO_RCCL")) return r;
+    if (getenv("ERASOR_HIP_NO_RCCL")) return &r;
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (r.lib) break;
     }
-    if (!r.lib) return r;
+    if (!r.lib) return &r;
     r.CommInitAll = (int (*)(void **, int, const int *))dlsym(r.lib, "ncclCommInitAll");
     r.CommDestroy = (int (*)(void *))dlsym(r.lib, "ncclCommDestroy");
     r.Broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(r.lib, "ncclBroadcast");
@@ -2168,7 +2175,7 @@ Rccl &rccl() {
     r.GroupEnd = (int (*)())dlsym(r.lib, "ncclGroupEnd");
     r.GetErrorString = (const char *(*)(int))dlsym(r.lib, "ncclGetErrorString");
     r.ok = r.CommInitAll && r.CommDestroy && r.Broadcast && r.GroupStart && r.GroupEnd;
-    return r;
+    return &r;
 }
 // the handle's whole map as ONE dense device array, in the reference's order: [VoI-resident part | outskirts | submap complement]
 int map_to_device(erasor_hip_handle *h, DBuf<float4> &dense, size_t *n_out) {
@@ -2238,7 +2245,7 @@ int erasor_hip_replicate_map(erasor_hip_handle *const *handles, int n, int root,
         }
     }
     int used = 0;
-    Rccl &R = rccl();
+    Rccl &R = *rccl_api();
     if (R.ok && distinct && total) {
         // single-process RCCL: one communicator per device, the broadcasts of all ranks in ONE group
         std::vector<void *> comms(n, nullptr);

@@ -39,6 +39,19 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
 
 // intra-wave visibility of LDS/global writes made by other lanes of the same wave
 __device__ __forceinline__ void wave_sync() { __threadfence_block(); }
+// The same for LDS ONLY.  A wavefront's LDS operations are performed in program order, so a lane sees what another lane of its
+// wavefront wrote to LDS by an earlier instruction without waiting for anything: all that is needed is that the COMPILER keeps the
+// order.  wave_sync() is a workgroup-scope fence: it also waits for every global load and store the wavefront has in flight
+// (s_waitcnt vmcnt(0)) -- behind a scattered store that is a memory round trip per call (round 4: eight of them per tile in
+// k_mb_scatter_w).  (The tests' CPU stand-in, where the lanes of a wavefront are threads of their own, keeps the meeting point.)
+__device__ __forceinline__ void wave_sync_lds() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#else
+    wave_sync();
+#endif
+}
 
 // One wavefront partitions [first,last) (size > kThreshold).  posL/posR: scratch, same index space
 // as K (entries [first+1,last) are used).  Returns the cut (wave-uniform).

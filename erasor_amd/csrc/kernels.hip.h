@@ -798,6 +798,35 @@ __global__ __launch_bounds__(1024) void k_scan_top(uint32_t *__restrict__ tops, 
 // (block, wave, round, lane) order == index order (stability).
 // ================================================================================================
 static constexpr int RTILE = 2048;
+// the lanes of the wavefront that hold the same key as this one (0 for an invalid lane).  Round 4: one round per DISTINCT key of the
+// wavefront -- pick the lowest lane not yet matched, read its key (v_readlane, the lane number is wave-uniform), one compare is the
+// group's mask -- instead of one ballot and a 64-bit select per key BIT: points that are neighbours in the map are neighbours in the
+// grid, a wavefront of 64 consecutive ones holds a handful of distinct bins (the bit-wise form: ~120 instructions per 64 keys of a
+// 12-bit grid, 6 us of a scatter workgroup's 13; this one: ~8 per distinct key).  `max_rounds` bounds the loop; what is left then
+// (a wavefront with more distinct keys than that) is matched bit by bit.
+__device__ __forceinline__ uint64_t match_any(uint32_t k, bool valid, int bits) {
+    uint64_t todo = __ballot(valid), mine = 0ull;
+    int rounds = 0;
+    while (todo != 0ull && rounds < 12) {
+        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t kk = __builtin_amdgcn_readlane(k, leader);
+        const uint64_t m = __ballot(valid && k == kk);
+        if (k == kk) mine = m;
+        todo &= ~m;
+        ++rounds;
+    }
+    if (todo != 0ull) {  // (many distinct keys: the rest bit by bit, among the lanes that are still unmatched)
+        const bool left = (todo >> (threadIdx.x & 63u)) & 1ull;
+        uint64_t p = todo;
+        for (int b = 0; b < bits; ++b) {
+            const bool bit = (k >> b) & 1u;
+            const uint64_t m = __ballot(left && bit);
+            p &= bit ? m : ~m;
+        }
+        if (left) mine = p;
+    }
+    return valid ? mine : 0ull;
+}
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
     uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -827,7 +856,7 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t *__restrict__
         const uint32_t d = valid ? ((keys[i] >> shift) & 0xFFu) : 0u;
         const uint64_t peers = match_digit(d, valid);
         if (valid && (peers & lt) == 0) wcnt[wave][d] += __popcll(peers);
-        esort::wave_sync();
+        esort::wave_sync_lds();
     }
     __syncthreads();
     const uint32_t tot = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
@@ -860,7 +889,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t *__restric
         const uint32_t d = (k[r] >> shift) & 0xFFu;
         const uint64_t peers = match_digit(d, valid);
         if (valid && (peers & lt) == 0) wcnt[wave][d] += __popcll(peers);
-        esort::wave_sync();
+        esort::wave_sync_lds();
     }
     __syncthreads();
     {
@@ -883,9 +912,9 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t *__restric
             keys_out[pos] = k[r];
             vals_out[pos] = v[r];
         }
-        esort::wave_sync();
+        esort::wave_sync_lds();
         if (valid && (peers & lt) == 0) wbase[wave][d] += __popcll(peers);
-        esort::wave_sync();
+        esort::wave_sync_lds();
     }
 }
 
@@ -990,7 +1019,7 @@ __global__ __launch_bounds__(1024) void k_qb_scatter(const uint32_t *__restrict_
     for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {  // waves take their turn in index order
         if (wave == w && valid) {
             r = cnt[k] + (uint32_t)__popcll(peers & lt);
-            esort::wave_sync();
+            esort::wave_sync_lds();
             if ((peers >> (threadIdx.x & 63u)) >> 1 == 0) cnt[k] += (uint32_t)__popcll(peers);  // highest lane of the group
         }
         __syncthreads();
@@ -1147,7 +1176,7 @@ __global__ __launch_bounds__(1024) void k_mb_scatter(const uint32_t *__restrict_
         for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {  // waves take their turn in index order
             if (wave == w && valid) {
                 d = cnt[k] + (uint32_t)__popcll(peers & lt);
-                esort::wave_sync();
+                esort::wave_sync_lds();
                 if ((peers >> (threadIdx.x & 63u)) >> 1 == 0) cnt[k] += (uint32_t)__popcll(peers);  // highest lane of the group
             }
             __syncthreads();
@@ -1165,12 +1194,19 @@ __global__ __launch_bounds__(1024) void k_mb_scatter(const uint32_t *__restrict_
 // wavefront-major and the ranks need three block barriers instead of one per wavefront turn: (1) private per-wavefront
 // bucket counts, (2) their prefix over the wavefronts (tile-relative, 16 bit), (3) each wavefront ranks its own keys.
 static constexpr uint32_t MBW_NB_MAX = 4096;
-__global__ __launch_bounds__(1024) void k_mb_scatter_w(const uint32_t *__restrict__ keys, const float4 *__restrict__ src,
+static constexpr uint32_t MBW_NB_SMALL = 2176;  // round 4: up to this many buckets a workgroup's tables take 78 KB -- TWO workgroups per compute unit
+// (NBC: bucket capacity of the LDS tables.  The usual grids -- 20 x 108 + 1 = 2161 buckets -- fit the small instance, whose two
+// workgroups per compute unit halve the rounds a dense map's ~800 tiles need on 256 compute units.)
+template <uint32_t NBC>
+__global__ __launch_bounds__(1024, NBC <= MBW_NB_SMALL ? 8 : 4) void k_mb_scatter_w(const uint32_t *__restrict__ keys, const float4 *__restrict__ src,
                                                         const uint32_t *__restrict__ src_aux, uint32_t n_host, const uint32_t *n_dev, uint32_t nb,
                                                         int bits, const uint32_t *__restrict__ base /* scanned hist */, float4 *__restrict__ dst,
-                                                        uint32_t *__restrict__ dst_aux, uint32_t *__restrict__ dst_keys) {
-    __shared__ uint16_t wcnt[16][MBW_NB_MAX];
-    __shared__ uint32_t sbase[MBW_NB_MAX];
+                                                        uint32_t *__restrict__ dst_aux, uint32_t *__restrict__ dst_keys,
+                                                        unsigned long long *dbg = nullptr) {
+    __shared__ uint16_t wcnt[16][NBC];
+    __shared__ uint32_t sbase[NBC];
+#define SC_STAMP(i) do { if (dbg && blockIdx.x == 3 && threadIdx.x == 0) dbg[72 + (i)] = wall_clock64(); } while (0)
+    SC_STAMP(0);
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1179,27 +1215,31 @@ __global__ __launch_bounds__(1024) void k_mb_scatter_w(const uint32_t *__restric
     for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) sbase[b] = base[(size_t)tile * mb_row_stride(nb) + b];
-    for (uint32_t i = threadIdx.x; i < 16 * MBW_NB_MAX / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(&wcnt[0][0])[i] = 0u;
+    {   // (only the columns in use: rows are NBC apart)
+        const uint32_t nb2 = (nb + 1) / 2;
+        for (uint32_t i = threadIdx.x; i < 16 * nb2; i += blockDim.x) reinterpret_cast<uint32_t *>(&wcnt[i / nb2][0])[i % nb2] = 0u;
+    }
     __syncthreads();
+    SC_STAMP(1);
     const uint32_t i0 = tile * MB_TILE + wave * (MB_TILE / 16) + lane;
     uint32_t k[R];
     uint64_t peers[R];
 #pragma unroll
+    for (uint32_t r = 0; r < R; ++r) {  // (all key loads in flight: the counting pass used to wait for them one by one)
+        const uint32_t i = i0 + r * 64;
+        k[r] = i < n ? min(keys[i], nb - 1) : 0u;
+    }
+#pragma unroll
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t i = i0 + r * 64;
         const bool valid = i < n;
-        k[r] = valid ? min(keys[i], nb - 1) : 0u;
-        uint64_t p = __ballot(valid);
-        for (int b = 0; b < bits; ++b) {
-            const bool bit = (k[r] >> b) & 1u;
-            const uint64_t m = __ballot(valid && bit);
-            p &= bit ? m : ~m;
-        }
-        peers[r] = valid ? p : 0ull;
+        const uint64_t p = match_any(k[r], valid, bits);
+        peers[r] = p;
         if (valid && (p >> lane) >> 1 == 0) wcnt[wave][k[r]] += (uint16_t)__popcll(p);  // highest lane of the group
-        esort::wave_sync();
+        esort::wave_sync_lds();
     }
     __syncthreads();
+    SC_STAMP(2);
     for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {  // exclusive prefix over the wavefronts (<= 8192: 16 bit)
         uint32_t run = 0;
 #pragma unroll
@@ -1210,6 +1250,7 @@ __global__ __launch_bounds__(1024) void k_mb_scatter_w(const uint32_t *__restric
         }
     }
     __syncthreads();
+    SC_STAMP(3);
 #pragma unroll
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t i = i0 + r * 64;
@@ -1219,11 +1260,13 @@ __global__ __launch_bounds__(1024) void k_mb_scatter_w(const uint32_t *__restric
             dst_aux[d] = src_aux[i];
             dst_keys[d] = k[r];
         }
-        esort::wave_sync();
+        esort::wave_sync_lds();
         if (i < n && (peers[r] >> lane) >> 1 == 0) wcnt[wave][k[r]] += (uint16_t)__popcll(peers[r]);
-        esort::wave_sync();
+        esort::wave_sync_lds();
     }
+    SC_STAMP(4);
     }
+#undef SC_STAMP
 }
 
 __global__ __launch_bounds__(256) void k_bin_offsets(const uint32_t *__restrict__ skeys, uint32_t n_host, const uint32_t *n_dev,

@@ -99,7 +99,7 @@ static void test_map_bucketing(std::mt19937 &rng) {
         simt::run_grid(std::max(1u, ntile / 2), 1024, [&] { k_mb_hist(keys.data(), n + 100, nd.data(), nb, hist.data(), tot.data()); });
         simt::run_grid((nb + MB_PAD - 1) / MB_PAD, 256, [&] { k_mb_colscan(hist.data(), n + 100, nd.data(), nb, tot.data(), off.data()); });
         simt::run_grid(std::max(1u, ntile / 2), 1024, [&] {
-            k_mb_scatter_w(keys.data(), pts.data(), src.data(), n + 100, nd.data(), nb, bits, hist.data(), dpts.data(), dsrc.data(), dkeys.data());
+            k_mb_scatter_w<MBW_NB_SMALL>(keys.data(), pts.data(), src.data(), n + 100, nd.data(), nb, bits, hist.data(), dpts.data(), dsrc.data(), dkeys.data(), nullptr);
         });
         std::vector<uint32_t> order(n);
         for (uint32_t i = 0; i < n; ++i) order[i] = i;
