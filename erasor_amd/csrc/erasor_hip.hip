@@ -182,6 +182,9 @@ struct erasor_hip_handle {
     struct {
         bool valid = false;
         double x = 0, y = 0;
+        bool scan = false;               // the chunk scan was launched ahead as well (buffers below)
+        const void *pvl = nullptr, *phl = nullptr;
+        uint32_t scan_cap = 0;
         unsigned long long seq = 0;      // h->step_seq when it was launched
         unsigned long long epoch = 0;    // h->store_epoch then
         int curF = 0;                    // the F buffer it read
@@ -268,7 +271,7 @@ struct erasor_hip_handle {
     DBuf<uint32_t> gsH;
     DBuf<float4> gsC, vox_out;
     // ---- state ----
-    DBuf<DevState> d_st;
+    DBuf<DevState> d_st, d_st_get;  // (d_st_get: a copy of the last finished step's state for the getters, see assemble_egocentric)
     DBuf<Counters> d_ctr;
     DevState st;
     Counters ctr;
@@ -876,7 +879,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->st1); release(h->status); release(h->action);
     release(h->curr_rejected);
     release(h->gsK); release(h->gsV); release(h->gsL); release(h->gsR); release(h->gsK2); release(h->gsV2); release(h->gsH); release(h->gsC);
-    release(h->vox_out); release(h->d_st); release(h->d_ctr);
+    release(h->vox_out); release(h->d_st); release(h->d_st_get); release(h->d_ctr);
     for (int k = 0; k < NSIDE; ++k) {
         if (h->q[k].ev_keys) (void)hipEventDestroy(h->q[k].ev_keys);
         if (h->q[k].ev_done) (void)hipEventDestroy(h->q[k].ev_done);
@@ -1408,8 +1411,26 @@ static void launch_split_ahead(erasor_hip_handle *h, double nx, double ny, uint3
     h->spec.vmask = h->vmask.p;
     h->spec.hmask = h->hmask.p;
     h->spec.cinfo = h->cinfo.p;
+    h->spec.scan = false;
     h->fly.spec_launched = true;
     ++h->n_spec_launched;
+    // round 4: ... and the next step's chunk scan behind it: the stream goes on while the host is still collecting this step's results
+    // and comes back with the next one (its turnaround, ~10 us, used to be idle time between the split and the scan)
+    static const bool no_early_scan = getenv("ERASOR_HIP_NO_AHEAD_SCAN") != nullptr;
+    const bool mb_count = h->B + 1 <= QB_NB_MAX;
+    const uint32_t scan_cap = (uint32_t)std::min<size_t>(std::min(h->pvl.cap, h->phl.cap) - 8, 16384);
+    if (!no_early_scan && nchunks_hint + 64u <= scan_cap && h->topv.cap >= 24 && h->toph.cap >= 24 && h->prof != 1) {
+        hipStream_t keep = h->cur;
+        h->cur = h->stream;
+        LAUNCH(h, "chunk_scan", k_chunk_scan_one, 1, 1024, (const uint32_t *)h->cinfo.p, 0u, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, 16u, 0u, h->d_st.p,
+               h->d_ctr.p, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? h->B + 1 : 0u,
+               h->use_ometa ? h->ometa.p : (OMeta *)nullptr, h->capO / CHUNK, scan_cap);
+        h->cur = keep;
+        h->spec.scan = true;
+        h->spec.scan_cap = scan_cap;
+        h->spec.pvl = h->pvl.p;
+        h->spec.phl = h->phl.p;
+    }
 }
 
 static int step_collect(erasor_hip_handle *h, erasor_step_result *res);
@@ -1544,7 +1565,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     if (chunks_room * CHUNK_TILES + 8 > h->vmask.cap || chunks_room * CHUNK_TILES + 8 > h->hmask.cap || chunks_room + 8 > h->cinfo.cap)
         h->spec.valid = false;  // (re-allocated below: a pass launched ahead wrote into the old buffers)
     if (ensure(h, h->vmask, chunks_room * CHUNK_TILES + 8) || ensure(h, h->hmask, chunks_room * CHUNK_TILES + 8) ||
-        ensure(h, h->cinfo, chunks_room + 8) || ensure(h, h->pvl, nchunks + 8) || ensure(h, h->phl, nchunks + 8) ||
+        ensure(h, h->cinfo, chunks_room + 8) || ensure(h, h->pvl, chunks_room + 8) || ensure(h, h->phl, chunks_room + 8) ||
         ensure(h, h->topv, nchunks / 1024 + 8) || ensure(h, h->toph, nchunks / 1024 + 8) || ensure(h, h->topr, nchunks / 1024 + 8))
         return ERASOR_E_NO_DEVICE;
     // No mid-step read-back: everything is launched on upper-bound grids and reads the actual counts
@@ -1576,7 +1597,10 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                                   h->spec.curF == h->curF && h->spec.x == xc && h->spec.y == yc && nchunks <= h->spec.cap_chunks &&
                                   h->spec.vmask == (const void *)h->vmask.p && h->spec.hmask == (const void *)h->hmask.p &&
                                   h->spec.cinfo == (const void *)h->cinfo.p;
+            const bool scan_done = use_spec && h->spec.scan && nchunks <= h->spec.scan_cap && h->spec.pvl == (const void *)h->pvl.p &&
+                                   h->spec.phl == (const void *)h->phl.p;
             h->spec.valid = false;
+            h->spec.scan = false;
             if (use_spec) ++h->n_spec_used;
             else
                 launch_voi_split(h, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, h->o_begin, o_chunk0, nOchunks, nchunks, xc, yc, voi_r2,
@@ -1586,10 +1610,12 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                 static const int mpad = getenv("ERASOR_HIP_MPAD_US") ? atoi(getenv("ERASOR_HIP_MPAD_US")) : 0;
                 if (mpad > 0) LAUNCH(h, "m_pad", k_pad, 1, 64, (unsigned long long)mpad * 100ull);
             }
-            if (nchunks <= 16384) {
+            if (scan_done) {
+                // (launched ahead behind the split, see launch_split_ahead)
+            } else if (nchunks <= 16384) {
                 LAUNCH(h, "chunk_scan", k_chunk_scan_one, 1, 1024, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, ntop,
                        nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u,
-                       h->use_ometa ? h->ometa.p : (OMeta *)nullptr);
+                       h->use_ometa ? h->ometa.p : (OMeta *)nullptr, 0u, 0u);
             } else {
                 LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p,
                        h->topr.p);
@@ -2364,6 +2390,10 @@ int erasor_hip_get_map(erasor_hip_handle *h, float *dst, size_t cap, size_t *n) 
 static int assemble_egocentric(erasor_hip_handle *h, float4 **out) {
     const DevState &s = h->st;
     if (ensure(h, h->F[h->curF ^ 1], (size_t)s.nF_new + 8)) return ERASOR_E_NO_DEVICE;
+    // the kernel reads the LAST step's state (sizes of its VoI and of its output): from a copy of the host mirror, not from the live
+    // device state -- the next step's chunk scan may have opened that already (launched ahead, round 4)
+    if (ensure(h, h->d_st_get, 1)) return ERASOR_E_NO_DEVICE;
+    HIPC(h, hipMemcpyAsync(h->d_st_get.p, &h->st, sizeof(DevState), hipMemcpyHostToDevice, h->stream));
     float4 *tmp = h->F[h->curF ^ 1].p;
     const DP &P = h->dp;
     const uint32_t B = h->B, n_voi = h->last_n_voi;
@@ -2372,7 +2402,7 @@ static int assemble_egocentric(erasor_hip_handle *h, float4 **out) {
                (const uint32_t *)h->rev_idx.p, h->last_skeys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p,
                (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p,
                h->out_off.p, h->ground_off.p, h->rej_off.p,
-               h->d_st.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr, 0u, (const uint32_t *)nullptr,
+               h->d_st_get.p, tmp, (float4 *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr, 0u, (const uint32_t *)nullptr,
                (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const float4 *)nullptr, (const uint32_t *)nullptr,
                (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     LAUNCH(h, "get_cloud", k_assemble_bins<false>, B, 256, P, h->Tb2o, (const uint8_t *)h->action.p, (const uint32_t *)h->rev_idx.p,

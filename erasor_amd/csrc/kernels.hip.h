@@ -523,11 +523,22 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ 
 __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restrict__ cinfo, uint32_t nchunks, uint32_t *__restrict__ pvl,
                                                           uint32_t *__restrict__ phl, uint32_t *__restrict__ topv, uint32_t *__restrict__ toph,
                                                           uint32_t ntop, uint32_t nFchunks, DevState *st, Counters *ctr, DevState init,
-                                                          unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n, OMeta *__restrict__ ometa) {
+                                                          unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n, OMeta *__restrict__ ometa,
+                                                          // round 4: != 0: launched AHEAD, right behind the next step's VoI split (which was launched
+                                                          // ahead too): the extents are what the step in front has committed on the device, and so is
+                                                          // the state this step starts from -- the host is still collecting that step's results
+                                                          uint32_t capO_chunks_dev, uint32_t cap_dev /* chunks the prefix arrays hold */) {
     __shared__ uint32_t sm[40];
     __shared__ uint32_t s_voiF, s_validF;
     const unsigned long long t_open = wall_clock64();
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (capO_chunks_dev) {
+        const uint32_t nF = st->nF, ob = st->o_begin;
+        nFchunks = (nF + CHUNK - 1) / CHUNK;
+        nchunks = min(nFchunks + (capO_chunks_dev - ob / CHUNK), min(cap_dev, 16384u));  // (beyond: the step sees that and runs the scan itself)
+        ntop = max(1u, (nchunks + 1023u) / 1024u);
+        init = *st;
+    }
     const uint32_t base = tid * 16;
     uint32_t ci[16];
 #pragma unroll

@@ -394,8 +394,9 @@ static void test_map_store(std::mt19937 &rng) {
         if (getenv("DBG_CINFO")) { printf("   [dbg] variant %d cinfo:", variant); for (uint32_t c = 0; c < nchunks; ++c) printf(" %08x", cinfo[c]); printf("\n"); }
         CHECK(warm ? (n_read > 0 && n_read + 3 <= nOchunks) : n_read == nOchunks, "outskirts chunks read: %u of %u (warm=%d)", n_read, nOchunks, warm);
         simt::run_grid(1, 1024, [&] {
-            k_chunk_scan_one(cinfo.data(), nchunks, pvl.data(), phl.data(), topv.data(), toph.data(), 1u, nFchunks, &st, &ctr, init, lab.data(), mb_tot.data(), 64u,
-                             ometa.data());
+            // (ahead: the scan is launched ahead like the split -- extents and starting state from the committed device state)
+            k_chunk_scan_one(cinfo.data(), ahead ? 0u : nchunks, pvl.data(), phl.data(), topv.data(), toph.data(), 1u, ahead ? 0u : nFchunks, &st, &ctr, init,
+                             lab.data(), mb_tot.data(), 64u, ometa.data(), ahead ? capO / CHUNK : 0u, ahead ? nchunks + 8u : 0u);
         });
         CHECK(st.n_o_read == n_read, "n_o_read %u vs %u", st.n_o_read, n_read);
         {   // the two-level scan (maps beyond 16384 chunks) opens the step with the same state and the same prefixes
