@@ -133,7 +133,7 @@ def committed_profile(prof_tag):
     """what the separate rocprofv3 passes of THIS build measured (profiles/*_latest*): k_voi_split's PMC traffic and average
     duration, and the kernel that tops the GPU-time table.  None for everything when the device sources have changed since."""
     import csv
-    out = {"traffic": None, "voi_split_avg_us": None, "dominant": None, "stale": None}
+    out = {"traffic": None, "voi_split_avg_us": None, "dominant": None, "stale": None, "step_traffic": None}
     try:
         with open(os.path.join(ROOT, "profiles", "latest_meta%s.json" % prof_tag)) as f:
             meta = json.load(f)
@@ -147,6 +147,7 @@ def committed_profile(prof_tag):
         with open(os.path.join(ROOT, "profiles", "pmc_latest%s.json" % prof_tag)) as f:
             j = json.load(f)
         out["traffic"] = int(j["traffic_bytes_per_launch"])
+        out["step_traffic"] = j.get("step_traffic_bytes")
         per_kernel = j.get("per_kernel_traffic_bytes", {})
     except Exception:
         pass
@@ -156,7 +157,7 @@ def committed_profile(prof_tag):
         for r in rows:
             if "k_voi_split" in r["Name"]:
                 out["voi_split_avg_us"] = round(float(r["AverageNs"]) / 1e3, 2)
-        steps = max([int(r["Calls"]) for r in rows if "k_step_end" in r["Name"]] + [1])
+        steps = max([int(r["Calls"]) for r in rows if "k_voi_gather" in r["Name"]] + [1])  # (one gather per step)
         top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
         name = top["Name"].split("(")[0].replace("void ", "").replace("ek::", "")
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -576,7 +577,7 @@ def main():
     if world_size == 1 and (not args.no_cpu_baseline or not args.no_pr_rr) and args.mode == "replicas" and first is not None:
         gpu_final = (first.g.get_map(), first.g.get_rejected_indices())  # (after the clock has stopped; compared with the oracle's below)
     prof = first.g.profile_get() if first is not None else {}
-    chain_us = first.g.chain_timing() if first is not None else (0.0, 0.0, 0)
+    chain_us = first.g.chain_timing() if first is not None else (0.0, 0.0, 0, 0.0)
     if first is not None:
         first.g.profiling(0)
     elapsed = ed.max_over_ranks(dist, elapsed_local, dev)
@@ -667,6 +668,7 @@ def main():
                               else "%.0f MB per launch, beyond the 256 MiB Infinity Cache: HBM-bound" % (alg_bytes / 1e6),
                 "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": traffic,
+                "step_traffic": cp["step_traffic"],  # every kernel of a step, PMC, corrected like `traffic` (profiles/pmc_latest*.json)
                 "traffic_source": src_note, "dominant_kernel": cp["dominant"],
                 "bytes_per_launch": int(alg_bytes),
                 "bytes_note": "what a launch has to READ: float4 of the VoI-resident part + {x,y} pairs (8 B) of the outskirts chunks whose bounding "
@@ -788,8 +790,9 @@ def main():
         # the main stream's dependency chain in the timed pass, on the device's own clock (chunk scan .. the step's end), and the time
         # the stream spends between two steps (host turnaround; the next step's VoI split, launched ahead, runs in there)
         "main_chain_us": round(chain_us[0], 1), "between_steps_us": round(chain_us[1], 1),
-        "steady_state_ms_per_step": round((chain_us[0] + chain_us[1]) / 1e3, 4),
-        "steady_state_note": "main_chain_us + between_steps_us: the period of the main stream in the timed pass.  ms_per_step (the contract's figure: "
+        "steady_state_ms_per_step": round(chain_us[3] / 1e3, 4),
+        "steady_state_note": "chunk scan to chunk scan of consecutive steps on the device's clock: the period of the main stream in the timed pass "
+                             "(main_chain_us contains the stream's wait for the host since the scan is launched ahead).  ms_per_step (the contract's figure: "
                              "K steps between two device synchronisations) also pays for draining the query chains of the nodes announced beyond "
                              "the last timed step, once per pass",
         "pr_rr": pr_rr, "callback_path": callback,

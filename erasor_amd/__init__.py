@@ -411,11 +411,11 @@ class Erasor:
         return a.value, b.value
 
     def chain_timing(self, reset=False):
-        """(average span of the main stream's chain per step, average time between a step's end and the next chunk scan, steps) --
-        on the device's own clock (erasor_hip_chain_timing)."""
-        a, b, n = C.c_double(0), C.c_double(0), C.c_uint64(0)
-        self._check(lib().erasor_hip_chain_timing(self._h, C.byref(a), C.byref(b), C.byref(n), C.c_int(1 if reset else 0)))
-        return a.value, b.value, n.value
+        """(average span of the main stream's chain per step, average time between a step's end and the next chunk scan, steps, average
+        period chunk scan -> chunk scan) -- on the device's own clock (erasor_hip_chain_timing)."""
+        a, b, p, n = C.c_double(0), C.c_double(0), C.c_double(0), C.c_uint64(0)
+        self._check(lib().erasor_hip_chain_timing(self._h, C.byref(a), C.byref(b), C.byref(p), C.byref(n), C.c_int(1 if reset else 0)))
+        return a.value, b.value, n.value, p.value
 
     def stream(self):
         return lib().erasor_hip_stream(self._h)

@@ -202,7 +202,8 @@ struct erasor_hip_handle {
     uint64_t mg_cnt_voxel = 0, mg_accum = 0;
     DBuf<uint32_t> mb_hist, mb_tot;   // the map's bucketing as a counting sort: [tiles][B + 1] table, [B + 1] totals
     DBuf<unsigned long long> lab_slots;  // [16][8] label tallies of the assemble kernels (one cache line per slot)
-    double tm_span = 0, tm_gap = 0;  // erasor_hip_chain_timing: sums in microseconds
+    double tm_span = 0, tm_gap = 0, tm_period = 0;  // erasor_hip_chain_timing: sums in microseconds
+    unsigned long long tm_last_open = 0;
     uint64_t tm_n = 0, tm_ngap = 0;
     unsigned long long tm_last_end = 0, tm_last_seq = 0;
     unsigned long long step_seq = 0;  // steps issued so far (k_step_end echoes it into the pinned block)
@@ -987,8 +988,7 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n, bool queues_open = 
     esort::Seg *qs3[3] = {Q(h).esq0.p, Q(h).esq1.p, Q(h).esq2.p};
     // a scan leaves ~120 segments for the finisher: 128 workgroups of 1024 threads take them in one round and leave the compute units
     // to the chains running beside this one (2048 measured 1.5 % slower per scan, gpurun_out/r03o); a whole map keeps the wide grid
-    static const uint32_t final_grid_env = getenv("ERASOR_HIP_FINAL_GRID") ? (uint32_t)atoi(getenv("ERASOR_HIP_FINAL_GRID")) : 0u;
-    const uint32_t final_grid = final_grid_env ? final_grid_env : (n <= (1u << 20) ? 128u : 2048u);
+    const uint32_t final_grid = n <= (1u << 20) ? 128u : 2048u;
     LAUNCH(h, "q_esort_final", k_esort_final, final_grid, 1024, Q(h).qk_a.p, Q(h).qv_a.p, Q(h).qposL.p, Q(h).qposR.p, Q(h).qhead.p, Q(h).qk_b.p, Q(h).qv_b.p,
            (const esort::Seg *)Q(h).essmall.p, (const esort::Seg *)qs3[bigcur], Q(h).esqs.p, bigcur, dc, h->dbg_stamps.p);
 }
@@ -1699,7 +1699,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         LAUNCH(h, "srt", k_srt, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
            (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
     // R-GPF and the per-bin voxelisation walk the reverted-bin LIST on a small fixed grid (n_rev is on the device)
-    static const uint32_t rev_grid = getenv("ERASOR_HIP_REV_GRID") ? (uint32_t)atoi(getenv("ERASOR_HIP_REV_GRID")) : 128u;
+    const uint32_t rev_grid = 128u;
     // v3: R-GPF and the per-bin voxelisation of a reverted bin in ONE launch (k_revert_bins); ERASOR_HIP_NO_FUSE=1: two launches (A/B)
     RevArgs ra;
     ra.moff = h->moff.p;
@@ -1901,11 +1901,13 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
             h->tm_span += (double)(t_end - t_open) * 0.01;
             if (h->tm_last_end && t_open > h->tm_last_end && h->tm_last_seq + 1 == step_seq) {
                 h->tm_gap += (double)(t_open - h->tm_last_end) * 0.01;
+                h->tm_period += (double)(t_open - h->tm_last_open) * 0.01;  // chunk scan to chunk scan: the main stream's period
                 ++h->tm_ngap;
             }
             ++h->tm_n;
         }
         h->tm_last_end = t_end;
+        h->tm_last_open = t_open;
         h->tm_last_seq = step_seq;
     }
     if (host_timing)
@@ -2785,13 +2787,14 @@ int erasor_hip_profiling(erasor_hip_handle *h, int enable) {
     h->prof = enable;
     return ERASOR_OK;
 }
-int erasor_hip_chain_timing(erasor_hip_handle *h, double *main_chain_us, double *between_steps_us, uint64_t *steps, int reset) {
+int erasor_hip_chain_timing(erasor_hip_handle *h, double *main_chain_us, double *between_steps_us, double *period_us, uint64_t *steps, int reset) {
     if (!h) return ERASOR_E_INVALID;
     if (main_chain_us) *main_chain_us = h->tm_n ? h->tm_span / (double)h->tm_n : 0.0;
     if (between_steps_us) *between_steps_us = h->tm_ngap ? h->tm_gap / (double)h->tm_ngap : 0.0;
+    if (period_us) *period_us = h->tm_ngap ? h->tm_period / (double)h->tm_ngap : 0.0;
     if (steps) *steps = h->tm_n;
     if (reset) {
-        h->tm_span = h->tm_gap = 0;
+        h->tm_span = h->tm_gap = h->tm_period = 0;
         h->tm_n = h->tm_ngap = 0;
         h->tm_last_end = 0;
     }

@@ -308,9 +308,11 @@ int erasor_hip_voi_split_bytes(erasor_hip_handle *h, uint64_t *algorithmic_bytes
 /* VoI splits launched ahead of their step (erasor_hip_prefetch_node) and how many of them the following step could use */
 int erasor_hip_ahead_split_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t *used);
 /* The main stream's dependency chain on the device's own clock (no events, no extra launches: the chunk scan and the step's end stamp
- * the 100 MHz counter): average span of a step from its chunk scan to its end, and average time the stream spent between a step's end
- * and the next step's chunk scan (host turnaround; the VoI split launched ahead runs in there).  reset != 0 clears the sums. */
-int erasor_hip_chain_timing(erasor_hip_handle *h, double *main_chain_us, double *between_steps_us, uint64_t *steps, int reset);
+ * the 100 MHz counter): average span of a step from its chunk scan to its end (when the scan is launched ahead, behind the next VoI
+ * split, that span contains the stream's wait for the host), average time between a step's end and the next step's chunk scan (the
+ * VoI split launched ahead runs in there), and the PERIOD: chunk scan to chunk scan of consecutive steps -- the steady-state time per
+ * scan of a sequence.  reset != 0 clears the sums. */
+int erasor_hip_chain_timing(erasor_hip_handle *h, double *main_chain_us, double *between_steps_us, double *period_us, uint64_t *steps, int reset);
 /* the hipStream_t the handle launches on (as void*) */
 void *erasor_hip_stream(erasor_hip_handle *h);
 

@@ -414,6 +414,7 @@ static void test_map_store(std::mt19937 &rng) {
                                  topr2.data(), ometa2.data());
             });
             CHECK(memcmp(ometa2.data(), ometa.data(), ometa.size() * sizeof(OMeta)) == 0, "both scans void the same chunk records");
+            st2.t_open = st.t_open = 0;  // (a time stamp)
             bool same = memcmp(&st2, &st, sizeof(st)) == 0;
             for (uint32_t c = 0; same && c < nchunks; ++c)
                 same = pvl2[c] + topv2[c >> 10] == pvl[c] + topv[c >> 10] && phl2[c] + toph2[c >> 10] == phl[c] + toph[c >> 10];

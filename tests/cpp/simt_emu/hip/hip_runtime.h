@@ -415,7 +415,9 @@ inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 inline unsigned long long clock64() { return 0; }
-inline unsigned long long wall_clock64() { return 0; }
+inline unsigned long long wall_clock64() {  // 100 MHz like the device's counter
+    return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
+}
 
 inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }

@@ -837,17 +837,29 @@ for version in (3, 2):
         assert np.array_equal(g.get_rejected_indices(), o.get_rejected_indices())
         assert np.array_equal(g.get_status(), o.get_status())
         assert np.array_equal(g.get_cloud(2).view(np.uint32), o.get_cloud(2).view(np.uint32))
+    t = erasor_amd.replicate_map([g], 0)  # a communicator of one; ERASOR_HIP_NO_RCCL=1: the peer-copy path
+    assert (t == 2) if os.environ.get("ERASOR_HIP_NO_RCCL") else (t in (1, 2)), t
+    assert np.array_equal(g.get_map().view(np.uint32), o.get_map().view(np.uint32)), "map after replicate_map"
 print("ALT-PATH-OK")
 """
 
 
 @pytest.mark.parametrize("env", [{"ERASOR_HIP_GRAPH": "1"}, {"ERASOR_HIP_NO_FUSE": "1", "ERASOR_HIP_NO_FOLD": "1", "ERASOR_HIP_NO_SRT_AHEAD": "1"},
-                                 {"ERASOR_HIP_NO_OMETA": "1", "ERASOR_HIP_STREAM_PRIORITIES": "1"}],
-                         ids=["query_chain_as_hipgraphs", "separate_rgpf_binvox_layout_srt_launches", "no_chunk_records_stream_priorities"])
+                                 {"ERASOR_HIP_NO_OMETA": "1", "ERASOR_HIP_STREAM_PRIORITIES": "1"},
+                                 {"ERASOR_HIP_NO_END_FOLD": "1", "ERASOR_HIP_NO_SRT_FOLD": "1", "ERASOR_HIP_NO_AHEAD_SCAN": "1"},
+                                 {"ERASOR_HIP_NO_AHEAD_SPLIT": "1", "ERASOR_HIP_NO_SPIN": "1", "ERASOR_HIP_NO_RCCL": "1", "ERASOR_HIP_HOST_TIMING": "1",
+                                  "ERASOR_HIP_SORT_STAMPS": "1", "ERASOR_HIP_DEBUG_SYNC": "1"},
+                                 {"ERASOR_HIP_QSTREAMS": "3", "ERASOR_HIP_QPAD_US": "20", "ERASOR_HIP_MPAD_US": "20"}],
+                         ids=["query_chain_as_hipgraphs", "separate_rgpf_binvox_layout_srt_launches", "no_chunk_records_stream_priorities",
+                              "step_end_and_srt_as_launches_no_ahead_scan", "nothing_ahead_blocking_wait_peer_copies_diagnostics",
+                              "three_query_streams_padded_chains"])
 def test_alternative_launch_paths_keep_parity(gpu_mod, tmp_path, env):
     """The paths behind the library's A/B switches are product code too: the query chain replayed as two hipGraphs per side
     (ERASOR_HIP_GRAPH=1: measured, no gain, opt-in) and the unfused launches (R-GPF and per-bin voxelisation apart, k_layout4,
-    the Scan Ratio Test's first pass inside k_srt4), the VoI pass without the outskirts' chunk records and rounds 1-2's stream priorities
+    the Scan Ratio Test's first pass inside k_srt4), the VoI pass without the outskirts' chunk records and rounds 1-2's stream priorities,
+    round 4's folds undone (the step's end and the Scan Ratio Test's second pass as launches, no chunk scan ahead), nothing launched
+    ahead + a blocking wait + peer copies in replicate_map + the three diagnostics, three query streams with both chains padded
+    (every getenv switch of the library is in one of these cases, in test_map_store_slack* or in test_gpu_hooks.py)
     -- five look-ahead steps of a v3 and a v2 sequence each, in a process of its
     own (the switches are read once), every step against the oracle."""
     import subprocess

@@ -12,7 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="timeout 200 python $ROOT/bench.py --steps 20 --warmup 3 $EXTRA"
+BENCH="timeout 300 python $ROOT/bench.py --steps 20 --warmup 5 --no-extra-workloads --no-pr-rr --no-callback-bench $EXTRA"
 $BENCH > $OUT/bench.json 2> $OUT/bench.stderr
 $BENCH --no-cpu-baseline --profile-all > /dev/null 2> $OUT/bench_kernel_breakdown.txt
 rm -rf /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write

@@ -31,7 +31,8 @@ def pmc(d, counter):
         name = row["Kernel_Name"].split("(")[0]
         per[name].append(float(row["Counter_Value"]))
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB
-    return {k: {"dispatches": len(v), "mean_KiB": round(sum(v) / len(v), 1), "max_KiB": round(max(v), 1)} for k, v in sorted(per.items())}
+    return {k: {"dispatches": len(v), "mean_KiB": round(sum(v) / len(v), 1), "max_KiB": round(max(v), 1), "total_KiB": round(sum(v), 1)}
+            for k, v in sorted(per.items())}
 
 
 res = {"FETCH_SIZE": pmc(fetch_dir, "FETCH_SIZE"), "WRITE_SIZE": pmc(write_dir, "WRITE_SIZE")}
@@ -54,6 +55,19 @@ if fs:
     latest["per_kernel_traffic_bytes"] = {
         k.replace("void ", "").replace("ek::", "").split("<")[0]: int(v["mean_KiB"] * 1024 * 2 + (res["WRITE_SIZE"].get(k, {}).get("mean_KiB", 0.0)) * 1024)
         for k, v in res["FETCH_SIZE"].items() if "ek::" in k}
+    # the WHOLE step's corrected traffic: every kernel's total over the pass divided by the steps of the pass (one k_voi_gather each)
+    steps = max(res["FETCH_SIZE"].get("ek::k_voi_gather", {}).get("dispatches", 0), 1)
+    tot = 0.0
+    per_step = {}
+    for k, v in res["FETCH_SIZE"].items():
+        if "ek::" not in k:
+            continue
+        b = v["total_KiB"] * 1024 * 2 + res["WRITE_SIZE"].get(k, {}).get("total_KiB", 0.0) * 1024
+        per_step[k.replace("void ", "").replace("ek::", "").split("<")[0]] = int(b / steps)
+        tot += b
+    latest["step_traffic_bytes"] = int(tot / steps)
+    latest["step_traffic_steps"] = steps
+    latest["per_kernel_traffic_bytes_per_step"] = dict(sorted(per_step.items(), key=lambda kv: -kv[1]))
     cal = res["FETCH_SIZE"].get("ek::k_store_outskirts")
     if cal:
         latest["calibration_k_store_outskirts_fetch_KiB"] = cal["max_KiB"]
