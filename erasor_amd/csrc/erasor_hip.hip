@@ -2900,6 +2900,36 @@ int erasor_hip_probe_math(erasor_hip_handle *h, const double *x, const double *y
     return ERASOR_OK;
 }
 
+// test hook: bin keys of n points (x y z i rows) by the product's bin_key and by the float64-only restatement; counters[0..3] =
+// n_ambiguous / n_neg_sector of the first, then of the second
+int erasor_hip_probe_bin_keys(erasor_hip_handle *h, const float *xyzi, size_t n, uint32_t *k_fast, uint32_t *k_exact, uint32_t *counters) {
+    NOFLY(h);
+    if (!h || !xyzi || !k_fast || !k_exact || !counters || !n) return ERASOR_E_INVALID;
+    HIPC(h, hipSetDevice(h->device));
+    float4 *d = nullptr;
+    uint32_t *dk = nullptr;
+    Counters *dc = nullptr;
+    HIPC(h, hipMalloc((void **)&d, n * sizeof(float4)));
+    HIPC(h, hipMalloc((void **)&dk, 2 * n * sizeof(uint32_t)));
+    HIPC(h, hipMalloc((void **)&dc, 2 * sizeof(Counters)));
+    HIPC(h, hipMemcpy(d, xyzi, n * sizeof(float4), hipMemcpyHostToDevice));
+    HIPC(h, hipMemset(dc, 0, 2 * sizeof(Counters)));
+    hipLaunchKernelGGL(k_probe_bin_keys, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, h->dp, (const float4 *)d, (uint32_t)n, dk, dk + n, dc, dc + 1);
+    HIPC(h, hipStreamSynchronize(h->stream));
+    HIPC(h, hipMemcpy(k_fast, dk, n * 4, hipMemcpyDeviceToHost));
+    HIPC(h, hipMemcpy(k_exact, dk + n, n * 4, hipMemcpyDeviceToHost));
+    Counters hc[2];
+    HIPC(h, hipMemcpy(hc, dc, sizeof(hc), hipMemcpyDeviceToHost));
+    counters[0] = hc[0].n_ambiguous;
+    counters[1] = hc[0].n_neg_sector;
+    counters[2] = hc[1].n_ambiguous;
+    counters[3] = hc[1].n_neg_sector;
+    (void)hipFree(d);
+    (void)hipFree(dk);
+    (void)hipFree(dc);
+    return ERASOR_OK;
+}
+
 // test hook: exact std::sort emulation of (key,payload) pairs on the device
 int erasor_hip_exact_sort_u32(erasor_hip_handle *h, uint32_t *keys, uint32_t *vals, size_t n, uint32_t *n_fallback) {
     NOFLY(h);

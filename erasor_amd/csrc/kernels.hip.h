@@ -90,7 +90,7 @@ __device__ __forceinline__ bool is_dynamic_label(float intensity) {
 // sector*R + ring, or B if the point fails a gate.  The reference's arithmetic, operation by operation, in float64.
 // (Round 3 measured a variant that decides ring and sector on float32 estimates and runs this path only near a boundary: bit-exact on
 // the whole GPU suite, but k_voi_gather is not bound by these ~250 float64 instructions per point -- 28 us either way -- so it was dropped.)
-__device__ __forceinline__ uint32_t bin_key(const DP &P, float x, float y, float z, Counters *ctr) {
+__device__ __forceinline__ uint32_t bin_key_exact(const DP &P, float x, float y, float z, Counters *ctr) {
     uint32_t key = (uint32_t)P.B;
     const double dx = (double)x, dy = (double)y;
     const double r = sqrt(dx * dx + dy * dy);
@@ -111,6 +111,60 @@ __device__ __forceinline__ uint32_t bin_key(const DP &P, float x, float y, float
         if (neg) atomicAdd(&ctr->n_neg_sector, 1u);
     }
     return key;
+}
+// Round 4: the same key WITHOUT float64 for every point that is not within a hair of a ring or sector boundary.  The reference's
+// arithmetic (float64 sqrt, atan2 and two divisions per point: ~270 instructions, the dominant cost of k_voi_gather) only matters
+// where its rounding could move a point across a boundary; a float32 radius (|error| < 3e-5 m up to 100 m) and a float32 angle
+// (8-term odd polynomial of min / max, |error| < 1e-6 rad with the quadrant folds) decide every point farther than
+// 5e-4 m / 1e-5 rad from the boundaries of the cell they land in, i.e. all but ~4 in 10^4; the rest -- and everything odd:
+// y == +-0 (the reference's negative-sector case), zeros, infinities, NaN -- takes bin_key_exact.  A point the fast path accepts
+// cannot be `ambiguous` (that needs |q - rint(q)| < 1e-11) nor in a negative sector, so the counters agree too.
+__device__ __forceinline__ float fast_rcpf(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(v);
+#else
+    return 1.0f / v;
+#endif
+}
+__device__ __forceinline__ float fast_sqrtf(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(v);
+#else
+    return sqrtf(v);
+#endif
+}
+__device__ __forceinline__ uint32_t bin_key(const DP &P, float x, float y, float z, Counters *ctr) {
+    const bool zgate = ((double)z < P.max_h) && ((double)z > P.min_h);
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float rf = fast_sqrtf(x * x + y * y);
+    const float max_rf = (float)P.max_r, ring_f = (float)P.ring_size, sector_f = (float)P.sector_size;
+    constexpr float M_R = 5e-4f, M_A = 1e-5f;  // metres, radians
+    if (zgate && rf > max_rf + M_R && rf < 3.0e38f) return (uint32_t)P.B;  // certainly beyond the range
+    bool sure = zgate && ay > 0.f && mx < 1.0e18f && rf <= max_rf - M_R;
+    const float a = mn * fast_rcpf(mx);
+    const float s2 = a * a;
+    float pl = -0.004054552409797907f;
+    pl = fmaf(pl, s2, 0.021862907335162163f);
+    pl = fmaf(pl, s2, -0.055912259966135025f);
+    pl = fmaf(pl, s2, 0.09642193466424942f);
+    pl = fmaf(pl, s2, -0.1390862762928009f);
+    pl = fmaf(pl, s2, 0.19946566224098206f);
+    pl = fmaf(pl, s2, -0.33329859375953674f);
+    pl = fmaf(pl, s2, 0.9999993443489075f);
+    float th = pl * a;                                   // atan(min / max) in [0, pi / 4]
+    if (ay > ax) th = 1.57079632679489662f - th;         // first quadrant
+    if (x < 0.f) th = 3.14159265358979324f - th;         // upper half plane
+    if (y < 0.f) th = 6.28318530717958648f - th;         // [0, 2 pi)
+    const int sf = (int)(th * (1.0f / sector_f));
+    const float slo = (float)sf * sector_f;
+    sure = sure && sf >= 0 && sf < P.S && (th - slo >= M_A) && ((slo + sector_f) - th >= M_A);
+    const int rfi = (int)(rf * (1.0f / ring_f));
+    const float rlo = (float)rfi * ring_f;
+    sure = sure && rfi < P.R && (rf - rlo >= M_R) && ((rlo + ring_f) - rf >= M_R);
+    if (sure) return (uint32_t)(sf * P.R + rfi);
+    if (!zgate) return (uint32_t)P.B;
+    return bin_key_exact(P, x, y, z, ctr);
 }
 // ---- small block-level helpers -------------------------------------------------------------------
 // exclusive scan of one value per thread; sm >= 34 uint32; returns prefix, writes block total.
@@ -664,29 +718,31 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
                                                      const uint32_t *__restrict__ toph, Xf To2b, DP P, DevState *st,
                                                      Counters *ctr, const Counters *qctr, float4 *__restrict__ voi_ego,
                                                      uint32_t *__restrict__ voi_key, uint32_t *__restrict__ voi_src, OMeta *__restrict__ ometa) {
-    if (ctr->err || qctr->err) return;  // the voxelisation of this step's scan failed: do not touch the map store
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint64_t lt = lanemask_lt();
+    // (round 4: the error flags, the step's state and the first item's records are fetched TOGETHER -- behind one another they were three
+    // dependent round trips at the head of a wavefront that lives five or six)
+    const uint32_t err_a = ctr->err, err_b = qctr->err;
     const uint32_t validF = st->validF, voiF = st->voiF, o_new_begin = st->o_new_begin;
     uint32_t dyn_leave = 0, stat_leave = 0, dyn_enter = 0, stat_enter = 0;
-    // Work items: a chunk of the VoI-resident region is nearly all VoI (every tile fetches, transforms and runs the f64
-    // sqrt / atan2 of the R-POD key), and there are only ~800 of them for a 0.8 M-point VoI -- fewer wavefronts than SIMDs,
-    // each with 16 dependent rounds.  They are cut into GATHER_SUB pieces of CHUNK_TILES / GATHER_SUB tiles (a piece finds
-    // its offsets from the popcounts of the chunk's earlier masks).  Outskirts chunks stay whole: almost all are skipped.
+    // Work items: a chunk of the VoI-resident region is nearly all VoI (every tile fetches, transforms and runs the R-POD key), and
+    // there are only ~800 of them for a 0.8 M-point VoI -- fewer wavefronts than SIMDs, each with 16 dependent rounds.  They are cut
+    // into GATHER_SUB pieces of CHUNK_TILES / GATHER_SUB tiles (a piece finds its offsets from the popcounts of the chunk's earlier
+    // masks).  Outskirts chunks stay whole: almost all are skipped.
     const uint32_t nitems = nFchunks * GATHER_SUB + nOchunks;
+    constexpr int PT = CHUNK_TILES / (int)GATHER_SUB;  // tiles of a piece
     for (uint32_t w = wid; w < nitems; w += nwaves) {
         const bool isF = w < nFchunks * GATHER_SUB;
         const uint32_t c = isF ? w / GATHER_SUB : w - nFchunks * (GATHER_SUB - 1);
-        const int t_lo = isF ? (int)(w % GATHER_SUB) * (CHUNK_TILES / (int)GATHER_SUB) : 0;
-        const int t_hi = isF ? t_lo + CHUNK_TILES / (int)GATHER_SUB : CHUNK_TILES;
-        // (round 4: everything the item needs is fetched TOGETHER -- the loads only depend on c; behind the early exit they were three
-        // dependent round trips at the head of every wavefront's life.  A skipped outskirts chunk wastes five small loads.)
+        const int t_lo = isF ? (int)(w % GATHER_SUB) * PT : 0;
+        const int t_hi = isF ? t_lo + PT : CHUNK_TILES;
         const uint32_t ci = cinfo[c];
         const uint32_t pvl_c = pvl[c], phl_c = phl[c], topv_c = topv[c >> 10], toph_c = toph[c >> 10];
         const unsigned long long mv = lane < CHUNK_TILES ? vmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
         const unsigned long long mh = lane < CHUNK_TILES ? hmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
+        if (err_a || err_b) return;  // the voxelisation of this step's scan failed: do not touch the map store
         const uint32_t cv = ci & 0xFFFFu, ch = (ci >> 16) & CINFO_HMASK;
         if (cv == 0 && !(isF && ch > cv)) continue;
         uint32_t pv = pvl_c + topv_c;
@@ -697,15 +753,26 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
             pv += a2 & 0xFFFFu;
             ph += a2 >> 16;
         }
-        for (int t = t_lo; t < t_hi; ++t) {
-            const unsigned long long vm = __shfl(mv, t, 64), hm = __shfl(mh, t, 64);
-            if (isF) {
+        if (isF) {
+            // the piece's points are fetched before the first of them is used: one round trip per piece instead of one per tile
+            float4 pp[PT];
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const unsigned long long hm = __shfl(mh, t_lo + j, 64);
+                pp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((hm >> lane) & 1ull) pp[j] = F[c * CHUNK + (t_lo + j) * TILE + lane];
+            }
+#pragma unroll 1
+            for (int j = 0; j < PT; ++j) {  // (one copy of the body: the fetched points rotate through pp[0])
+                const unsigned long long vm = __shfl(mv, t_lo + j, 64), hm = __shfl(mh, t_lo + j, 64);
                 const unsigned long long lm = hm & ~vm;
+                const float4 p = pp[0];
+#pragma unroll
+                for (int q = 0; q + 1 < PT; ++q) pp[q] = pp[q + 1];
                 if (hm != 0ull) {
-                    const uint32_t idx = c * CHUNK + t * TILE + lane;
+                    const uint32_t idx = c * CHUNK + (t_lo + j) * TILE + lane;
                     const bool in = (vm >> lane) & 1ull, lv = (lm >> lane) & 1ull;
                     if (in || lv) {
-                        const float4 p = F[idx];
                         if (in) {
                             const uint32_t rank = pv + __popcll(vm & lt);
                             const float4 e = xform(To2b, p);
@@ -722,21 +789,28 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
                         }
                     }
                 }
-            } else if (vm != 0ull) {
-                const uint32_t idx = (c - nFchunks + o_chunk0) * CHUNK + t * TILE + lane;
-                if ((vm >> lane) & 1ull) {
-                    const float2 a = Oxy[idx], b = Ozi[idx];
-                    const uint32_t rank = pv + __popcll(vm & lt);
-                    const float4 e = xform(To2b, make_float4(a.x, a.y, b.x, b.y));
-                    voi_ego[rank] = e;
-                    voi_key[rank] = bin_key(P, e.x, e.y, e.z, ctr);
-                    voi_src[rank] = nF + (ph - validF) + __popcll(hm & lt);
-                    reinterpret_cast<uint32_t *>(Oxy)[(size_t)idx * 2] = HOLE_BITS;  // tombstone
-                    if (is_dynamic_label(b.y)) ++dyn_enter; else ++stat_enter;
-                }
+                pv += __popcll(vm);
+                ph += __popcll(hm);
             }
-            pv += __popcll(vm);
-            ph += __popcll(hm);
+        } else {
+            for (int t = t_lo; t < t_hi; ++t) {
+                const unsigned long long vm = __shfl(mv, t, 64), hm = __shfl(mh, t, 64);
+                if (vm != 0ull) {
+                    const uint32_t idx = (c - nFchunks + o_chunk0) * CHUNK + t * TILE + lane;
+                    if ((vm >> lane) & 1ull) {
+                        const float2 a = Oxy[idx], b = Ozi[idx];
+                        const uint32_t rank = pv + __popcll(vm & lt);
+                        const float4 e = xform(To2b, make_float4(a.x, a.y, b.x, b.y));
+                        voi_ego[rank] = e;
+                        voi_key[rank] = bin_key(P, e.x, e.y, e.z, ctr);
+                        voi_src[rank] = nF + (ph - validF) + __popcll(hm & lt);
+                        reinterpret_cast<uint32_t *>(Oxy)[(size_t)idx * 2] = HOLE_BITS;  // tombstone
+                        if (is_dynamic_label(b.y)) ++dyn_enter; else ++stat_enter;
+                    }
+                }
+                pv += __popcll(vm);
+                ph += __popcll(hm);
+            }
         }
         // (the chunk's entering entries are tombstones now: its record counts the valid ones)
         if (!isF && ometa && lane == 0) ometa[c - nFchunks + o_chunk0].valid = ch - cv;
@@ -3660,6 +3734,14 @@ __global__ __launch_bounds__(256) void k_count_labels_zi(const float2 *__restric
 }
 
 // device libm probe: sqrt / div / atan2 in double, as the binning uses them (tests pin these vs host libm)
+// test hook: the bin key both ways (float32 decision with float64 fallback | float64 only) + how many points the fast path decided
+__global__ void k_probe_bin_keys(DP P, const float4 *pts, uint32_t n, uint32_t *k_fast, uint32_t *k_exact, Counters *ca, Counters *cb) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q = pts[i];
+    k_fast[i] = bin_key(P, q.x, q.y, q.z, ca);
+    k_exact[i] = bin_key_exact(P, q.x, q.y, q.z, cb);
+}
 __global__ void k_probe_math(const double *x, const double *y, uint32_t n, double *o_sqrt, double *o_div, double *o_atan2) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -21,10 +21,11 @@
 #ifndef ERASOR_REVERT_BINS_HIP_H
 #define ERASOR_REVERT_BINS_HIP_H
 
-static constexpr uint32_t RG_RS = RG_CH + 4;  // padded row stride of the covariance product rows (floats)
+static constexpr uint32_t RG2_CH = 896;        // list elements per set of covariance product rows (two sets: one is added while the other is formed)
+static constexpr uint32_t RG_RS = RG2_CH + 4;  // padded row stride of the covariance product rows (floats)
 static constexpr uint32_t PB_CAP = 4096;      // points of a bin / of a bin's cloud that take the LDS-resident path
 static constexpr uint32_t BV2_LMAX = PB_CAP;
-static_assert(RG_LMAX == PB_CAP && 9 * RG_RS * sizeof(float) <= PB_CAP * sizeof(float4), "the stages share the pool");
+static_assert(RG_LMAX == PB_CAP && 2 * 9 * RG_RS * sizeof(float) <= PB_CAP * sizeof(float4), "the stages share the pool");
 
 __device__ __forceinline__ float key_to_float(uint32_t k) {  // inverse of esort::float_key (-0 comes back as +0)
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
@@ -203,44 +204,100 @@ __device__ __attribute__((noinline)) void rg_fit_call() {
         // The nine products of every list element are formed by ALL threads (parallel, order-free) into LDS rows padded to RG_RS floats
         // (nine lanes, nine banks, 128-bit reads); then lane a of wave 0 adds row a strictly in list order -- the only part that has to be
         // sequential (float32 addition order is what PCL's result depends on).  x*x etc. are single IEEE multiplies either way.
+        // Wave 0 adds chunk c while the other waves form the products of chunk c + 1 in the second set of rows.
         float acc = 0.f;
-        for (uint32_t cb = 0; cb < ng; cb += RG_CH) {
-            const uint32_t cn = min(RG_CH, ng - cb);
-            for (uint32_t t = tid; t < cn; t += bs) {
+        auto form = [&](uint32_t cb, float *dst, uint32_t t0, uint32_t step) {
+            const uint32_t cn = min(RG2_CH, ng - cb);
+            for (uint32_t t = t0; t < cn; t += step) {
                 const uint32_t gi = glist[cb + t];
                 const float x = X[gi], y = Y[gi], z = Z[gi];
-                sProd[0 * RG_RS + t] = x * x;
-                sProd[1 * RG_RS + t] = x * y;
-                sProd[2 * RG_RS + t] = x * z;
-                sProd[3 * RG_RS + t] = y * y;
-                sProd[4 * RG_RS + t] = y * z;
-                sProd[5 * RG_RS + t] = z * z;
-                sProd[6 * RG_RS + t] = x;
-                sProd[7 * RG_RS + t] = y;
-                sProd[8 * RG_RS + t] = z;
+                dst[0 * RG_RS + t] = x * x;
+                dst[1 * RG_RS + t] = x * y;
+                dst[2 * RG_RS + t] = x * z;
+                dst[3 * RG_RS + t] = y * y;
+                dst[4 * RG_RS + t] = y * z;
+                dst[5 * RG_RS + t] = z * z;
+                dst[6 * RG_RS + t] = x;
+                dst[7 * RG_RS + t] = y;
+                dst[8 * RG_RS + t] = z;
             }
-            __syncthreads();
+        };
+        if (ng) form(0, sProd, tid, bs);
+        __syncthreads();
+        uint32_t par = 0;
+        for (uint32_t cb = 0; cb < ng; cb += RG2_CH, par ^= 1u) {
+            const uint32_t cn = min(RG2_CH, ng - cb);
+            const float *cur = sProd + par * (9 * RG_RS);
+            if (wave != 0 || nw == 1) {
+                if (cb + RG2_CH < ng) form(cb + RG2_CH, sProd + (par ^ 1u) * (9 * RG_RS), nw == 1 ? tid : tid - 64u, nw == 1 ? bs : bs - 64u);
+            }
             if (wave == 0 && lane < 9) {
-                const float4 *row4 = reinterpret_cast<const float4 *>(sProd + lane * RG_RS);
+                // the loads run one group of four 128-bit reads ahead of the adds (the chain of adds is the only latency left);
+                // reads past cn stay inside the pool and are not used
+                const float4 *row4 = reinterpret_cast<const float4 *>(cur + lane * RG_RS);
                 const uint32_t c4 = cn >> 2;
-#pragma unroll 4
-                for (uint32_t k = 0; k < c4; ++k) {
-                    const float4 v = row4[k];
-                    acc += v.x;
-                    acc += v.y;
-                    acc += v.z;
-                    acc += v.w;
+#define RG_ADD4(v) do { acc += (v).x; acc += (v).y; acc += (v).z; acc += (v).w; } while (0)
+#define RG_ADD16(p) do { RG_ADD4(p##0); RG_ADD4(p##1); RG_ADD4(p##2); RG_ADD4(p##3); } while (0)
+                uint32_t k = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+                // Three sets of four 128-bit reads in rotation, each issued 32 adds (~160 cycles) before its use.  The reads and their
+                // waits are written out: left to itself the compiler waits for ALL outstanding reads before the first add of a set
+                // (lgkmcnt(0) in the loop whatever the order), i.e. one LDS latency per 16 adds.  A wait names the set it releases as
+                // in/out operands, so no use can move above it; LDS reads return in order, two younger sets may stay outstanding.
+#define RG_READ4(p, byte_off)                                                                                   \
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%5+16\n\t"                      \
+                 "ds_read_b128 %2, %4 offset:%5+32\n\tds_read_b128 %3, %4 offset:%5+48"                         \
+                 : "=&v"(p##0), "=&v"(p##1), "=&v"(p##2), "=&v"(p##3) : "v"(addr), "n"(byte_off))
+#define RG_WAIT4(p, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(p##0), "+v"(p##1), "+v"(p##2), "+v"(p##3))
+#define RG_SB() __builtin_amdgcn_sched_barrier(0)  // (keeps the adds between the reads they are meant to cover)
+                if (c4 >= 12) {
+                    uint32_t addr = (uint32_t)(uintptr_t)(row4);  // (LDS byte address of the row)
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    f32x4 a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+                    RG_READ4(a, 0);
+                    RG_READ4(b, 64);
+                    for (; k + 12 <= c4; k += 12, addr += 192) {
+                        RG_READ4(c, 128);
+                        RG_WAIT4(a, 8);
+                        RG_SB();
+                        RG_ADD16(a);
+                        RG_SB();
+                        RG_READ4(a, 192);
+                        RG_WAIT4(b, 8);
+                        RG_SB();
+                        RG_ADD16(b);
+                        RG_SB();
+                        RG_READ4(b, 256);
+                        RG_WAIT4(c, 8);
+                        RG_SB();
+                        RG_ADD16(c);
+                        RG_SB();
+                    }
+                    RG_WAIT4(a, 0);  // (the reads past the last full group: drained, unused)
+                    RG_WAIT4(b, 0);
                 }
-                const float *row = sProd + lane * RG_RS;
-                for (uint32_t k = c4 << 2; k < cn; ++k) acc += row[k];
+#undef RG_SB
+#undef RG_WAIT4
+#undef RG_READ4
+#endif
+                for (; k < c4; ++k) {
+                    const float4 v = row4[k];
+                    RG_ADD4(v);
+                }
+#undef RG_ADD16
+#undef RG_ADD4
+                const float *row = cur + lane * RG_RS;
+                for (uint32_t r = c4 << 2; r < cn; ++r) acc += row[r];
             }
             __syncthreads();
         }
         if (it == 0) RG_STAMP(3);
         if (wave == 0) {
+            // (lane k divides its own sum by the count: one division instead of nine in the lane that goes on alone)
+            const float accn = ng ? acc / (float)ng : acc;
             float a[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) a[k] = __shfl(acc, k, 64);
+            for (int k = 0; k < 9; ++k) a[k] = __shfl(accn, k, 64);
             if (lane == 0) {
                 float cov[9], mean[3], U[9], sv[3];
                 if (ng == 0) {
@@ -248,8 +305,6 @@ __device__ __attribute__((noinline)) void rg_fit_call() {
                     mean[0] = mean[1] = mean[2] = 0.f;
                     atomicAdd(&ctr->n_degenerate, 1u);
                 } else {
-                    const float fn = (float)ng;
-                    for (int k = 0; k < 9; ++k) a[k] /= fn;
                     mean[0] = a[6];
                     mean[1] = a[7];
                     mean[2] = a[8];

@@ -162,6 +162,7 @@ static void test_per_bin(std::mt19937 &rng) {
             if (r < 0.7f) z = -1.70f + 0.02f * (x - x0) + 0.01f * (float)(int)(6.f * u01(rng));  // ground, 1 cm steps
             else if (r < 0.97f) z = -1.5f + 3.5f * u01(rng);                                      // a wall / a car
             else z = -1.9f - u01(rng);                                                            // below min_h
+            if (b % 2 == 1) z = roundf(z * 64.f) / 64.f;  // every other bin: equal z everywhere (the order of equal keys is the introsort's)
             map_bin[b].push_back(make_float4(x, y, z, (rng() % 5 == 0) ? 252.f : 40.f));
         }
         for (uint32_t i = 0; i < sizes[b] / 3 + 2; ++i)
@@ -464,9 +465,58 @@ static void test_map_store(std::mt19937 &rng) {
     }
 }
 
+// Round 4: bin_key decides most points in float32 and hands the rest to the float64 restatement of the reference (bin_key_exact).
+// Sound iff every point the fast path accepts gets the exact key: random points, points ON and next to every ring / sector boundary
+// (constructed in float64, offsets from 1e-9 to 1e-3 of a cell), the axes, signed zeros, tiny and huge coordinates.
+static void test_bin_key(std::mt19937 &rng) {
+    Counters ca, cb;
+    for (int cfg = 0; cfg < 3; ++cfg) {
+        erasor_params p = seq05_params();
+        if (cfg == 1) { p.num_rings = 15; p.num_sectors = 60; p.max_range = 60.0; }
+        if (cfg == 2) { p.num_rings = 7; p.num_sectors = 31; p.max_range = 9.7; p.max_h = 1.0; p.min_h = -0.25; }
+        const DP P = make_dp(p);
+        memset(&ca, 0, sizeof(ca));
+        memset(&cb, 0, sizeof(cb));
+        size_t n = 0, bad = 0;
+        auto one = [&](float x, float y, float z) {
+            const uint32_t a = bin_key(P, x, y, z, &ca), b = bin_key_exact(P, x, y, z, &cb);
+            ++n;
+            if (a != b && ++bad < 5) printf("  bin_key(%a, %a, %a) = %u, exact %u\n", x, y, z, a, b);
+        };
+        std::uniform_real_distribution<double> U(-1.0, 1.0), U01(0.0, 1.0);
+        const double R = p.max_range;
+        for (int i = 0; i < 3000000; ++i) one((float)(U(rng) * R * 1.05), (float)(U(rng) * R * 1.05), (float)(U(rng) * 4.0));
+        const double offs[] = {0.0, 1e-9, 1e-8, 1e-7, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 3e-4, 1e-3};
+        for (int sidx = 0; sidx <= p.num_sectors; ++sidx)      // sector boundaries at many radii
+            for (double o : offs)
+                for (int sg = -1; sg <= 1; sg += 2)
+                    for (int k = 0; k < 60; ++k) {
+                        const double th = sidx * P.sector_size + sg * o * P.sector_size, r = U01(rng) * R * 1.01;
+                        one((float)(r * cos(th)), (float)(r * sin(th)), 0.5f);
+                    }
+        for (int ridx = 0; ridx <= p.num_rings; ++ridx)        // ring boundaries at many angles
+            for (double o : offs)
+                for (int sg = -1; sg <= 1; sg += 2)
+                    for (int k = 0; k < 300; ++k) {
+                        const double th = U01(rng) * 2 * PI_REF, r = ridx * P.ring_size + sg * o * P.ring_size;
+                        one((float)(r * cos(th)), (float)(r * sin(th)), 0.5f);
+                    }
+        const float sp[] = {0.f, -0.f, 1e-45f, -1e-45f, 1e-30f, -1e-30f, 1e-3f, -1e-3f, 1.f, -1.f, 39.99999f, 40.f, 40.00001f, -40.f,
+                            79.99999f, 80.f, 80.00001f, -80.f, 1e10f, -1e10f, 1e20f, -1e20f, 3e38f, -3e38f};
+        for (float x : sp)
+            for (float y : sp)
+                for (float z : {-1.3f, -1.29999f, 0.f, 3.19999f, 3.2f, 100.f}) one(x, y, z);
+        CHECK(bad == 0, "bin_key: %zu of %zu points differ from the exact key (config %d)", bad, n, cfg);
+        CHECK(ca.n_ambiguous == cb.n_ambiguous && ca.n_neg_sector == cb.n_neg_sector, "bin_key: counters %u %u vs %u %u", ca.n_ambiguous,
+              ca.n_neg_sector, cb.n_ambiguous, cb.n_neg_sector);
+    }
+    printf("bin_key (float32 decision, float64 fallback) == the float64 key  %s\n", g_fail ? "FAILED" : "ok");
+}
+
 int main() {
     setvbuf(stdout, nullptr, _IONBF, 0);
     std::mt19937 rng(20210310);
+    test_bin_key(rng);
     test_runs(rng);
     test_map_store(rng);
     test_map_bucketing(rng);

@@ -390,6 +390,8 @@ template <class T>
 inline T __shfl_xor(T v, int m, int = 64) { return simt_shfl_from(v, (int)(simt_lane() ^ (unsigned)m)); }
 inline uint32_t __builtin_amdgcn_readlane(uint32_t v, uint32_t lane) { return simt_shfl_from(v, (int)(lane & 63u)); }
 inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t v) { return simt_shfl_from(v, 0); }
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_waitcnt(int) {}
 
 // DPP controls used by esort::wave_incl_scan: row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143); a lane without a
 // source (or switched off by row_mask / bank_mask) keeps `old`

@@ -42,6 +42,15 @@ def probe_math(g, x, y):
     return o
 
 
+def probe_bin_keys(g, pts):
+    pts = np.ascontiguousarray(pts, np.float32)
+    kf = np.zeros(len(pts), np.uint32)
+    ke = np.zeros(len(pts), np.uint32)
+    ctr = np.zeros(4, np.uint32)
+    g._check(erasor_amd.lib().erasor_hip_probe_bin_keys(g._h, _p(pts), C.c_size_t(len(pts)), _p(kf), _p(ke), _p(ctr)))
+    return kf, ke, ctr
+
+
 def exact_sort_u32(g, keys, vals):
     keys = np.ascontiguousarray(keys, np.uint32).copy()
     vals = np.ascontiguousarray(vals, np.uint32).copy()

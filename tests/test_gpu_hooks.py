@@ -38,6 +38,46 @@ def test_device_libm_as_used_by_the_binning(gpu_mod):
     assert ulp.max() <= 4.0   # OCML vs glibc differ by <= 2 ulp: the reason for the n_ambiguous guard band (1e-11 >> 1e-15)
 
 
+def test_bin_key_float32_decision_never_disagrees_with_the_float64_key(gpu_mod):
+    """Round 4: bin_key decides a point's ring / sector in float32 (hardware rcp / sqrt, an 8-term atan polynomial) unless it lies within
+    5e-4 m / 1e-5 rad of a boundary of the cell it lands in, where the reference's float64 arithmetic (bin_key_exact: erasor.cpp:124-139
+    restated) takes over.  Sound iff no accepted point ever differs: random points, points on and next to every boundary (offsets
+    1e-9 ... 1e-3 of a cell, built in float64), axes, signed zeros, tiny / huge coordinates; and against the oracle's own keys."""
+    from oracle import orc
+    for rings, sectors, rng_m in ((20, 108, 80.0), (15, 60, 60.0), (7, 31, 9.7)):
+        p = gpu_mod.params_default()
+        p.num_rings, p.num_sectors, p.max_range = rings, sectors, rng_m
+        g = gpu_mod.Erasor(p)
+        rng = np.random.default_rng(rings)
+        ring, sector = rng_m / rings, 2 * 3.1415926535 / sectors
+        pts = [np.column_stack([rng.uniform(-1.05 * rng_m, 1.05 * rng_m, (2000000, 2)), rng.uniform(-4, 4, 2000000), np.zeros(2000000)])]
+        offs = np.array([0.0, 1e-9, 1e-8, 1e-7, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 3e-4, 1e-3])
+        offs = np.concatenate([offs, -offs])
+        th = (np.arange(sectors + 1)[:, None, None] + offs[None, :, None]) * sector + np.zeros((1, 1, 200))
+        r = rng.uniform(0, 1.01 * rng_m, th.shape)
+        pts.append(np.column_stack([(r * np.cos(th)).ravel(), (r * np.sin(th)).ravel(), np.full(th.size, 0.5), np.zeros(th.size)]))
+        r = (np.arange(rings + 1)[:, None, None] + offs[None, :, None]) * ring + np.zeros((1, 1, 2000))
+        th = rng.uniform(0, 2 * np.pi, r.shape)
+        pts.append(np.column_stack([(r * np.cos(th)).ravel(), (r * np.sin(th)).ravel(), np.full(th.size, 0.5), np.zeros(th.size)]))
+        sp = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-30, -1e-30, 1e-3, -1e-3, 1, -1, 39.99999, 40, 40.00001, -40, 79.99999, 80, 80.00001, -80,
+                       1e10, -1e10, 1e20, -1e20, 3e38, -3e38], np.float32)
+        zs = np.array([-1.3, -1.29999, 0, 3.19999, 3.2, 100], np.float32)
+        gx, gy, gz = np.meshgrid(sp, sp, zs, indexing="ij")
+        pts.append(np.column_stack([gx.ravel(), gy.ravel(), gz.ravel(), np.zeros(gx.size, np.float32)]))
+        pts = np.ascontiguousarray(np.concatenate(pts), np.float32)
+        kf, ke, ctr = hooks.probe_bin_keys(g, pts)
+        bad = np.flatnonzero(kf != ke)
+        assert len(bad) == 0, (rings, sectors, len(bad), pts[bad[:5]], kf[bad[:5]], ke[bad[:5]])
+        assert ctr[0] == ctr[2] and ctr[1] == ctr[3], ctr
+        po = orc.Params()   # (same layout, distinct ctypes class)
+        C.memmove(C.byref(po), C.byref(p), C.sizeof(po))
+        n_spec = gx.size
+        for i in rng.choice(len(pts) - n_spec, 3000, replace=False):   # the oracle itself, one call per point
+            ko = orc.bin_of(po, *pts[i, :3])
+            ko = rings * sectors if ko < 0 else (ko % sectors) * rings + ko // sectors   # (the oracle numbers ring-major, the device sector-major)
+            assert ko == int(kf[i]), (i, pts[i], ko, kf[i])
+
+
 @pytest.mark.parametrize("n,key_range", [(0, 5), (1, 5), (16, 3), (17, 3), (100, 7), (5000, 50), (5000, 1 << 30), (70000, 300),
                                          (200000, 40000), (300000, 5)])
 def test_exact_std_sort_emulation(gpu_mod, n, key_range):
