@@ -74,7 +74,9 @@ def parse_args():
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="stop the CPU leg after this much CPU work")
     ap.add_argument("--profile-all", action="store_true", help="second pass with per-kernel HIP events (breakdown on stderr)")
-    ap.add_argument("--lookahead", type=int, default=2, choices=[1, 2, 3], help="scans announced ahead (erasor_hip_prefetch_scan)")
+    ap.add_argument("--lookahead", type=int, default=3, choices=[1, 2, 3],
+                    help="nodes announced ahead (erasor_hip_run_nodes / erasor_hip_prefetch_node); round 4: three -- with the main chain at 0.2 ms the\n"
+                         "query chains of two nodes no longer always finish in its shadow (0.204 vs 0.210 ms per scan, gpurun_out/r04al)")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not announce the next scan (erasor_hip_prefetch_scan): every step runs its own query chain first")
     ap.add_argument("--seqs", type=int, default=len(SEQS), help="seq-per-gpu: use only the first N of the five sequences (e.g. 2: what one GPU of config 3's four gets)")
