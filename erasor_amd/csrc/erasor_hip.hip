@@ -734,6 +734,14 @@ int reassign_submap(erasor_hip_handle *h, double pose_x, double pose_y) {
     return 0;
 }
 
+// large-scale mode: would the node at (x, y) move the submap (reassign_submap above)?  Then nothing of its step can be launched ahead.
+bool submap_would_move(const erasor_hip_handle *h, double pose_x, double pose_y) {
+    if (!h->P.is_large_scale) return false;
+    if (h->submap_not_initialized) return true;
+    const double half_size = h->P.submap_size / 2.0;
+    return fabs(h->submap_cx - pose_x) > half_size || fabs(h->submap_cy - pose_y) > half_size;
+}
+
 int push_state(erasor_hip_handle *h) {
     h->st.nF = h->nF;
     h->st.o_begin = h->o_begin;
@@ -1430,6 +1438,26 @@ static void launch_split_ahead(erasor_hip_handle *h, double nx, double ny, uint3
         h->spec.scan_cap = scan_cap;
         h->spec.pvl = h->pvl.p;
         h->spec.phl = h->phl.p;
+    } else if (!no_early_scan && h->prof != 1) {
+        // maps beyond k_chunk_scan_one's 16384 chunks (config 4: 38 k): the two-level scan ahead, its grid an upper bound
+        const size_t room = std::min(h->pvl.cap, h->phl.cap);
+        const uint32_t grid = (uint32_t)cdiv(nchunks_hint + 64u, 1024);
+        const size_t top_cap = std::min(std::min(h->topv.cap, h->toph.cap), h->topr.cap);
+        if (room >= 8 && (size_t)grid * 1024 + 8 <= room && grid + 1 <= top_cap) {
+            const uint32_t cap2 = grid * 1024u;
+            hipStream_t keep = h->cur;
+            h->cur = h->stream;
+            LAUNCH(h, "chunk_scan", k_chunk_scan_local, grid, 256, (const uint32_t *)h->cinfo.p, 0u, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, h->topr.p,
+                   (const DevState *)h->d_st.p, h->capO / CHUNK, cap2);
+            LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, grid, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p, 0u, 0u,
+                   h->d_st.p, h->d_ctr.p, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? h->B + 1 : 0u,
+                   (const uint32_t *)h->topr.p, h->use_ometa ? h->ometa.p : (OMeta *)nullptr, h->capO / CHUNK, cap2);
+            h->cur = keep;
+            h->spec.scan = true;
+            h->spec.scan_cap = cap2;
+            h->spec.pvl = h->pvl.p;
+            h->spec.phl = h->phl.p;
+        }
     }
 }
 
@@ -1618,10 +1646,10 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                        h->use_ometa ? h->ometa.p : (OMeta *)nullptr, 0u, 0u);
             } else {
                 LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p,
-                       h->topr.p);
+                       h->topr.p, (const DevState *)nullptr, 0u, 0u);
                 LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
                        nchunks, nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u,
-                       (const uint32_t *)h->topr.p, h->use_ometa ? h->ometa.p : (OMeta *)nullptr);
+                       (const uint32_t *)h->topr.p, h->use_ometa ? h->ometa.p : (OMeta *)nullptr, 0u, 0u);
             }
         }
         (void)hipStreamWaitEvent(h->stream, Q(h).ev_keys, 0);  // k_voi_gather must see the query side's error flag
@@ -1813,7 +1841,8 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             nx = h->ann.pose_x;
             ny = h->ann.pose_y;
         }
-        const bool spec = have_pose && !no_spec && !flags && !h->P.is_large_scale;
+        // (large-scale mode, round 4: ahead as well, unless the next node's pose moves the submap)
+        const bool spec = have_pose && !no_spec && !flags && !submap_would_move(h, nx, ny);
         StepEnd se;
         se.st = ds;
         se.ctr = dc;
@@ -2090,7 +2119,7 @@ static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n
         const double nx = h->ann.pose_x, ny = h->ann.pose_y;
         rc = flush_announced(h);
         if (rc) return rc;
-        if (next_in_line && pose && !no_spec && !h->fly.flags && !h->P.is_large_scale && !h->fly.spec_launched) {
+        if (next_in_line && pose && !no_spec && !h->fly.flags && !h->fly.spec_launched && !submap_would_move(h, nx, ny)) {
             hipStream_t keep = h->cur;
             h->cur = h->stream;
             launch_split_ahead(h, nx, ny, h->fly.nchunks, nullptr);

@@ -465,8 +465,15 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
 // level 1 of the chunk-count scan: 1024 chunks per workgroup, local prefixes + workgroup totals
 __global__ __launch_bounds__(256) void k_chunk_scan_local(const uint32_t *__restrict__ cinfo, uint32_t nchunks,
                                                            uint32_t *__restrict__ pvl, uint32_t *__restrict__ phl,
-                                                           uint32_t *__restrict__ topv, uint32_t *__restrict__ toph, uint32_t *__restrict__ topr) {
+                                                           uint32_t *__restrict__ topv, uint32_t *__restrict__ toph, uint32_t *__restrict__ topr,
+                                                           // round 4: != 0: launched AHEAD (see k_chunk_scan_one): the extents come from the
+                                                           // committed device state, the grid is an upper bound (workgroups beyond write zeros)
+                                                           const DevState *st_dev, uint32_t capO_chunks_dev, uint32_t cap_dev) {
     __shared__ uint32_t sm[40];
+    if (capO_chunks_dev) {
+        const uint32_t nF = st_dev->nF, ob = st_dev->o_begin;
+        nchunks = min((nF + CHUNK - 1) / CHUNK + (capO_chunks_dev - ob / CHUNK), cap_dev);
+    }
     const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
     uint32_t v[4], h[4];
     uint32_t sv = 0, sh = 0, sr = 0;
@@ -506,9 +513,18 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ 
                                                           const uint32_t *__restrict__ pvl, const uint32_t *__restrict__ phl,
                                                           uint32_t nchunks, uint32_t nFchunks, DevState *st, Counters *ctr, DevState init,
                                                           unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n,
-                                                          const uint32_t *__restrict__ topr, OMeta *__restrict__ ometa) {
+                                                          const uint32_t *__restrict__ topr, OMeta *__restrict__ ometa,
+                                                          uint32_t capO_chunks_dev, uint32_t cap_dev /* ahead: see k_chunk_scan_one */) {
     __shared__ uint32_t sm[40];
     __shared__ uint32_t carry[2];
+    if (capO_chunks_dev) {
+        const uint32_t nF = st->nF, ob = st->o_begin;
+        nFchunks = (nF + CHUNK - 1) / CHUNK;
+        nchunks = min(nFchunks + (capO_chunks_dev - ob / CHUNK), cap_dev);  // (beyond: the step sees that and runs the scan itself)
+        ntop = max(1u, (nchunks + 1023u) / 1024u);
+        init = *st;
+        __syncthreads();  // (everybody has read the state before thread 0 replaces it)
+    }
     uint32_t n_read = 0;
     if (topr)
         for (uint32_t i = threadIdx.x; i < ntop; i += blockDim.x) n_read += topr[i];
@@ -1146,9 +1162,17 @@ __global__ __launch_bounds__(1024) void k_mb_hist(const uint32_t *__restrict__ k
         uint32_t k[MB_TILE / 1024];
 #pragma unroll
         for (uint32_t r = 0; r < MB_TILE / 1024; ++r) k[r] = i0 + r * 1024 < n ? keys[i0 + r * 1024] : 0xFFFFFFFFu;
+        // one LDS add per DISTINCT key of a wavefront (round 4): the VoI arrives in the previous step's bin order, neighbours share their
+        // bin, and 64 adds to one counter are served one after the other (config 4: 17.7 us for 14 MB of keys)
+        const int bits = 32 - __builtin_clz(nb | 1u);
+        const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-        for (uint32_t r = 0; r < MB_TILE / 1024; ++r)
-            if (k[r] != 0xFFFFFFFFu) atomicAdd(&cnt[min(k[r], nb - 1)], 1u);
+        for (uint32_t r = 0; r < MB_TILE / 1024; ++r) {
+            const bool valid = k[r] != 0xFFFFFFFFu;
+            const uint32_t key = min(k[r], nb - 1);
+            const uint64_t peers = match_any(key, valid, bits);
+            if (valid && lane == (uint32_t)__builtin_ctzll(peers)) atomicAdd(&cnt[key], (uint32_t)__popcll(peers));
+        }
         __syncthreads();
         for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
             const uint32_t c = cnt[b];

@@ -400,7 +400,7 @@ static void test_map_store(std::mt19937 &rng) {
                              lab.data(), mb_tot.data(), 64u, ometa.data(), ahead ? capO / CHUNK : 0u, ahead ? nchunks + 8u : 0u);
         });
         CHECK(st.n_o_read == n_read, "n_o_read %u vs %u", st.n_o_read, n_read);
-        {   // the two-level scan (maps beyond 16384 chunks) opens the step with the same state and the same prefixes
+        {   // the two-level scan (maps beyond k_chunk_scan_one's 131072 chunks) opens the step with the same state and the same prefixes
             std::vector<uint32_t> pvl2(nchunks + 8, 0), phl2(nchunks + 8, 0), topv2(8, 0), toph2(8, 0), mb2(64, 5);
             std::vector<unsigned long long> lab2(128, 1);
             DevState st2 = init;
@@ -409,10 +409,10 @@ static void test_map_store(std::mt19937 &rng) {
             const uint32_t ntop = (nchunks + 1023) / 1024;
             std::vector<uint32_t> topr2(8, 77);
             std::vector<OMeta> ometa2(ometa);
-            simt::run_grid(ntop, 256, [&] { k_chunk_scan_local(cinfo.data(), nchunks, pvl2.data(), phl2.data(), topv2.data(), toph2.data(), topr2.data()); });
+            simt::run_grid(ntop, 256, [&] { k_chunk_scan_local(cinfo.data(), nchunks, pvl2.data(), phl2.data(), topv2.data(), toph2.data(), topr2.data(), nullptr, 0u, 0u); });
             simt::run_grid(1, 1024, [&] {
                 k_chunk_scan_top(topv2.data(), toph2.data(), ntop, pvl2.data(), phl2.data(), nchunks, nFchunks, &st2, &ctr2, init, lab2.data(), mb2.data(), 64u,
-                                 topr2.data(), ometa2.data());
+                                 topr2.data(), ometa2.data(), 0u, 0u);
             });
             CHECK(memcmp(ometa2.data(), ometa.data(), ometa.size() * sizeof(OMeta)) == 0, "both scans void the same chunk records");
             st2.t_open = st.t_open = 0;  // (a time stamp)
@@ -463,6 +463,79 @@ static void test_map_store(std::mt19937 &rng) {
                n_read, nOchunks, ok ? "ok" : "MISMATCH");
         CHECK(ok, "map store variant=%d", variant);
     }
+}
+
+// Round 4: the two-level chunk scan launched AHEAD (extents and starting state from the committed device state, grid an upper bound)
+// against the same scan with the host's arguments -- config 4's 38 k chunks -- and against k_chunk_scan_one where that applies
+static void test_chunk_scan_ahead(std::mt19937 &rng) {
+    for (uint32_t nchunks : {1u, 1000u, 16384u, 16385u, 40000u, 49152u, 70001u}) {
+        for (uint32_t nFchunks : {0u, 1u, 16383u, 16384u, 20000u, 32768u, 39999u, 70001u}) {
+            if (nFchunks > nchunks) continue;
+            std::vector<uint32_t> cinfo(nchunks + 2048, 0);
+            uint32_t n_read = 0;
+            for (uint32_t c = 0; c < nchunks; ++c) {
+                const uint32_t h = rng() % 1025u, v = h ? rng() % (h + 1u) : 0u, r = (c >= nFchunks && rng() % 3u == 0) ? 1u : 0u;
+                cinfo[c] = v | (h << 16) | (r << 31);
+                n_read += r;
+            }
+            const uint32_t ntop = std::max(1u, (nchunks + 1023) / 1024), grid = (nchunks + 64 + 1023) / 1024, ob_chunks = 100000u;
+            DevState init;
+            memset(&init, 0, sizeof(init));
+            init.o_begin = ob_chunks * CHUNK + 17u;
+            init.nF = nFchunks ? (nFchunks - 1) * CHUNK + 5u : 0u;
+            const uint32_t capO_chunks = ob_chunks + (nchunks - nFchunks);
+            struct Run {
+                std::vector<uint32_t> pvl, phl, topv, toph, topr, mb;
+                std::vector<unsigned long long> lab;
+                DevState st;
+                Counters ctr;
+            } a, b, c1;
+            for (Run *r : {&a, &b, &c1}) {
+                r->pvl.assign(nchunks + 2048, 0);
+                r->phl.assign(nchunks + 2048, 0);
+                r->topv.assign(grid + 8, 9);
+                r->toph.assign(grid + 8, 9);
+                r->topr.assign(grid + 8, 7);
+                r->mb.assign(64, 5);
+                r->lab.assign(128, 1);
+                r->st = init;
+                memset(&r->ctr, 0, sizeof(r->ctr));
+            }
+            simt::run_grid(ntop, 256, [&] {
+                k_chunk_scan_local(cinfo.data(), nchunks, a.pvl.data(), a.phl.data(), a.topv.data(), a.toph.data(), a.topr.data(), nullptr, 0u, 0u);
+            });
+            simt::run_grid(1, 1024, [&] {
+                k_chunk_scan_top(a.topv.data(), a.toph.data(), ntop, a.pvl.data(), a.phl.data(), nchunks, nFchunks, &a.st, &a.ctr, init, a.lab.data(),
+                                 a.mb.data(), 64u, a.topr.data(), nullptr, 0u, 0u);
+            });
+            DevState junk;
+            memset(&junk, 0x5a, sizeof(junk));
+            simt::run_grid(grid, 256, [&] {
+                k_chunk_scan_local(cinfo.data(), 0u, b.pvl.data(), b.phl.data(), b.topv.data(), b.toph.data(), b.topr.data(), &b.st, capO_chunks, grid * 1024u);
+            });
+            simt::run_grid(1, 1024, [&] {
+                k_chunk_scan_top(b.topv.data(), b.toph.data(), grid, b.pvl.data(), b.phl.data(), 0u, 0u, &b.st, &b.ctr, junk, b.lab.data(), b.mb.data(), 64u,
+                                 b.topr.data(), nullptr, capO_chunks, grid * 1024u);
+            });
+            a.st.t_open = b.st.t_open = 0;
+            bool same = memcmp(&a.st, &b.st, sizeof(a.st)) == 0 && a.st.n_o_read == n_read;
+            for (uint32_t c = 0; same && c < nchunks; ++c)
+                same = a.pvl[c] + a.topv[c >> 10] == b.pvl[c] + b.topv[c >> 10] && a.phl[c] + a.toph[c >> 10] == b.phl[c] + b.toph[c >> 10];
+            CHECK(same, "two-level chunk scan ahead: %u chunks, %u of them VoI-resident", nchunks, nFchunks);
+            if (nchunks <= 16384) {
+                simt::run_grid(1, 1024, [&] {
+                    k_chunk_scan_one(cinfo.data(), nchunks, c1.pvl.data(), c1.phl.data(), c1.topv.data(), c1.toph.data(), ntop, nFchunks, &c1.st, &c1.ctr, init,
+                                     c1.lab.data(), c1.mb.data(), 64u, nullptr, 0u, 0u);
+                });
+                c1.st.t_open = 0;
+                bool s1 = memcmp(&a.st, &c1.st, sizeof(a.st)) == 0;
+                for (uint32_t c = 0; s1 && c < nchunks; ++c)
+                    s1 = a.pvl[c] + a.topv[c >> 10] == c1.pvl[c] + c1.topv[c >> 10] && a.phl[c] + a.toph[c >> 10] == c1.phl[c] + c1.toph[c >> 10];
+                CHECK(s1, "one-launch chunk scan == two-level: %u chunks, %u of them VoI-resident", nchunks, nFchunks);
+            }
+        }
+    }
+    printf("two-level chunk scan launched ahead == with the host's arguments (1 .. 70001 chunks)  %s\n", g_fail ? "FAILED" : "ok");
 }
 
 // Round 4: bin_key decides most points in float32 and hands the rest to the float64 restatement of the reference (bin_key_exact).
@@ -517,6 +590,7 @@ int main() {
     setvbuf(stdout, nullptr, _IONBF, 0);
     std::mt19937 rng(20210310);
     test_bin_key(rng);
+    test_chunk_scan_ahead(rng);
     test_runs(rng);
     test_map_store(rng);
     test_map_bucketing(rng);
