@@ -192,6 +192,41 @@ def test_large_scale_submap_mode(gpu_mod, submap_size):
         compare_step(g, o, rg, ro, full=(f < 2))
 
 
+@pytest.mark.parametrize("submap_size", [25.0, 8.0, 500.0])
+def test_large_scale_mode_with_nodes_announced_ahead(gpu_mod, submap_size):
+    """Round 4: in large-scale mode the next step's VoI split / chunk scan are launched ahead too -- unless the announced pose would
+    move the submap (reassign_submap, OMU.cpp:332-358: the store is rewritten then).  Twelve nodes announced two ahead across
+    several re-centrings (8 m and 25 m submaps on a 12 m path; 500 m: never), every step against the oracle; passes ahead are
+    launched only for the nodes that leave the submap where it is, and used."""
+    import copy
+    sc = scenarios.small()
+    p = copy.copy(sc["params"])
+    p.is_large_scale, p.submap_size = 1, submap_size
+    g, o = make_pair(gpu_mod, p)
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    n, ahead = 12, 2
+    scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"][:n]]
+    Tb, To = sc["T_b2o"], sc["T_o2b"]
+    for j in range(ahead):
+        g.prefetch(scans[j], sc["T_l2b"], Tb[j])
+    cx = cy = None
+    moves = 0
+    for k in range(n):
+        if k + ahead < n:
+            g.prefetch(scans[k + ahead], sc["T_l2b"], Tb[k + ahead])
+        x, y = float(np.asarray(Tb[k]).reshape(-1)[3]), float(np.asarray(Tb[k]).reshape(-1)[7])  # (OMU.cpp:246-247)
+        if cx is None or abs(cx - x) > submap_size / 2 or abs(cy - y) > submap_size / 2:  # (reassign_submap's rule)
+            cx, cy, moves = x, y, moves + 1
+        rg = g.step(scans[k], sc["T_l2b"], Tb[k], To[k])
+        ro = o.step(scans[k], sc["T_l2b"], Tb[k], To[k])
+        assert g.map_size() == o.map_size()
+        compare_step(g, o, rg, ro, full=(k % 4 == 0))
+    launched, used = g.ahead_split_counts()
+    assert launched <= n - 1 and launched >= n - 1 - moves and used >= launched - 3 and (submap_size < 100 or used > 0), (launched, used, moves)
+    same(g.get_map(), o.get_map(), "submap + complement after the sequence")
+
+
 def test_revisiting_the_same_pose_and_moving_back(gpu_mod):
     """points leave the VoI and come back: F <-> outskirts traffic in both directions, duplicates of reverted ground included"""
     sc = scenarios.small()

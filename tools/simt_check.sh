@@ -23,12 +23,12 @@ quick)
   ;;
 suite)
   $CXX -x c++ -fPIC -shared -DERASOR_HIP_TEST_HOOKS -o $OUT/liberasor_hip_simt.so erasor_amd/csrc/erasor_hip.hip
-  ERASOR_TEST_SIMT_LIB=$OUT/liberasor_hip_simt.so python -m pytest tests/test_gpu_parity.py tests/test_gpu_hooks.py tests/test_golden.py -m gpu -q -p no:cacheprovider -k "$EXPR"
+  ERASOR_TEST_SIMT_LIB=$OUT/liberasor_hip_simt.so python -m pytest tests/test_gpu_parity.py tests/test_gpu_hooks.py tests/test_golden.py -m gpu -q -p no:cacheprovider -o timeout=1800 -k "$EXPR"
   ;;
 asan)
   $CXX -g -fsanitize=address -fno-omit-frame-pointer -x c++ -fPIC -shared -DERASOR_HIP_TEST_HOOKS -o $OUT/liberasor_hip_asan.so erasor_amd/csrc/erasor_hip.hip
   LD_PRELOAD=$(g++ -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1 \
-    ERASOR_TEST_SIMT_LIB=$OUT/liberasor_hip_asan.so python -m pytest tests/test_gpu_parity.py tests/test_gpu_hooks.py -m gpu -q -x -p no:cacheprovider -k "$EXPR"
+    ERASOR_TEST_SIMT_LIB=$OUT/liberasor_hip_asan.so python -m pytest tests/test_gpu_parity.py tests/test_gpu_hooks.py -m gpu -q -x -p no:cacheprovider -o timeout=3600 -k "$EXPR"
   ;;
 *) echo "usage: $0 quick | suite [-k expr] | asan [-k expr]"; exit 2;;
 esac
