@@ -135,7 +135,7 @@ def committed_profile(prof_tag):
     """what the separate rocprofv3 passes of THIS build measured (profiles/*_latest*): k_voi_split's PMC traffic and average
     duration, and the kernel that tops the GPU-time table.  None for everything when the device sources have changed since."""
     import csv
-    out = {"traffic": None, "voi_split_avg_us": None, "dominant": None, "stale": None, "step_traffic": None}
+    out = {"traffic": None, "voi_split_avg_us": None, "dominant": None, "stale": None, "step_traffic": None, "step_traffic_steps_only": None}
     try:
         with open(os.path.join(ROOT, "profiles", "latest_meta%s.json" % prof_tag)) as f:
             meta = json.load(f)
@@ -150,6 +150,7 @@ def committed_profile(prof_tag):
             j = json.load(f)
         out["traffic"] = int(j["traffic_bytes_per_launch"])
         out["step_traffic"] = j.get("step_traffic_bytes")
+        out["step_traffic_steps_only"] = j.get("step_traffic_bytes_without_setup_kernels")
         per_kernel = j.get("per_kernel_traffic_bytes", {})
     except Exception:
         pass
@@ -670,7 +671,8 @@ def main():
                               else "%.0f MB per launch, beyond the 256 MiB Infinity Cache: HBM-bound" % (alg_bytes / 1e6),
                 "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": traffic,
-                "step_traffic": cp["step_traffic"],  # every kernel of a step, PMC, corrected like `traffic` (profiles/pmc_latest*.json)
+                "step_traffic": cp["step_traffic"],  # every kernel of the PMC pass / its steps, corrected like `traffic` (profiles/pmc_latest*.json)
+                "step_traffic_steps_only": cp["step_traffic_steps_only"],  # ... without the kernels that run once per pass (set_map)
                 "traffic_source": src_note, "dominant_kernel": cp["dominant"],
                 "bytes_per_launch": int(alg_bytes),
                 "bytes_note": "what a launch has to READ: float4 of the VoI-resident part + {x,y} pairs (8 B) of the outskirts chunks whose bounding "

@@ -58,6 +58,7 @@ if fs:
     # the WHOLE step's corrected traffic: every kernel's total over the pass divided by the steps of the pass (one k_voi_gather each)
     steps = max(res["FETCH_SIZE"].get("ek::k_voi_gather", {}).get("dispatches", 0), 1)
     tot = 0.0
+    tot_steps_only = 0.0
     per_step = {}
     for k, v in res["FETCH_SIZE"].items():
         if "ek::" not in k:
@@ -65,7 +66,10 @@ if fs:
         b = v["total_KiB"] * 1024 * 2 + res["WRITE_SIZE"].get(k, {}).get("total_KiB", 0.0) * 1024
         per_step[k.replace("void ", "").replace("ek::", "").split("<")[0]] = int(b / steps)
         tot += b
+        if v.get("dispatches", 0) >= steps:  # (a kernel of every step; the others belong to set_map / the pass's set-up, once)
+            tot_steps_only += b
     latest["step_traffic_bytes"] = int(tot / steps)
+    latest["step_traffic_bytes_without_setup_kernels"] = int(tot_steps_only / steps)
     latest["step_traffic_steps"] = steps
     latest["per_kernel_traffic_bytes_per_step"] = dict(sorted(per_step.items(), key=lambda kv: -kv[1]))
     cal = res["FETCH_SIZE"].get("ek::k_store_outskirts")
