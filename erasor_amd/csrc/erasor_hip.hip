@@ -784,6 +784,11 @@ int erasor_hip_params_default(erasor_params *p) {
 }
 
 static bool create_sides(erasor_hip_handle *h, int prio) {
+    // round 4: three query streams where the process has the hardware queues for them (main + 3 + copy = 5 streams; HIP's default is 4
+    // queues): 233 k-point scans 0.291 -> 0.230 ms, 127 k-point scans the same either way; two otherwise
+    if (const char *q = getenv("GPU_MAX_HW_QUEUES")) {
+        if (atoi(q) >= 8) h->nqs = 3;
+    }
     if (const char *e = getenv("ERASOR_HIP_QSTREAMS")) h->nqs = std::max(1, std::min((int)erasor_hip_handle::NQS_MAX, atoi(e)));
     for (int k = 0; k < h->nqs; ++k)
         if (hipStreamCreateWithPriority(&h->qstream[k], hipStreamNonBlocking, prio) != hipSuccess) return false;

@@ -1,6 +1,7 @@
 // erasor_offline_demo — ROS-free driver shaped like src/offline_map_updater/main_in_your_env.cpp:61-127:
 //   <dir>/map.pcd, <dir>/pcds/%06d.pcd, <dir>/poses.csv (header line; idx,?,x,y,z,qx,qy,qz,qw per line, cols 2..8)
 // processes every node through erasor::OfflineMapUpdater and writes <dir>/<data_name>_result.pcd and map_final.pcd.
+#include <cstdlib>
 #include <array>
 #include <chrono>
 #include <cstdio>
@@ -411,6 +412,8 @@ static int bench_mode(int argc, char **argv) {
 }
 
 int main(int argc, char **argv) {
+    // an APPLICATION's decision (the library only warns): hardware queues for several updaters' streams, before HIP starts
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     if (argc >= 2 && std::string(argv[1]) == "--bench") {
         try {
             return bench_mode(argc, argv);
