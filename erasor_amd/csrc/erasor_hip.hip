@@ -1229,8 +1229,10 @@ static int enqueue_passthrough(erasor_hip_handle *h, const float4 *d_src, uint32
     return ERASOR_OK;
 }
 
+// staged: 0 = the scan comes from the caller now; 1 = announced (h->ann): a host scan lies in the side's staging copy already;
+// 2 = the side's OWN announcement once more (its chain ran in the wrong VoxelGrid mode, step_collect): scan, ticket, hash and pose stay
 static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_src, uint32_t ns, bool src_is_device, const float T_l2b[16],
-                               bool prevox, bool staged = false, bool passthrough = false, RowFmt fmt = RowFmt()) {
+                               bool prevox, int staged = 0, bool passthrough = false, RowFmt fmt = RowFmt()) {
     SideGuard guard(h);
     h->qi = side;
     // (the radix fallback for very fine R-POD grids -- and the pass-through chain's radix sort -- share their scratch bank
@@ -1337,11 +1339,13 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     q.src_n = ns;
     q.ns = ns;
     q.src_dev = src_is_device;
-    q.pose_valid = false;  // (flush_announced adds the pose of an announced node)
-    if (!src_is_device && staged) q.fp = h->ann.fp;  // (not staged: the hash the staging pass has just taken)
+    if (staged != 2) {
+        q.pose_valid = false;  // (flush_announced adds the pose of an announced node)
+        if (!src_is_device && staged) q.fp = h->ann.fp;  // (not staged: the hash the staging pass has just taken)
+        q.ticket = staged ? h->ann.ticket : 0ull;
+    }
     q.fmt = fmt;
-    q.ticket = staged ? h->ann.ticket : 0ull;
-    memcpy(q.Tl, T_l2b, sizeof(q.Tl));
+    if (q.Tl != T_l2b) memcpy(q.Tl, T_l2b, sizeof(q.Tl));
     return ERASOR_OK;
 }
 
@@ -1349,7 +1353,7 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
 static int flush_announced(erasor_hip_handle *h) {
     if (!h->ann.valid) return ERASOR_OK;
     h->ann.valid = false;
-    const int rc = enqueue_query_chain(h, h->ann.side, h->ann.src, (uint32_t)h->ann.n, h->ann.is_device, h->ann.Tl, false, /*staged=*/true,
+    const int rc = enqueue_query_chain(h, h->ann.side, h->ann.src, (uint32_t)h->ann.n, h->ann.is_device, h->ann.Tl, false, /*staged=*/1,
                                        h->q_passthrough, h->ann.fmt);
     if (rc) return rc;
     h->q[h->ann.side].pose_valid = h->ann.pose_valid;
@@ -1522,10 +1526,10 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         int side = -1;
         // (recognition WITHOUT a ticket: pointer, size, T_lidar2body -- and, for a host scan, the hash of every record of the caller's
         // buffer against the hash of the copy that was staged: only taken when the cheap tests have passed)
-        const bool ann_cand = !ticket && h->npend == 0 && h->ann.valid && !prevox && h->ann.src == scan_src && h->ann.n == n_scan &&
+        const bool ann_cand = !ticket && !(flags & STEP_RETRIED) && h->npend == 0 && h->ann.valid && !prevox && h->ann.src == scan_src && h->ann.n == n_scan &&
                               h->ann.is_device == src_is_device && memcmp(h->ann.Tl, T_l2b, sizeof(h->ann.Tl)) == 0 &&
                               h->ann.fmt.stride == fmt.stride && h->ann.fmt.ioff == fmt.ioff;
-        const bool pend_cand = !ticket && h->npend > 0 && !prevox && h->q[h->pend[0]].src == scan_src && h->q[h->pend[0]].src_n == n_scan &&
+        const bool pend_cand = !ticket && !(flags & STEP_RETRIED) && h->npend > 0 && !prevox && h->q[h->pend[0]].src == scan_src && h->q[h->pend[0]].src_n == n_scan &&
                                h->q[h->pend[0]].src_dev == src_is_device && memcmp(h->q[h->pend[0]].Tl, T_l2b, sizeof(h->q[0].Tl)) == 0 &&
                                h->q[h->pend[0]].fmt.stride == fmt.stride && h->q[h->pend[0]].fmt.ioff == fmt.ioff;
         const uint64_t fp_now = (!src_is_device && (ann_cand || pend_cand)) ? scan_fingerprint(scan_src, n_scan, fmt) : 0ull;
@@ -1533,7 +1537,10 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             rc = flush_announced(h);  // announced, not yet started (first scan of a sequence): start it now, it is ours
             if (rc) return rc;
         }
-        if (h->npend > 0) {
+        if (flags & STEP_RETRIED) {
+            // the step runs again in the other VoxelGrid mode (step_collect): the nodes announced behind it are NOT this scan and are not
+            // dropped -- a ticket has no caller buffer to come back with --; their chains (which ran in the old mode) go again below
+        } else if (h->npend > 0) {
             const QSide &c = h->q[h->pend[0]];
             if (ticket || (!prevox && c.src == scan_src && c.src_n == n_scan && c.src_dev == src_is_device && (src_is_device || c.fp == fp_now) &&
                            memcmp(c.Tl, T_l2b, sizeof(c.Tl)) == 0 && c.fmt.stride == fmt.stride && c.fmt.ioff == fmt.ioff)) {
@@ -1549,9 +1556,15 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         if (side < 0) {
             // (an announcement that is not this scan is the NEXT scan: it keeps the side it was staged into)
             side = pick_side(h);
-            rc = enqueue_query_chain(h, side, scan_src, ns, src_is_device, T_l2b, prevox, false, h->q_passthrough && !prevox, fmt);
+            rc = enqueue_query_chain(h, side, scan_src, ns, src_is_device, T_l2b, prevox, 0, h->q_passthrough && !prevox, fmt);
             if (rc) return rc;
         }
+        if (flags & STEP_RETRIED)
+            for (int j = 0; j < h->npend; ++j) {  // (in announcement order, behind this step's own chain; a host scan still lies in q.scan)
+                QSide &c = h->q[h->pend[j]];
+                rc = enqueue_query_chain(h, h->pend[j], c.src, (uint32_t)c.src_n, c.src_dev, c.Tl, false, 2, h->q_passthrough, c.fmt);
+                if (rc) return rc;
+            }
         h->qi = side;
     }
     MARK("query chain");
@@ -1599,7 +1612,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         h->spec.valid = false;  // (re-allocated below: a pass launched ahead wrote into the old buffers)
     if (ensure(h, h->vmask, chunks_room * CHUNK_TILES + 8) || ensure(h, h->hmask, chunks_room * CHUNK_TILES + 8) ||
         ensure(h, h->cinfo, chunks_room + 8) || ensure(h, h->pvl, chunks_room + 8) || ensure(h, h->phl, chunks_room + 8) ||
-        ensure(h, h->topv, nchunks / 1024 + 8) || ensure(h, h->toph, nchunks / 1024 + 8) || ensure(h, h->topr, nchunks / 1024 + 8))
+        ensure(h, h->topv, chunks_room / 1024 + 8) || ensure(h, h->toph, chunks_room / 1024 + 8) || ensure(h, h->topr, chunks_room / 1024 + 8))
         return ERASOR_E_NO_DEVICE;
     // No mid-step read-back: everything is launched on upper-bound grids and reads the actual counts
     // (st->voi_total, st->q_nvox) from device memory.  n_voi <= logical map size, nq <= n_scan.
@@ -1990,7 +2003,12 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
             // 4: the pass-through chain found that VoxelGrid would NOT overflow -> back to the voxelising chain.
             h->q_passthrough = h->ctr.err == 2;
             if (!(flags & STEP_RETRIED)) {
-                q_drain(h);  // chains announced ahead were enqueued in the other mode: dropped, their steps enqueue their own
+                // chains announced ahead were enqueued in the other mode: they run out, then go again in the new one behind this step's own
+                // (step_enqueue, STEP_RETRIED).  The announcements themselves stay: a node announced by ticket has no caller buffer its
+                // step could come back with (erasor_hip_step_ticket used to fail with "not the oldest announced scan" here)
+                for (int k = 0; k < h->nqs; ++k) (void)hipStreamSynchronize(h->qstream[k]);
+                if (h->cstream) (void)hipStreamSynchronize(h->cstream);
+                for (int k = 0; k < NSIDE; ++k) h->q[k].h2d_pending = false;
                 float Tl[16], Tb[16], To[16];  // (step_enqueue stores its arguments into h->fly: no aliasing copies)
                 memcpy(Tl, h->fly.Tl, sizeof(Tl));
                 memcpy(Tb, h->fly.Tb, sizeof(Tb));
@@ -2091,6 +2109,12 @@ static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n
     int rc = flush_announced(h);  // an earlier announcement nobody stepped on yet: its chain starts now
     if (rc) return rc;
     const int side = pick_side(h);
+    if (h->fly.active && side == h->qi) {
+        // every other side holds an announced scan: the one left is the side of the step in flight, whose Scan Ratio Test, R-GPF and
+        // write-back are still reading it (and whose staged copy a step that has to run again reads)
+        h->err = "erasor_hip_prefetch_*: all query sides are taken while a step is in flight: call erasor_hip_step_wait first";
+        return ERASOR_E_STATE;
+    }
     if (n && !src_is_device) {  // a host scan is taken over at once
         SideGuard guard(h);
         h->qi = side;
@@ -2244,26 +2268,32 @@ int map_to_device(erasor_hip_handle *h, DBuf<float4> &dense, size_t *n_out) {
     const size_t total = (size_t)h->nF + (size_t)h->o_valid + (size_t)h->nC;
     *n_out = total;
     if (ensure(h, dense, total + 8)) return ERASOR_E_NO_DEVICE;
-    hipStream_t keep = h->cur;
+    struct Restore {  // (also on the error returns below: the stream LAUNCH() targets, the temporaries)
+        erasor_hip_handle *h;
+        hipStream_t keep;
+        DBuf<uint32_t> flag, pl, tops;
+        ~Restore() {
+            release(flag);
+            release(pl);
+            release(tops);
+            h->cur = keep;
+        }
+    } rs{h, h->cur, {}, {}, {}};
+    DBuf<uint32_t> &flag = rs.flag, &pl = rs.pl, &tops = rs.tops;
     h->cur = h->stream;
     if (h->nF) HIPC(h, hipMemcpyAsync(dense.p, h->F[h->curF].p, (size_t)h->nF * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
     const uint32_t span = h->capO - h->o_begin;
     if (span && h->o_valid) {
-        DBuf<uint32_t> flag, pl, tops;
         if (ensure(h, flag, span + 1) || ensure(h, pl, span + 1) || ensure(h, tops, span / 1024 + 4)) return ERASOR_E_NO_DEVICE;
         LAUNCH(h, "replicate", k_o_valid, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, h->o_begin, h->capO, flag.p);
         scan_u32(h, flag.p, pl.p, tops.p, span, span, nullptr, nullptr, "replicate");
         LAUNCH(h, "replicate", k_o_compact, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, (const float2 *)h->Ozi.p, h->o_begin, h->capO,
                (const uint32_t *)flag.p, (const uint32_t *)pl.p, (const uint32_t *)tops.p, dense.p + h->nF);
         HIPC(h, hipStreamSynchronize(h->stream));
-        release(flag);
-        release(pl);
-        release(tops);
     }
     if (h->nC)
         HIPC(h, hipMemcpyAsync(dense.p + (size_t)h->nF + h->o_valid, h->Cbuf.p, (size_t)h->nC * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
-    h->cur = keep;
     return ERASOR_OK;
 }
 }  // namespace

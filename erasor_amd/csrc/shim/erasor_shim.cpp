@@ -386,6 +386,11 @@ void OfflineMapUpdater::stage_deferred() {
     auto_seq_ = def_seq_;
 }
 void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, const Cloud &lidar, uint64_t ticket) {
+    // the deferred announcement points at a caller local: whatever way this callback ends, it does not outlive it
+    struct ClearDeferred {
+        const Cloud *&p;
+        ~ClearDeferred() { p = nullptr; }
+    } clear_deferred{def_cloud_};
     stack_count_++;
     if (!ticket && auto_ticket_ && auto_seq_ == seq) ticket = auto_ticket_;  // announced through announce_next_deferred
     auto_ticket_ = 0;
@@ -407,7 +412,13 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
             // (in two halves: a deferred announcement of the node behind this one is staged while this step runs on the GPU)
             check(h_, erasor_hip_step_ticket_async(h_, ticket, Tb, To), "erasor_hip_step_ticket_async");
             has_next_ = false;
-            stage_deferred();
+            try {
+                stage_deferred();
+            } catch (...) {
+                // the step in flight is collected whatever the announcement did: a handle with an uncollected step takes no other call
+                (void)erasor_hip_step_wait(h_, &last);
+                throw;
+            }
             check(h_, erasor_hip_step_wait(h_, &last), "erasor_hip_step_wait");
         } else {
             check(h_, erasor_hip_step_rows(h_, lidar.points.data(), lidar.size(), kRowStride, kRowIntensity, Tl, Tb, To, &last), "erasor_hip_step_rows");
