@@ -221,6 +221,7 @@ struct erasor_hip_handle {
         float Tl[16], Tb[16], To[16];
         uint32_t nchunks = 0;     // chunk count of the step's own VoI pass (grid hint of a split launched ahead later)
         bool spec_launched = false;
+        bool reserved = false;    // the write-back uses the reserved layout (round 5)
     } fly;
     HostOut *pin = nullptr;         // pinned host block k_step_end reports into
     int bank = 0;                   // scratch bank of scan/radix helpers (0: query chains, 1: map chain)
@@ -236,7 +237,14 @@ struct erasor_hip_handle {
     DBuf<float4> F[2];
     int curF = 0;
     DBuf<float2> Oxy, Ozi;
-    uint32_t nF = 0, o_begin = 0;  // host mirrors
+    uint32_t nF = 0, o_begin = 0;  // host mirrors (nF: the EXTENT of the VoI-resident region)
+    uint32_t nFv = 0;              // ... the POINTS in it (round 5: a region written in the reserved layout holds holes, see DevState::nF_valid)
+    // round 5, reserved layout (srt4_body / k_assemble_late): offsets with the reverted bins at full size, the late tables of the region in
+    // F[curF] (late_idx) and of the one being written (late_idx ^ 1), the holes before every entry
+    DBuf<uint32_t> out_offR, gres_off, late_holes[2];
+    DBuf<LateEnt> late[2];
+    int late_idx = 0;
+    uint32_t n_late_F = 0;         // entries of late[late_idx] (0: F[curF] is dense)
     // large-scale mode (OMU.cpp:332-379): everything outside the current submap
     DBuf<float4> Cbuf;
     uint32_t nC = 0;
@@ -497,6 +505,8 @@ int alloc_bins(erasor_hip_handle *h) {
     rc |= ensure(h, h->mmin, B) | ensure(h, h->mmax, B);
     rc |= ensure(h, h->st1, B) | ensure(h, h->status, B) | ensure(h, h->action, B) | ensure(h, h->rev_idx, B) | ensure(h, h->rev_list, B);
     rc |= ensure(h, h->out_off0, B + 2) | ensure(h, h->rev_before, B + 2) | ensure(h, h->st1b, B + 8);
+    rc |= ensure(h, h->out_offR, B + 2) | ensure(h, h->gres_off, B + 2);
+    for (int k = 0; k < 2; ++k) rc |= ensure(h, h->late[k], 2 * B + 4) | ensure(h, h->late_holes[k], 2 * B + 4);
     rc |= ensure(h, h->vox_off, B) | ensure(h, h->nvox, B) | ensure(h, h->ng, B) | ensure(h, h->out_off, B) | ensure(h, h->ground_off, B);
     rc |= ensure(h, h->rej_off, B) | ensure(h, h->crej_off, B);
     rc |= ensure(h, h->plane_n, B * (size_t)std::max(h->P.gf_iter, 1) * 3) | ensure(h, h->plane_d, B * (size_t)std::max(h->P.gf_iter, 1));
@@ -573,7 +583,9 @@ int alloc_step(erasor_hip_handle *h, uint32_t n_voi, uint32_t nq) {
     rc |= ensure(h, h->gsK, 2 * G) | ensure(h, h->gsV, 2 * G) | ensure(h, h->gsL, 2 * G) | ensure(h, h->gsR, 2 * G) | ensure(h, h->gsK2, 2 * G) |
           ensure(h, h->gsV2, 2 * G);
     rc |= ensure(h, h->gsH, 2 * (G / 32 + 2 * (size_t)h->B + 16)) | ensure(h, h->gsC, G) | ensure(h, h->vox_out, G);
-    const size_t needF = 2 * (size_t)n_voi + nq + 64;
+    // (round 5: the reserved layout keeps mc + cc slots for a reverted bin and mc for its ground, twice that where its points may leave
+    // the next VoI: at most 4 n_voi + 2 nq in all)
+    const size_t needF = (h->P.version == 3 ? 4 : 2) * (size_t)n_voi + 2 * (size_t)nq + 64;
     rc |= ensure(h, h->F[h->curF ^ 1], needF);
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
@@ -587,6 +599,35 @@ static int ometa_reset(erasor_hip_handle *h) {
     const size_t nrec = (size_t)h->capO / CHUNK + 8;
     if (ensure(h, h->ometa, nrec)) return ERASOR_E_NO_DEVICE;
     HIPC(h, hipMemsetAsync(h->ometa.p, 0, nrec * sizeof(OMeta), h->stream));
+    return ERASOR_OK;
+}
+
+// the POINTS of the VoI-resident region, in order, into dst[0 .. nFv) on the device (main stream; returns once they are there): the
+// region as it lies when it is dense, a stable compaction when the reserved layout has left holes in it (round 5)
+int copy_F_dense(erasor_hip_handle *h, float4 *dst) {
+    if (!h->nF) return ERASOR_OK;
+    if (h->nFv == h->nF) {
+        HIPC(h, hipMemcpyAsync(dst, h->F[h->curF].p, (size_t)h->nF * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+        return ERASOR_OK;
+    }
+    DBuf<uint32_t> flag, pl, tops;
+    if (ensure(h, flag, (size_t)h->nF + 1) || ensure(h, pl, (size_t)h->nF + 1) || ensure(h, tops, h->nF / 1024 + 4)) return ERASOR_E_NO_DEVICE;
+    hipStream_t keep = h->cur;
+    h->cur = h->stream;
+    LAUNCH(h, "f_dense", k_f_valid, cdiv(h->nF, 256), 256, (const float4 *)h->F[h->curF].p, h->nF, flag.p);
+    scan_u32(h, flag.p, pl.p, tops.p, h->nF, h->nF, nullptr, nullptr, "f_dense");
+    LAUNCH(h, "f_dense", k_f_compact, cdiv(h->nF, 256), 256, (const float4 *)h->F[h->curF].p, h->nF, (const uint32_t *)flag.p, (const uint32_t *)pl.p,
+           (const uint32_t *)tops.p, dst);
+    h->cur = keep;
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    release(flag);
+    release(pl);
+    release(tops);
+    if (e != hipSuccess) {
+        h->err = std::string("copy_F_dense: ") + hipGetErrorString(e);
+        return ERASOR_E_NO_DEVICE;
+    }
     return ERASOR_OK;
 }
 
@@ -637,7 +678,7 @@ int push_state(erasor_hip_handle *h);
 // into the new submap (stored as outskirts, F empty) and the new complement.  Rare (every ~submap_size/2 of travel).
 int split_submap(erasor_hip_handle *h, double x, double y) {
     ++h->store_epoch;
-    const uint64_t total64 = (uint64_t)h->nF + h->o_valid + h->nC;
+    const uint64_t total64 = (uint64_t)h->nFv + h->o_valid + h->nC;
     if (total64 > 0x7FFFFFF0ull) {
         h->err = "map too large for 32-bit indexing";
         return ERASOR_E_INVALID;
@@ -649,7 +690,10 @@ int split_submap(erasor_hip_handle *h, double x, double y) {
         ensure(h, tops, total / 1024 + 4))
         return ERASOR_E_NO_DEVICE;
     // logical global map = *map_arranged_ + *map_arranged_complement_ (OMU.cpp:349)
-    if (h->nF) HIPC(h, hipMemcpyAsync(G.p, h->F[h->curF].p, (size_t)h->nF * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    {
+        const int rc_f = copy_F_dense(h, G.p);
+        if (rc_f) return rc_f;
+    }
     const uint32_t span = h->capO - h->o_begin;
     if (span && h->o_valid) {
         DBuf<uint32_t> f2, p2, t2;
@@ -657,13 +701,13 @@ int split_submap(erasor_hip_handle *h, double x, double y) {
         LAUNCH(h, "submap", k_o_valid, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, h->o_begin, h->capO, f2.p);
         scan_u32(h, f2.p, p2.p, t2.p, span, span, nullptr, nullptr, "submap");
         LAUNCH(h, "submap", k_o_compact, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, (const float2 *)h->Ozi.p, h->o_begin, h->capO,
-               (const uint32_t *)f2.p, (const uint32_t *)p2.p, (const uint32_t *)t2.p, G.p + h->nF);
+               (const uint32_t *)f2.p, (const uint32_t *)p2.p, (const uint32_t *)t2.p, G.p + h->nFv);
         HIPC(h, hipStreamSynchronize(h->stream));
         release(f2);
         release(p2);
         release(t2);
     }
-    if (h->nC) HIPC(h, hipMemcpyAsync(G.p + h->nF + h->o_valid, h->Cbuf.p, (size_t)h->nC * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    if (h->nC) HIPC(h, hipMemcpyAsync(G.p + h->nFv + h->o_valid, h->Cbuf.p, (size_t)h->nC * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
     uint32_t n_sub = 0;
     if (total) {
         LAUNCH(h, "submap", k_box_flag, cdiv(total, 256), 256, (const float4 *)G.p, total, x, y, h->P.submap_size, flag.p);
@@ -690,6 +734,8 @@ int split_submap(erasor_hip_handle *h, double x, double y) {
         if (rc_m) return rc_m;
     }
     h->nF = 0;
+    h->nFv = 0;
+    h->n_late_F = 0;
     h->o_begin = dst0;
     h->o_valid = n_sub;
     memset(&h->st, 0, sizeof(h->st));
@@ -744,6 +790,7 @@ bool submap_would_move(const erasor_hip_handle *h, double pose_x, double pose_y)
 
 int push_state(erasor_hip_handle *h) {
     h->st.nF = h->nF;
+    h->st.nF_valid = h->nFv;
     h->st.o_begin = h->o_begin;
     HIPC(h, hipMemcpyAsync(h->d_st.p, &h->st, sizeof(DevState), hipMemcpyHostToDevice, h->stream));
     return 0;
@@ -888,6 +935,8 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->rk_a); release(h->rk_b); release(h->rv_a); release(h->rv_b); release(h->hist); release(h->hist_l); release(h->hist_t); release(h->hist2); release(h->hist2_l); release(h->hist2_t); release(h->dn); release(h->lab_slots); release(h->mb_hist); release(h->mb_tot); release(h->mg_curr); release(h->mg_map); release(h->mg_done); release(h->mg_tmp);
     release(h->moff); release(h->mcnt); release(h->rev_idx); release(h->rev_list); release(h->vox_off);
     release(h->out_off0); release(h->rev_before); release(h->st1b);
+    release(h->out_offR); release(h->gres_off);
+    for (int k = 0; k < 2; ++k) { release(h->late[k]); release(h->late_holes[k]); }
     release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
     release(h->mmin); release(h->mmax); release(h->plane_n); release(h->plane_d);
     release(h->st1); release(h->status); release(h->action);
@@ -926,6 +975,8 @@ static int set_map_common(erasor_hip_handle *h, const void *src, size_t n, bool 
         HIPC(h, hipMemcpyAsync(h->voi_ego.p, src, n * sizeof(float4), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
     }
     h->nF = 0;
+    h->nFv = 0;
+    h->n_late_F = 0;
     h->curF = 0;
     h->o_begin = h->capO - (uint32_t)n;
     h->o_valid = n;
@@ -1586,7 +1637,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         rc = rebuild_outskirts(h, h->nF + CHUNK);
         if (rc) return rc;
     }
-    const uint64_t n_map_in = (uint64_t)h->nF + h->o_valid;
+    const uint64_t n_map_in = (uint64_t)h->nFv + h->o_valid;
     if (n_map_in + ns + 64 > h->capV) {
         // the reference's map_arranged_ simply grows (scan points enter every reverted bin, erasor.cpp:512; v2 merges whole
         // query bins, erasor.cpp:296-307): enlarge the map-sized scratch between steps (it carries no state across steps)
@@ -1594,6 +1645,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         if (rc) return rc;
     }
     h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_chunk_scan_top
+    h->st.nF_valid = h->nFv;
     h->st.o_begin = h->o_begin;
     const bool mb_count = B + 1 <= QB_NB_MAX;  // the map's bucketing as a one-digit counting sort (else: LSD radix passes)
     // (state push, counters and tallies are reset by k_chunk_scan_top, the first launch of the step that needs them)
@@ -1734,13 +1786,47 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     static const bool no_fuse = getenv("ERASOR_HIP_NO_FUSE") != nullptr;
     static const bool no_srt_fold = getenv("ERASOR_HIP_NO_SRT_FOLD") != nullptr;
     const bool srt_in_revert = st1_ahead && P.version == 3 && !no_fuse && !no_srt_fold && h->prof != 1;
-    if (srt_in_revert) {
+    // round 5: the RESERVED layout (srt4_body): the write-back of everything but the reverted bins does not wait for the per-bin launch
+    static const bool no_reserved = getenv("ERASOR_HIP_NO_RESERVED") != nullptr;
+    static const bool leave_all = getenv("ERASOR_HIP_LEAVE_ALL") != nullptr;  // (test switch: every reverted bin reserves places in the outskirts' order)
+    const bool reserved = srt_in_revert && fold && mb_count && !no_reserved && !flags;
+    bool have_pose = false;  // the NEXT node's pose, if it was announced with it (erasor_hip_prefetch_node)
+    double nx = 0, ny = 0;
+    if (h->npend > 0) {
+        const QSide &nq_ = h->q[h->pend[0]];
+        have_pose = nq_.pose_valid;
+        nx = nq_.pose_x;
+        ny = nq_.pose_y;
+    } else if (h->ann.valid) {
+        have_pose = h->ann.pose_valid;
+        nx = h->ann.pose_x;
+        ny = h->ann.pose_y;
+    }
+    float4 *Fnew = h->F[h->curF ^ 1].p;
+    LateEnt *late_out = h->late[h->late_idx ^ 1].p;
+    if (reserved) {
+        // a reverted bin whose points may lie outside the NEXT VoI circle reserves places in the outskirts' order as well: without the
+        // next pose, every bin does
+        const double leave_lim = (have_pose && !leave_all) ? sqrt(P.voi_r2) - hypot(nx - xc, ny - yc) - 0.05 : -1.0;
+        LAUNCH(h, "srt", k_srt4, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
+               (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds,
+               h->out_off0.p, h->rev_before.p, h->crej_off.p, (const uint8_t *)h->st1b.p, (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).qoff.p,
+               h->out_offR.p, h->gres_off.p, late_out, leave_lim);
+        if (n_voi)
+            LAUNCH(h, "assemble", (k_assemble_map<true, false, true>), std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p,
+                   (const uint32_t *)h->rev_idx.p, sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p,
+                   (const uint32_t *)Q(h).ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p, h->out_off.p, h->ground_off.p, h->rej_off.p, ds, Fnew,
+                   h->rejected.p, h->rejected_src.p, h->lab_slots.p, 0u, (const uint32_t *)h->rev_list.p, (const uint32_t *)Q(h).qoff.p,
+                   (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p, (const float4 *)h->vox_out.p, (const uint32_t *)h->out_offR.p,
+                   (const uint32_t *)h->rev_before.p, (const uint32_t *)h->ng.p);
+    } else if (srt_in_revert) {
         // (no launch)
     } else if (B <= 1024 * SRT_KPT)
         LAUNCH(h, "srt", k_srt4, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
            (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds,
            fold ? h->out_off0.p : (uint32_t *)nullptr, fold ? h->rev_before.p : (uint32_t *)nullptr, fold ? h->crej_off.p : (uint32_t *)nullptr,
-           st1_ahead ? (const uint8_t *)h->st1b.p : (const uint8_t *)nullptr);
+           st1_ahead ? (const uint8_t *)h->st1b.p : (const uint8_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+           (uint32_t *)nullptr, (LateEnt *)nullptr, -1.0);
     else
         LAUNCH(h, "srt", k_srt, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
            (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
@@ -1794,7 +1880,15 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         sa.st1_in = h->st1b.p;
         sa.moff = h->moff.p;
         sa.qoff = Q(h).qoff.p;
-        LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins_srt, std::min<uint32_t>(rev_grid, B) + 1u, 1024, P, sa, ra);
+        if (reserved) sa.status = nullptr;  // (k_srt4 has run as a launch of its own: no extra workgroup)
+        LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins_srt, std::min<uint32_t>(rev_grid, B) + (reserved ? 0u : 1u), 1024, P, sa, ra);
+        if (reserved)
+            LAUNCH(h, "assemble", k_assemble_late, std::min<uint32_t>(rev_grid, B), 256, P, h->Tb2o, (const uint32_t *)h->rev_list.p, (const float4 *)h->spts.p,
+                   (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).qoff.p, (const uint8_t *)h->gflag.p,
+                   (const uint32_t *)h->grank.p, (const uint32_t *)h->ng.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
+                   (const float4 *)h->vox_out.p, (const uint32_t *)h->out_offR.p, (const uint32_t *)h->gres_off.p, (const uint32_t *)h->out_off0.p,
+                   (const uint32_t *)h->rev_before.p, late_out, h->late_holes[h->late_idx ^ 1].p, h->out_off.p, h->ground_off.p, h->rej_off.p, ds, Fnew,
+                   h->rejected.p, h->rejected_src.p, h->lab_slots.p, (const LateEnt *)nullptr, (const uint32_t *)nullptr, 0u);
     } else if (P.version == 3 && !no_fuse && h->prof != 1) {
         LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds,
                (const uint32_t *)h->vox_off.p, ra);
@@ -1819,8 +1913,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
            h->ground_off.p, h->rej_off.p, h->crej_off.p, ds);
 
     // ---- map write-back (OMU.cpp:281-290) ----
-    float4 *Fnew = h->F[h->curF ^ 1].p;
-    {
+    if (!reserved) {
         // v3: the voxelised reverted bins are written by `tail` extra workgroups of the same launch (from the reverted list)
         const uint32_t tail = (P.version == 3 && n_voi) ? 32u : 0u;
 #define ASM_ARGS(FOLDPTR)                                                                                                                   \
@@ -1847,18 +1940,6 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         // Round 4: that launch also ENDS this step (its last workgroup does k_step_end's work, ERASOR_HIP_NO_END_FOLD=1: a launch of its own)
         static const bool no_spec = getenv("ERASOR_HIP_NO_AHEAD_SPLIT") != nullptr;
         static const bool no_end_fold = getenv("ERASOR_HIP_NO_END_FOLD") != nullptr;
-        bool have_pose = false;
-        double nx = 0, ny = 0;
-        if (h->npend > 0) {
-            const QSide &nq_ = h->q[h->pend[0]];
-            have_pose = nq_.pose_valid;
-            nx = nq_.pose_x;
-            ny = nq_.pose_y;
-        } else if (h->ann.valid) {
-            have_pose = h->ann.pose_valid;
-            nx = h->ann.pose_x;
-            ny = h->ann.pose_y;
-        }
         // (large-scale mode, round 4: ahead as well, unless the next node's pose moves the submap)
         const bool spec = have_pose && !no_spec && !flags && !submap_would_move(h, nx, ny);
         StepEnd se;
@@ -1887,6 +1968,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         }
     }
     h->fly.active = true;
+    h->fly.reserved = reserved;
     h->fly.seq = step_seq;
     h->fly.n_map_in = n_map_in;
     h->fly.ns = ns;
@@ -1996,6 +2078,7 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
         // errors raised by the query chain (2, 3, 4) are seen by k_voi_gather before it touches the map store: the step left
         // no trace and the host mirror of the state is simply restored.
         h->st.nF = h->nF;
+        h->st.nF_valid = h->nFv;
         h->st.o_begin = h->o_begin;
         if (!h->ctr.sort_qoverflow && (h->ctr.err == 2 || h->ctr.err == 4)) {
             // 2: PCL's VoxelGrid would overflow its int32 voxel indices on this scan and pass it through unchanged
@@ -2040,6 +2123,12 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
     const uint32_t n_voi_act = h->st.voi_total, nq_act = h->st.q_nvox;
     h->curF ^= 1;
     h->nF = h->st.nF;
+    h->nFv = h->st.nF_valid;
+    if (h->fly.reserved) {  // (the region just written lies in the reserved layout: its late table is the one that was filled)
+        h->late_idx ^= 1;
+        h->n_late_F = h->st.n_late;
+    } else
+        h->n_late_F = 0;
     h->o_begin = h->st.o_begin;
     const uint64_t n_out = (uint64_t)(h->o_valid) - (n_voi_act - h->st.voiF) + h->st.n_leaving;
     h->o_valid = n_out;
@@ -2059,7 +2148,7 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
     r.n_map_rejected = h->st.n_rejected;
     r.n_curr_rejected = h->st.n_curr_rejected;
     r.n_ground = h->st.n_ground;
-    r.n_map_out = (uint64_t)h->nF + n_out;
+    r.n_map_out = (uint64_t)h->nFv + n_out;
     r.n_static = h->st.F_static + h->st.O_static;
     r.n_dynamic = h->st.F_dynamic + h->st.O_dynamic;
     r.n_reverted_bins = h->st.n_rev;
@@ -2265,7 +2354,7 @@ Rccl *rccl_api() {
 }
 // the handle's whole map as ONE dense device array, in the reference's order: [VoI-resident part | outskirts | submap complement]
 int map_to_device(erasor_hip_handle *h, DBuf<float4> &dense, size_t *n_out) {
-    const size_t total = (size_t)h->nF + (size_t)h->o_valid + (size_t)h->nC;
+    const size_t total = (size_t)h->nFv + (size_t)h->o_valid + (size_t)h->nC;
     *n_out = total;
     if (ensure(h, dense, total + 8)) return ERASOR_E_NO_DEVICE;
     struct Restore {  // (also on the error returns below: the stream LAUNCH() targets, the temporaries)
@@ -2281,18 +2370,21 @@ int map_to_device(erasor_hip_handle *h, DBuf<float4> &dense, size_t *n_out) {
     } rs{h, h->cur, {}, {}, {}};
     DBuf<uint32_t> &flag = rs.flag, &pl = rs.pl, &tops = rs.tops;
     h->cur = h->stream;
-    if (h->nF) HIPC(h, hipMemcpyAsync(dense.p, h->F[h->curF].p, (size_t)h->nF * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    {
+        const int rc_f = copy_F_dense(h, dense.p);
+        if (rc_f) return rc_f;
+    }
     const uint32_t span = h->capO - h->o_begin;
     if (span && h->o_valid) {
         if (ensure(h, flag, span + 1) || ensure(h, pl, span + 1) || ensure(h, tops, span / 1024 + 4)) return ERASOR_E_NO_DEVICE;
         LAUNCH(h, "replicate", k_o_valid, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, h->o_begin, h->capO, flag.p);
         scan_u32(h, flag.p, pl.p, tops.p, span, span, nullptr, nullptr, "replicate");
         LAUNCH(h, "replicate", k_o_compact, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, (const float2 *)h->Ozi.p, h->o_begin, h->capO,
-               (const uint32_t *)flag.p, (const uint32_t *)pl.p, (const uint32_t *)tops.p, dense.p + h->nF);
+               (const uint32_t *)flag.p, (const uint32_t *)pl.p, (const uint32_t *)tops.p, dense.p + h->nFv);
         HIPC(h, hipStreamSynchronize(h->stream));
     }
     if (h->nC)
-        HIPC(h, hipMemcpyAsync(dense.p + (size_t)h->nF + h->o_valid, h->Cbuf.p, (size_t)h->nC * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+        HIPC(h, hipMemcpyAsync(dense.p + (size_t)h->nFv + h->o_valid, h->Cbuf.p, (size_t)h->nC * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     return ERASOR_OK;
 }
@@ -2400,7 +2492,7 @@ int erasor_hip_map_size(erasor_hip_handle *h, size_t *n) {
     NOFLY(h);
     if (!h || !n) return ERASOR_E_INVALID;
     if (!h->have_map) return ERASOR_E_STATE;
-    *n = (size_t)h->nF + (size_t)h->o_valid + (size_t)h->nC;  // large-scale: *map_arranged_ + *map_arranged_complement_ (OMU.cpp:181)
+    *n = (size_t)h->nFv + (size_t)h->o_valid + (size_t)h->nC;  // large-scale: *map_arranged_ + *map_arranged_complement_ (OMU.cpp:181)
     return ERASOR_OK;
 }
 
@@ -2425,12 +2517,20 @@ int erasor_hip_get_map(erasor_hip_handle *h, float *dst, size_t cap, size_t *n) 
     if (!h) return ERASOR_E_INVALID;
     if (!h->have_map) return ERASOR_E_STATE;
     HIPC(h, hipSetDevice(h->device));
-    const size_t total = (size_t)h->nF + (size_t)h->o_valid + (size_t)h->nC;
+    const size_t total = (size_t)h->nFv + (size_t)h->o_valid + (size_t)h->nC;
     if (n) *n = total;
     if (!dst) return ERASOR_OK;
     if (total > cap) return ERASOR_E_CAPACITY;
-    if (h->nC) HIPC(h, hipMemcpy(dst + ((size_t)h->nF + h->o_valid) * 4, h->Cbuf.p, (size_t)h->nC * sizeof(float4), hipMemcpyDeviceToHost));
-    if (h->nF) HIPC(h, hipMemcpy(dst, h->F[h->curF].p, (size_t)h->nF * sizeof(float4), hipMemcpyDeviceToHost));
+    if (h->nC) HIPC(h, hipMemcpy(dst + ((size_t)h->nFv + h->o_valid) * 4, h->Cbuf.p, (size_t)h->nC * sizeof(float4), hipMemcpyDeviceToHost));
+    if (h->nF && h->nFv == h->nF) HIPC(h, hipMemcpy(dst, h->F[h->curF].p, (size_t)h->nF * sizeof(float4), hipMemcpyDeviceToHost));
+    else if (h->nF) {  // (round 5: the region holds reserved slots nothing filled: its points, compacted)
+        DBuf<float4> tmpF;
+        if (ensure(h, tmpF, (size_t)h->nFv + 1)) return ERASOR_E_NO_DEVICE;
+        const int rc_f = copy_F_dense(h, tmpF.p);
+        if (!rc_f && h->nFv) (void)hipMemcpy(dst, tmpF.p, (size_t)h->nFv * sizeof(float4), hipMemcpyDeviceToHost);
+        release(tmpF);
+        if (rc_f) return rc_f;
+    }
     const uint32_t span = h->capO - h->o_begin;
     if (span && h->o_valid) {
         DBuf<uint32_t> flag, pl, tops;
@@ -2442,7 +2542,7 @@ int erasor_hip_get_map(erasor_hip_handle *h, float *dst, size_t cap, size_t *n) 
         LAUNCH(h, "get_map", k_o_compact, cdiv(span, 256), 256, (const float2 *)h->Oxy.p, (const float2 *)h->Ozi.p, h->o_begin, h->capO,
                (const uint32_t *)flag.p, (const uint32_t *)pl.p, (const uint32_t *)tops.p, tmp.p);
         HIPC(h, hipStreamSynchronize(h->stream));
-        HIPC(h, hipMemcpy(dst + (size_t)h->nF * 4, tmp.p, (size_t)h->o_valid * sizeof(float4), hipMemcpyDeviceToHost));
+        HIPC(h, hipMemcpy(dst + (size_t)h->nFv * 4, tmp.p, (size_t)h->o_valid * sizeof(float4), hipMemcpyDeviceToHost));
         release(flag);
         release(pl);
         release(tops);

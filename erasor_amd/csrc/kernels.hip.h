@@ -64,6 +64,21 @@ struct DevState {
     unsigned long long F_static, F_dynamic, O_static, O_dynamic;
     // measurement: the constant-rate counter (100 MHz) when the step's chunk scan began
     unsigned long long t_open;
+    // round 5: the VoI-resident region may hold HOLES (x == HOLE_BITS, like a tombstoned outskirts slot): a step whose write-back does
+    // not wait for its per-bin launch reserves every reverted bin's place at full size (RESERVED layout, see k_srt4 / k_assemble_late)
+    // and what R-GPF / the voxelisation do not fill stays empty.  nF / nF_new are EXTENTS; these count the points.
+    uint32_t nF_valid, nF_valid_new;
+    uint32_t total_binsR, ground_res;  // reserved layout: extent of the bin part, of the ground_viz part
+    uint32_t n_late;                   // entries of the late table the step leaves (LateEnt: two per reverted bin)
+    uint32_t n_voi_dead;               // VoI-order slots kept for the previous step's late points that turned out to hold none (overlapped steps)
+    uint32_t n_late_leaving, pad_r5;
+};
+
+// A reserved range of the VoI-resident region (round 5).  [start, start + ndata): data slots -- the first `actual` hold points once the
+// per-bin launch and k_assemble_late are through, the rest are holes; [start + ndata, start + ntotal): leaving reservations -- never
+// points: they give the late points of a bin that may leave the next VoI their places in the outskirts' order (phantoms).
+struct LateEnt {
+    uint32_t start, ndata, ntotal, actual;
 };
 
 __device__ __forceinline__ uint64_t lanemask_lt() { return esort::lanemask_lt(); }
@@ -272,6 +287,7 @@ __device__ __forceinline__ void step_end_body(DevState *st, Counters *ctr, HostO
     s.q_nvox = nv;
     if (!(c.err || c.sort_qoverflow)) {
         s.nF = s.nF_new;
+        s.nF_valid = s.nF_valid_new;
         s.o_begin = s.o_new_begin;
     }
     *st = s;
@@ -436,7 +452,7 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
 #pragma unroll
                 for (int t = 0; t < CHUNK_TILES / 2; ++t) {
                     const int tt = hlf * (CHUNK_TILES / 2) + t;
-                    const bool valid = base + tt * TILE < nF;
+                    const bool valid = base + tt * TILE < nF && __float_as_uint(px[t]) != HOLE_BITS;  // (round 5: a reserved slot nothing filled)
                     const double dx = (double)px[t] - xc, dy = (double)py[t] - yc;
                     const bool in = valid && (dx * dx + dy * dy < r2);
                     const unsigned long long vm = __ballot(in), hm = __ballot(valid);
@@ -786,7 +802,6 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
 #pragma unroll
                 for (int q = 0; q + 1 < PT; ++q) pp[q] = pp[q + 1];
                 if (hm != 0ull) {
-                    const uint32_t idx = c * CHUNK + (t_lo + j) * TILE + lane;
                     const bool in = (vm >> lane) & 1ull, lv = (lm >> lane) & 1ull;
                     if (in || lv) {
                         if (in) {
@@ -794,7 +809,7 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
                             const float4 e = xform(To2b, p);
                             voi_ego[rank] = e;
                             voi_key[rank] = bin_key(P, e.x, e.y, e.z, ctr);
-                            voi_src[rank] = idx;
+                            voi_src[rank] = ph + __popcll(hm & lt);  // pre-step LOGICAL map index: the valid entries before it (== idx without holes)
                         } else {
                             // leaving: logical order of the new outskirts = [leaving (F order) | old outskirts]
                             const uint32_t lr = (ph - pv) + __popcll(lm & lt);
@@ -819,7 +834,7 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
                         const float4 e = xform(To2b, make_float4(a.x, a.y, b.x, b.y));
                         voi_ego[rank] = e;
                         voi_key[rank] = bin_key(P, e.x, e.y, e.z, ctr);
-                        voi_src[rank] = nF + (ph - validF) + __popcll(hm & lt);
+                        voi_src[rank] = ph + __popcll(hm & lt);  // (== points of the VoI-resident region + valid outskirts entries before it)
                         reinterpret_cast<uint32_t *>(Oxy)[(size_t)idx * 2] = HOLE_BITS;  // tombstone
                         if (is_dynamic_label(b.y)) ++dyn_enter; else ++stat_enter;
                     }
@@ -832,6 +847,7 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
         if (!isF && ometa && lane == 0) ometa[c - nFchunks + o_chunk0].valid = ch - cv;
     }
     (void)voiF;
+    (void)validF;
     // outskirts label counters (parse_dynamic_obj is maintained incrementally, OMU.cpp:294)
     dyn_leave = wave_sum(dyn_leave);
     stat_leave = wave_sum(stat_leave);
@@ -2624,7 +2640,15 @@ __device__ __forceinline__ void srt4_body(const DP &P, uint32_t *sm, S1P s_st1, 
                                                 // fused launch (k_revert_bins_srt): a reverted bin's share of the voxel scratch begins at
                                                 // moff[key] + qoff[key] (disjoint ranges of mc + cc entries, like the prefix of capacities, but
                                                 // a per-bin workgroup knows it without a scan); nullptr: the prefix
-                                                const uint32_t *__restrict__ moff_pos = nullptr, const uint32_t *__restrict__ qoff_pos = nullptr) {
+                                                const uint32_t *__restrict__ moff_pos = nullptr, const uint32_t *__restrict__ qoff_pos = nullptr,
+                                                // round 5, RESERVED layout (v3): every reverted bin keeps room for all it could become -- mc + cc
+                                                // voxels, mc ground points --, so the offsets of everything else are known HERE, before R-GPF has
+                                                // run: out_offR[key], gres_off[rk] (within the ground part), the late table (LateEnt: entry rk =
+                                                // the bin's range, entry n_rev + rk = its ground range) and the extents in *st.  A bin whose points
+                                                // may lie outside the NEXT step's VoI circle (outer radius beyond leave_lim) reserves twice: the
+                                                // second half gives its points places in the outskirts' order.  nullptr: the dense layout only
+                                                uint32_t *__restrict__ out_offR = nullptr, uint32_t *__restrict__ gres_off = nullptr,
+                                                LateEnt *__restrict__ late = nullptr, double leave_lim = -1.0, const uint32_t *__restrict__ moff_all = nullptr) {
     const int B = P.B;
     const int k0 = threadIdx.x * SRT_KPT;
     BinStat bs[SRT_KPT];
@@ -2725,6 +2749,66 @@ __device__ __forceinline__ void srt4_body(const DP &P, uint32_t *sm, S1P s_st1, 
             st->n_curr_rejected = t3;
         }
     }
+    if (out_offR) {
+        const double zb = fmax(fabs(P.min_h), fabs(P.max_h));
+        uint32_t szR[SRT_KPT], gR[SRT_KPT], ssz = 0, sg = 0;
+        bool ml[SRT_KPT];
+#pragma unroll
+        for (int j = 0; j < SRT_KPT; ++j) {
+            szR[j] = gR[j] = 0;
+            ml[j] = false;
+            if (k0 + j < B) {
+                const uint32_t mc = bs[j].mc, cc = bs[j].cc;
+                if (act[j] == 1) {
+                    // can a point of this bin lie outside the next VoI circle?  Its egocentric radius is below the ring's outer edge (a
+                    // voxel centroid is a mean of such points), |z| below zb; the sensor moves by what leave_lim has been reduced by
+                    const int ring = (k0 + j) % P.R;
+                    const double rho = (ring + 1 >= P.R) ? P.max_r : (double)(ring + 1) * P.ring_size;
+                    ml[j] = !(sqrt(rho * rho + zb * zb) * (1.0 + 1e-5) < leave_lim);
+                    szR[j] = cc > 0 ? (mc + cc) * (ml[j] ? 2u : 1u) : 0u;
+                    gR[j] = mc * (ml[j] ? 2u : 1u);
+                } else {
+                    szR[j] = mc;  // (v3: a bin that is not reverted keeps its map points)
+                }
+                ssz += szR[j];
+                sg += gR[j];
+            }
+        }
+        uint32_t t4, t5, t6;
+        uint32_t p4 = block_excl_scan(ssz, sm, t4);
+        uint32_t p5 = block_excl_scan(sg, sm, t5);
+        uint32_t pr = block_excl_scan(nrv, sm, t6);
+#pragma unroll
+        for (int j = 0; j < SRT_KPT; ++j)
+            if (k0 + j < B) {
+                out_offR[k0 + j] = p4;
+                if (act[j] == 1) {
+                    const uint32_t mc = bs[j].mc, cc = bs[j].cc;
+                    gres_off[pr] = p5;
+                    LateEnt e;
+                    e.start = p4;
+                    e.ndata = cc > 0 ? mc + cc : 0u;
+                    e.ntotal = szR[j];
+                    e.actual = 0u;
+                    late[pr] = e;
+                    e.start = t4 + p5;
+                    e.ndata = mc;
+                    e.ntotal = gR[j];
+                    late[t6 + pr] = e;
+                    ++pr;
+                }
+                p4 += szR[j];
+                p5 += gR[j];
+            }
+        if (threadIdx.x == 0) {
+            const uint32_t ncompl = moff_all[B + 1] - moff_all[B];
+            st->total_binsR = t4;
+            st->ground_res = t5;
+            st->n_late = 2u * t6;
+            st->n_compl = ncompl;
+            st->nF_new = t4 + t5 + ncompl;  // (an EXTENT; nF_valid_new follows when the reverted bins are through: k_assemble_late)
+        }
+    }
 }
 __global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict__ mcnt, const float *__restrict__ mmin,
                                                 const float *__restrict__ mmax, const uint32_t *__restrict__ ccnt,
@@ -2732,11 +2816,16 @@ __global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict_
                                                 uint8_t *__restrict__ status, uint8_t *__restrict__ action, uint32_t *__restrict__ rev_idx,
                                                 uint32_t *__restrict__ rev_list, uint32_t *__restrict__ vox_off, DevState *st,
                                                 uint32_t *__restrict__ out_off0, uint32_t *__restrict__ rev_before,
-                                                uint32_t *__restrict__ crej_off, const uint8_t *__restrict__ st1_in) {
+                                                uint32_t *__restrict__ crej_off, const uint8_t *__restrict__ st1_in,
+                                                // round 5: the bins' shares of the voxel scratch by position (the per-bin launch finds its bins
+                                                // itself, see k_revert_bins_srt) and the RESERVED layout (see srt4_body); nullptr: neither
+                                                const uint32_t *__restrict__ moff_pos = nullptr, const uint32_t *__restrict__ qoff_pos = nullptr,
+                                                uint32_t *__restrict__ out_offR = nullptr, uint32_t *__restrict__ gres_off = nullptr,
+                                                LateEnt *__restrict__ late = nullptr, double leave_lim = -1.0) {
     __shared__ uint32_t sm[40];
     __shared__ uint8_t s_st1[1024 * SRT_KPT];
     srt4_body(P, sm, s_st1, mcnt, mmin, mmax, ccnt, cmin, cmax, st1, status, action, rev_idx, rev_list, vox_off, st, out_off0, rev_before, crej_off,
-              st1_in);
+              st1_in, moff_pos, qoff_pos, out_offR, gres_off, late, leave_lim, moff_pos);
 }
 
 // Round 4: which bin is entry `rk` of the reverted list -- WITHOUT the list.  In v3 a bin is reverted iff its first-pass status
@@ -3282,6 +3371,7 @@ __global__ __launch_bounds__(1024) void k_layout(DP P, const uint8_t *__restrict
         st->n_static_est = carry[0] + carry[1];
         st->n_compl = ncompl;
         st->nF_new = carry[0] + carry[1] + ncompl;
+        st->nF_valid_new = carry[0] + carry[1] + ncompl;
     }
 }
 
@@ -3355,6 +3445,7 @@ __global__ __launch_bounds__(1024) void k_layout4(DP P, const uint8_t *__restric
         st->n_static_est = t0 + t1;
         st->n_compl = ncompl;
         st->nF_new = t0 + t1 + ncompl;
+        st->nF_valid_new = t0 + t1 + ncompl;
     }
 }
 
@@ -3391,7 +3482,10 @@ __device__ __forceinline__ void block_commit_labels(uint32_t d, uint32_t s, unsi
 // exclusive prefixes over the (few) reverted bins of their output sizes, their ground and their rejected points, in LDS -- and
 // workgroup 0 also leaves the final tables and totals for the getters and k_step_end.
 static constexpr uint32_t ASM_RVMAX = 1024;  // reverted bins whose prefixes fit the LDS tables (more: summed on the fly, correct and slow)
-template <bool XFORM, bool FOLD>
+// RES (round 5): the EARLY half of a write-back in the reserved layout (see srt4_body): everything that does not wait for the per-bin launch
+// -- the bins that are not reverted, the complement -- at the offsets `out_off0` (= out_offR here) and the extents in *st; the reverted
+// bins' voxels, ground and rejected points follow in k_assemble_late.  No FOLD, no tail.
+template <bool XFORM, bool FOLD, bool RES = false>
 __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8_t *__restrict__ action,
                                                        const uint32_t *__restrict__ rev_idx, const uint32_t *__restrict__ skeys,
                                                        const float4 *__restrict__ spts, const uint32_t *__restrict__ ssrc,
@@ -3475,6 +3569,9 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
         }
         total_bins = st->total_bins0 + s_carry[0];
         n_static_est = total_bins + s_carry[1];
+    } else if constexpr (RES) {
+        total_bins = st->total_binsR;
+        n_static_est = total_bins + st->ground_res;
     } else {
         total_bins = st->total_bins;
         n_static_est = st->n_static_est;
@@ -3492,6 +3589,7 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
     };
     auto OUT_OFF = [&](uint32_t key) -> uint32_t {
         if constexpr (FOLD) return out_off0[key] + cum(rev_before[key], 0);
+        else if constexpr (RES) return out_off0[key];
         else return out_off[key];
     };
     auto GROUND_OFF = [&](uint32_t rk) -> uint32_t {
@@ -3517,6 +3615,7 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
                 st->n_static_est = n_static_est;
                 st->n_compl = ncompl;
                 st->nF_new = n_static_est + ncompl;
+                st->nF_valid_new = n_static_est + ncompl;
             }
         }
     }
@@ -3541,6 +3640,7 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_act; i += gmap * blockDim.x) {
         uint32_t nwr = 0;
         const uint32_t key = skeys[i];
+        if (key > (uint32_t)P.B) continue;  // (round 5: a VoI-order slot kept for a late point that never came, bucket B + 1)
         const float4 p = spts[i];
         const float4 w = XFORM ? xform(Tb2o, p) : p;
         if (key == (uint32_t)P.B) {
@@ -3549,7 +3649,9 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
         } else {
             const uint8_t act = action[key];
             const uint32_t r = i - moff[key];
-            if (act == 1) {
+            if (RES && act == 1) {
+                // (k_assemble_late, once the bin's ground is known)
+            } else if (act == 1) {
                 const uint32_t rk = rev_idx[key];
                 const uint32_t gr = grank[i];
                 if (gflag[i]) {
@@ -3609,6 +3711,178 @@ __global__ __launch_bounds__(256) void k_assemble_bins(DP P, Xf Tb2o, const uint
             const float4 p = sq[qo + j];
             Fnew[oo + j] = XFORM ? xform(Tb2o, p) : p;
             if (is_dynamic_label(p.w)) ++nd; else ++nst;
+        }
+    }
+    block_commit_labels(nd, nst, cnt);
+}
+
+// Round 5: the LATE half of a write-back in the reserved layout -- what had to wait for the per-bin launch.  One workgroup per reverted bin
+// (grid-stride over the list): the bin's voxels (erasor.cpp:521-528) into its reserved range, its ground into its range of the ground_viz
+// part (erasor.cpp:527, 616), holes (x = HOLE_BITS) into whatever of both stays empty, its rejected points into map_rejected
+// (erasor.cpp:528) with their pre-step map indices; workgroup 0 leaves the DENSE tables and totals the getters and the step's end read
+// (what k_layout4 / k_assemble_map<., true> leave), the late table's `actual` column and the holes before every entry.
+// src_late / src_holes / n_src_late: the late table of the step that WROTE the region this step read (its source indices count reserved
+// slots: idx - holes before idx = the logical index), nullptr / 0: that region was dense.
+__device__ __forceinline__ uint32_t late_logical(uint32_t src, const LateEnt *__restrict__ tab, const uint32_t *__restrict__ holes, uint32_t n) {
+    if (!n) return src;
+    uint32_t lo = 0, hi = n;  // first entry whose range ends beyond src
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tab[mid].start + tab[mid].ntotal <= src) lo = mid + 1;
+        else hi = mid;
+    }
+    return src - holes[lo];  // (src lies before or inside entry lo: inside, its data slots are dense from the range's start)
+}
+__global__ __launch_bounds__(256) void k_assemble_late(DP P, Xf Tb2o, const uint32_t *__restrict__ rev_list, const float4 *__restrict__ spts,
+                                                        const uint32_t *__restrict__ ssrc, const uint32_t *__restrict__ moff,
+                                                        const uint32_t *__restrict__ qoff, const uint8_t *__restrict__ gflag,
+                                                        const uint32_t *__restrict__ grank, const uint32_t *__restrict__ ng_arr,
+                                                        const uint32_t *__restrict__ nvox, const uint32_t *__restrict__ vox_off,
+                                                        const float4 *__restrict__ vox_out, const uint32_t *__restrict__ out_offR,
+                                                        const uint32_t *__restrict__ gres_off, const uint32_t *__restrict__ out_off0,
+                                                        const uint32_t *__restrict__ rev_before, LateEnt *__restrict__ late,
+                                                        uint32_t *__restrict__ late_holes, uint32_t *__restrict__ out_off,
+                                                        uint32_t *__restrict__ ground_off, uint32_t *__restrict__ rej_off, DevState *st,
+                                                        float4 *__restrict__ Fnew, float4 *__restrict__ rejected,
+                                                        uint32_t *__restrict__ rejected_src, unsigned long long *cnt,
+                                                        const LateEnt *__restrict__ src_late, const uint32_t *__restrict__ src_holes,
+                                                        uint32_t n_src_late) {
+    __shared__ uint32_t s_sm[40];
+    __shared__ uint32_t s_carry[4];
+    __shared__ uint32_t s_cvl[ASM_RVMAX + 1];
+    const uint32_t n_rev = st->n_rev;
+    const uint32_t total_binsR = st->total_binsR;
+    const float4 hole = make_float4(__uint_as_float(HOLE_BITS), 0.f, 0.f, 0.f);
+    auto sizes = [&](uint32_t rk, uint32_t &sz, uint32_t &g, uint32_t &rj) {
+        const uint32_t key = rev_list[rk];
+        const uint32_t cc = qoff[key + 1] - qoff[key], mc = moff[key + 1] - moff[key];
+        g = ng_arr[rk];
+        rj = mc - g;
+        sz = cc > 0 ? nvox[rk] : 0u;  // an unoccupied bin_curr: r_pod2pc skips the bin (erasor.cpp:313)
+    };
+    // rejected points before reverted bin rk (dense map_rejected): summed by the workgroup that needs it
+    auto rej_before = [&](uint32_t rk) -> uint32_t {
+        uint32_t a = 0;
+        for (uint32_t r = threadIdx.x; r < rk; r += blockDim.x) {
+            uint32_t sz, g, rj;
+            sizes(r, sz, g, rj);
+            a += rj;
+        }
+        uint32_t t;
+        (void)block_excl_scan(a, s_sm, t);
+        return t;
+    };
+    uint32_t nd = 0, nst = 0;
+    for (uint32_t rk = blockIdx.x; rk < n_rev; rk += gridDim.x) {
+        const uint32_t key = rev_list[rk];
+        const uint32_t o0 = moff[key], mc = moff[key + 1] - o0;
+        uint32_t nv, ng, rj;
+        sizes(rk, nv, ng, rj);
+        const uint32_t rej0 = rej_before(rk);
+        const LateEnt eb = late[rk], eg = late[n_rev + rk];
+        const uint32_t vo = vox_off[rk];
+        for (uint32_t v = threadIdx.x; v < eb.ntotal; v += blockDim.x) {
+            float4 w = hole;
+            if (v < nv) {
+                const float4 p = vox_out[vo + v];
+                w = xform(Tb2o, p);
+                if (is_dynamic_label(p.w)) ++nd; else ++nst;
+            }
+            Fnew[eb.start + v] = w;
+        }
+        for (uint32_t j = threadIdx.x; j < mc; j += blockDim.x) {
+            const uint32_t i = o0 + j;
+            const float4 p = spts[i];
+            const uint32_t gr = grank[i];
+            if (gflag[i]) {
+                Fnew[eg.start + gr] = xform(Tb2o, p);  // ground_viz copy (the bin itself holds the voxelised curr + ground)
+                if (is_dynamic_label(p.w)) ++nd; else ++nst;
+            } else {
+                rejected[rej0 + gr] = xform(Tb2o, p);  // map_rejected_ is handed out in the map frame (OMU.cpp:287)
+                rejected_src[rej0 + gr] = late_logical(ssrc[i], src_late, src_holes, n_src_late);
+            }
+        }
+        for (uint32_t v = ng + threadIdx.x; v < eg.ntotal; v += blockDim.x) Fnew[eg.start + v] = hole;
+        if (threadIdx.x == 0) {
+            late[rk].actual = nv;
+            late[n_rev + rk].actual = ng;
+        }
+        __syncthreads();
+    }
+    (void)gres_off;
+    (void)total_binsR;
+    if (blockIdx.x == 0) {
+        // dense tables and totals (k_layout4's): prefixes over the reverted bins of their output sizes, ground, rejected points
+        if (threadIdx.x < 4) s_carry[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t base = 0; base < n_rev; base += blockDim.x) {
+            const uint32_t rk = base + threadIdx.x;
+            uint32_t sz = 0, g = 0, rj = 0, hl = 0;
+            if (rk < n_rev) {
+                sizes(rk, sz, g, rj);
+                hl = late[rk].ntotal - sz;
+            }
+            uint32_t t0, t1, t2, t3;
+            const uint32_t p0 = block_excl_scan(sz, s_sm, t0);
+            const uint32_t p1 = block_excl_scan(g, s_sm, t1);
+            const uint32_t p2 = block_excl_scan(rj, s_sm, t2);
+            const uint32_t p3 = block_excl_scan(hl, s_sm, t3);
+            const uint32_t c0 = s_carry[0], c1 = s_carry[1], c2 = s_carry[2], c3 = s_carry[3];
+            if (rk < n_rev) {
+                // (late_holes[i]: holes in the ranges before entry i; the bins' entries first, the ground entries follow below)
+                late_holes[rk] = c3 + p3;
+                ground_off[rk] = c1 + p1;
+                rej_off[rk] = c2 + p2;
+                if (rk < ASM_RVMAX) s_cvl[rk] = c0 + p0;  // voxels of the reverted bins before rk (out_off by key, below)
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                s_carry[0] = c0 + t0;
+                s_carry[1] = c1 + t1;
+                s_carry[2] = c2 + t2;
+                s_carry[3] = c3 + t3;
+            }
+            __syncthreads();
+        }
+        const uint32_t sum_sz = s_carry[0], sum_g = s_carry[1], sum_rj = s_carry[2], holes_bins = s_carry[3];
+        if (threadIdx.x == 0 && n_rev < ASM_RVMAX + 1) s_cvl[n_rev] = sum_sz;
+        __syncthreads();
+        // ground entries' holes
+        if (threadIdx.x == 0) s_carry[3] = holes_bins;
+        __syncthreads();
+        for (uint32_t base = 0; base < n_rev; base += blockDim.x) {
+            const uint32_t rk = base + threadIdx.x;
+            uint32_t hl = 0;
+            if (rk < n_rev) hl = late[n_rev + rk].ntotal - ng_arr[rk];
+            uint32_t t3;
+            const uint32_t p3 = block_excl_scan(hl, s_sm, t3);
+            const uint32_t c3 = s_carry[3];
+            if (rk < n_rev) late_holes[n_rev + rk] = c3 + p3;
+            __syncthreads();
+            if (threadIdx.x == 0) s_carry[3] = c3 + t3;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) late_holes[2 * n_rev] = s_carry[3];  // (all of them: what a source index behind the last range is reduced by)
+        // dense out_off by key: out_off0[key] + the voxels of the reverted bins before it
+        for (uint32_t key = threadIdx.x; key < (uint32_t)P.B; key += blockDim.x) {
+            const uint32_t rb = rev_before[key];
+            uint32_t a = 0;
+            if (rb <= ASM_RVMAX && n_rev <= ASM_RVMAX) a = s_cvl[rb];
+            else
+                for (uint32_t r = 0; r < rb; ++r) {  // (more reverted bins than the table holds: walk them)
+                    uint32_t sz, g, rj;
+                    sizes(r, sz, g, rj);
+                    a += sz;
+                }
+            out_off[key] = out_off0[key] + a;
+        }
+        if (threadIdx.x == 0) {
+            const uint32_t total_bins = st->total_bins0 + sum_sz;
+            st->total_bins = total_bins;
+            st->n_ground = sum_g;
+            st->n_rejected = sum_rj;
+            st->n_static_est = total_bins + sum_g;
+            st->nF_valid_new = total_bins + sum_g + st->n_compl;
         }
     }
     block_commit_labels(nd, nst, cnt);
@@ -3705,6 +3979,17 @@ __global__ __launch_bounds__(256) void k_o_compact(const float2 *__restrict__ Ox
     if (!flag[i]) return;
     const float2 a = Oxy[o_begin + i], b = Ozi[o_begin + i];
     dst[pl[i] + tops[i >> 10]] = make_float4(a.x, a.y, b.x, b.y);
+}
+
+// round 5: the same for the VoI-resident region when it holds reserved slots nothing filled (x == HOLE_BITS)
+__global__ __launch_bounds__(256) void k_f_valid(const float4 *__restrict__ F, uint32_t n, uint32_t *__restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (__float_as_uint(F[i].x) != HOLE_BITS) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_f_compact(const float4 *__restrict__ F, uint32_t n, const uint32_t *__restrict__ flag,
+                                                    const uint32_t *__restrict__ pl, const uint32_t *__restrict__ tops, float4 *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) dst[pl[i] + tops[i >> 10]] = F[i];
 }
 
 // ---- large-scale mode: set_submap (OMU.cpp:360-379) ------------------------------------------------

@@ -806,8 +806,11 @@ __device__ __attribute__((noinline)) void srt4_call() {
     srt4_body(P, sm, s_st1, a.mcnt, a.mmin, a.mmax, a.ccnt, a.cmin, a.cmax, a.st1, a.status, a.action, a.rev_idx, a.rev_list, a.vox_off, a.st, a.out_off0,
               a.rev_before, a.crej_off, a.st1_in, a.moff, a.qoff);
 }
+// (round 5: sa.status == nullptr -- no extra workgroup: k_srt4 runs as a launch of its own on the stream that writes the map back EARLY)
 __global__ __launch_bounds__(1024) void k_revert_bins_srt(DP P, SrtArgs sa, RevArgs ra) {
-    if (blockIdx.x == gridDim.x - 1) {
+    const bool has_srt = sa.status != nullptr;
+    const uint32_t stride = gridDim.x - (has_srt ? 1u : 0u);
+    if (has_srt && blockIdx.x == gridDim.x - 1) {
         if (threadIdx.x == 0) {
             g_srt_args = sa;
             g_dp = P;
@@ -818,7 +821,7 @@ __global__ __launch_bounds__(1024) void k_revert_bins_srt(DP P, SrtArgs sa, RevA
     }
     const unsigned long long w0 = ra.dbg ? wall_clock64() : 0ull;
     rev_open(P, ra);
-    for (uint32_t rk = blockIdx.x;; rk += gridDim.x - 1) {
+    for (uint32_t rk = blockIdx.x;; rk += stride) {
         __syncthreads();  // (g_sel of the previous round has been read)
         const unsigned long long w1 = ra.dbg ? wall_clock64() : 0ull;
         rev_select_call(P.B, sa.st1_in, rk);
