@@ -889,7 +889,7 @@ def main():
             ("large_scale_05", "config 4 with the chunk records OFF (ERASOR_HIP_NO_OMETA=1): the VoI pass streams the whole map store -- "
                                "the HBM-bound measurement of k_voi_split", [], {"ERASOR_HIP_NO_OMETA": "1"}, False),
             ("seq05_yaml", "config 2, config/seq_05.yaml verbatim", [], {}, False),
-            ("ouster128", "config 5 shape, 1 GPU", ["--lookahead", "3"], {"ERASOR_HIP_QSTREAMS": "3"}, False),
+            ("ouster128", "config 5 shape, 1 GPU", ["--lookahead", "3"], {}, False),
         )
         for wname, label, xargs, xenv, verified in passes:
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", wname, "--steps", "12" if verified else "20", "--warmup",

@@ -196,8 +196,10 @@ class Erasor:
         return self.get_cloud(CLOUD_MAP)
 
     # -- step --
-    def prefetch(self, scan, T_l2b, T_b2o=None):
-        """announce the next scan (host array): its query chain starts now, beside the step in flight"""
+    def prefetch(self, scan, T_l2b, T_b2o=None, T_o2b=None):
+        """announce the next scan (host array): its query chain starts now, beside the step in flight.  With the node's pose its VoI
+        split goes ahead as well; with T_o2b too (erasor_hip_announce_origin2body) the whole front of its step runs beside the per-bin
+        launch of the step before it (overlapped steps)"""
         scan = _f32(scan).reshape(-1, 4)
         # every announced buffer stays alive until a step has consumed it (up to four scans can be outstanding; a freed
         # buffer's address could be handed to the next np.ascontiguousarray)
@@ -206,14 +208,18 @@ class Erasor:
             self._check(lib().erasor_hip_prefetch_scan(self._h, _p(scan), C.c_size_t(len(scan)), C.c_int(0), _m(T_l2b)))
         else:
             self._check(lib().erasor_hip_prefetch_node(self._h, _p(scan), C.c_size_t(len(scan)), C.c_int(0), _m(T_l2b), _m(T_b2o)))
+            if T_o2b is not None:
+                self._check(lib().erasor_hip_announce_origin2body(self._h, _m(T_o2b)))
         return scan
 
-    def prefetch_device(self, d_ptr, n, T_l2b, T_b2o=None):
+    def prefetch_device(self, d_ptr, n, T_l2b, T_b2o=None, T_o2b=None):
         """announce the next scan (device buffer, read in place); with its pose the next step's VoI split is launched ahead"""
         if T_b2o is None:
             self._check(lib().erasor_hip_prefetch_scan(self._h, C.c_void_p(d_ptr), C.c_size_t(n), C.c_int(1), _m(T_l2b)))
         else:
             self._check(lib().erasor_hip_prefetch_node(self._h, C.c_void_p(d_ptr), C.c_size_t(n), C.c_int(1), _m(T_l2b), _m(T_b2o)))
+            if T_o2b is not None:
+                self._check(lib().erasor_hip_announce_origin2body(self._h, _m(T_o2b)))
 
     def step(self, scan, T_l2b, T_b2o, T_o2b):
         scan = _f32(scan).reshape(-1, 4)
@@ -408,6 +414,12 @@ class Erasor:
     def ahead_split_counts(self):
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._check(lib().erasor_hip_ahead_split_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def overlap_counts(self):
+        """(steps whose front was launched beside the previous step's per-bin launch, steps that took it)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(lib().erasor_hip_overlap_counts(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def chain_timing(self, reset=False):

@@ -17,8 +17,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/erasor_hip.h"
@@ -132,6 +136,12 @@ struct QSide {
     bool h2d_pending = false;         // the chain that reads q.scan has to wait for ev_h2d
     hipEvent_t ev_keys = nullptr;     // voxel keys (and the VoxelGrid overflow flag) are final
     hipEvent_t ev_done = nullptr;     // the whole query chain of the scan is done
+    // round 5: with the steps overlapped two query streams are all the hardware queues leave (main + early + 2: a fifth busy queue slows
+    // every kernel of every queue 3-8 x), and the two chains in flight bound the step.  The chain of a node announced with both transforms
+    // therefore ENDS behind its centroids (ev_p1); its label search, bucketing and bin statistics -- a quarter of its time -- run on the
+    // early stream, behind the early passes of the step in front of the node's own (enqueue_chain_part2), where that stream idles
+    hipEvent_t ev_p1 = nullptr;
+    bool p2_pending = false;          // the chain's second part has not been enqueued yet
     // bookkeeping of a chain that has been enqueued (erasor_hip_prefetch_scan) but not yet consumed by a step
     const void *src = nullptr;
     size_t src_n = 0;
@@ -144,6 +154,8 @@ struct QSide {
     bool used = false;                // ev_done has been recorded at least once
     bool pose_valid = false;          // the scan was announced together with its pose (erasor_hip_prefetch_node)
     double pose_x = 0, pose_y = 0;    // T_body2origin translation (OMU.cpp:246-247): all fetch_VoI needs
+    bool to_valid = false;            // ... and with T_origin2body (erasor_hip_announce_origin2body): the next step's gather can go ahead too
+    float To[16] = {0};
     GSeg gseg[2];                     // the chain as two graphs: up to the voxel keys (ev_keys), the rest (ev_done)
 };
 
@@ -158,6 +170,11 @@ struct erasor_hip_handle {
     hipStream_t qstream[NQS_MAX] = {nullptr, nullptr, nullptr, nullptr};
     int nqs = 2;  // query streams in use (ERASOR_HIP_QSTREAMS, 1..4)
     hipStream_t cstream = nullptr;  // host scans on their way into a query side (staged, asynchronous)
+    // round 5: the stream of the EARLY write-back and of the next step's passes that run beside the per-bin launch (k_srt4, k_assemble_map<RES>,
+    // k_voi_split / k_chunk_scan_* / k_voi_gather in overlap mode), and the events the two streams meet at
+    hipStream_t bstream = nullptr;
+    bool bstream_own = false;
+    hipEvent_t ev_stats = nullptr, ev_srt4 = nullptr, ev_asm = nullptr, ev_early = nullptr;
     unsigned n_chain = 0;
     hipStream_t cur = nullptr;      // stream LAUNCH() currently targets
     std::vector<GNode> *rec = nullptr;  // non-null: LAUNCH() records instead of launching (the query chain as a graph)
@@ -176,7 +193,10 @@ struct erasor_hip_handle {
         RowFmt fmt;
         bool pose_valid = false;
         double pose_x = 0, pose_y = 0;
+        bool to_valid = false;
+        float To[16] = {0};
     } ann;
+    int last_ann_side = -1;  // the side of the most recent announcement (erasor_hip_announce_origin2body attaches to it)
     uint64_t next_ticket = 1;
     // the NEXT step's VoI split, launched ahead (behind this step's k_step_end) when the next scan was announced with its pose
     struct {
@@ -191,6 +211,34 @@ struct erasor_hip_handle {
         uint32_t cap_chunks = 0;
         const void *vmask = nullptr, *hmask = nullptr, *cinfo = nullptr;
     } spec;
+    // round 5: what was launched for the NEXT step beside this step's per-bin launch (OVERLAPPED steps): split, chunk scan and gather
+    // without the late table's slots on bstream, then -- behind the per-bin launch -- k_late_gather (which also ends the step in
+    // flight), the bucket histogram and its column scan.  The step that follows takes all of it if it is exactly the step assumed here.
+    struct {
+        bool valid = false;
+        unsigned long long seq = 0, epoch = 0;
+        int curF = 0, qside = -1;
+        double x = 0, y = 0;
+        float To[16] = {0};
+        uint32_t cap_chunks = 0, cap_voi = 0, nbk = 0;
+        const void *vmask = nullptr, *hmask = nullptr, *lmask = nullptr, *cinfo = nullptr, *pvl = nullptr, *phl = nullptr, *voi_ego = nullptr,
+                   *mb_hist = nullptr;
+    } ov;
+    unsigned long long n_ov_launched = 0, n_ov_used = 0;
+    bool ov_mode = false;  // the last step used the reserved layout / the early stream: query chains keep to TWO streams then
+    // round 5: a step is ~45 launches, ~30 of them the query chain of a scan announced ahead -- with the steps overlapped the HOST had
+    // become the bound (180 us of launch calls per step against a 120 us chain on the device).  The chain's launches go to a worker
+    // thread of the handle: the caller's thread dispatches a job (allocations, staging, bookkeeping stay with it) and goes on with the
+    // main chain; whoever needs the chain's events first waits until the worker has recorded them (chain_wait).
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<std::function<int()>> jobs;
+        bool stop = false;
+        std::atomic<int> busy[NSIDE];  // jobs of a side that are not enqueued yet
+        std::atomic<int> err{0};
+    } *worker = nullptr;
     unsigned long long store_epoch = 0;  // bumped by everything that rewrites the map store outside a step
     unsigned long long n_spec_used = 0, n_spec_launched = 0;
     unsigned n_split_launch = 0;         // k_voi_split launches seen by the sampled roofline measurement (erasor_hip_profiling(h, 3))
@@ -253,7 +301,7 @@ struct erasor_hip_handle {
     uint32_t n_reassign = 0;
     uint64_t o_valid = 0;          // live outskirts entries
     // ---- VoI split ----
-    DBuf<unsigned long long> vmask, hmask;
+    DBuf<unsigned long long> vmask, hmask, lmask;  // (lmask: the late table's slots, overlapped steps)
     DBuf<uint32_t> cinfo, pvl, phl, topv, toph, topr;
     DBuf<OMeta> ometa;  // one record per outskirts chunk (bounding box, valid count): chunks outside the VoI circle are not read
     bool use_ometa = true;
@@ -279,6 +327,16 @@ struct erasor_hip_handle {
     DBuf<uint32_t> gsK, gsV, gsL, gsR, gsK2, gsV2;
     DBuf<uint32_t> gsH;
     DBuf<float4> gsC, vox_out;
+    // ---- round 5: what consecutive steps must not share (an overlapped step's early passes run while the step in flight still reads its
+    // own): VoI-order arrays, bin offsets, state, counters, label tallies.  The names above / below are the CURRENT step's set; `alt` is
+    // the other one, where the passes launched ahead write; the two change places when a step is enqueued (swap_sides)
+    struct {
+        DBuf<float4> voi_ego;
+        DBuf<uint32_t> voi_key, voi_src, moff;
+        DBuf<DevState> d_st;
+        DBuf<Counters> d_ctr;
+        DBuf<unsigned long long> lab_slots;
+    } alt;
     // ---- state ----
     DBuf<DevState> d_st, d_st_get;  // (d_st_get: a copy of the last finished step's state for the getters, see assemble_egocentric)
     DBuf<Counters> d_ctr;
@@ -297,7 +355,16 @@ struct erasor_hip_handle {
     std::vector<hipEvent_t> evt_pool;
 };
 
-#define Q(h) ((h)->q[(h)->qi])
+// (round 5: the worker thread launches a query chain with its OWN target stream and query side -- the caller's thread goes on using
+// the handle's --: LAUNCH() and Q() look here first)
+struct TlCtx {
+    const erasor_hip_handle *h = nullptr;
+    hipStream_t cur = nullptr;
+    int qi = 0;
+};
+static thread_local TlCtx g_tl;
+#define Q(h) ((h)->q[g_tl.h == (h) ? g_tl.qi : (h)->qi])
+#define CUR(h) (g_tl.h == (h) ? g_tl.cur : (h)->cur)
 // between erasor_hip_step_async and erasor_hip_step_wait the handle takes no other call: the step's scratch, query side and
 // host mirror are in use
 #define NOFLY(h)                                                                                              \
@@ -396,16 +463,16 @@ void prof_collect(erasor_hip_handle *h, bool force = false) {
             pe_.name_id = prof_id((h), name);                                     \
             pe_.a = get_evt(h);                                                   \
             pe_.b = get_evt(h);                                                   \
-            (void)hipEventRecord(pe_.a, (h)->cur);                                \
+            (void)hipEventRecord(pe_.a, CUR(h));                                  \
         }                                                                         \
         if (g_debug_sync) fprintf(stderr, "[erasor_hip] launch %s grid=%u\n", name, (unsigned)(grid)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (h)->cur, __VA_ARGS__); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, CUR(h), __VA_ARGS__);   \
         if (g_debug_sync) {                                                       \
-            hipError_t e2_ = hipStreamSynchronize((h)->cur);                      \
+            hipError_t e2_ = hipStreamSynchronize(CUR(h));                        \
             if (e2_ != hipSuccess) fprintf(stderr, "[erasor_hip]   -> %s\n", hipGetErrorString(e2_)); \
         }                                                                         \
         if (prof_) {                                                              \
-            (void)hipEventRecord(pe_.b, (h)->cur);                                \
+            (void)hipEventRecord(pe_.b, CUR(h));                                  \
             (h)->pending.push_back(pe_);                                          \
         }                                                                         \
     } while (0)
@@ -501,7 +568,7 @@ int alloc_bins(erasor_hip_handle *h) {
         rc |= ensure(h, Q(h).d_nvox, 4) | ensure(h, Q(h).d_qctr, 1);
     }
     h->qi = keep;
-    rc |= ensure(h, h->moff, B + 2) | ensure(h, h->mcnt, B);
+    rc |= ensure(h, h->moff, B + 4) | ensure(h, h->alt.moff, B + 4) | ensure(h, h->mcnt, B);
     rc |= ensure(h, h->mmin, B) | ensure(h, h->mmax, B);
     rc |= ensure(h, h->st1, B) | ensure(h, h->status, B) | ensure(h, h->action, B) | ensure(h, h->rev_idx, B) | ensure(h, h->rev_list, B);
     rc |= ensure(h, h->out_off0, B + 2) | ensure(h, h->rev_before, B + 2) | ensure(h, h->st1b, B + 8);
@@ -510,7 +577,8 @@ int alloc_bins(erasor_hip_handle *h) {
     rc |= ensure(h, h->vox_off, B) | ensure(h, h->nvox, B) | ensure(h, h->ng, B) | ensure(h, h->out_off, B) | ensure(h, h->ground_off, B);
     rc |= ensure(h, h->rej_off, B) | ensure(h, h->crej_off, B);
     rc |= ensure(h, h->plane_n, B * (size_t)std::max(h->P.gf_iter, 1) * 3) | ensure(h, h->plane_d, B * (size_t)std::max(h->P.gf_iter, 1));
-    rc |= ensure(h, h->d_st, 1) | ensure(h, h->d_ctr, 1) | ensure(h, h->dn, 16) | ensure(h, h->lab_slots, 128) | ensure(h, h->mb_tot, B + 2);
+    rc |= ensure(h, h->d_st, 1) | ensure(h, h->d_ctr, 1) | ensure(h, h->dn, 16) | ensure(h, h->lab_slots, 128) | ensure(h, h->mb_tot, B + 4);
+    rc |= ensure(h, h->alt.d_st, 1) | ensure(h, h->alt.d_ctr, 1) | ensure(h, h->alt.lab_slots, 128);
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
 
@@ -531,6 +599,7 @@ int alloc_map(erasor_hip_handle *h, uint32_t n) {
     rc |= ensure(h, h->Oxy, h->capO) | ensure(h, h->Ozi, h->capO);
     const uint32_t V = h->capV;
     rc |= ensure(h, h->voi_ego, V) | ensure(h, h->spts, V) | ensure(h, h->voi_key, V) | ensure(h, h->voi_src, V) | ensure(h, h->ssrc, V);
+    rc |= ensure(h, h->alt.voi_ego, V) | ensure(h, h->alt.voi_key, V) | ensure(h, h->alt.voi_src, V);
     rc |= ensure(h, h->rejected, V) | ensure(h, h->rejected_src, V) | ensure(h, h->grank, V) | ensure(h, h->glist, V) | ensure(h, h->gflag, V);
     rc |= ensure(h, h->rk_a, V) | ensure(h, h->rk_b, V) | ensure(h, h->rv_a, V) | ensure(h, h->rv_b, V);
     return rc ? ERASOR_E_NO_DEVICE : 0;
@@ -551,6 +620,7 @@ int grow_map_scratch(erasor_hip_handle *h, uint64_t need) {
     const uint32_t V = h->capV;
     int rc = 0;
     rc |= ensure(h, h->voi_ego, V) | ensure(h, h->spts, V) | ensure(h, h->voi_key, V) | ensure(h, h->voi_src, V) | ensure(h, h->ssrc, V);
+    rc |= ensure(h, h->alt.voi_ego, V) | ensure(h, h->alt.voi_key, V) | ensure(h, h->alt.voi_src, V);
     rc |= ensure(h, h->rejected, V) | ensure(h, h->rejected_src, V) | ensure(h, h->grank, V) | ensure(h, h->glist, V) | ensure(h, h->gflag, V);
     rc |= ensure(h, h->rk_a, V) | ensure(h, h->rk_b, V) | ensure(h, h->rv_a, V) | ensure(h, h->rv_b, V);
     h->have_step = false;  // the previous step's read-back clouds lived in these arrays
@@ -634,6 +704,11 @@ int copy_F_dense(erasor_hip_handle *h, float4 *dst) {
 // rebuild the outskirts region without tombstones at the end of the buffer (stable)
 int rebuild_outskirts(erasor_hip_handle *h, uint32_t min_front_room) {
     ++h->store_epoch;
+    if (getenv("ERASOR_HIP_CHAIN_STAMPS"))
+        fprintf(stderr, "[rebuild_outskirts] o_begin %u, capO %u, o_valid %llu, nF %u (points %u), front room wanted %u\n", h->o_begin, h->capO,
+                (unsigned long long)h->o_valid, h->nF, h->nFv, min_front_room);
+    if (h->bstream) HIPC(h, hipStreamSynchronize(h->bstream));  // (passes launched ahead of the next step write into the region's front)
+    HIPC(h, hipStreamSynchronize(h->stream));
     const uint32_t span = h->capO - h->o_begin;
     DBuf<uint32_t> flag, pl, tops;
     DBuf<float4> tmp;
@@ -678,6 +753,8 @@ int push_state(erasor_hip_handle *h);
 // into the new submap (stored as outskirts, F empty) and the new complement.  Rare (every ~submap_size/2 of travel).
 int split_submap(erasor_hip_handle *h, double x, double y) {
     ++h->store_epoch;
+    if (h->bstream) HIPC(h, hipStreamSynchronize(h->bstream));
+    HIPC(h, hipStreamSynchronize(h->stream));
     const uint64_t total64 = (uint64_t)h->nFv + h->o_valid + h->nC;
     if (total64 > 0x7FFFFFF0ull) {
         h->err = "map too large for 32-bit indexing";
@@ -830,20 +907,37 @@ int erasor_hip_params_default(erasor_params *p) {
     return ERASOR_OK;
 }
 
+static void worker_start(erasor_hip_handle *h);
+static void worker_stop(erasor_hip_handle *h);
 static bool create_sides(erasor_hip_handle *h, int prio) {
     // round 4: three query streams where the process has the hardware queues for them (main + 3 + copy = 5 streams; HIP's default is 4
     // queues): 233 k-point scans 0.291 -> 0.230 ms, 127 k-point scans the same either way; two otherwise
     if (const char *q = getenv("GPU_MAX_HW_QUEUES")) {
         if (atoi(q) >= 8) h->nqs = 3;
     }
+    // (round 5: FOUR busy compute queues are all the hardware runs side by side -- with a fifth every kernel of every queue slows down
+    // 3-8 x: main + 4 query streams 0.19 -> 0.26 ms per scan, main + early + 3: 0.34 --, so the steps that use the early stream keep their
+    // chains to two of these, see enqueue_query_chain)
     if (const char *e = getenv("ERASOR_HIP_QSTREAMS")) h->nqs = std::max(1, std::min((int)erasor_hip_handle::NQS_MAX, atoi(e)));
     for (int k = 0; k < h->nqs; ++k)
         if (hipStreamCreateWithPriority(&h->qstream[k], hipStreamNonBlocking, prio) != hipSuccess) return false;
     for (int k = 0; k < NSIDE; ++k)
-        if (hipEventCreateWithFlags(&h->q[k].ev_keys, hipEventDisableTiming) != hipSuccess ||
+        if (hipEventCreateWithFlags(&h->q[k].ev_p1, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->q[k].ev_keys, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->q[k].ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->q[k].ev_h2d, hipEventDisableTiming) != hipSuccess)
             return false;
+    // (round 5: every stream that has run something keeps a hardware queue, and with more than four of them in this process' reach -- main,
+    // query streams, early stream; the framework's own on top -- every kernel of every queue slows down 3-8 x, busy or not.  So the early
+    // stream IS the third query stream where there is one: a step uses it either for a chain or for its early passes, see ov_mode)
+    if (h->nqs >= 3) h->bstream = h->qstream[2];
+    else if (hipStreamCreateWithPriority(&h->bstream, hipStreamNonBlocking, prio) != hipSuccess) return false;
+    h->bstream_own = h->nqs < 3;
+    // (events between two streams of ONE device: no system-scope fence -- the cache write-back and invalidation it brings cost the kernels
+    // around it tens of microseconds; ERASOR_HIP_EVT_SYSFENCE=1: the default flags, A/B)
+    const unsigned evf = hipEventDisableTiming | (getenv("ERASOR_HIP_EVT_SYSFENCE") ? 0u : hipEventDisableSystemFence);
+    for (hipEvent_t *e : {&h->ev_stats, &h->ev_srt4, &h->ev_asm, &h->ev_early})
+        if (hipEventCreateWithFlags(e, evf) != hipSuccess) return false;
     return hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) == hipSuccess;
 }
 
@@ -892,6 +986,10 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
     // third handle; 0 of 6 without priorities).  ERASOR_HIP_STREAM_PRIORITIES=1 restores them.
     int prio_lo = 0, prio_hi = 0;
     if (getenv("ERASOR_HIP_STREAM_PRIORITIES")) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (getenv("ERASOR_HIP_QUERY_PRIORITY")) {  // (A/B, round 5: the query streams above the main and the early stream)
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        std::swap(prio_lo, prio_hi);
+    }
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         !create_sides(h, prio_lo) ||
         hipHostMalloc((void **)&h->pin, sizeof(HostOut), hipHostMallocDefault) != hipSuccess) {
@@ -911,6 +1009,7 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
         return ERASOR_E_NO_DEVICE;
     }
     if (g_handles_created.fetch_add(1) >= 1) warn_hw_queues_once();
+    worker_start(h);
     *out = h;
     return ERASOR_OK;
 }
@@ -918,9 +1017,11 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
 void erasor_hip_destroy(erasor_hip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    worker_stop(h);
     for (int k = 0; k < erasor_hip_handle::NQS_MAX; ++k)
         if (h->qstream[k]) (void)hipStreamSynchronize(h->qstream[k]);
     if (h->cstream) (void)hipStreamSynchronize(h->cstream);
+    if (h->bstream) (void)hipStreamSynchronize(h->bstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     prof_collect(h, true);
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
@@ -937,6 +1038,12 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->out_off0); release(h->rev_before); release(h->st1b);
     release(h->out_offR); release(h->gres_off);
     for (int k = 0; k < 2; ++k) { release(h->late[k]); release(h->late_holes[k]); }
+    release(h->lmask);
+    release(h->alt.voi_ego); release(h->alt.voi_key); release(h->alt.voi_src); release(h->alt.moff); release(h->alt.d_st); release(h->alt.d_ctr);
+    release(h->alt.lab_slots);
+    for (hipEvent_t e : {h->ev_stats, h->ev_srt4, h->ev_asm, h->ev_early})
+        if (e) (void)hipEventDestroy(e);
+    if (h->bstream && h->bstream_own) (void)hipStreamDestroy(h->bstream);
     release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
     release(h->mmin); release(h->mmax); release(h->plane_n); release(h->plane_d);
     release(h->st1); release(h->status); release(h->action);
@@ -945,6 +1052,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->vox_out); release(h->d_st); release(h->d_st_get); release(h->d_ctr);
     for (int k = 0; k < NSIDE; ++k) {
         if (h->q[k].ev_keys) (void)hipEventDestroy(h->q[k].ev_keys);
+        if (h->q[k].ev_p1) (void)hipEventDestroy(h->q[k].ev_p1);
         if (h->q[k].ev_done) (void)hipEventDestroy(h->q[k].ev_done);
         if (h->q[k].ev_h2d) (void)hipEventDestroy(h->q[k].ev_h2d);
         if (h->q[k].stage) (void)hipHostFree(h->q[k].stage);
@@ -967,6 +1075,8 @@ static int set_map_common(erasor_hip_handle *h, const void *src, size_t n, bool 
     if (!h) return ERASOR_E_INVALID;
     if (!src && n) return ERASOR_E_INVALID;
     HIPC(h, hipSetDevice(h->device));
+    if (h->bstream) HIPC(h, hipStreamSynchronize(h->bstream));  // (passes launched ahead of a step that will not come)
+    h->ov.valid = false;
     if (n > 0x7FFFFFF0ull) return ERASOR_E_INVALID;
     int rc = alloc_map(h, (uint32_t)n);
     if (rc) return rc;
@@ -1020,7 +1130,8 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n, bool queues_open = 
 #ifndef ESORT_WIDE_SLACK
 #define ESORT_WIDE_SLACK 4
 #endif
-        const int wl = std::min(std::min(esort::lg2_floor(n / WIDE_MIN) + ESORT_WIDE_SLACK, 16), level_cap);
+        static const int wide_slack = getenv("ERASOR_HIP_WIDE_SLACK") ? atoi(getenv("ERASOR_HIP_WIDE_SLACK")) : ESORT_WIDE_SLACK;
+        const int wl = std::min(std::min(esort::lg2_floor(n / WIDE_MIN) + wide_slack, 16), level_cap);
         for (int l = 0; l < wl; ++l) {
             const int cur = l & 1;
             // two launches per level (round 2: three -- the children's routing and median move had a kernel of their own)
@@ -1227,6 +1338,59 @@ static int graph_flush(erasor_hip_handle *h, GSeg &seg, std::vector<GNode> &rec,
     return ERASOR_OK;
 }
 
+// ---- the handle's worker thread (see erasor_hip_handle::Worker) ----
+static void worker_main(erasor_hip_handle *h) {
+    (void)hipSetDevice(h->device);
+    auto *w = h->worker;
+    for (;;) {
+        std::function<int()> job;
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->stop || !w->jobs.empty(); });
+            if (w->jobs.empty()) return;  // (stop, nothing left)
+            job = std::move(w->jobs.front());
+            w->jobs.pop_front();
+        }
+        const int rc = job();
+        if (rc) w->err.store(rc);
+    }
+}
+static void worker_start(erasor_hip_handle *h) {
+#ifndef ERASOR_SIMT_EMU_HIP_RUNTIME_H  // (the CPU stand-in runs a launch synchronously: one thread)
+    if (getenv("ERASOR_HIP_NO_WORKER")) return;
+    h->worker = new erasor_hip_handle::Worker();
+    for (int k = 0; k < NSIDE; ++k) h->worker->busy[k].store(0);
+    h->worker->th = std::thread(worker_main, h);
+#else
+    (void)h;
+#endif
+}
+static void worker_stop(erasor_hip_handle *h) {
+    if (!h->worker) return;
+    {
+        std::lock_guard<std::mutex> lk(h->worker->mu);
+        h->worker->stop = true;
+    }
+    h->worker->cv.notify_all();
+    if (h->worker->th.joinable()) h->worker->th.join();
+    delete h->worker;
+    h->worker = nullptr;
+}
+// the launches (and event records) of side `side`'s chain have all been made; side < 0: of every side
+static int chain_wait(erasor_hip_handle *h, int side) {
+    if (!h->worker) return ERASOR_OK;
+    for (int k = 0; k < NSIDE; ++k) {
+        if (side >= 0 && k != side) continue;
+        while (h->worker->busy[k].load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+    }
+    const int e = h->worker->err.exchange(0);
+    if (e) {
+        h->err = "a query chain could not be enqueued (worker thread)";
+        return e;
+    }
+    return ERASOR_OK;
+}
+
 // a query side no announced / in-flight chain owns; the side of the last finished step only if nothing else is free
 // (its query-derived outputs are then gone)
 static int pick_side(const erasor_hip_handle *h) {
@@ -1284,11 +1448,17 @@ static int enqueue_passthrough(erasor_hip_handle *h, const float4 *d_src, uint32
 // 2 = the side's OWN announcement once more (its chain ran in the wrong VoxelGrid mode, step_collect): scan, ticket, hash and pose stay
 static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_src, uint32_t ns, bool src_is_device, const float T_l2b[16],
                                bool prevox, int staged = 0, bool passthrough = false, RowFmt fmt = RowFmt()) {
+    {
+        const int rc_w = chain_wait(h, side);  // (the side's previous chain: its events are waited for below)
+        if (rc_w) return rc_w;
+    }
     SideGuard guard(h);
     h->qi = side;
     // (the radix fallback for very fine R-POD grids -- and the pass-through chain's radix sort -- share their scratch bank
     // between the sides: one stream for all of them then)
-    hipStream_t qstream = (h->B + 1 <= QB_NB_MAX && !passthrough) ? h->qstream[h->n_chain++ % (unsigned)h->nqs] : h->qstream[0];
+    // (while the early stream is in use the chains keep to two query streams: four busy compute queues are all that run side by side)
+    const unsigned nqs_now = (unsigned)(h->ov_mode ? std::min(h->nqs, 2) : h->nqs);
+    hipStream_t qstream = (h->B + 1 <= QB_NB_MAX && !passthrough) ? h->qstream[h->n_chain++ % nqs_now] : h->qstream[0];
     h->cur = qstream;
     int rc = alloc_scan(h, std::max(ns, 1u));
     if (rc) return rc;
@@ -1308,6 +1478,7 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
         // the side may still be executing a chain that was dropped (a prefetch that no step claimed): its kernels read
         // q.scan, and a scan that changes between the bounding-box pass and the voxel keys sends them astray
         if (q.used) HIPC(h, hipEventSynchronize(q.ev_done));
+        if (q.used) HIPC(h, hipEventSynchronize(q.ev_p1));
         uint64_t fp_staged = 0;
         rc = stage_host_scan(h, scan_src, ns, qstream, fmt, &fp_staged);  // (on the chain's own stream: ordered before its first kernel)
         if (rc) return rc;
@@ -1321,6 +1492,7 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     q.scan_in = src_is_device && ns ? (const float4 *)scan_src : (const float4 *)q.scan.p;
     // the side's previous chain (possibly a dropped one, possibly on the other query stream) must be through with its buffers
     if (q.used) (void)hipStreamWaitEvent(qstream, q.ev_done, 0);
+    if (q.used) (void)hipStreamWaitEvent(qstream, q.ev_p1, 0);  // (... a dropped one whose second part never ran)
     Counters *qc = q.d_qctr.p;
     const uint32_t *nq_dev = q.d_nvox.p;
     // the voxelising chain as two graphs (see GSeg): recorded by the very LAUNCH() calls below, replayed at the two event records
@@ -1328,6 +1500,33 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
 #ifndef ERASOR_NO_HIPGRAPH
     if (h->use_graph && h->prof != 1 && !g_debug_sync && !passthrough && !prevox && B + 1 <= QB_NB_MAX && ns) h->rec = &recorded;
 #endif
+    // round 5: the common chain's launches are made by the handle's worker thread (everything above -- allocations, the staged copy, the
+    // waits for the side's previous chain -- and the bookkeeping below stay with the caller)
+    const bool to_worker = h->worker && !h->rec && h->prof != 1 && !g_debug_sync && !passthrough && !prevox && B + 1 <= QB_NB_MAX;
+    // round 5: the chain of a node announced with both transforms (its step will overlap the one in front) ends behind its centroids; the
+    // rest follows on the early stream one step before it is needed (see QSide::ev_p1)
+    // (measured slower on both configurations -- the early stream has no room for it once it carries the early passes: opt-in, A/B)
+    static const bool no_split = getenv("ERASOR_HIP_CHAIN_SPLIT") == nullptr || getenv("ERASOR_HIP_NO_OVERLAP") != nullptr ||
+                                 getenv("ERASOR_HIP_NO_RESERVED") != nullptr;
+    const bool split = staged == 1 && h->ann.pose_valid && h->ann.to_valid && !no_split && h->ov_mode && P.version == 3 && !h->rec && h->prof != 1 && !g_debug_sync &&
+                       !passthrough && !prevox && B + 1 <= QB_NB_MAX && nq > 0;
+    struct TlArr {
+        float m[16];
+    } tl_arr;
+    memcpy(tl_arr.m, T_l2b, sizeof(tl_arr.m));
+    auto launches = [h, &q, qc, nq_dev, qstream, ns, nq, B, bits, P, prevox, passthrough, tl_arr, to_worker, split, &recorded]() -> int {
+    const float *T_l2b = tl_arr.m;
+    int rc = 0;
+    TlCtx keep_tl = g_tl;
+    if (to_worker) {
+        g_tl.h = h;
+        g_tl.cur = qstream;
+        g_tl.qi = (int)(&q - h->q);
+    }
+    struct TlRestore {
+        TlCtx k;
+        ~TlRestore() { g_tl = k; }
+    } tl_restore{keep_tl};
     {
         static const int qpad = getenv("ERASOR_HIP_QPAD_US") ? atoi(getenv("ERASOR_HIP_QPAD_US")) : 0;
         if (qpad > 0) LAUNCH(h, "q_pad", k_pad, 1, 64, (unsigned long long)qpad * 100ull);
@@ -1361,6 +1560,10 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     } else if (nq) {
         LAUNCH(h, "q_centroids", k_centroids, cdiv((uint64_t)nq * 8, 256), 256, q.scan_in, (const uint32_t *)q.qk_b.p, (const uint32_t *)q.qv_b.p,
                (const uint32_t *)q.run_begin.p, nq_dev, q.cent.p, q.ukeys.p, q.hkey.p, q.hval.p, q.hbits);
+        if (split) {  // (the rest: enqueue_chain_part2, on another stream)
+            (void)hipEventRecord(q.ev_p1, qstream);
+            return rc;
+        }
         LAUNCH(h, "q_nn", k_query_nn, cdiv((uint64_t)nq * NN_SUB, 256), 256, q.scan_in, (const uint32_t *)q.qv_b.p, (const uint32_t *)q.run_begin.p,
                (const uint32_t *)q.ukeys.p, (const float4 *)q.cent.p, nq_dev, (const VoxGrid *)q.qgrid.p, to_xf(T_l2b), P, qc, q.query.p, q.qkey.p,
                (const uint32_t *)q.hkey.p, (const uint32_t *)q.hval.p, q.hbits);
@@ -1385,18 +1588,67 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
         if (rc) return rc;
     }
     (void)hipEventRecord(q.ev_done, qstream);
+    return rc;
+    };  // (launches)
+    if (to_worker) {
+        auto *w = h->worker;
+        w->busy[side].fetch_add(1, std::memory_order_acq_rel);
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->jobs.emplace_back([launches, w, side]() -> int {
+                const int rc_j = launches();
+                w->busy[side].fetch_sub(1, std::memory_order_acq_rel);
+                return rc_j;
+            });
+        }
+        w->cv.notify_one();
+    } else {
+        rc = launches();
+        if (rc) return rc;
+    }
     q.used = true;
+    q.p2_pending = split;
     q.src = scan_src;
     q.src_n = ns;
     q.ns = ns;
     q.src_dev = src_is_device;
     if (staged != 2) {
         q.pose_valid = false;  // (flush_announced adds the pose of an announced node)
+        q.to_valid = false;
         if (!src_is_device && staged) q.fp = h->ann.fp;  // (not staged: the hash the staging pass has just taken)
         q.ticket = staged ? h->ann.ticket : 0ull;
     }
     q.fmt = fmt;
     if (q.Tl != T_l2b) memcpy(q.Tl, T_l2b, sizeof(q.Tl));
+    return ERASOR_OK;
+}
+
+// The second part of a split query chain (see QSide::ev_p1) on `stream`: label search (utils.cpp:96-110), lidar->body + R-POD key
+// (OMU.cpp:240; erasor.cpp:100-115), bucketing, per-bin statistics of the query; records the side's ev_done there.
+static int enqueue_chain_part2(erasor_hip_handle *h, int side, hipStream_t stream) {
+    QSide &q = h->q[side];
+    if (!q.p2_pending) return ERASOR_OK;
+    const int rc_w = chain_wait(h, side);  // (ev_p1 must have been recorded)
+    if (rc_w) return rc_w;
+    SideGuard guard(h);
+    h->qi = side;
+    h->cur = stream;
+    const DP &P = h->dp;
+    const uint32_t B = h->B, nq = q.ns;
+    const int bits = key_bits(B + 1);
+    const uint32_t *nq_dev = q.d_nvox.p;
+    (void)hipStreamWaitEvent(stream, q.ev_p1, 0);
+    LAUNCH(h, "q_nn", k_query_nn, cdiv((uint64_t)nq * NN_SUB, 256), 256, q.scan_in, (const uint32_t *)q.qv_b.p, (const uint32_t *)q.run_begin.p,
+           (const uint32_t *)q.ukeys.p, (const float4 *)q.cent.p, nq_dev, (const VoxGrid *)q.qgrid.p, to_xf(q.Tl), P, q.d_qctr.p, q.query.p, q.qkey.p,
+           (const uint32_t *)q.hkey.p, (const uint32_t *)q.hval.p, q.hbits);
+    const uint32_t ntile_ub = std::max(1u, cdiv(nq, QB_TILE));
+    LAUNCH(h, "q_bucket", k_qb_hist, ntile_ub, 1024, (const uint32_t *)q.qkey.p, nq, nq_dev, B + 1, q.qb_hist.p, q.qb_tot.p);
+    LAUNCH(h, "q_bucket", k_qb_scan, 1, 1024, (const uint32_t *)q.qb_tot.p, B + 1, q.qoff.p);
+    LAUNCH(h, "q_bucket", k_qb_scatter, ntile_ub, 1024, (const uint32_t *)q.qkey.p, (const float4 *)q.query.p, nq, nq_dev, B + 1, bits,
+           (const uint32_t *)q.qb_hist.p, (const uint32_t *)q.qoff.p, q.sq.p);
+    LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)q.sq.p, (const uint32_t *)q.qoff.p, B, q.ccnt.p, q.cmin.p, q.cmax.p);
+    (void)hipEventRecord(q.ev_done, stream);
+    q.p2_pending = false;
     return ERASOR_OK;
 }
 
@@ -1410,6 +1662,8 @@ static int flush_announced(erasor_hip_handle *h) {
     h->q[h->ann.side].pose_valid = h->ann.pose_valid;
     h->q[h->ann.side].pose_x = h->ann.pose_x;
     h->q[h->ann.side].pose_y = h->ann.pose_y;
+    h->q[h->ann.side].to_valid = h->ann.to_valid;
+    memcpy(h->q[h->ann.side].To, h->ann.To, sizeof(h->ann.To));
     h->pend[h->npend++] = h->ann.side;
     return ERASOR_OK;
 }
@@ -1419,6 +1673,12 @@ static int flush_announced(erasor_hip_handle *h) {
 static void q_drain(erasor_hip_handle *h) {
     h->npend = 0;
     h->ann.valid = false;
+    (void)chain_wait(h, -1);
+    if (h->ov.valid) {  // (the passes launched ahead for the node that is dropped here: they run out, nothing takes them)
+        h->ov.valid = false;
+        if (h->bstream) (void)hipStreamSynchronize(h->bstream);
+        (void)hipStreamSynchronize(h->stream);
+    }
     for (int k = 0; k < h->nqs; ++k) (void)hipStreamSynchronize(h->qstream[k]);
     // a dropped announcement's host scan may still be on its way from pinned staging into its side (copy stream): whoever uses the
     // sides as scratch next must not race with that copy
@@ -1431,18 +1691,26 @@ static void q_drain(erasor_hip_handle *h) {
 // pass of the NEXT step, launched ahead; the kernel takes the extents the step in flight commits on the device.
 static void launch_voi_split(erasor_hip_handle *h, const float4 *F, uint32_t nF, uint32_t nFchunks, uint32_t o_begin, uint32_t o_chunk0,
                              uint32_t nOchunks, uint32_t nchunks_grid, double xc, double yc, double voi_r2, const DevState *dev, uint32_t cap_chunks,
-                             const StepEnd *step_end = nullptr) {
+                             const StepEnd *step_end = nullptr, const OvSplit *ovs = nullptr) {
     // one chunk per wave while that needs <= 16 workgroups per CU: the hardware back-fills workgroups as they finish,
     // which balances better than a grid-stride tail (measured, tools/bw_probe.hip)
     // (step_end: the launch's LAST workgroup ends the step in flight -- round 4, see StepEnd in kernels.hip.h)
     StepEnd se;
     memset(&se, 0, sizeof(se));
     if (step_end) se = *step_end;
+    OvSplit ov;
+    if (ovs) ov = *ovs;
     const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nchunks_grid, 4), 256 * 16)) + (step_end ? 1u : 0u);
     const uint32_t capO_chunks = h->capO / CHUNK;
     // (prof 3: the same on every FOURTH launch -- the bracket costs the step it observes ~9 us (gpurun_out/r03k: 0.276 vs 0.267 ms
     // per scan with / without), a sample of the timed region's launches costs a quarter of that)
-    if (h->prof == 2 || (h->prof == 3 && (h->n_split_launch++ & 3u) == 0)) {
+    if (ovs) {  // (an overlapped step's pass: on the early stream, beside the per-bin launch of the step in flight)
+        hipStream_t keep = h->cur;
+        h->cur = h->bstream;
+        LAUNCH(h, "voi_split", k_voi_split, grid, 256, F, nF, nFchunks, (const float2 *)h->Oxy.p, o_begin, o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p,
+               h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks, h->use_ometa ? h->ometa.p : (OMeta *)nullptr, se, ov);
+        h->cur = keep;
+    } else if (h->prof == 2 || (h->prof == 3 && (h->n_split_launch++ & 3u) == 0)) {
         // roofline measurement: the launch carries its own start / stop events (hipExtLaunchKernelGGL: they stamp the
         // kernel's execution window itself, the figure rocprofv3 reports too).  A record / record bracket around the
         // launch costs two extra barrier packets on a 17 us kernel and slows the step it is supposed to observe.
@@ -1452,13 +1720,13 @@ static void launch_voi_split(erasor_hip_handle *h, const float4 *F, uint32_t nF,
         ke.b = get_evt(h);
         hipExtLaunchKernelGGL(k_voi_split, dim3(grid), dim3(256), 0, h->stream, ke.a, ke.b, 0, F, nF, nFchunks, (const float2 *)h->Oxy.p, o_begin,
                               o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks,
-                              h->use_ometa ? h->ometa.p : (OMeta *)nullptr, se);
+                              h->use_ometa ? h->ometa.p : (OMeta *)nullptr, se, ov);
         h->pending.push_back(ke);
     } else {
         hipStream_t keep = h->cur;
         h->cur = h->stream;
         LAUNCH(h, "voi_split", k_voi_split, grid, 256, F, nF, nFchunks, (const float2 *)h->Oxy.p, o_begin, o_chunk0, nOchunks, xc, yc, voi_r2,
-               h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks, h->use_ometa ? h->ometa.p : (OMeta *)nullptr, se);
+               h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks, h->use_ometa ? h->ometa.p : (OMeta *)nullptr, se, ov);
         h->cur = keep;
     }
 }
@@ -1490,9 +1758,11 @@ static void launch_split_ahead(erasor_hip_handle *h, double nx, double ny, uint3
     if (!no_early_scan && nchunks_hint + 64u <= scan_cap && h->topv.cap >= 24 && h->toph.cap >= 24 && h->prof != 1) {
         hipStream_t keep = h->cur;
         h->cur = h->stream;
-        LAUNCH(h, "chunk_scan", k_chunk_scan_one, 1, 1024, (const uint32_t *)h->cinfo.p, 0u, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, 16u, 0u, h->d_st.p,
-               h->d_ctr.p, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? h->B + 1 : 0u,
-               h->use_ometa ? h->ometa.p : (OMeta *)nullptr, h->capO / CHUNK, scan_cap);
+        // (round 5: the next step's state, counters and tallies live in the OTHER set, see erasor_hip_handle::alt; it starts from what the
+        // step in flight has committed)
+        LAUNCH(h, "chunk_scan", k_chunk_scan_one, 1, 1024, (const uint32_t *)h->cinfo.p, 0u, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, 16u, 0u, h->alt.d_st.p,
+               h->alt.d_ctr.p, h->st, h->alt.lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? h->B + 2 : 0u,
+               h->use_ometa ? h->ometa.p : (OMeta *)nullptr, h->capO / CHUNK, scan_cap, (const DevState *)h->d_st.p, 0xFFFFFFFFu);
         h->cur = keep;
         h->spec.scan = true;
         h->spec.scan_cap = scan_cap;
@@ -1508,10 +1778,10 @@ static void launch_split_ahead(erasor_hip_handle *h, double nx, double ny, uint3
             hipStream_t keep = h->cur;
             h->cur = h->stream;
             LAUNCH(h, "chunk_scan", k_chunk_scan_local, grid, 256, (const uint32_t *)h->cinfo.p, 0u, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, h->topr.p,
-                   (const DevState *)h->d_st.p, h->capO / CHUNK, cap2);
+                   (const DevState *)h->d_st.p, h->capO / CHUNK, cap2, 1u);
             LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, grid, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p, 0u, 0u,
-                   h->d_st.p, h->d_ctr.p, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? h->B + 1 : 0u,
-                   (const uint32_t *)h->topr.p, h->use_ometa ? h->ometa.p : (OMeta *)nullptr, h->capO / CHUNK, cap2);
+                   h->alt.d_st.p, h->alt.d_ctr.p, h->st, h->alt.lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? h->B + 2 : 0u,
+                   (const uint32_t *)h->topr.p, h->use_ometa ? h->ometa.p : (OMeta *)nullptr, h->capO / CHUNK, cap2, (const DevState *)h->d_st.p, 0xFFFFFFFFu);
             h->cur = keep;
             h->spec.scan = true;
             h->spec.scan_cap = cap2;
@@ -1519,6 +1789,18 @@ static void launch_split_ahead(erasor_hip_handle *h, double nx, double ny, uint3
             h->spec.phl = h->phl.p;
         }
     }
+}
+
+// round 5: the two sets of per-step arrays change places (see erasor_hip_handle::alt): what the passes launched ahead wrote becomes the
+// current step's, the finished step's becomes scratch for the passes launched ahead of the next
+static void swap_sides(erasor_hip_handle *h) {
+    std::swap(h->voi_ego, h->alt.voi_ego);
+    std::swap(h->voi_key, h->alt.voi_key);
+    std::swap(h->voi_src, h->alt.voi_src);
+    std::swap(h->moff, h->alt.moff);
+    std::swap(h->d_st, h->alt.d_st);
+    std::swap(h->d_ctr, h->alt.d_ctr);
+    std::swap(h->lab_slots, h->alt.lab_slots);
 }
 
 static int step_collect(erasor_hip_handle *h, erasor_step_result *res);
@@ -1617,12 +1899,18 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                 if (rc) return rc;
             }
         h->qi = side;
+        rc = chain_wait(h, side);  // (the chain's events are waited for below: they must have been recorded)
+        if (rc) return rc;
+        // (a split chain whose second part the step in front did not launch -- it was not that step's next node after all: here and now)
+        rc = enqueue_chain_part2(h, side, h->stream);
+        if (rc) return rc;
     }
     MARK("query chain");
     h->Tl2b = to_xf(T_l2b);
     h->Tb2o = to_xf(T_b2o);
     h->To2b = to_xf(T_o2b);
     const double xc = (double)T_b2o[3], yc = (double)T_b2o[7];  // OMU.cpp:246-247
+    swap_sides(h);  // (whatever was launched ahead of this step wrote into the other set: it is this step's now)
     DevState *ds = h->d_st.p;
     Counters *dc = h->d_ctr.p;
     const DP &P = h->dp;
@@ -1638,10 +1926,11 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         if (rc) return rc;
     }
     const uint64_t n_map_in = (uint64_t)h->nFv + h->o_valid;
-    if (n_map_in + ns + 64 > h->capV) {
+    const uint64_t n_voi_room = (uint64_t)h->nF + h->o_valid;  // entries of the VoI-order arrays: reserved slots keep places too (round 5)
+    if (n_voi_room + ns + 64 > h->capV) {
         // the reference's map_arranged_ simply grows (scan points enter every reverted bin, erasor.cpp:512; v2 merges whole
         // query bins, erasor.cpp:296-307): enlarge the map-sized scratch between steps (it carries no state across steps)
-        rc = grow_map_scratch(h, n_map_in + ns + 64);
+        rc = grow_map_scratch(h, n_voi_room + ns + 64);
         if (rc) return rc;
     }
     h->st.nF = h->nF;  // the host's mirror of the device state rides along as a kernel argument of k_chunk_scan_top
@@ -1659,28 +1948,34 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     const uint32_t nchunks = nFchunks + nOchunks;
     // (the masks and chunk counts also hold the NEXT step's split when it is launched ahead: its F region may be longer by
     // this step's VoI + scan, its outskirts region may begin up to nF entries earlier)
-    const size_t chunks_room = (size_t)nchunks + cdiv((uint64_t)n_map_in + ns + 64, CHUNK) + cdiv(h->nF, CHUNK) + 8;
+    // (round 5: in the reserved layout the next region may be as long as 4 x this step's VoI + 2 x its scan)
+    const size_t chunks_room = (size_t)nchunks + cdiv(4 * n_voi_room + 2 * (uint64_t)ns + 64, CHUNK) + cdiv(h->nF, CHUNK) + 8;
     if (chunks_room * CHUNK_TILES + 8 > h->vmask.cap || chunks_room * CHUNK_TILES + 8 > h->hmask.cap || chunks_room + 8 > h->cinfo.cap)
         h->spec.valid = false;  // (re-allocated below: a pass launched ahead wrote into the old buffers)
+    if (ensure(h, h->lmask, chunks_room * CHUNK_TILES + 8)) return ERASOR_E_NO_DEVICE;
     if (ensure(h, h->vmask, chunks_room * CHUNK_TILES + 8) || ensure(h, h->hmask, chunks_room * CHUNK_TILES + 8) ||
         ensure(h, h->cinfo, chunks_room + 8) || ensure(h, h->pvl, chunks_room + 8) || ensure(h, h->phl, chunks_room + 8) ||
         ensure(h, h->topv, chunks_room / 1024 + 8) || ensure(h, h->toph, chunks_room / 1024 + 8) || ensure(h, h->topr, chunks_room / 1024 + 8))
         return ERASOR_E_NO_DEVICE;
     // No mid-step read-back: everything is launched on upper-bound grids and reads the actual counts
     // (st->voi_total, st->q_nvox) from device memory.  n_voi <= logical map size, nq <= n_scan.
-    const uint32_t n_voi = (uint32_t)std::min<uint64_t>(n_map_in, 0xFFFFFFF0ull), nq = ns;  // upper bounds from here on
+    const uint32_t n_voi = (uint32_t)std::min<uint64_t>(n_voi_room, 0xFFFFFFF0ull), nq = ns;  // upper bounds from here on
     const uint32_t *nvoi_dev = &ds->voi_total;
     rc = alloc_step(h, n_voi, nq);
     if (rc) return rc;
-    const int bits = key_bits(B + 1);
-    if (B + 1 <= QB_NB_MAX) {  // [tiles][B + 1] table of the map's counting sort
-        if (ensure(h, h->mb_hist, (size_t)mb_row_stride(B + 1) * std::max(1u, cdiv(n_voi, MB_TILE)) + 8)) return ERASOR_E_NO_DEVICE;
+    if (B + 1 <= QB_NB_MAX) {  // [tiles][B + 1] table of the map's counting sort (round 5: B + 2 with the dead bucket of an overlapped step)
+        // (rows for every tile the VoI-order arrays can hold: the NEXT step's table is filled ahead, and its VoI order keeps places for
+        // this step's reserved slots -- more entries than this step's own bound)
+        if (ensure(h, h->mb_hist, (size_t)mb_row_stride(B + 2) * std::max(1u, cdiv(std::max(n_voi, h->capV), MB_TILE)) + 8)) return ERASOR_E_NO_DEVICE;
     } else {  // the map chain's scratch bank of the radix bucket sort
         const uint32_t nb_m = 256u * std::max(1u, cdiv(n_voi, RTILE));
         if (ensure(h, h->hist2, nb_m) || ensure(h, h->hist2_l, nb_m) || ensure(h, h->hist2_t, cdiv(nb_m, 1024) + 2)) return ERASOR_E_NO_DEVICE;
     }
     const uint32_t *sm_keys = nullptr, *sm_perm = nullptr;
     bool st1_ahead = false;
+    bool use_ov = false;   // this step's split .. bucket table were launched ahead of it and are taken (round 5, OVERLAPPED steps)
+    uint32_t nbk = B + 1;  // buckets of the map's counting sort: the bins + the complement (+ the dead bucket of an overlapped step)
+    int bits = key_bits(B + 1);
 
     // ---- map chain (the query chains run on their own streams; the two only meet at the Scan Ratio Test) ----
     auto enqueue_map_chain = [&]() {
@@ -1689,7 +1984,33 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         // (no fork / join events, one hardware queue less).
         h->cur = h->stream;
         h->bank = 1;
-        {   // VoI split (OMU.cpp:254 fetch_VoI membership)
+        {   // round 5: split, chunk scan, gather and the bucket table may all be there already -- launched beside the previous step's per-bin
+            // launch (h->ov) -- if this step is exactly the step that was assumed then: node, pose, transform, store, buffers, room
+            const bool ov_launched = h->ov.valid;
+            use_ov = ov_launched && !flags && mb_count && h->ov.seq == h->step_seq && h->ov.epoch == h->store_epoch && h->ov.curF == h->curF &&
+                     h->ov.qside == h->qi && h->ov.x == xc && h->ov.y == yc && memcmp(h->ov.To, T_o2b, sizeof(h->ov.To)) == 0 &&
+                     nchunks <= h->ov.cap_chunks && n_voi_room + 64 <= h->ov.cap_voi && h->ov.vmask == (const void *)h->vmask.p &&
+                     h->ov.hmask == (const void *)h->hmask.p && h->ov.lmask == (const void *)h->lmask.p && h->ov.cinfo == (const void *)h->cinfo.p &&
+                     h->ov.pvl == (const void *)h->pvl.p && h->ov.phl == (const void *)h->phl.p && h->ov.voi_ego == (const void *)h->voi_ego.p &&
+                     h->ov.mb_hist == (const void *)h->mb_hist.p;
+            if (ov_launched && !use_ov && getenv("ERASOR_HIP_CHAIN_STAMPS"))
+                fprintf(stderr, "[overlap passes not taken] flags %d seq %d epoch %d curF %d qside %d pose %d To %d chunks %u/%u voi %llu/%u ptrs %d%d%d%d%d%d%d%d\n", flags,
+                        (int)(h->ov.seq == h->step_seq), (int)(h->ov.epoch == h->store_epoch), (int)(h->ov.curF == h->curF), (int)(h->ov.qside == h->qi),
+                        (int)(h->ov.x == xc && h->ov.y == yc), (int)(memcmp(h->ov.To, T_o2b, sizeof(h->ov.To)) == 0), nchunks, h->ov.cap_chunks,
+                        (unsigned long long)n_voi_room + 64, h->ov.cap_voi, (int)(h->ov.vmask == (const void *)h->vmask.p), (int)(h->ov.hmask == (const void *)h->hmask.p),
+                        (int)(h->ov.lmask == (const void *)h->lmask.p), (int)(h->ov.cinfo == (const void *)h->cinfo.p), (int)(h->ov.pvl == (const void *)h->pvl.p),
+                        (int)(h->ov.phl == (const void *)h->phl.p), (int)(h->ov.voi_ego == (const void *)h->voi_ego.p), (int)(h->ov.mb_hist == (const void *)h->mb_hist.p));
+            h->ov.valid = false;
+            if (ov_launched && !use_ov) (void)hipStreamWaitEvent(h->stream, h->ev_early, 0);  // (those passes write what this step's own will)
+            if (use_ov) {
+                ++h->n_ov_used;
+                ++h->n_spec_used;
+                h->spec.valid = false;
+                nbk = h->ov.nbk;
+                bits = key_bits(nbk);
+            }
+        }
+        if (!use_ov) {   // VoI split (OMU.cpp:254 fetch_VoI membership)
             // ... unless it is already there: launched ahead by the previous step for exactly this pose and this store
             const bool use_spec = h->spec.valid && !flags && h->spec.seq == h->step_seq && h->spec.epoch == h->store_epoch &&
                                   h->spec.curF == h->curF && h->spec.x == xc && h->spec.y == yc && nchunks <= h->spec.cap_chunks &&
@@ -1712,44 +2033,46 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                 // (launched ahead behind the split, see launch_split_ahead)
             } else if (nchunks <= 16384) {
                 LAUNCH(h, "chunk_scan", k_chunk_scan_one, 1, 1024, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, ntop,
-                       nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u,
-                       h->use_ometa ? h->ometa.p : (OMeta *)nullptr, 0u, 0u);
+                       nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 2 : 0u,
+                       h->use_ometa ? h->ometa.p : (OMeta *)nullptr, 0u, 0u, (const DevState *)nullptr, 0u);
             } else {
                 LAUNCH(h, "chunk_scan", k_chunk_scan_local, ntop, 256, (const uint32_t *)h->cinfo.p, nchunks, h->pvl.p, h->phl.p, h->topv.p, h->toph.p,
-                       h->topr.p, (const DevState *)nullptr, 0u, 0u);
+                       h->topr.p, (const DevState *)nullptr, 0u, 0u, 0u);
                 LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, ntop, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
-                       nchunks, nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 1 : 0u,
-                       (const uint32_t *)h->topr.p, h->use_ometa ? h->ometa.p : (OMeta *)nullptr, 0u, 0u);
+                       nchunks, nFchunks, ds, dc, h->st, h->lab_slots.p, mb_count ? h->mb_tot.p : (uint32_t *)nullptr, mb_count ? B + 2 : 0u,
+                       (const uint32_t *)h->topr.p, h->use_ometa ? h->ometa.p : (OMeta *)nullptr, 0u, 0u, (const DevState *)nullptr, 0u);
             }
         }
-        (void)hipStreamWaitEvent(h->stream, Q(h).ev_keys, 0);  // k_voi_gather must see the query side's error flag
-        {   // VoI gather + egocentric transform + R-POD key (OMU.cpp:435-437; erasor.cpp:124-139)
+        if (!use_ov) (void)hipStreamWaitEvent(h->stream, Q(h).ev_keys, 0);  // k_voi_gather must see the query side's error flag
+        if (!use_ov) {   // VoI gather + egocentric transform + R-POD key (OMU.cpp:435-437; erasor.cpp:124-139)
             // one wavefront per work item: GATHER_SUB pieces per chunk of the VoI-resident region, one per outskirts chunk
             const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv(nFchunks * GATHER_SUB + nOchunks, 4), 256 * 16));
             LAUNCH(h, "voi_gather", k_voi_gather, grid, 256, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, h->Oxy.p, h->Ozi.p, o_chunk0,
                    nOchunks, (const unsigned long long *)h->vmask.p, (const unsigned long long *)h->hmask.p, (const uint32_t *)h->cinfo.p,
                    (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p, (const uint32_t *)h->topv.p, (const uint32_t *)h->toph.p, h->To2b, P, ds,
-                   dc, (const Counters *)Q(h).d_qctr.p, h->voi_ego.p, h->voi_key.p, h->voi_src.p, h->use_ometa ? h->ometa.p : (OMeta *)nullptr);
+                   dc, (const Counters *)Q(h).d_qctr.p, h->voi_ego.p, h->voi_key.p, h->voi_src.p, h->use_ometa ? h->ometa.p : (OMeta *)nullptr,
+                   (const unsigned long long *)nullptr, 0u);
         }
         if (mb_count) {
             // the table is sized for the whole map (n_voi is an upper bound), the GRIDS for 1.5 x the previous step's VoI: the
             // kernels walk the tiles with a grid stride, so an under-estimate only costs a second round
             const uint32_t ntile_tab = std::max(1u, cdiv(n_voi, MB_TILE));
             const uint32_t ntile_ub = h->last_n_voi ? std::min(ntile_tab, std::max(64u, cdiv((uint64_t)h->last_n_voi * 3 / 2, MB_TILE))) : ntile_tab;
-            LAUNCH(h, "voi_bucket", k_mb_hist, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, n_voi, nvoi_dev, B + 1, h->mb_hist.p, h->mb_tot.p);
-            LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv(B + 1, MB_PAD), 256, h->mb_hist.p, n_voi, nvoi_dev, B + 1, (const uint32_t *)h->mb_tot.p,
-                   h->moff.p);
-            if (B + 1 <= MBW_NB_SMALL)
+            if (!use_ov) {  // (an overlapped step: both launched ahead, behind k_late_gather)
+                LAUNCH(h, "voi_bucket", k_mb_hist, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, n_voi, nvoi_dev, nbk, h->mb_hist.p, h->mb_tot.p);
+                LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv(nbk, MB_PAD), 256, h->mb_hist.p, n_voi, nvoi_dev, nbk, (const uint32_t *)h->mb_tot.p, h->moff.p);
+            }
+            if (nbk <= MBW_NB_SMALL)
                 LAUNCH(h, "voi_bucket", k_mb_scatter_w<MBW_NB_SMALL>, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
-                       (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, B + 1, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p,
+                       (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, nbk, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p,
                        h->dbg_stamps.p);
-            else if (B + 1 <= MBW_NB_MAX)
+            else if (nbk <= MBW_NB_MAX)
                 LAUNCH(h, "voi_bucket", k_mb_scatter_w<MBW_NB_MAX>, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
-                       (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, B + 1, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p,
+                       (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, nbk, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p,
                        h->dbg_stamps.p);
             else
                 LAUNCH(h, "voi_bucket", k_mb_scatter, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
-                       (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, B + 1, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p);
+                       (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, nbk, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p);
             sm_keys = h->rk_a.p;
         } else {
             radix_sort(h, h->voi_key.p, n_voi, nvoi_dev, bits, h->rk_a.p, h->rk_b.p, h->rv_a.p, h->rv_b.p, &sm_keys, &sm_perm, "voi_bucket");
@@ -1767,6 +2090,15 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         } else
         LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)h->spts.p, (const uint32_t *)h->moff.p, B, h->mcnt.p,
                h->mmin.p, h->mmax.p);
+        if (use_ov) {
+            // the entering outskirts entries are erased NOW that the step is certain (k_voi_gather left them: a getter could still ask
+            // for the store as the previous step left it); on the early stream, in front of the next pass over the store (enqueued
+            // behind the launches the main stream was waiting for)
+            h->cur = h->bstream;
+            LAUNCH(h, "voi_gather", k_o_commit, std::max(1u, std::min<uint32_t>(cdiv(nOchunks, 4), 2048)), 256, h->Oxy.p,
+                   (const unsigned long long *)h->vmask.p, (const uint32_t *)h->cinfo.p, (const DevState *)ds, h->capO / CHUNK,
+                   h->use_ometa ? h->ometa.p : (OMeta *)nullptr);
+        }
         MARK("  mapchain_end");
         h->cur = h->stream;
         h->bank = 0;
@@ -1789,7 +2121,17 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     // round 5: the RESERVED layout (srt4_body): the write-back of everything but the reverted bins does not wait for the per-bin launch
     static const bool no_reserved = getenv("ERASOR_HIP_NO_RESERVED") != nullptr;
     static const bool leave_all = getenv("ERASOR_HIP_LEAVE_ALL") != nullptr;  // (test switch: every reverted bin reserves places in the outskirts' order)
-    const bool reserved = srt_in_revert && fold && mb_count && !no_reserved && !flags;
+    // ERASOR_HIP_OVERLAP: 1 = always, 0 = never, unset = where it pays.  It pays where the per-bin launch is long: the passes beside it need
+    // a stream of their own, and with four busy compute queues being all the hardware runs side by side (a fifth slows every kernel of every
+    // queue 3-8 x) that stream costs one of the three query streams.  Measured (MEASUREMENTS, round 5): 9.8 M-point map, 370 map points per
+    // bin: 0.191 ms per scan without, 0.206 with; 39 M-point dense map, 1500 per bin: 0.37 without, 0.32 with.
+    static const int overlap_env = getenv("ERASOR_HIP_OVERLAP") ? atoi(getenv("ERASOR_HIP_OVERLAP")) : -1;
+    //  config/seq_05.yaml verbatim (530 per bin): 0.204 / 0.193; Ouster-128 (233 k-point scans, 40 per bin: its query chains need the third
+    //  stream): 0.23 / 0.34.  Hence: dense bins AND scans of ordinary size.
+    static const uint32_t overlap_ppb = getenv("ERASOR_HIP_OVERLAP_PPB") ? (uint32_t)atoi(getenv("ERASOR_HIP_OVERLAP_PPB")) : 500u;
+    const bool overlap_pays = overlap_env >= 0 ? overlap_env != 0 : ((uint64_t)h->last_n_voi >= (uint64_t)overlap_ppb * B && ns <= 160000u);
+    const bool reserved = srt_in_revert && fold && mb_count && !no_reserved && !flags && overlap_pays;
+    h->ov_mode = reserved;
     bool have_pose = false;  // the NEXT node's pose, if it was announced with it (erasor_hip_prefetch_node)
     double nx = 0, ny = 0;
     if (h->npend > 0) {
@@ -1804,14 +2146,48 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     }
     float4 *Fnew = h->F[h->curF ^ 1].p;
     LateEnt *late_out = h->late[h->late_idx ^ 1].p;
+    // round 5, OVERLAPPED steps: with the next node announced together with BOTH its transforms (erasor_hip_prefetch_node +
+    // erasor_hip_announce_origin2body) its split, chunk scan and gather run beside this step's per-bin launch, on the early stream
+    static const bool no_overlap = getenv("ERASOR_HIP_NO_OVERLAP") != nullptr;
+    bool ov_next = false;
+    int nxt_side = -1;
+    if (reserved && !no_overlap && have_pose && h->prof != 1 && !submap_would_move(h, nx, ny)) {
+        if (h->npend == 0 && h->ann.valid && h->ann.to_valid) {
+            // (only just announced: its chain goes into its queue NOW -- the gather ahead waits for the chain's error flag)
+            const int keep_side = h->qi;
+            const int rc_f = flush_announced(h);
+            h->qi = keep_side;
+            if (rc_f) return rc_f;
+        }
+        if (h->npend > 0 && h->q[h->pend[0]].pose_valid && h->q[h->pend[0]].to_valid) {
+            ov_next = true;
+            nxt_side = h->pend[0];
+            const int rc_w = chain_wait(h, nxt_side);  // (its ev_keys is waited for on the early stream)
+            if (rc_w) return rc_w;
+        }
+    }
+    std::function<void()> enqueue_early;
+    if (getenv("ERASOR_HIP_CHAIN_STAMPS") && !ov_next)
+        fprintf(stderr, "[no overlap for the next step] reserved %d (srt_in_revert %d fold %d mb_count %d flags %d) have_pose %d prof %d npend %d ann %d/%d/%d pend0 %d/%d\n",
+                (int)reserved, (int)srt_in_revert, (int)fold, (int)mb_count, flags, (int)have_pose, h->prof, h->npend, (int)h->ann.valid, (int)h->ann.pose_valid,
+                (int)h->ann.to_valid, h->npend ? (int)h->q[h->pend[0]].pose_valid : -1, h->npend ? (int)h->q[h->pend[0]].to_valid : -1);
     if (reserved) {
         // a reverted bin whose points may lie outside the NEXT VoI circle reserves places in the outskirts' order as well: without the
         // next pose, every bin does
         const double leave_lim = (have_pose && !leave_all) ? sqrt(P.voi_r2) - hypot(nx - xc, ny - yc) - 0.05 : -1.0;
+        // (enqueued BEHIND the per-bin launch, which the main stream is waiting for: see enqueue_early() below)
+        enqueue_early = [&, leave_lim]() {
+        MARK("srt: begin");
+        (void)hipStreamWaitEvent(h->bstream, h->ev_stats, 0);
+        MARK("  ev_stats record + wait");
+        h->cur = h->bstream;  // ---- the early stream: beside the per-bin launch
         LAUNCH(h, "srt", k_srt4, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
                (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds,
                h->out_off0.p, h->rev_before.p, h->crej_off.p, (const uint8_t *)h->st1b.p, (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).qoff.p,
                h->out_offR.p, h->gres_off.p, late_out, leave_lim);
+        MARK("  k_srt4");
+        (void)hipEventRecord(h->ev_srt4, h->bstream);
+        MARK("  ev_srt4 record");
         if (n_voi)
             LAUNCH(h, "assemble", (k_assemble_map<true, false, true>), std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p,
                    (const uint32_t *)h->rev_idx.p, sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p,
@@ -1819,6 +2195,81 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                    h->rejected.p, h->rejected_src.p, h->lab_slots.p, 0u, (const uint32_t *)h->rev_list.p, (const uint32_t *)Q(h).qoff.p,
                    (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p, (const float4 *)h->vox_out.p, (const uint32_t *)h->out_offR.p,
                    (const uint32_t *)h->rev_before.p, (const uint32_t *)h->ng.p);
+        MARK("  assemble early");
+        (void)hipEventRecord(h->ev_asm, h->bstream);
+        MARK("  ev_asm record");
+        if (ov_next) {
+            const QSide &nq_ = h->q[nxt_side];
+            const size_t cap_chunks = std::min(std::min(std::min(h->vmask.cap, h->hmask.cap), h->lmask.cap) / CHUNK_TILES, h->cinfo.cap) - 8;
+            const uint32_t cap_voi = h->capV - 64u;
+            OvSplit ovs;
+            ovs.late = late_out;
+            ovs.prev = ds;
+            ovs.lmask = h->lmask.p;
+            // (its extents come from *ds: the region this step writes and the outskirts as its gather has left them)
+            launch_voi_split(h, (const float4 *)Fnew, 0u, 0u, 0u, 0u, 0u, nchunks + 64 + cdiv((uint64_t)ns + 4096, CHUNK), nx, ny, P.voi_r2,
+                             (const DevState *)nullptr, (uint32_t)cap_chunks, (const StepEnd *)nullptr, &ovs);
+            const uint32_t scan_cap1 = (uint32_t)std::min<size_t>(std::min(h->pvl.cap, h->phl.cap) - 8, 16384);
+            // (the next region's extent is not known here: it keeps this step's reserved places -- up to 4 x the VoI + 2 x the scan, see
+            // alloc_step --, and the outskirts grow by what leaves; one workgroup scans up to 16384 chunk counts, beyond that two levels
+            // over everything the buffers hold.  What the scan ahead can take is recorded: a step with more chunks runs its own passes)
+            const uint32_t hint = nchunks + 64 + cdiv(4 * (uint64_t)std::max(h->last_n_voi, 1u << 16) + 2 * (uint64_t)ns + 4096, CHUNK);
+            uint32_t scan_cap_used = 0;
+            if (hint <= scan_cap1) {
+                scan_cap_used = std::min<uint32_t>(scan_cap1, (uint32_t)cap_chunks);
+                LAUNCH(h, "chunk_scan", k_chunk_scan_one, 1, 1024, (const uint32_t *)h->cinfo.p, 0u, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, 16u, 0u,
+                       h->alt.d_st.p, h->alt.d_ctr.p, h->st, h->alt.lab_slots.p, h->mb_tot.p, B + 2, h->use_ometa ? h->ometa.p : (OMeta *)nullptr,
+                       h->capO / CHUNK, std::min<uint32_t>(scan_cap1, (uint32_t)cap_chunks), (const DevState *)ds, cap_voi);
+            } else {
+                const size_t top_cap = std::min(std::min(h->topv.cap, h->toph.cap), h->topr.cap);
+                const uint32_t grid2 = (uint32_t)std::min<size_t>(cdiv(std::min<size_t>(cap_chunks, std::min(h->pvl.cap, h->phl.cap) - 8), 1024), top_cap - 2);
+                const uint32_t cap2 = std::min<uint32_t>(grid2 * 1024u, (uint32_t)cap_chunks);
+                scan_cap_used = cap2;
+                LAUNCH(h, "chunk_scan", k_chunk_scan_local, grid2, 256, (const uint32_t *)h->cinfo.p, 0u, h->pvl.p, h->phl.p, h->topv.p, h->toph.p, h->topr.p,
+                       (const DevState *)ds, h->capO / CHUNK, cap2, 1u);
+                LAUNCH(h, "chunk_scan", k_chunk_scan_top, 1, 1024, h->topv.p, h->toph.p, grid2, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p, 0u, 0u,
+                       h->alt.d_st.p, h->alt.d_ctr.p, h->st, h->alt.lab_slots.p, h->mb_tot.p, B + 2, (const uint32_t *)h->topr.p,
+                       h->use_ometa ? h->ometa.p : (OMeta *)nullptr, h->capO / CHUNK, cap2, (const DevState *)ds, cap_voi);
+            }
+            MARK("  split + scan ahead");
+            (void)hipStreamWaitEvent(h->bstream, nq_.ev_keys, 0);  // k_voi_gather must see that query side's error flag
+            MARK("  ev_keys wait");
+            {
+                const uint32_t grid = std::max(1u, std::min<uint32_t>(cdiv((nFchunks + 64) * GATHER_SUB + nOchunks + 64, 4), 256 * 16));
+                LAUNCH(h, "voi_gather", k_voi_gather, grid, 256, (const float4 *)Fnew, 0u, 0u, h->Oxy.p, h->Ozi.p, 0u, 0u, (const unsigned long long *)h->vmask.p,
+                       (const unsigned long long *)h->hmask.p, (const uint32_t *)h->cinfo.p, (const uint32_t *)h->pvl.p, (const uint32_t *)h->phl.p,
+                       (const uint32_t *)h->topv.p, (const uint32_t *)h->toph.p, to_xf(nq_.To), P, h->alt.d_st.p, h->alt.d_ctr.p,
+                       (const Counters *)nq_.d_qctr.p, h->alt.voi_ego.p, h->alt.voi_key.p, h->alt.voi_src.p, h->use_ometa ? h->ometa.p : (OMeta *)nullptr,
+                       (const unsigned long long *)h->lmask.p, h->capO / CHUNK);
+            }
+            MARK("  gather ahead");
+            (void)hipEventRecord(h->ev_early, h->bstream);
+            MARK("  ev_early record");
+            h->ov.valid = true;
+            h->ov.seq = h->step_seq + 1;  // (this step's number: checked by the step that follows before it takes a number of its own)
+            h->ov.epoch = h->store_epoch;
+            h->ov.curF = h->curF ^ 1;
+            h->ov.qside = nxt_side;
+            h->ov.x = nx;
+            h->ov.y = ny;
+            memcpy(h->ov.To, nq_.To, sizeof(h->ov.To));
+            h->ov.cap_chunks = std::min<uint32_t>((uint32_t)cap_chunks, scan_cap_used);
+            h->ov.cap_voi = cap_voi;
+            h->ov.nbk = B + 2;
+            h->ov.vmask = h->vmask.p;
+            h->ov.hmask = h->hmask.p;
+            h->ov.lmask = h->lmask.p;
+            h->ov.cinfo = h->cinfo.p;
+            h->ov.pvl = h->pvl.p;
+            h->ov.phl = h->phl.p;
+            h->ov.voi_ego = h->alt.voi_ego.p;
+            h->ov.mb_hist = h->mb_hist.p;
+            ++h->n_ov_launched;
+            ++h->n_spec_launched;  // (it is the split ahead of this node, with company)
+            h->fly.spec_launched = true;
+        }
+        h->cur = h->stream;  // ---- back on the main stream
+        };
     } else if (srt_in_revert) {
         // (no launch)
     } else if (B <= 1024 * SRT_KPT)
@@ -1880,15 +2331,27 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         sa.st1_in = h->st1b.p;
         sa.moff = h->moff.p;
         sa.qoff = Q(h).qoff.p;
-        if (reserved) sa.status = nullptr;  // (k_srt4 has run as a launch of its own: no extra workgroup)
+        if (reserved) sa.status = nullptr;  // (k_srt4 runs as a launch of its own, on the early stream: no extra workgroup)
+        if (reserved) (void)hipEventRecord(h->ev_stats, h->stream);  // (the bin statistics are there: the early stream may start)
         LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins_srt, std::min<uint32_t>(rev_grid, B) + (reserved ? 0u : 1u), 1024, P, sa, ra);
+        MARK("per-bin launch");
+        if (reserved) enqueue_early();
+        if (ov_next) {  // (behind the early passes, where that stream idles; needed by the next step's bin statistics)
+            const int rc_p2 = enqueue_chain_part2(h, nxt_side, h->bstream);
+            if (rc_p2) return rc_p2;
+        }
+        if (reserved) (void)hipStreamWaitEvent(h->stream, h->ev_srt4, 0);  // (the reverted list, the reserved offsets, the late table)
+        MARK("  ev_srt4 wait");
         if (reserved)
             LAUNCH(h, "assemble", k_assemble_late, std::min<uint32_t>(rev_grid, B), 256, P, h->Tb2o, (const uint32_t *)h->rev_list.p, (const float4 *)h->spts.p,
                    (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).qoff.p, (const uint8_t *)h->gflag.p,
                    (const uint32_t *)h->grank.p, (const uint32_t *)h->ng.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
                    (const float4 *)h->vox_out.p, (const uint32_t *)h->out_offR.p, (const uint32_t *)h->gres_off.p, (const uint32_t *)h->out_off0.p,
                    (const uint32_t *)h->rev_before.p, late_out, h->late_holes[h->late_idx ^ 1].p, h->out_off.p, h->ground_off.p, h->rej_off.p, ds, Fnew,
-                   h->rejected.p, h->rejected_src.p, h->lab_slots.p, (const LateEnt *)nullptr, (const uint32_t *)nullptr, 0u);
+                   h->rejected.p, h->rejected_src.p, h->lab_slots.p,
+                   // (an overlapped step read a region with reserved slots as if they were entries: its source indices count them)
+                   use_ov ? (const LateEnt *)h->late[h->late_idx].p : (const LateEnt *)nullptr,
+                   use_ov ? (const uint32_t *)h->late_holes[h->late_idx].p : (const uint32_t *)nullptr, use_ov ? h->n_late_F : 0u);
     } else if (P.version == 3 && !no_fuse && h->prof != 1) {
         LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds,
                (const uint32_t *)h->vox_off.p, ra);
@@ -1950,13 +2413,34 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         se.qctr = (const Counters *)Q(h).d_qctr.p;
         se.q_nvox = (const uint32_t *)Q(h).d_nvox.p;
         se.seq = step_seq;
-        const bool end_in_split = spec && !no_end_fold && h->prof != 1;
-        if (!end_in_split)
-            LAUNCH(h, "step_end", k_step_end, 1, 1, se.st, se.ctr, se.out, se.lab_slots, se.qctr, se.q_nvox, se.seq);
+        const bool end_in_split = spec && !no_end_fold && h->prof != 1 && !ov_next;
         h->fly.nchunks = nchunks;
-        h->fly.spec_launched = false;
-        if (spec) launch_split_ahead(h, nx, ny, nchunks, end_in_split ? &se : (const StepEnd *)nullptr);
+        h->fly.spec_launched = ov_next;
+        if (ov_next) {
+            // round 5: behind the per-bin launch and the late write-back, the late half of the NEXT step's gather -- its last workgroup ends
+            // THIS step --, then that step's bucket histogram and column scan: the stream works through the host's turnaround
+            const QSide &nq_ = h->q[nxt_side];
+            MARK("assemble late");
+            (void)hipStreamWaitEvent(h->stream, h->ev_early, 0);
+            MARK("  ev_early wait");
+            LAUNCH(h, "voi_gather", k_late_gather, std::min<uint32_t>(2 * B, 128u) + 1u, 256, (const float4 *)Fnew, (const LateEnt *)late_out, (const DevState *)ds,
+                   h->Oxy.p, h->Ozi.p, (const unsigned long long *)h->vmask.p, (const unsigned long long *)h->hmask.p, (const uint32_t *)h->pvl.p,
+                   (const uint32_t *)h->phl.p, (const uint32_t *)h->topv.p, (const uint32_t *)h->toph.p, nx, ny, P.voi_r2, to_xf(nq_.To), P, h->alt.d_st.p,
+                   h->alt.d_ctr.p, (const Counters *)nq_.d_qctr.p, h->alt.voi_ego.p, h->alt.voi_key.p, h->alt.voi_src.p, se);
+            const uint32_t ntile_tab = std::max(1u, cdiv(n_voi, MB_TILE));
+            const uint32_t ntile_ub = h->last_n_voi ? std::min(ntile_tab, std::max(64u, cdiv((uint64_t)h->last_n_voi * 3 / 2, MB_TILE))) : ntile_tab;
+            const uint32_t *nvoi_next = &h->alt.d_st.p->voi_total;
+            LAUNCH(h, "voi_bucket", k_mb_hist, ntile_ub, 1024, (const uint32_t *)h->alt.voi_key.p, n_voi, nvoi_next, B + 2, h->mb_hist.p, h->mb_tot.p);
+            LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv(B + 2, MB_PAD), 256, h->mb_hist.p, n_voi, nvoi_next, B + 2, (const uint32_t *)h->mb_tot.p,
+                   h->alt.moff.p);
+        } else {
+            if (reserved) (void)hipStreamWaitEvent(h->stream, h->ev_asm, 0);  // (the early half of the write-back, its label tallies)
+            if (!end_in_split)
+                LAUNCH(h, "step_end", k_step_end, 1, 1, se.st, se.ctr, se.out, se.lab_slots, se.qctr, se.q_nvox, se.seq);
+            if (spec) launch_split_ahead(h, nx, ny, nchunks, end_in_split ? &se : (const StepEnd *)nullptr);
+        }
     }
+    MARK("late gather + table ahead / end");
     {   // the NEXT scan's query chain goes into its queue now, behind this step's own launches; it runs while we wait
         const int keep_side = h->qi;
         const int rc_next = flush_announced(h);
@@ -2041,6 +2525,27 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
     }
     if (host_timing)
         fprintf(stderr, "[step host] wait %.1f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host1).count());
+    {   // diagnostics: the launches' start times on the device's clock, relative to the per-bin launch of this step (see CHAIN_STAMP)
+        static const bool stamps = getenv("ERASOR_HIP_CHAIN_STAMPS") != nullptr;
+        if (stamps) {
+            static bool on = false;
+            if (!on) {
+                const int one = 1;
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_on), &one, sizeof(one));
+                on = true;
+            }
+            unsigned long long t[32];
+            (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_stamps), sizeof(t));
+            static unsigned long long prev_rev = 0;
+            static const char *nm[16] = {"scatter", "bin_stats", "per-bin", "srt4", "asm_early", "split'", "scan'", "gather'", "asm_late", "late_gather'", "hist'",
+                                         "colscan'", "o_commit", "", "", "end"};
+            fprintf(stderr, "[stamps, us after this step's per-bin launch; period %.1f]", prev_rev ? (double)(t[2] - prev_rev) * 0.01 : 0.0);
+            for (int i = 0; i < 16; ++i)
+                if (nm[i][0]) fprintf(stderr, " %s %.1f", nm[i], ((double)t[i] - (double)t[2]) * 0.01);
+            fprintf(stderr, "\n");
+            prev_rev = t[2];
+        }
+    }
     if (h->dbg_stamps.p) {
         unsigned long long t[96];
         (void)hipMemcpy(t, h->dbg_stamps.p, sizeof(t), hipMemcpyDeviceToHost);
@@ -2070,11 +2575,17 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
         h->spec.valid = false;
+        h->ov.valid = false;
         h->err = std::string("kernel launch: ") + hipGetErrorString(le);
         return ERASOR_E_NO_DEVICE;
     }
     if (h->ctr.err || h->ctr.sort_qoverflow) {
         h->spec.valid = false;  // (launched ahead on the assumption that this step succeeds)
+        if (h->ov.valid) {
+            h->ov.valid = false;
+            (void)hipStreamSynchronize(h->bstream);
+            (void)hipStreamSynchronize(h->stream);
+        }
         // errors raised by the query chain (2, 3, 4) are seen by k_voi_gather before it touches the map store: the step left
         // no trace and the host mirror of the state is simply restored.
         h->st.nF = h->nF;
@@ -2089,6 +2600,7 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
                 // chains announced ahead were enqueued in the other mode: they run out, then go again in the new one behind this step's own
                 // (step_enqueue, STEP_RETRIED).  The announcements themselves stay: a node announced by ticket has no caller buffer its
                 // step could come back with (erasor_hip_step_ticket used to fail with "not the oldest announced scan" here)
+                (void)chain_wait(h, -1);
                 for (int k = 0; k < h->nqs; ++k) (void)hipStreamSynchronize(h->qstream[k]);
                 if (h->cstream) (void)hipStreamSynchronize(h->cstream);
                 for (int k = 0; k < NSIDE; ++k) h->q[k].h2d_pending = false;
@@ -2120,7 +2632,8 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
         return ERASOR_E_UNSUPPORTED;
     }
     // commit (from here on n_voi / nq are the actual sizes)
-    const uint32_t n_voi_act = h->st.voi_total, nq_act = h->st.q_nvox;
+    // (round 5: an overlapped step kept VoI-order places for the previous step's late slots; the ones no point came to are not VoI points)
+    const uint32_t n_voi_act = h->st.voi_total - h->st.n_voi_dead, nq_act = h->st.q_nvox;
     h->curF ^= 1;
     h->nF = h->st.nF;
     h->nFv = h->st.nF_valid;
@@ -2130,7 +2643,8 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
     } else
         h->n_late_F = 0;
     h->o_begin = h->st.o_begin;
-    const uint64_t n_out = (uint64_t)(h->o_valid) - (n_voi_act - h->st.voiF) + h->st.n_leaving;
+    // (outskirts entries that entered the VoI: none of the reserved places lies in the outskirts' part of VoI order)
+    const uint64_t n_out = (uint64_t)(h->o_valid) - (h->st.voi_total - h->st.voiF) + h->st.n_leaving;
     h->o_valid = n_out;
     h->last_n_voi = n_voi_act;
     h->last_nq = nq_act;
@@ -2209,6 +2723,8 @@ static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n
         h->qi = side;
         rc = alloc_scan(h, (uint32_t)n);
         if (rc) return rc;
+        rc = chain_wait(h, side);
+        if (rc) return rc;
         if (Q(h).used) HIPC(h, hipEventSynchronize(Q(h).ev_done));  // (a dropped chain may still be reading this side's scan)
         rc = stage_host_scan(h, scan_xyzi, (uint32_t)n, h->cstream, fmt, &h->ann.fp);
         if (rc) return rc;
@@ -2228,6 +2744,8 @@ static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n
     h->ann.pose_valid = T_b2o != nullptr;
     h->ann.pose_x = T_b2o ? (double)T_b2o[3] : 0.0;  // OMU.cpp:246-247
     h->ann.pose_y = T_b2o ? (double)T_b2o[7] : 0.0;
+    h->ann.to_valid = false;
+    h->last_ann_side = side;
     if (h->fly.active) {
         // the step in flight has enqueued everything of its own already: the announced chain starts NOW (nothing to go first), and if
         // this is the node right behind that step and its pose is known, its VoI split goes behind the step as well
@@ -2237,7 +2755,7 @@ static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n
         const double nx = h->ann.pose_x, ny = h->ann.pose_y;
         rc = flush_announced(h);
         if (rc) return rc;
-        if (next_in_line && pose && !no_spec && !h->fly.flags && !h->fly.spec_launched && !submap_would_move(h, nx, ny)) {
+        if (next_in_line && pose && !no_spec && !h->fly.flags && !h->fly.spec_launched && !h->ov.valid && !submap_would_move(h, nx, ny)) {
             hipStream_t keep = h->cur;
             h->cur = h->stream;
             launch_split_ahead(h, nx, ny, h->fly.nchunks, nullptr);
@@ -2245,6 +2763,29 @@ static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n
         }
     }
     return ERASOR_OK;
+}
+
+// Round 5: the announced node's OTHER transform.  fetch_VoI's egocentric transform uses tf_body2origin_.inverse() (OMU.cpp:436), which the
+// caller computes and hands to the step (see erasor_hip_step); announced together with the node (right after erasor_hip_prefetch_node*)
+// it lets that step's split, chunk scan AND gather run beside the per-bin launch of the step in front of it (OVERLAPPED steps).  The
+// step must then pass the very same 16 floats; anything else and it simply runs its own passes.
+int erasor_hip_announce_origin2body(erasor_hip_handle *h, const float T_origin2body[16]) {
+    if (!h || !T_origin2body) return ERASOR_E_INVALID;
+    if (h->ann.valid && h->ann.pose_valid) {
+        memcpy(h->ann.To, T_origin2body, sizeof(h->ann.To));
+        h->ann.to_valid = true;
+        return ERASOR_OK;
+    }
+    const int sd = h->last_ann_side;
+    bool pending = false;
+    for (int j = 0; j < h->npend; ++j) pending = pending || h->pend[j] == sd;
+    if (sd >= 0 && pending && h->q[sd].pose_valid) {  // (announced while a step was in flight: its chain is in its queue already)
+        memcpy(h->q[sd].To, T_origin2body, sizeof(h->q[sd].To));
+        h->q[sd].to_valid = true;
+        return ERASOR_OK;
+    }
+    h->err = "erasor_hip_announce_origin2body: no node announced with its pose to attach the transform to";
+    return ERASOR_E_STATE;
 }
 
 int erasor_hip_step(erasor_hip_handle *h, const float *scan_xyzi, size_t n_scan, const float T_lidar2body[16], const float T_body2origin[16],
@@ -2305,7 +2846,8 @@ int erasor_hip_run_nodes(erasor_hip_handle *h, const void *const *scans, const s
         while (*announced < want) {
             const size_t j = *announced;
             if (j >= i && lookahead > 0) {
-                const int rc = erasor_hip_prefetch_node(h, scans[j], n_pts[j], src_is_device, T_lidar2body, T_body2origin + 16 * j);
+                int rc = erasor_hip_prefetch_node(h, scans[j], n_pts[j], src_is_device, T_lidar2body, T_body2origin + 16 * j);
+                if (!rc) rc = erasor_hip_announce_origin2body(h, T_origin2body + 16 * j);
                 if (rc) return rc;
             }
             ++*announced;
@@ -2589,7 +3131,31 @@ int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap
     const DevState &s = h->st;
     switch (which) {
         case ERASOR_CLOUD_QUERY_VOI: return out_cloud(h, Q(h).query.p, h->last_nq, dst, cap, n);
-        case ERASOR_CLOUD_MAP_VOI: return out_cloud(h, h->voi_ego.p, h->last_n_voi, dst, cap, n);
+        case ERASOR_CLOUD_MAP_VOI: {
+            if (!s.n_voi_dead) return out_cloud(h, h->voi_ego.p, h->last_n_voi, dst, cap, n);
+            // (round 5: an overlapped step's VoI-order array keeps places no point came to, key B + 1: the VoI is what is left)
+            if (n) *n = h->last_n_voi;
+            if (!dst) return ERASOR_OK;
+            if (h->last_n_voi > cap) return ERASOR_E_CAPACITY;
+            const uint32_t tot = s.voi_total;
+            DBuf<uint32_t> flag, pl, tops;
+            DBuf<float4> tmp;
+            if (ensure(h, flag, (size_t)tot + 1) || ensure(h, pl, (size_t)tot + 1) || ensure(h, tops, tot / 1024 + 4) || ensure(h, tmp, (size_t)h->last_n_voi + 1))
+                return ERASOR_E_NO_DEVICE;
+            hipStream_t keep = h->cur;
+            h->cur = h->stream;
+            LAUNCH(h, "get_cloud", k_voi_live, cdiv(tot, 256), 256, (const uint32_t *)h->voi_key.p, tot, h->B, flag.p);
+            scan_u32(h, flag.p, pl.p, tops.p, tot, tot, nullptr, nullptr, "get_cloud");
+            LAUNCH(h, "get_cloud", k_f_compact, cdiv(tot, 256), 256, (const float4 *)h->voi_ego.p, tot, (const uint32_t *)flag.p, (const uint32_t *)pl.p,
+                   (const uint32_t *)tops.p, tmp.p);
+            h->cur = keep;
+            const int rc_c = d2h(h, dst, tmp.p, (size_t)h->last_n_voi * sizeof(float4));
+            release(flag);
+            release(pl);
+            release(tops);
+            release(tmp);
+            return rc_c;
+        }
         case ERASOR_CLOUD_MAP_REJECTED: return out_cloud(h, h->rejected.p, s.n_rejected, dst, cap, n);
         case ERASOR_CLOUD_CURR_REJECTED: return out_cloud(h, h->curr_rejected.p, s.n_curr_rejected, dst, cap, n);
         case ERASOR_CLOUD_STATIC_ESTIMATE:
@@ -3001,6 +3567,12 @@ int erasor_hip_voi_split_bytes(erasor_hip_handle *h, uint64_t *algorithmic_bytes
         return ERASOR_OK;
     }
     if (algorithmic_bytes) *algorithmic_bytes = 16ull * h->nF + 8ull * oe + ((uint64_t)h->nF + oe) / 4;
+    return ERASOR_OK;
+}
+int erasor_hip_overlap_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t *used) {
+    if (!h || !launched || !used) return ERASOR_E_INVALID;
+    *launched = h->n_ov_launched;
+    *used = h->n_ov_used;
     return ERASOR_OK;
 }
 int erasor_hip_ahead_split_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t *used) {

@@ -36,6 +36,15 @@ struct Xf {
     float m[12];
 };
 
+// diagnostics (ERASOR_HIP_CHAIN_STAMPS=1): the 100 MHz counter when the first thread of a launch starts, by launch (see erasor_hip.hip:
+// print_chain_stamps) -- the untraced timeline of a step's launches over the streams; off: one uniform load per launch
+__device__ unsigned long long g_stamps[32];
+__device__ int g_stamps_on;
+#define CHAIN_STAMP(i)                                                                    \
+    do {                                                                                  \
+        if (g_stamps_on && blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); \
+    } while (0)
+
 struct DP {  // device copy of the parameters
     double max_r, ring_size, sector_size, max_h, min_h, th_bin_max_h, srt_thr, gf_dist, gf_seeds_h, voi_r2;
     int32_t R, S, B, num_lowest, min_pts, gf_iter, gf_lpr, version;
@@ -71,7 +80,8 @@ struct DevState {
     uint32_t total_binsR, ground_res;  // reserved layout: extent of the bin part, of the ground_viz part
     uint32_t n_late;                   // entries of the late table the step leaves (LateEnt: two per reverted bin)
     uint32_t n_voi_dead;               // VoI-order slots kept for the previous step's late points that turned out to hold none (overlapped steps)
-    uint32_t n_late_leaving, pad_r5;
+    uint32_t n_late_leaving;           // ... of them points that left the VoI (counted into n_leaving)
+    uint32_t ov_bad;                   // the passes launched ahead of this step found no room (front of the outskirts / VoI-order arrays): they did nothing
 };
 
 // A reserved range of the VoI-resident region (round 5).  [start, start + ndata): data slots -- the first `actual` hold points once the
@@ -331,6 +341,11 @@ struct OMeta {
     float xmin, xmax, ymin, ymax;
     uint32_t valid, known, pad0, pad1;
 };
+struct OvSplit {  // round 5: the split of an OVERLAPPED step (see k_voi_split); late == nullptr: off
+    const LateEnt *late = nullptr;
+    const DevState *prev = nullptr;        // the state of the step in flight: extents of the region it writes, entries of its late table
+    unsigned long long *lmask = nullptr;   // per tile of the VoI-resident region: the slots that belong to the late table
+};
 static constexpr uint32_t CINFO_READ = 0x80000000u;  // cinfo: voi count | valid count << 16 | "the chunk was read"
 static constexpr uint32_t CINFO_HMASK = 0x7FFFu;
 __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F, uint32_t nF, uint32_t nFchunks,
@@ -339,11 +354,25 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
                                                     unsigned long long *__restrict__ vmask,
                                                     unsigned long long *__restrict__ hmask, uint32_t *__restrict__ cinfo,
                                                     const DevState *__restrict__ dev, uint32_t capO_chunks, uint32_t cap_chunks,
-                                                    OMeta *__restrict__ ometa, StepEnd se) {
+                                                    OMeta *__restrict__ ometa, StepEnd se, OvSplit ov = OvSplit()) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    if (dev && se.st) {
+    uint32_t n_late = 0;
+    if (ov.late) {
+        CHAIN_STAMP(5);
+        // round 5, OVERLAPPED steps: the pass of step k + 1 beside step k's per-bin launch.  The region it reads is being written in the
+        // reserved layout: its extents are final (k_srt4), the slots of the late table are NOT -- their masks come from the table:
+        // a data slot counts as a VoI entry (it keeps a place in VoI order for the point that may come), a leaving reservation as a
+        // valid entry outside the VoI (a place in the outskirts' order); lmask marks both for the gather, which leaves them alone
+        nF = ov.prev->nF_new;
+        nFchunks = (nF + CHUNK - 1) / CHUNK;
+        o_begin = ov.prev->o_new_begin;
+        o_chunk0 = o_begin / CHUNK;
+        nOchunks = capO_chunks - o_chunk0;
+        n_late = ov.prev->n_late;
+        if (nFchunks + nOchunks > cap_chunks) return;  // (k_chunk_scan_* sees that too: ov_bad)
+    } else if (dev && se.st) {
         // the launch also ENDS the previous step (se): its last workgroup is k_step_end; the others take the extents that commit will
         // publish straight from what the step left (the same decision, the same values whichever comes first)
         if (blockIdx.x == gridDim.x - 1) {
@@ -372,7 +401,7 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
     }
     const uint32_t nchunks = nFchunks + nOchunks;
     for (uint32_t c = wid; c < nchunks; c += nwaves) {
-        unsigned long long myv = 0, myh = 0;
+        unsigned long long myv = 0, myh = 0, myl = 0;
         uint32_t cv = 0, ch = 0, read_flag = 0;
         float bxmin = __int_as_float(0x7F800000), bxmax = __int_as_float(0xFF800000), bymin = bxmin, bymax = bxmax;
         if (c >= nFchunks) {
@@ -439,6 +468,17 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
         } else {
             // ---- F region: dense float4, two half-chunks to bound the registers ----
             const uint32_t base = c * CHUNK + lane;
+            uint32_t e0 = 0;  // first late entry that ends beyond the chunk's start (the table is sorted by position)
+            if (n_late) {
+                uint32_t lo = 0, hi = n_late;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const LateEnt e = ov.late[mid];
+                    if (e.start + e.ntotal <= c * CHUNK) lo = mid + 1;
+                    else hi = mid;
+                }
+                e0 = lo;
+            }
 #pragma unroll
             for (int hlf = 0; hlf < 2; ++hlf) {
                 float px[CHUNK_TILES / 2], py[CHUNK_TILES / 2];
@@ -452,13 +492,31 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
 #pragma unroll
                 for (int t = 0; t < CHUNK_TILES / 2; ++t) {
                     const int tt = hlf * (CHUNK_TILES / 2) + t;
-                    const bool valid = base + tt * TILE < nF && __float_as_uint(px[t]) != HOLE_BITS;  // (round 5: a reserved slot nothing filled)
+                    bool valid = base + tt * TILE < nF && __float_as_uint(px[t]) != HOLE_BITS;  // (round 5: a reserved slot nothing filled)
                     const double dx = (double)px[t] - xc, dy = (double)py[t] - yc;
-                    const bool in = valid && (dx * dx + dy * dy < r2);
+                    bool in = valid && (dx * dx + dy * dy < r2);
+                    unsigned long long lm = 0ull;
+                    if (n_late) {  // (uniform: the table entries that meet this tile)
+                        const uint32_t pos = base + tt * TILE, tile0 = c * CHUNK + tt * TILE;
+                        bool ldat = false, lph = false;
+                        for (uint32_t e = e0; e < n_late; ++e) {
+                            const LateEnt le = ov.late[e];
+                            if (le.start >= tile0 + TILE) break;
+                            if (le.start + le.ntotal <= tile0) continue;
+                            ldat = ldat || (pos >= le.start && pos < le.start + le.ndata);
+                            lph = lph || (pos >= le.start + le.ndata && pos < le.start + le.ntotal);
+                        }
+                        if (ldat || lph) {
+                            valid = true;
+                            in = ldat;
+                        }
+                        lm = __ballot(ldat || lph);
+                    }
                     const unsigned long long vm = __ballot(in), hm = __ballot(valid);
                     if ((int)lane == tt) {
                         myv = vm;
                         myh = hm;
+                        myl = lm;
                     }
                     cv += __popcll(vm);
                     ch += __popcll(hm);
@@ -468,6 +526,7 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
         if (lane < CHUNK_TILES) {
             vmask[(size_t)c * CHUNK_TILES + lane] = myv;
             hmask[(size_t)c * CHUNK_TILES + lane] = myh;
+            if (ov.lmask && c < nFchunks) ov.lmask[(size_t)c * CHUNK_TILES + lane] = myl;
         }
         if (lane == 0) cinfo[c] = cv | (ch << 16) | read_flag;
     }
@@ -484,10 +543,13 @@ __global__ __launch_bounds__(256) void k_chunk_scan_local(const uint32_t *__rest
                                                            uint32_t *__restrict__ topv, uint32_t *__restrict__ toph, uint32_t *__restrict__ topr,
                                                            // round 4: != 0: launched AHEAD (see k_chunk_scan_one): the extents come from the
                                                            // committed device state, the grid is an upper bound (workgroups beyond write zeros)
-                                                           const DevState *st_dev, uint32_t capO_chunks_dev, uint32_t cap_dev) {
+                                                           const DevState *st_dev, uint32_t capO_chunks_dev, uint32_t cap_dev,
+                                                           // round 5 (overlapped steps): st_dev is the state of the step IN FLIGHT, the extents are
+                                                           // those of the region it is writing
+                                                           uint32_t from_new = 0u) {
     __shared__ uint32_t sm[40];
     if (capO_chunks_dev) {
-        const uint32_t nF = st_dev->nF, ob = st_dev->o_begin;
+        const uint32_t nF = from_new ? st_dev->nF_new : st_dev->nF, ob = from_new ? st_dev->o_new_begin : st_dev->o_begin;
         nchunks = min((nF + CHUNK - 1) / CHUNK + (capO_chunks_dev - ob / CHUNK), cap_dev);
     }
     const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
@@ -530,15 +592,21 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ 
                                                           uint32_t nchunks, uint32_t nFchunks, DevState *st, Counters *ctr, DevState init,
                                                           unsigned long long *lab_slots, uint32_t *mb_tot, uint32_t mb_n,
                                                           const uint32_t *__restrict__ topr, OMeta *__restrict__ ometa,
-                                                          uint32_t capO_chunks_dev, uint32_t cap_dev /* ahead: see k_chunk_scan_one */) {
+                                                          uint32_t capO_chunks_dev, uint32_t cap_dev /* ahead: see k_chunk_scan_one */,
+                                                          const DevState *prev = nullptr, uint32_t cap_voi = 0u /* round 5: see k_chunk_scan_one */) {
     __shared__ uint32_t sm[40];
     __shared__ uint32_t carry[2];
+    bool ov_bad = false;
     if (capO_chunks_dev) {
-        const uint32_t nF = st->nF, ob = st->o_begin;
+        const DevState *src = prev ? prev : st;
+        const uint32_t nF = prev ? src->nF_new : src->nF, ob = prev ? src->o_new_begin : src->o_begin;
         nFchunks = (nF + CHUNK - 1) / CHUNK;
+        ov_bad = nFchunks + (capO_chunks_dev - ob / CHUNK) > cap_dev;
         nchunks = min(nFchunks + (capO_chunks_dev - ob / CHUNK), cap_dev);  // (beyond: the step sees that and runs the scan itself)
         ntop = max(1u, (nchunks + 1023u) / 1024u);
-        init = *st;
+        init = *src;
+        init.nF = nF;
+        init.o_begin = ob;
         __syncthreads();  // (everybody has read the state before thread 0 replaces it)
     }
     uint32_t n_read = 0;
@@ -593,6 +661,9 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_top(uint32_t *__restrict__ 
         s.o_new_begin = s.o_begin - (validF - voiF);
         s.n_o_read = n_read;
         s.t_open = wall_clock64();  // (the two-launch scan: stamped here, one launch late)
+        s.n_voi_dead = s.n_late_leaving = 0;
+        s.ov_bad = (prev && (ov_bad || (uint64_t)(validF - voiF) + CHUNK > s.o_begin || voi_total > cap_voi)) ? 1u : 0u;
+        if (s.ov_bad) s.o_new_begin = s.o_begin;
         *st = s;
         // the chunks that receive this step's leaving points (k_voi_gather prepends them to the outskirts): their records are void
         if (ometa && s.o_new_begin < s.o_begin)
@@ -613,17 +684,29 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restr
                                                           // round 4: != 0: launched AHEAD, right behind the next step's VoI split (which was launched
                                                           // ahead too): the extents are what the step in front has committed on the device, and so is
                                                           // the state this step starts from -- the host is still collecting that step's results
-                                                          uint32_t capO_chunks_dev, uint32_t cap_dev /* chunks the prefix arrays hold */) {
+                                                          uint32_t capO_chunks_dev, uint32_t cap_dev /* chunks the prefix arrays hold */,
+                                                          // round 5, OVERLAPPED steps (prev != nullptr): launched beside the per-bin launch of the
+                                                          // step in flight, whose state is *prev -- this step starts from it, with the extents of
+                                                          // the region that step is writing (final since its k_srt4) --, into a state of its own
+                                                          // (*st); cap_voi: entries the VoI-order arrays hold (beyond, or without room in front of
+                                                          // the outskirts: ov_bad, and the passes behind do nothing)
+                                                          const DevState *prev = nullptr, uint32_t cap_voi = 0u) {
     __shared__ uint32_t sm[40];
     __shared__ uint32_t s_voiF, s_validF;
     const unsigned long long t_open = wall_clock64();
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    CHAIN_STAMP(6);
+    bool ov_bad = false;
     if (capO_chunks_dev) {
-        const uint32_t nF = st->nF, ob = st->o_begin;
+        const DevState *src = prev ? prev : st;
+        const uint32_t nF = prev ? src->nF_new : src->nF, ob = prev ? src->o_new_begin : src->o_begin;
         nFchunks = (nF + CHUNK - 1) / CHUNK;
+        ov_bad = nFchunks + (capO_chunks_dev - ob / CHUNK) > min(cap_dev, 16384u);
         nchunks = min(nFchunks + (capO_chunks_dev - ob / CHUNK), min(cap_dev, 16384u));  // (beyond: the step sees that and runs the scan itself)
         ntop = max(1u, (nchunks + 1023u) / 1024u);
-        init = *st;
+        init = *src;
+        init.nF = nF;
+        init.o_begin = ob;
     }
     const uint32_t base = tid * 16;
     uint32_t ci[16];
@@ -729,6 +812,9 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restr
         s.o_new_begin = s.o_begin - (validF - voiF);
         s.n_o_read = sm[32];
         s.t_open = t_open;
+        s.n_voi_dead = s.n_late_leaving = 0;
+        s.ov_bad = (prev && (ov_bad || (uint64_t)(validF - voiF) + CHUNK > s.o_begin || voi_total > cap_voi)) ? 1u : 0u;
+        if (s.ov_bad) s.o_new_begin = s.o_begin;
         *st = s;
         // the chunks that receive this step's leaving points (k_voi_gather prepends them to the outskirts): their records are void
         if (ometa && s.o_new_begin < s.o_begin)
@@ -749,11 +835,26 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
                                                      const uint32_t *__restrict__ phl, const uint32_t *__restrict__ topv,
                                                      const uint32_t *__restrict__ toph, Xf To2b, DP P, DevState *st,
                                                      Counters *ctr, const Counters *qctr, float4 *__restrict__ voi_ego,
-                                                     uint32_t *__restrict__ voi_key, uint32_t *__restrict__ voi_src, OMeta *__restrict__ ometa) {
+                                                     uint32_t *__restrict__ voi_key, uint32_t *__restrict__ voi_src, OMeta *__restrict__ ometa,
+                                                     // round 5, OVERLAPPED steps (lmask != nullptr): launched beside the per-bin launch of the
+                                                     // step in flight.  The extents come from *st (opened by the chunk scan ahead); the slots of
+                                                     // the late table (lmask) are left alone -- k_late_gather fills their places when the points
+                                                     // are there --; entering outskirts entries are NOT tombstoned yet (k_o_commit, once the step
+                                                     // is certain: until then a getter may still read the store as the step in flight leaves it)
+                                                     const unsigned long long *__restrict__ lmask = nullptr, uint32_t capO_chunks = 0u) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint64_t lt = lanemask_lt();
+    const bool ovm = lmask != nullptr;
+    if (ovm) {
+        CHAIN_STAMP(7);
+        if (st->ov_bad) return;
+        nF = st->nF;
+        nFchunks = (nF + CHUNK - 1) / CHUNK;
+        o_chunk0 = st->o_begin / CHUNK;
+        nOchunks = capO_chunks - o_chunk0;
+    }
     // (round 4: the error flags, the step's state and the first item's records are fetched TOGETHER -- behind one another they were three
     // dependent round trips at the head of a wavefront that lives five or six)
     const uint32_t err_a = ctr->err, err_b = qctr->err;
@@ -774,6 +875,7 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
         const uint32_t pvl_c = pvl[c], phl_c = phl[c], topv_c = topv[c >> 10], toph_c = toph[c >> 10];
         const unsigned long long mv = lane < CHUNK_TILES ? vmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
         const unsigned long long mh = lane < CHUNK_TILES ? hmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
+        const unsigned long long ml = (ovm && isF && lane < CHUNK_TILES) ? lmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
         if (err_a || err_b) return;  // the voxelisation of this step's scan failed: do not touch the map store
         const uint32_t cv = ci & 0xFFFFu, ch = (ci >> 16) & CINFO_HMASK;
         if (cv == 0 && !(isF && ch > cv)) continue;
@@ -790,7 +892,7 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
             float4 pp[PT];
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
-                const unsigned long long hm = __shfl(mh, t_lo + j, 64);
+                const unsigned long long hm = __shfl(mh, t_lo + j, 64) & ~__shfl(ml, t_lo + j, 64);
                 pp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((hm >> lane) & 1ull) pp[j] = F[c * CHUNK + (t_lo + j) * TILE + lane];
             }
@@ -798,11 +900,13 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
             for (int j = 0; j < PT; ++j) {  // (one copy of the body: the fetched points rotate through pp[0])
                 const unsigned long long vm = __shfl(mv, t_lo + j, 64), hm = __shfl(mh, t_lo + j, 64);
                 const unsigned long long lm = hm & ~vm;
+                const unsigned long long late = __shfl(ml, t_lo + j, 64);  // (slots of the late table: counted, not touched)
                 const float4 p = pp[0];
 #pragma unroll
                 for (int q = 0; q + 1 < PT; ++q) pp[q] = pp[q + 1];
                 if (hm != 0ull) {
-                    const bool in = (vm >> lane) & 1ull, lv = (lm >> lane) & 1ull;
+                    const bool mine = !((late >> lane) & 1ull);
+                    const bool in = mine && ((vm >> lane) & 1ull), lv = mine && ((lm >> lane) & 1ull);
                     if (in || lv) {
                         if (in) {
                             const uint32_t rank = pv + __popcll(vm & lt);
@@ -835,7 +939,7 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
                         voi_ego[rank] = e;
                         voi_key[rank] = bin_key(P, e.x, e.y, e.z, ctr);
                         voi_src[rank] = ph + __popcll(hm & lt);  // (== points of the VoI-resident region + valid outskirts entries before it)
-                        reinterpret_cast<uint32_t *>(Oxy)[(size_t)idx * 2] = HOLE_BITS;  // tombstone
+                        if (!ovm) reinterpret_cast<uint32_t *>(Oxy)[(size_t)idx * 2] = HOLE_BITS;  // tombstone
                         if (is_dynamic_label(b.y)) ++dyn_enter; else ++stat_enter;
                     }
                 }
@@ -844,7 +948,7 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
             }
         }
         // (the chunk's entering entries are tombstones now: its record counts the valid ones)
-        if (!isF && ometa && lane == 0) ometa[c - nFchunks + o_chunk0].valid = ch - cv;
+        if (!isF && ometa && lane == 0 && !ovm) ometa[c - nFchunks + o_chunk0].valid = ch - cv;
     }
     (void)voiF;
     (void)validF;
@@ -856,6 +960,132 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
     if (lane == 0) {
         if (dyn_leave | dyn_enter) atomicAdd(&st->O_dynamic, (unsigned long long)dyn_leave - (unsigned long long)dyn_enter);
         if (stat_leave | stat_enter) atomicAdd(&st->O_static, (unsigned long long)stat_leave - (unsigned long long)stat_enter);
+    }
+}
+
+// ================================================================================================
+// Round 5, OVERLAPPED steps: the late half of step k + 1's gather.  Step k's per-bin launch and k_assemble_late have filled the slots of
+// the late table (reverted bins' voxels and ground; holes where nothing came); k_voi_split / k_voi_gather of step k + 1, which ran BESIDE
+// that, kept a place in VoI order for every data slot and a place in the outskirts' order for every leaving reservation.  Here every
+// data slot that holds a point inside the VoI circle goes to its place (egocentric transform, R-POD key: exactly k_voi_gather's
+// arithmetic); every other data slot's place gets the key of the dead bucket (B + 1), which the bucketing moves behind everything; a
+// point outside the circle goes to the place its reservation holds in front of the outskirts (a bin without reservations cannot have such
+// a point: srt4_body's radius test -- err 7 otherwise), unused reservations are tombstoned.  One workgroup per table entry (grid
+// stride), one wavefront per 64-slot tile of its range; the launch's LAST workgroup ends step k (see StepEnd): everything that step wrote
+// is visible at this kernel's boundary.
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_late_gather(const float4 *__restrict__ F, const LateEnt *__restrict__ late, const DevState *__restrict__ prev,
+                                                      float2 *__restrict__ Oxy, float2 *__restrict__ Ozi,
+                                                      const unsigned long long *__restrict__ vmask, const unsigned long long *__restrict__ hmask,
+                                                      const uint32_t *__restrict__ pvl, const uint32_t *__restrict__ phl,
+                                                      const uint32_t *__restrict__ topv, const uint32_t *__restrict__ toph, double xc, double yc,
+                                                      double r2, Xf To2b, DP P, DevState *st, Counters *ctr, const Counters *qctr,
+                                                      float4 *__restrict__ voi_ego, uint32_t *__restrict__ voi_key, uint32_t *__restrict__ voi_src,
+                                                      StepEnd se) {
+    if (blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x == 0 && g_stamps_on) g_stamps[15] = wall_clock64();
+        if (threadIdx.x == 0 && se.st) step_end_body(se.st, se.ctr, se.out, se.lab_slots, se.qctr, se.q_nvox, se.seq);
+        return;
+    }
+    if (st->ov_bad || ctr->err || qctr->err) return;  // (the step that finds this out runs its own passes / fails like any other)
+    CHAIN_STAMP(9);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint64_t lt = lanemask_lt();
+    const uint32_t n_late = prev->n_late;
+    const uint32_t o_new_begin = st->o_new_begin;
+    uint32_t dead = 0, ph_unused = 0, n_left = 0, dyn_leave = 0, stat_leave = 0, bad = 0;
+    for (uint32_t e = blockIdx.x; e < n_late; e += gridDim.x - 1) {
+        const LateEnt le = late[e];
+        if (!le.ntotal) continue;
+        const uint32_t T0 = le.start / TILE, T1 = (le.start + le.ntotal - 1) / TILE;
+        for (uint32_t T = T0 + wave; T <= T1; T += nw) {
+            const uint32_t c = T / CHUNK_TILES, t = T % CHUNK_TILES;
+            const unsigned long long mv = lane < CHUNK_TILES ? vmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
+            const unsigned long long mh = lane < CHUNK_TILES ? hmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
+            uint32_t pv = pvl[c] + topv[c >> 10], ph = phl[c] + toph[c >> 10];
+            const uint32_t a2 = wave_sum((lane < t) ? ((uint32_t)__popcll(mv) | ((uint32_t)__popcll(mh) << 16)) : 0u);
+            pv += a2 & 0xFFFFu;
+            ph += a2 >> 16;
+            const unsigned long long vm = __shfl(mv, (int)t, 64), hm = __shfl(mh, (int)t, 64);
+            const uint32_t pos = T * TILE + lane;
+            const bool isdat = pos >= le.start && pos < le.start + le.ndata;
+            const bool isph = pos >= le.start + le.ndata && pos < le.start + le.ntotal;
+            if (isdat || isph) {
+                const float4 p = F[isdat ? pos : pos - le.ndata];
+                const bool point = __float_as_uint(p.x) != HOLE_BITS;
+                // double dist_square = pow(pt.x - x_criterion, 2) + pow(pt.y - y_criterion, 2)  (OMU.cpp:394)
+                const double dx = (double)p.x - xc, dy = (double)p.y - yc;
+                const bool in = point && (dx * dx + dy * dy < r2);
+                if (isdat) {
+                    const uint32_t rank = pv + (uint32_t)__popcll(vm & lt);
+                    if (in) {
+                        const float4 eg = xform(To2b, p);
+                        voi_ego[rank] = eg;
+                        voi_key[rank] = bin_key(P, eg.x, eg.y, eg.z, ctr);
+                        voi_src[rank] = ph + (uint32_t)__popcll(hm & lt);
+                    } else {
+                        voi_ego[rank] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        voi_key[rank] = (uint32_t)P.B + 1u;
+                        voi_src[rank] = 0u;
+                        ++dead;
+                        if (point && le.ntotal == le.ndata) ++bad;  // a point left a VoI it could not leave
+                    }
+                } else {
+                    const uint32_t lr = (ph - pv) + (uint32_t)__popcll((hm & ~vm) & lt);
+                    const uint32_t dst = o_new_begin + lr;
+                    if (point && !in) {
+                        Oxy[dst] = make_float2(p.x, p.y);
+                        Ozi[dst] = make_float2(p.z, p.w);
+                        ++n_left;
+                        if (is_dynamic_label(p.w)) ++dyn_leave; else ++stat_leave;
+                    } else {
+                        reinterpret_cast<uint32_t *>(Oxy)[(size_t)dst * 2] = HOLE_BITS;
+                        ++ph_unused;
+                    }
+                }
+            }
+        }
+    }
+    dead = wave_sum(dead);
+    ph_unused = wave_sum(ph_unused);
+    n_left = wave_sum(n_left);
+    dyn_leave = wave_sum(dyn_leave);
+    stat_leave = wave_sum(stat_leave);
+    bad = wave_sum(bad);
+    if (lane == 0) {
+        if (dead) atomicAdd(&st->n_voi_dead, dead);
+        if (ph_unused) atomicAdd(&st->n_leaving, 0u - ph_unused);
+        if (n_left) atomicAdd(&st->n_late_leaving, n_left);
+        if (dyn_leave) atomicAdd(&st->O_dynamic, (unsigned long long)dyn_leave);
+        if (stat_leave) atomicAdd(&st->O_static, (unsigned long long)stat_leave);
+        if (bad) atomicMax(&ctr->err, 7u);
+    }
+}
+
+// ... and its tombstones: the outskirts entries that entered the VoI of an overlapped step, erased once the step is certain (enqueued
+// with the step itself, not ahead of it: see k_voi_gather).  One wavefront per outskirts chunk that holds VoI entries; the chunk's
+// record counts what stays.
+__global__ __launch_bounds__(256) void k_o_commit(float2 *__restrict__ Oxy, const unsigned long long *__restrict__ vmask,
+                                                   const uint32_t *__restrict__ cinfo, const DevState *__restrict__ st, uint32_t capO_chunks,
+                                                   OMeta *__restrict__ ometa) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    if (st->ov_bad) return;
+    const uint32_t nFchunks = (st->nF + CHUNK - 1) / CHUNK, o_chunk0 = st->o_begin / CHUNK;
+    CHAIN_STAMP(12);
+    const uint32_t nOchunks = capO_chunks - o_chunk0;
+    for (uint32_t w = wid; w < nOchunks; w += nwaves) {
+        const uint32_t c = nFchunks + w;
+        const uint32_t ci = cinfo[c];
+        const uint32_t cv = ci & 0xFFFFu, ch = (ci >> 16) & CINFO_HMASK;
+        if (!cv) continue;
+        const unsigned long long mv = lane < CHUNK_TILES ? vmask[(size_t)c * CHUNK_TILES + lane] : 0ull;
+        for (int t = 0; t < CHUNK_TILES; ++t) {
+            const unsigned long long vm = __shfl(mv, t, 64);
+            if ((vm >> lane) & 1ull) reinterpret_cast<uint32_t *>(Oxy)[(size_t)((o_chunk0 + w) * CHUNK + t * TILE + lane) * 2] = HOLE_BITS;
+        }
+        if (ometa && lane == 0) ometa[o_chunk0 + w].valid = ch - cv;
     }
 }
 
@@ -1168,6 +1398,7 @@ __global__ __launch_bounds__(1024) void k_mb_hist(const uint32_t *__restrict__ k
                                                    uint32_t *__restrict__ hist /* [tile][nbs] */, uint32_t *__restrict__ tot /* [nb] */) {
     const uint32_t nbs = mb_row_stride(nb);
     __shared__ uint32_t cnt[QB_NB_MAX];
+    CHAIN_STAMP(10);
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t ntile = (n + MB_TILE - 1) / MB_TILE;
     // (the grid is sized from the previous step's VoI, not from the whole map: tiles are walked with a grid stride)
@@ -1212,6 +1443,7 @@ __global__ __launch_bounds__(256) void k_mb_colscan(uint32_t *__restrict__ hist 
     __shared__ uint32_t s_off[MB_PAD];
     __shared__ uint32_t s_blk[256][MB_PAD + 1];
     const uint32_t nbs = mb_row_stride(nb);
+    CHAIN_STAMP(11);
     const uint32_t b0 = blockIdx.x * MB_PAD;  // first of this workgroup's buckets
     {
         const uint32_t per = (nb + blockDim.x - 1) / blockDim.x;
@@ -1330,6 +1562,7 @@ __global__ __launch_bounds__(1024, NBC <= MBW_NB_SMALL ? 8 : 4) void k_mb_scatte
                                                         unsigned long long *dbg = nullptr) {
     __shared__ uint16_t wcnt[16][NBC];
     __shared__ uint32_t sbase[NBC];
+    CHAIN_STAMP(0);
 #define SC_STAMP(i) do { if (dbg && blockIdx.x == 3 && threadIdx.x == 0) dbg[72 + (i)] = wall_clock64(); } while (0)
     SC_STAMP(0);
     const uint32_t n = n_dev ? *n_dev : n_host;
@@ -2477,6 +2710,7 @@ __global__ __launch_bounds__(256) void k_bin_stats_srt(DP P, const float4 *__res
                                                         const uint32_t *__restrict__ ccnt, const float *__restrict__ cmin,
                                                         const float *__restrict__ cmax, uint8_t *__restrict__ st1) {
     const uint32_t lane = threadIdx.x & 63u;
+    CHAIN_STAMP(1);
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= B) return;
     const uint32_t s = off[b], e = off[b + 1];
@@ -2824,6 +3058,7 @@ __global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict_
                                                 LateEnt *__restrict__ late = nullptr, double leave_lim = -1.0) {
     __shared__ uint32_t sm[40];
     __shared__ uint8_t s_st1[1024 * SRT_KPT];
+    CHAIN_STAMP(3);
     srt4_body(P, sm, s_st1, mcnt, mmin, mmax, ccnt, cmin, cmax, st1, status, action, rev_idx, rev_list, vox_off, st, out_off0, rev_before, crej_off,
               st1_in, moff_pos, qoff_pos, out_offR, gres_off, late, leave_lim, moff_pos);
 }
@@ -3507,6 +3742,7 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
     __shared__ uint32_t s_sm[40];
     __shared__ uint32_t s_carry[3];
     uint32_t total_bins = 0, n_static_est = 0, n_rev_all = 0;
+    if (RES) CHAIN_STAMP(4);
     // size of reverted bin rk in the output, its ground and its rejected points
     auto rev_sizes = [&](uint32_t rk, uint32_t &sz, uint32_t &g, uint32_t &rj) {
         const uint32_t key = rev_list[rk];
@@ -3751,6 +3987,7 @@ __global__ __launch_bounds__(256) void k_assemble_late(DP P, Xf Tb2o, const uint
     __shared__ uint32_t s_carry[4];
     __shared__ uint32_t s_cvl[ASM_RVMAX + 1];
     const uint32_t n_rev = st->n_rev;
+    CHAIN_STAMP(8);
     const uint32_t total_binsR = st->total_binsR;
     const float4 hole = make_float4(__uint_as_float(HOLE_BITS), 0.f, 0.f, 0.f);
     auto sizes = [&](uint32_t rk, uint32_t &sz, uint32_t &g, uint32_t &rj) {
@@ -3985,6 +4222,10 @@ __global__ __launch_bounds__(256) void k_o_compact(const float2 *__restrict__ Ox
 __global__ __launch_bounds__(256) void k_f_valid(const float4 *__restrict__ F, uint32_t n, uint32_t *__restrict__ flag) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flag[i] = (__float_as_uint(F[i].x) != HOLE_BITS) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_voi_live(const uint32_t *__restrict__ voi_key, uint32_t n, uint32_t B, uint32_t *__restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = voi_key[i] <= B ? 1u : 0u;  // (B + 1: a place kept for a late point that did not come, see k_late_gather)
 }
 __global__ __launch_bounds__(256) void k_f_compact(const float4 *__restrict__ F, uint32_t n, const uint32_t *__restrict__ flag,
                                                     const uint32_t *__restrict__ pl, const uint32_t *__restrict__ tops, float4 *__restrict__ dst) {

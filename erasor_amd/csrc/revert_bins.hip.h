@@ -820,6 +820,7 @@ __global__ __launch_bounds__(1024) void k_revert_bins_srt(DP P, SrtArgs sa, RevA
         return;
     }
     const unsigned long long w0 = ra.dbg ? wall_clock64() : 0ull;
+    CHAIN_STAMP(2);
     rev_open(P, ra);
     for (uint32_t rk = blockIdx.x;; rk += stride) {
         __syncthreads();  // (g_sel of the previous round has been read)

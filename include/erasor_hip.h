@@ -307,6 +307,16 @@ int erasor_hip_profile_get(erasor_hip_handle *h, const char **names, double *tot
 int erasor_hip_voi_split_bytes(erasor_hip_handle *h, uint64_t *algorithmic_bytes, uint64_t *physical_entries);
 /* VoI splits launched ahead of their step (erasor_hip_prefetch_node) and how many of them the following step could use */
 int erasor_hip_ahead_split_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t *used);
+/* Round 5 -- OVERLAPPED steps.  The scans of one sequence are a sequential fold over the map (OfflineMapUpdater.cpp:290 -> :393), but only
+ * the points of the bins the Scan Ratio Test reverts (erasor.cpp:510-528) have to wait for R-GPF: a step writes everything else back
+ * at once, reserving the reverted bins' places at full size, and -- when the NEXT node was announced with its pose
+ * (erasor_hip_prefetch_node*) AND its inverse transform (this call, right after the announcement; the step must then pass the very same
+ * 16 floats, tf_body2origin_.inverse() of OfflineMapUpdater.cpp:436) -- that node's fetch_VoI pass, transform and R-POD keys run beside
+ * this step's per-bin launch on a second stream; the reserved places are filled in (or left as holes) when the per-bin launch is
+ * through.  Results are bit-identical to the plain sequence.  ERASOR_HIP_NO_OVERLAP=1 / ERASOR_HIP_NO_RESERVED=1: off (A/B). */
+int erasor_hip_announce_origin2body(erasor_hip_handle *h, const float T_origin2body[16]);
+/* steps whose early passes were launched ahead like that / steps that took them */
+int erasor_hip_overlap_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t *used);
 /* The main stream's dependency chain on the device's own clock (no events, no extra launches: the chunk scan and the step's end stamp
  * the 100 MHz counter): average span of a step from its chunk scan to its end (when the scan is launched ahead, behind the next VoI
  * split, that span contains the stream's wait for the host), average time between a step's end and the next step's chunk scan (the

@@ -53,10 +53,10 @@ o2.set_map(sc["map"])
 ptr = [s.ctypes.data for s in scans]
 n3 = n_steps + 3  # (long enough for the chains announced after the first finished step: they take the one-launch query bucketing)
 for j in range(2):
-    g2.prefetch_device(ptr[j], len(scans[j]), sc["T_l2b"], sc["T_b2o"][j])
+    g2.prefetch_device(ptr[j], len(scans[j]), sc["T_l2b"], sc["T_b2o"][j], sc["T_o2b"][j])
 for k in range(n3):
     if k + 2 < n3:
-        g2.prefetch_device(ptr[k + 2], len(scans[k + 2]), sc["T_l2b"], sc["T_b2o"][k + 2])
+        g2.prefetch_device(ptr[k + 2], len(scans[k + 2]), sc["T_l2b"], sc["T_b2o"][k + 2], sc["T_o2b"][k + 2])
     rg = g2.step_device(ptr[k], len(scans[k]), sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
     ro = o2.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
     dg, do = rg.as_dict(), ro.as_dict()
@@ -64,6 +64,7 @@ for k in range(n3):
     ok = ok and not bad
 same_map = np.array_equal(g2.get_map().view(np.uint32), o2.get_cloud(7).view(np.uint32))
 l2, u2 = g2.ahead_split_counts()
+print("overlapped steps: launched %d, taken %d" % g2.overlap_counts())
 print("bench.py's call pattern (device scans, two nodes ahead), %d steps: result blocks equal %s, final map bit-exact %s; splits ahead %d launched / %d used"
       % (n3, ok, same_map, l2, u2))
 ok = ok and same_map and l2 == n3 - 1

@@ -209,12 +209,12 @@ def test_large_scale_mode_with_nodes_announced_ahead(gpu_mod, submap_size):
     scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"][:n]]
     Tb, To = sc["T_b2o"], sc["T_o2b"]
     for j in range(ahead):
-        g.prefetch(scans[j], sc["T_l2b"], Tb[j])
+        g.prefetch(scans[j], sc["T_l2b"], Tb[j], To[j])
     cx = cy = None
     moves = 0
     for k in range(n):
         if k + ahead < n:
-            g.prefetch(scans[k + ahead], sc["T_l2b"], Tb[k + ahead])
+            g.prefetch(scans[k + ahead], sc["T_l2b"], Tb[k + ahead], To[k + ahead])
         x, y = float(np.asarray(Tb[k]).reshape(-1)[3]), float(np.asarray(Tb[k]).reshape(-1)[7])  # (OMU.cpp:246-247)
         if cx is None or abs(cx - x) > submap_size / 2 or abs(cy - y) > submap_size / 2:  # (reassign_submap's rule)
             cx, cy, moves = x, y, moves + 1
@@ -516,16 +516,18 @@ def test_full_size_bench_call_pattern_device_scans_two_nodes_ahead(gpu_mod):
     d_scans = [g.device_array(s) for s in scans]
     cTb, cTo = [gpu_mod.c_mat(t) for t in Tb], [gpu_mod.c_mat(t) for t in To]
     for j in range(LA):
-        g.prefetch_device(d_scans[j], len(scans[j]), Tl, cTb[j])
+        g.prefetch_device(d_scans[j], len(scans[j]), Tl, cTb[j], cTo[j])
     for k in range(n):
         if k + LA < n:
-            g.prefetch_device(d_scans[k + LA], len(scans[k + LA]), Tl, cTb[k + LA])
+            g.prefetch_device(d_scans[k + LA], len(scans[k + LA]), Tl, cTb[k + LA], cTo[k + LA])
         rg = g.step_device(d_scans[k], len(scans[k]), Tl, cTb[k], cTo[k])
         ro = o.step(scans[k], np.asarray(Tl, np.float32), Tb[k], To[k])
         assert rg.n_reverted_bins > 0 or k == 0
         compare_step(g, o, rg, ro, full=(k == n - 1))
     launched, used = g.ahead_split_counts()
     assert launched == n - 1 and used >= 1, (launched, used)
+    ol, ou = g.overlap_counts()  # (round 5: announced with both transforms, the steps overlap)
+    assert ol == n - 1 and ou >= n - 3, (ol, ou)
 
 
 @pytest.mark.parametrize("large_scale", [0, 1])
@@ -781,8 +783,8 @@ def test_api_error_two_handles_interleaved_with_step_async(gpu_mod):
         compare_step(gb, ob, rgb, rob, full=(k % 2 == 1))
 
 
-@pytest.mark.parametrize("version,ahead", [(3, 1), (3, 2), (2, 2), (3, 3)])
-def test_nodes_announced_with_their_pose_split_ahead(gpu_mod, version, ahead):
+@pytest.mark.parametrize("version,ahead,inv", [(3, 1, False), (3, 2, False), (2, 2, True), (3, 3, False), (3, 1, True), (3, 2, True), (3, 3, True)])
+def test_nodes_announced_with_their_pose_split_ahead(gpu_mod, version, ahead, inv):
     """erasor_hip_prefetch_node: with the next node's pose known, the step in flight launches the next step's VoI split
     behind its own last kernel (it reads the store that step has just written and the extents it commits on the device).
     Every output of every step must still be the oracle's; a pose that is not the announced one, a store touched in between,
@@ -794,22 +796,28 @@ def test_nodes_announced_with_their_pose_split_ahead(gpu_mod, version, ahead):
     n = 9
     scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"][:n + 3]]
     Tb, To = sc["T_b2o"], sc["T_o2b"]
+    # inv (round 5): the node is announced with T_origin2body as well: v3 steps overlap -- the next step's split, chunk scan and gather run
+    # beside this step's per-bin launch, its bucket table behind it; v2 has no such path and must not care
+    inv_of = (lambda j: To[j]) if inv else (lambda j: None)
     for j in range(ahead):
-        g.prefetch(scans[j], sc["T_l2b"], Tb[j])
+        g.prefetch(scans[j], sc["T_l2b"], Tb[j], inv_of(j))
     for k in range(n):
         if k + ahead < n:
-            g.prefetch(scans[k + ahead], sc["T_l2b"], Tb[k + ahead])
+            g.prefetch(scans[k + ahead], sc["T_l2b"], Tb[k + ahead], inv_of(k + ahead))
         rg = g.step(scans[k], sc["T_l2b"], Tb[k], To[k])
         ro = o.step(scans[k], sc["T_l2b"], Tb[k], To[k])
         compare_step(g, o, rg, ro, full=(k % 3 == 0))  # (the read-backs in between run on the same stream as the pass ahead)
+    if inv and version == 3:
+        ol, ou = g.overlap_counts()
+        assert ol == n - 1 and ou >= ol - 2, (ol, ou)
     launched, used = g.ahead_split_counts()
     # v3: scratch growth in the first steps may drop one or two.  v2 merges every query bin into the map (erasor.cpp:296-307):
     # the VoI-resident region grows by thousands of points per scan and the outskirts region is rebuilt before most steps
     assert launched == n - 1 and used >= (launched - 2 if version == 3 else 0), (launched, used)
     # the announced pose is NOT the pose of the step that follows: the pass ahead is ignored
     k = n
-    g.prefetch(scans[k], sc["T_l2b"], Tb[k])
-    g.prefetch(scans[k + 1], sc["T_l2b"], Tb[k + 2])  # (wrong pose for node k + 1)
+    g.prefetch(scans[k], sc["T_l2b"], Tb[k], inv_of(k))
+    g.prefetch(scans[k + 1], sc["T_l2b"], Tb[k + 2], inv_of(k + 2))  # (wrong pose for node k + 1)
     for kk in (k, k + 1):
         rg = g.step(scans[kk], sc["T_l2b"], Tb[kk], To[kk])
         ro = o.step(scans[kk], sc["T_l2b"], Tb[kk], To[kk])
@@ -817,8 +825,8 @@ def test_nodes_announced_with_their_pose_split_ahead(gpu_mod, version, ahead):
     l0, u0 = g.ahead_split_counts()
     assert l0 == launched + 1 and (u0 == used or version != 3), (launched, used, l0, u0)
     # stationary sensor: the same pose twice in a row, announced -> the pass ahead IS the second step's pass
-    g.prefetch(scans[k], sc["T_l2b"], Tb[k + 1])
-    g.prefetch(scans[k + 1], sc["T_l2b"], Tb[k + 1])
+    g.prefetch(scans[k], sc["T_l2b"], Tb[k + 1], inv_of(k + 1))
+    g.prefetch(scans[k + 1], sc["T_l2b"], Tb[k + 1], inv_of(k + 1))
     for kk in (k, k + 1):
         rg = g.step(scans[kk], sc["T_l2b"], Tb[k + 1], To[k + 1])
         ro = o.step(scans[kk], sc["T_l2b"], Tb[k + 1], To[k + 1])
@@ -826,8 +834,8 @@ def test_nodes_announced_with_their_pose_split_ahead(gpu_mod, version, ahead):
     l1, u1 = g.ahead_split_counts()
     assert l1 == l0 + 1 and (u1 == u0 + 1 or version != 3), (l0, u0, l1, u1)
     # the store is replaced between the announcement and the step: the pass ahead belongs to the old store
-    g.prefetch(scans[0], sc["T_l2b"], Tb[0])
-    g.prefetch(scans[1], sc["T_l2b"], Tb[1])
+    g.prefetch(scans[0], sc["T_l2b"], Tb[0], inv_of(0))
+    g.prefetch(scans[1], sc["T_l2b"], Tb[1], inv_of(1))
     rg = g.step(scans[0], sc["T_l2b"], Tb[0], To[0])
     ro = o.step(scans[0], sc["T_l2b"], Tb[0], To[0])
     compare_step(g, o, rg, ro)
@@ -860,10 +868,10 @@ for version in (3, 2):
     g.set_map(sc["map"])
     o.set_map(sc["map"])
     scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"][:5]]
-    g.prefetch(scans[0], sc["T_l2b"], sc["T_b2o"][0])
+    g.prefetch(scans[0], sc["T_l2b"], sc["T_b2o"][0], sc["T_o2b"][0])
     for k in range(5):
         if k + 1 < 5:
-            g.prefetch(scans[k + 1], sc["T_l2b"], sc["T_b2o"][k + 1])
+            g.prefetch(scans[k + 1], sc["T_l2b"], sc["T_b2o"][k + 1], sc["T_o2b"][k + 1])
         rg = g.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         ro = o.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         dg, do = rg.as_dict(), ro.as_dict()
@@ -963,11 +971,11 @@ if case == "ouster128":
 d_scans = [g.device_array(s) for s in scans]
 cTb, cTo = [erasor_amd.c_mat(t) for t in Tb], [erasor_amd.c_mat(t) for t in To]
 for j in range(min(LA, n)):
-    g.prefetch_device(d_scans[j], len(scans[j]), Tl, cTb[j])
+    g.prefetch_device(d_scans[j], len(scans[j]), Tl, cTb[j], cTo[j])
 rev = 0
 for k in range(n):
     if k + LA < n:
-        g.prefetch_device(d_scans[k + LA], len(scans[k + LA]), Tl, cTb[k + LA])
+        g.prefetch_device(d_scans[k + LA], len(scans[k + LA]), Tl, cTb[k + LA], cTo[k + LA])
     rg = g.step_device(d_scans[k], len(scans[k]), Tl, cTb[k], cTo[k])
     ro = o.step(scans[k], np.asarray(Tl, np.float32), Tb[k], To[k])
     rev += rg.n_reverted_bins
