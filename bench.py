@@ -297,7 +297,7 @@ class Sequence:
     def prime(self):
         if self.lookahead and not self.primed:
             for j in range(min(self.LA, self.n_frames)):
-                self.g.prefetch_device(self.d_ptr[j], self.n_pts[j], self.c_Tl, self.c_Tb[j] if self.with_pose else None)
+                self.g.prefetch_device(self.d_ptr[j], self.n_pts[j], self.c_Tl, self.c_Tb[j] if self.with_pose else None, self.c_To[j] if self.with_pose else None)
         self.primed = True
 
     def run(self, k):
@@ -305,14 +305,16 @@ class Sequence:
         # not depend on the map) overlap step k's map-side stages; step k returns with ITS results on the host as before
         g = self.g
         if self.lookahead and k + self.LA < self.n_frames:
-            g.prefetch_device(self.d_ptr[k + self.LA], self.n_pts[k + self.LA], self.c_Tl, self.c_Tb[k + self.LA] if self.with_pose else None)
+            g.prefetch_device(self.d_ptr[k + self.LA], self.n_pts[k + self.LA], self.c_Tl, self.c_Tb[k + self.LA] if self.with_pose else None,
+                              self.c_To[k + self.LA] if self.with_pose else None)
         return g.step_device(self.d_ptr[k], self.n_pts[k], self.c_Tl, self.c_Tb[k], self.c_To[k])
 
     def run_async(self, k):
         """the same step in two halves (erasor_hip_step_async / erasor_hip_step_wait): announce, enqueue, return"""
         g = self.g
         if self.lookahead and k + self.LA < self.n_frames:
-            g.prefetch_device(self.d_ptr[k + self.LA], self.n_pts[k + self.LA], self.c_Tl, self.c_Tb[k + self.LA] if self.with_pose else None)
+            g.prefetch_device(self.d_ptr[k + self.LA], self.n_pts[k + self.LA], self.c_Tl, self.c_Tb[k + self.LA] if self.with_pose else None,
+                              self.c_To[k + self.LA] if self.with_pose else None)
         g.step_async(self.d_ptr[k], self.n_pts[k], self.c_Tl, self.c_Tb[k], self.c_To[k], device=True)
 
     def wait(self):
@@ -860,6 +862,9 @@ def main():
                              "(main_chain_us contains the stream's wait for the host since the scan is launched ahead).  ms_per_step (the contract's figure: "
                              "K steps between two device synchronisations) also pays for draining the query chains of the nodes announced beyond "
                              "the last timed step, once per pass",
+        # round 5: steps whose split / chunk scan / gather / bucket table were launched beside the previous step's per-bin launch, and how many
+        # of them the step took (the library overlaps where it pays: dense bins, ERASOR_HIP_OVERLAP unset = auto, 1 = always, 0 = never)
+        "overlapped_steps": dict(zip(("launched_ahead", "taken"), g.overlap_counts()), mode=os.environ.get("ERASOR_HIP_OVERLAP", "auto")),
         "pr_rr": pr_rr, "callback_path": callback,
         "roofline": roofline, "cpu_baseline": cpu, "cpu_port": cpu_port, "host": host_identity(),
         "parity_checked_steps": parity["parity_checked_steps"], "parity": parity.get("parity"), "final_map_checked": parity.get("final_map_checked", False),
@@ -904,6 +909,7 @@ def main():
                 extra.append({"workload": wname, "baseline_config": label, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                               "ms_per_step_without_lookahead": d["ms_per_step_without_lookahead"], "main_chain_us": d.get("main_chain_us"),
                               "repeats": d.get("repeats"), "ms_per_step_min": d.get("ms_per_step_min"), "ms_per_step_max": d.get("ms_per_step_max"),
+                              "overlapped_steps": d.get("overlapped_steps"),
                               "between_steps_us": d.get("between_steps_us"), "steps": d["steps"], "warmup": d["warmup"],
                               "map_points": d["config"]["map_points"], "scan_points": d["config"]["scan_points"],
                               "is_large_scale": d["config"].get("is_large_scale"), "lookahead_scans": d["config"].get("lookahead_scans"),

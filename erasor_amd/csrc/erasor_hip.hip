@@ -1356,7 +1356,7 @@ static void worker_main(erasor_hip_handle *h) {
     }
 }
 static void worker_start(erasor_hip_handle *h) {
-#ifndef ERASOR_SIMT_EMU_HIP_RUNTIME_H  // (the CPU stand-in runs a launch synchronously: one thread)
+#ifndef ERASOR_NO_WORKER_THREAD  // (a build option, like ERASOR_NO_HIPGRAPH: every launch from the caller's thread)
     if (getenv("ERASOR_HIP_NO_WORKER")) return;
     h->worker = new erasor_hip_handle::Worker();
     for (int k = 0; k < NSIDE; ++k) h->worker->busy[k].store(0);

@@ -306,6 +306,7 @@ __device__ __forceinline__ void step_end_body(DevState *st, Counters *ctr, HostO
         out->st = s;
         out->ctr = c;
         out->t_end = wall_clock64();
+        if (g_stamps_on) g_stamps[15] = out->t_end;
         __threadfence_system();
         *(volatile unsigned long long *)&out->seq = seq;
     }
@@ -359,8 +360,8 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     uint32_t n_late = 0;
+    CHAIN_STAMP(5);
     if (ov.late) {
-        CHAIN_STAMP(5);
         // round 5, OVERLAPPED steps: the pass of step k + 1 beside step k's per-bin launch.  The region it reads is being written in the
         // reserved layout: its extents are final (k_srt4), the slots of the late table are NOT -- their masks come from the table:
         // a data slot counts as a VoI entry (it keeps a place in VoI order for the point that may come), a leaving reservation as a
@@ -847,8 +848,8 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint64_t lt = lanemask_lt();
     const bool ovm = lmask != nullptr;
+    CHAIN_STAMP(7);
     if (ovm) {
-        CHAIN_STAMP(7);
         if (st->ov_bad) return;
         nF = st->nF;
         nFchunks = (nF + CHUNK - 1) / CHUNK;
@@ -983,7 +984,6 @@ __global__ __launch_bounds__(256) void k_late_gather(const float4 *__restrict__ 
                                                       float4 *__restrict__ voi_ego, uint32_t *__restrict__ voi_key, uint32_t *__restrict__ voi_src,
                                                       StepEnd se) {
     if (blockIdx.x == gridDim.x - 1) {
-        if (threadIdx.x == 0 && g_stamps_on) g_stamps[15] = wall_clock64();
         if (threadIdx.x == 0 && se.st) step_end_body(se.st, se.ctr, se.out, se.lab_slots, se.qctr, se.q_nvox, se.seq);
         return;
     }
@@ -3742,7 +3742,7 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
     __shared__ uint32_t s_sm[40];
     __shared__ uint32_t s_carry[3];
     uint32_t total_bins = 0, n_static_est = 0, n_rev_all = 0;
-    if (RES) CHAIN_STAMP(4);
+    CHAIN_STAMP(4);
     // size of reverted bin rk in the output, its ground and its rejected points
     auto rev_sizes = [&](uint32_t rk, uint32_t &sz, uint32_t &g, uint32_t &rj) {
         const uint32_t key = rev_list[rk];

@@ -383,12 +383,18 @@ static int bench_mode(int argc, char **argv) {
             const Eigen::Matrix4f T = erasor_utils::geoPose2eigen(odom[i]), Ti = erasor_utils::inverse(T);
             for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { Tb[i][4 * r + c] = T(r, c); To[i][4 * r + c] = Ti(r, c); }
         }
-        for (int j = 0; j < 2; ++j) erasor_hip_prefetch_node(h, d_scan[j], n_scan[j], 1, Tl, Tb[j].data());
+        for (int j = 0; j < 2; ++j) {
+            erasor_hip_prefetch_node(h, d_scan[j], n_scan[j], 1, Tl, Tb[j].data());
+            erasor_hip_announce_origin2body(h, To[j].data());
+        }
         double t0 = 0;
         erasor_step_result res;
         for (int i = 0; i < W + K; ++i) {
             if (i == W) t0 = now_ms();
-            if (i + 2 < W + K + 2) erasor_hip_prefetch_node(h, d_scan[i + 2], n_scan[i + 2], 1, Tl, Tb[i + 2].data());
+            if (i + 2 < W + K + 2) {
+                erasor_hip_prefetch_node(h, d_scan[i + 2], n_scan[i + 2], 1, Tl, Tb[i + 2].data());
+                erasor_hip_announce_origin2body(h, To[i + 2].data());
+            }
             if (erasor_hip_step_device(h, d_scan[i], n_scan[i], Tl, Tb[i].data(), To[i].data(), &res) != ERASOR_OK) {
                 fprintf(stderr, "step %d: %s\n", i, erasor_hip_last_error(h));
                 return 4;

@@ -381,6 +381,11 @@ void OfflineMapUpdater::stage_deferred() {
     mat16(erasor_utils::geoPose2eigen(def_odom_), Tb);
     uint64_t t = 0;
     check(h_, erasor_hip_prefetch_node_rows(h_, lidar.points.data(), lidar.size(), kRowStride, kRowIntensity, Tl, Tb, &t), "erasor_hip_prefetch_node_rows");
+    {
+        float To[16];
+        mat16(erasor_utils::inverse(erasor_utils::geoPose2eigen(def_odom_)), To);
+        check(h_, erasor_hip_announce_origin2body(h_, To), "erasor_hip_announce_origin2body");
+    }
     has_next_ = true;
     auto_ticket_ = t;
     auto_seq_ = def_seq_;
@@ -451,6 +456,11 @@ uint64_t OfflineMapUpdater::announce(const Cloud &lidar, const geometry_msgs::Po
     uint64_t ticket = 0;
     check(h_, erasor_hip_prefetch_node_rows(h_, lidar.points.data(), lidar.size(), kRowStride, kRowIntensity, Tl, odom ? Tb : nullptr, &ticket),
           "erasor_hip_prefetch_node_rows");
+    if (odom) {  // (round 5: ... and the inverse callback_node will compute, OMU.cpp:436: that step may then overlap the one in front)
+        float To[16];
+        mat16(erasor_utils::inverse(erasor_utils::geoPose2eigen(*odom)), To);
+        check(h_, erasor_hip_announce_origin2body(h_, To), "erasor_hip_announce_origin2body");
+    }
     has_next_ = true;
     return ticket;
 }

@@ -39,6 +39,7 @@
 #include <vector>
 
 #define ERASOR_NO_HIPGRAPH 1  // (the stand-in has no graph API: the product code launches kernel by kernel)
+#define ERASOR_NO_WORKER_THREAD 1  // (a launch runs synchronously here, on the caller's thread: no second launching thread)
 #define __device__
 #define __host__
 #define __global__
@@ -486,7 +487,7 @@ inline float __int_as_float(int u) {
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorNotReady = 600 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipEventDisableSystemFence = 0x20000000 };
 struct simt_stream_t {
     int id;
 };
@@ -532,6 +533,18 @@ inline hipError_t hipHostFree(void *p) {
 }
 inline hipError_t hipMemcpy(void *d, const void *s_, size_t n, hipMemcpyKind) {
     if (n) memmove(d, s_, n);
+    return hipSuccess;
+}
+// (a __device__ variable is a plain global here)
+#define HIP_SYMBOL(x) x
+template <class T>
+inline hipError_t hipMemcpyToSymbol(T &sym, const void *src, size_t n) {
+    memcpy((void *)&sym, src, n);
+    return hipSuccess;
+}
+template <class T>
+inline hipError_t hipMemcpyFromSymbol(void *dst, const T &sym, size_t n) {
+    memcpy(dst, (const void *)&sym, n);
     return hipSuccess;
 }
 inline hipError_t hipMemset(void *d, int v, size_t n) {

@@ -892,10 +892,18 @@ print("ALT-PATH-OK")
                                  {"ERASOR_HIP_NO_END_FOLD": "1", "ERASOR_HIP_NO_SRT_FOLD": "1", "ERASOR_HIP_NO_AHEAD_SCAN": "1"},
                                  {"ERASOR_HIP_NO_AHEAD_SPLIT": "1", "ERASOR_HIP_NO_SPIN": "1", "ERASOR_HIP_NO_RCCL": "1", "ERASOR_HIP_HOST_TIMING": "1",
                                   "ERASOR_HIP_SORT_STAMPS": "1", "ERASOR_HIP_DEBUG_SYNC": "1"},
-                                 {"ERASOR_HIP_QSTREAMS": "3", "ERASOR_HIP_QPAD_US": "20", "ERASOR_HIP_MPAD_US": "20"}],
+                                 {"ERASOR_HIP_QSTREAMS": "3", "ERASOR_HIP_QPAD_US": "20", "ERASOR_HIP_MPAD_US": "20"},
+                                 {"ERASOR_HIP_OVERLAP": "0", "ERASOR_HIP_NO_WORKER": "1", "ERASOR_HIP_WIDE_SLACK": "2"},
+                                 {"ERASOR_HIP_OVERLAP": "1", "ERASOR_HIP_NO_OVERLAP": "1", "ERASOR_HIP_LEAVE_ALL": "1", "ERASOR_HIP_EVT_SYSFENCE": "1",
+                                  "ERASOR_HIP_QUERY_PRIORITY": "1"},
+                                 {"ERASOR_HIP_OVERLAP": "1", "ERASOR_HIP_CHAIN_SPLIT": "1", "ERASOR_HIP_CHAIN_STAMPS": "1", "ERASOR_HIP_LEAVE_ALL": "1",
+                                  "GPU_MAX_HW_QUEUES": "16"},
+                                 {"ERASOR_HIP_OVERLAP": "", "ERASOR_HIP_OVERLAP_PPB": "1", "ERASOR_HIP_NO_RESERVED": ""}],
                          ids=["query_chain_as_hipgraphs", "separate_rgpf_binvox_layout_srt_launches", "no_chunk_records_stream_priorities",
                               "step_end_and_srt_as_launches_no_ahead_scan", "nothing_ahead_blocking_wait_peer_copies_diagnostics",
-                              "three_query_streams_padded_chains"])
+                              "three_query_streams_padded_chains", "no_overlap_no_worker_thread_fewer_wide_levels",
+                              "reserved_layout_without_passes_ahead_every_bin_may_leave", "overlap_with_split_chains_stamps_third_stream_shared",
+                              "overlap_where_the_bins_are_dense_enough"])
 def test_alternative_launch_paths_keep_parity(gpu_mod, tmp_path, env):
     """The paths behind the library's A/B switches are product code too: the query chain replayed as two hipGraphs per side
     (ERASOR_HIP_GRAPH=1: measured, no gain, opt-in) and the unfused launches (R-GPF and per-bin voxelisation apart, k_layout4,
@@ -912,7 +920,11 @@ def test_alternative_launch_paths_keep_parity(gpu_mod, tmp_path, env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "alt_worker.py"
     script.write_text(ALT_PATH_WORKER % (root, root))
-    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=280, env=dict(os.environ, **env))
+    e2 = dict(os.environ, **env)
+    for k, v in env.items():
+        if v == "":
+            e2.pop(k, None)  # ("": unset for this case)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=280, env=e2)
     assert out.returncode == 0 and "ALT-PATH-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 

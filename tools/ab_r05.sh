@@ -1,13 +1,9 @@
-B="timeout 120 python bench.py --no-cpu-baseline --no-extra-workloads --no-callback-bench --no-pr-rr --repeats 5"
+B="timeout 200 python bench.py --no-cpu-baseline --no-extra-workloads --no-callback-bench --no-pr-rr --mode seq-per-gpu --seqs 2"
 run() { echo "== $1 $2"; env $1 $B $2 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print(d['ms_per_step'], d['ms_per_step_all'], d['last_step']['n_voi'], d['config']['rings']*d['config']['sectors'])"; }
-run "ERASOR_HIP_OVERLAP=0"
-run "ERASOR_HIP_OVERLAP=1"
-run "ERASOR_HIP_OVERLAP=0" "--workload large_scale_05"
-run "ERASOR_HIP_OVERLAP=1" "--workload large_scale_05"
-run "ERASOR_HIP_OVERLAP=0" "--workload large_scale_05 --large-scale-mode on"
-run "ERASOR_HIP_OVERLAP=1" "--workload large_scale_05 --large-scale-mode on"
-run "ERASOR_HIP_OVERLAP=0" "--workload seq05_yaml"
-run "ERASOR_HIP_OVERLAP=1" "--workload seq05_yaml"
-run "ERASOR_HIP_OVERLAP=0" "--workload ouster128"
-run "ERASOR_HIP_OVERLAP=1" "--workload ouster128"
+import json,sys; d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print(d['value'], 'scans/s', d['ms_per_step'], 'ms per scan')"; }
+run "ERASOR_HIP_OVERLAP=0" "--interleave off"
+run "ERASOR_HIP_OVERLAP=0" "--interleave async"
+run "ERASOR_HIP_OVERLAP=0 ERASOR_HIP_QSTREAMS=1" "--interleave async"
+run "ERASOR_HIP_OVERLAP=0 ERASOR_HIP_QSTREAMS=1" "--interleave threads"
+run "ERASOR_HIP_OVERLAP=0 ERASOR_HIP_QSTREAMS=1 GPU_MAX_HW_QUEUES=4" "--interleave async"
+run "ERASOR_HIP_OVERLAP=0 ERASOR_HIP_QSTREAMS=2 GPU_MAX_HW_QUEUES=4" "--interleave async"
