@@ -221,6 +221,7 @@ struct erasor_hip_handle {
         double x = 0, y = 0;
         float To[16] = {0};
         uint32_t cap_chunks = 0, cap_voi = 0, nbk = 0;
+        bool stats_done = false;  // ... and the stable scatter + bin statistics + first Scan Ratio Test pass (the query chain was through)
         const void *vmask = nullptr, *hmask = nullptr, *lmask = nullptr, *cinfo = nullptr, *pvl = nullptr, *phl = nullptr, *voi_ego = nullptr,
                    *mb_hist = nullptr;
     } ov;
@@ -331,8 +332,10 @@ struct erasor_hip_handle {
     // own): VoI-order arrays, bin offsets, state, counters, label tallies.  The names above / below are the CURRENT step's set; `alt` is
     // the other one, where the passes launched ahead write; the two change places when a step is enqueued (swap_sides)
     struct {
-        DBuf<float4> voi_ego;
-        DBuf<uint32_t> voi_key, voi_src, moff;
+        DBuf<float4> voi_ego, spts;
+        DBuf<uint32_t> voi_key, voi_src, moff, ssrc, rk_a, mcnt;
+        DBuf<float> mmin, mmax;
+        DBuf<uint8_t> st1b;
         DBuf<DevState> d_st;
         DBuf<Counters> d_ctr;
         DBuf<unsigned long long> lab_slots;
@@ -568,7 +571,8 @@ int alloc_bins(erasor_hip_handle *h) {
         rc |= ensure(h, Q(h).d_nvox, 4) | ensure(h, Q(h).d_qctr, 1);
     }
     h->qi = keep;
-    rc |= ensure(h, h->moff, B + 4) | ensure(h, h->alt.moff, B + 4) | ensure(h, h->mcnt, B);
+    rc |= ensure(h, h->moff, B + 4) | ensure(h, h->alt.moff, B + 4) | ensure(h, h->mcnt, B) | ensure(h, h->alt.mcnt, B);
+    rc |= ensure(h, h->alt.mmin, B) | ensure(h, h->alt.mmax, B) | ensure(h, h->alt.st1b, B + 8);
     rc |= ensure(h, h->mmin, B) | ensure(h, h->mmax, B);
     rc |= ensure(h, h->st1, B) | ensure(h, h->status, B) | ensure(h, h->action, B) | ensure(h, h->rev_idx, B) | ensure(h, h->rev_list, B);
     rc |= ensure(h, h->out_off0, B + 2) | ensure(h, h->rev_before, B + 2) | ensure(h, h->st1b, B + 8);
@@ -600,6 +604,7 @@ int alloc_map(erasor_hip_handle *h, uint32_t n) {
     const uint32_t V = h->capV;
     rc |= ensure(h, h->voi_ego, V) | ensure(h, h->spts, V) | ensure(h, h->voi_key, V) | ensure(h, h->voi_src, V) | ensure(h, h->ssrc, V);
     rc |= ensure(h, h->alt.voi_ego, V) | ensure(h, h->alt.voi_key, V) | ensure(h, h->alt.voi_src, V);
+    rc |= ensure(h, h->alt.spts, V) | ensure(h, h->alt.ssrc, V) | ensure(h, h->alt.rk_a, V);
     rc |= ensure(h, h->rejected, V) | ensure(h, h->rejected_src, V) | ensure(h, h->grank, V) | ensure(h, h->glist, V) | ensure(h, h->gflag, V);
     rc |= ensure(h, h->rk_a, V) | ensure(h, h->rk_b, V) | ensure(h, h->rv_a, V) | ensure(h, h->rv_b, V);
     return rc ? ERASOR_E_NO_DEVICE : 0;
@@ -621,6 +626,7 @@ int grow_map_scratch(erasor_hip_handle *h, uint64_t need) {
     int rc = 0;
     rc |= ensure(h, h->voi_ego, V) | ensure(h, h->spts, V) | ensure(h, h->voi_key, V) | ensure(h, h->voi_src, V) | ensure(h, h->ssrc, V);
     rc |= ensure(h, h->alt.voi_ego, V) | ensure(h, h->alt.voi_key, V) | ensure(h, h->alt.voi_src, V);
+    rc |= ensure(h, h->alt.spts, V) | ensure(h, h->alt.ssrc, V) | ensure(h, h->alt.rk_a, V);
     rc |= ensure(h, h->rejected, V) | ensure(h, h->rejected_src, V) | ensure(h, h->grank, V) | ensure(h, h->glist, V) | ensure(h, h->gflag, V);
     rc |= ensure(h, h->rk_a, V) | ensure(h, h->rk_b, V) | ensure(h, h->rv_a, V) | ensure(h, h->rv_b, V);
     h->have_step = false;  // the previous step's read-back clouds lived in these arrays
@@ -1040,6 +1046,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     for (int k = 0; k < 2; ++k) { release(h->late[k]); release(h->late_holes[k]); }
     release(h->lmask);
     release(h->alt.voi_ego); release(h->alt.voi_key); release(h->alt.voi_src); release(h->alt.moff); release(h->alt.d_st); release(h->alt.d_ctr);
+    release(h->alt.spts); release(h->alt.ssrc); release(h->alt.rk_a); release(h->alt.mcnt); release(h->alt.mmin); release(h->alt.mmax); release(h->alt.st1b);
     release(h->alt.lab_slots);
     for (hipEvent_t e : {h->ev_stats, h->ev_srt4, h->ev_asm, h->ev_early})
         if (e) (void)hipEventDestroy(e);
@@ -1801,6 +1808,14 @@ static void swap_sides(erasor_hip_handle *h) {
     std::swap(h->d_st, h->alt.d_st);
     std::swap(h->d_ctr, h->alt.d_ctr);
     std::swap(h->lab_slots, h->alt.lab_slots);
+    // (the bucketed VoI and the bins' statistics too: an overlapped step's scatter and first Scan Ratio Test pass are launched ahead)
+    std::swap(h->spts, h->alt.spts);
+    std::swap(h->ssrc, h->alt.ssrc);
+    std::swap(h->rk_a, h->alt.rk_a);
+    std::swap(h->mcnt, h->alt.mcnt);
+    std::swap(h->mmin, h->alt.mmin);
+    std::swap(h->mmax, h->alt.mmax);
+    std::swap(h->st1b, h->alt.st1b);
 }
 
 static int step_collect(erasor_hip_handle *h, erasor_step_result *res);
@@ -1974,6 +1989,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     const uint32_t *sm_keys = nullptr, *sm_perm = nullptr;
     bool st1_ahead = false;
     bool use_ov = false;   // this step's split .. bucket table were launched ahead of it and are taken (round 5, OVERLAPPED steps)
+    bool stats_ahead = false;  // ... its scatter and bin statistics too
     uint32_t nbk = B + 1;  // buckets of the map's counting sort: the bins + the complement (+ the dead bucket of an overlapped step)
     int bits = key_bits(B + 1);
 
@@ -2001,6 +2017,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                         (int)(h->ov.lmask == (const void *)h->lmask.p), (int)(h->ov.cinfo == (const void *)h->cinfo.p), (int)(h->ov.pvl == (const void *)h->pvl.p),
                         (int)(h->ov.phl == (const void *)h->phl.p), (int)(h->ov.voi_ego == (const void *)h->voi_ego.p), (int)(h->ov.mb_hist == (const void *)h->mb_hist.p));
             h->ov.valid = false;
+            stats_ahead = use_ov && h->ov.stats_done && P.version == 3 && B <= 1024 * SRT_KPT && !getenv("ERASOR_HIP_NO_SRT_AHEAD");
             if (ov_launched && !use_ov) (void)hipStreamWaitEvent(h->stream, h->ev_early, 0);  // (those passes write what this step's own will)
             if (use_ov) {
                 ++h->n_ov_used;
@@ -2062,7 +2079,9 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                 LAUNCH(h, "voi_bucket", k_mb_hist, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, n_voi, nvoi_dev, nbk, h->mb_hist.p, h->mb_tot.p);
                 LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv(nbk, MB_PAD), 256, h->mb_hist.p, n_voi, nvoi_dev, nbk, (const uint32_t *)h->mb_tot.p, h->moff.p);
             }
-            if (nbk <= MBW_NB_SMALL)
+            if (use_ov && stats_ahead) {
+                // (scatter, statistics and first Scan Ratio Test pass were launched ahead as well)
+            } else if (nbk <= MBW_NB_SMALL)
                 LAUNCH(h, "voi_bucket", k_mb_scatter_w<MBW_NB_SMALL>, ntile_ub, 1024, (const uint32_t *)h->voi_key.p, (const float4 *)h->voi_ego.p,
                        (const uint32_t *)h->voi_src.p, n_voi, nvoi_dev, nbk, bits, (const uint32_t *)h->mb_hist.p, h->spts.p, h->ssrc.p, h->rk_a.p,
                        h->dbg_stamps.p);
@@ -2083,7 +2102,9 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         // v3: the Scan Ratio Test's first pass rides along, bin by bin (the query's statistics are needed: the join with its chain
         // comes before this launch instead of after it; with nodes announced ahead the chain finished long ago)
         st1_ahead = P.version == 3 && B <= 1024 * SRT_KPT && !getenv("ERASOR_HIP_NO_SRT_AHEAD");
-        if (st1_ahead) {
+        if (use_ov && stats_ahead) {
+            // (done)
+        } else if (st1_ahead) {
             (void)hipStreamWaitEvent(h->stream, Q(h).ev_done, 0);
             LAUNCH(h, "bin_stats", k_bin_stats_srt, cdiv((uint64_t)B * 64, 256), 256, P, (const float4 *)h->spts.p, (const uint32_t *)h->moff.p, B, h->mcnt.p,
                    h->mmin.p, h->mmax.p, (const uint32_t *)Q(h).ccnt.p, (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1b.p);
@@ -2433,6 +2454,26 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             LAUNCH(h, "voi_bucket", k_mb_hist, ntile_ub, 1024, (const uint32_t *)h->alt.voi_key.p, n_voi, nvoi_next, B + 2, h->mb_hist.p, h->mb_tot.p);
             LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv(B + 2, MB_PAD), 256, h->mb_hist.p, n_voi, nvoi_next, B + 2, (const uint32_t *)h->mb_tot.p,
                    h->alt.moff.p);
+            // ... and the stable scatter, the bins' statistics and the Scan Ratio Test's first pass (into the OTHER set of arrays: a getter may
+            // still ask for this step's): what is left for the next step's call is its per-bin launch -- the host's turnaround is off the chain
+            static const bool no_ahead_scatter = getenv("ERASOR_HIP_NO_AHEAD_SCATTER") != nullptr;
+            h->ov.stats_done = false;
+            if (!no_ahead_scatter && B + 2 <= MBW_NB_MAX) {
+                const int bits2 = key_bits(B + 2);
+                if (B + 2 <= MBW_NB_SMALL)
+                    LAUNCH(h, "voi_bucket", k_mb_scatter_w<MBW_NB_SMALL>, ntile_ub, 1024, (const uint32_t *)h->alt.voi_key.p, (const float4 *)h->alt.voi_ego.p,
+                           (const uint32_t *)h->alt.voi_src.p, n_voi, nvoi_next, B + 2, bits2, (const uint32_t *)h->mb_hist.p, h->alt.spts.p, h->alt.ssrc.p,
+                           h->alt.rk_a.p, h->dbg_stamps.p);
+                else
+                    LAUNCH(h, "voi_bucket", k_mb_scatter_w<MBW_NB_MAX>, ntile_ub, 1024, (const uint32_t *)h->alt.voi_key.p, (const float4 *)h->alt.voi_ego.p,
+                           (const uint32_t *)h->alt.voi_src.p, n_voi, nvoi_next, B + 2, bits2, (const uint32_t *)h->mb_hist.p, h->alt.spts.p, h->alt.ssrc.p,
+                           h->alt.rk_a.p, h->dbg_stamps.p);
+                (void)hipStreamWaitEvent(h->stream, nq_.ev_done, 0);  // (the query's bins: its chain was enqueued steps ago)
+                LAUNCH(h, "bin_stats", k_bin_stats_srt, cdiv((uint64_t)B * 64, 256), 256, P, (const float4 *)h->alt.spts.p, (const uint32_t *)h->alt.moff.p, B,
+                       h->alt.mcnt.p, h->alt.mmin.p, h->alt.mmax.p, (const uint32_t *)nq_.ccnt.p, (const float *)nq_.cmin.p, (const float *)nq_.cmax.p,
+                       h->alt.st1b.p);
+                h->ov.stats_done = true;
+            }
         } else {
             if (reserved) (void)hipStreamWaitEvent(h->stream, h->ev_asm, 0);  // (the early half of the write-back, its label tallies)
             if (!end_in_split)
