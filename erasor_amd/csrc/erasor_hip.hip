@@ -2357,9 +2357,14 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins_srt, std::min<uint32_t>(rev_grid, B) + (reserved ? 0u : 1u), 1024, P, sa, ra);
         MARK("per-bin launch");
         if (reserved) enqueue_early();
-        if (ov_next) {  // (behind the early passes, where that stream idles; needed by the next step's bin statistics)
-            const int rc_p2 = enqueue_chain_part2(h, nxt_side, h->bstream);
-            if (rc_p2) return rc_p2;
+        if (ov_next) {
+            // the second parts of the chains announced behind this step (QSide::ev_p1), behind the early passes, where that stream idles:
+            // the next node's if it is still due, and the node's behind it -- ONE STEP EARLY, so that it is through long before that
+            // node's bin statistics (launched ahead themselves) ask for it
+            for (int j = 0; j < h->npend && j < 2; ++j) {
+                const int rc_p2 = enqueue_chain_part2(h, h->pend[j], h->bstream);
+                if (rc_p2) return rc_p2;
+            }
         }
         if (reserved) (void)hipStreamWaitEvent(h->stream, h->ev_srt4, 0);  // (the reverted list, the reserved offsets, the late table)
         MARK("  ev_srt4 wait");
