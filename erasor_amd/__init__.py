@@ -252,12 +252,14 @@ class Erasor:
         self._last_res = res
         return res
 
-    def prefetch_node_rows(self, rows, intensity_col, T_l2b, T_b2o=None):
+    def prefetch_node_rows(self, rows, intensity_col, T_l2b, T_b2o=None, T_o2b=None):
         """announce the next node (host records); returns its ticket.  The buffer is the caller's again on return."""
         rows, stride = self._rows(rows)
         t = C.c_uint64(0)
         self._check(lib().erasor_hip_prefetch_node_rows(self._h, _p(rows), C.c_size_t(len(rows)), C.c_size_t(stride), C.c_size_t(4 * intensity_col),
                                                         _m(T_l2b), None if T_b2o is None else _m(T_b2o), C.byref(t)))
+        if T_b2o is not None and T_o2b is not None:
+            self._check(lib().erasor_hip_announce_origin2body(self._h, _m(T_o2b)))
         return t.value
 
     def step_ticket(self, ticket, T_b2o, T_o2b):

@@ -400,6 +400,7 @@ int ensure(erasor_hip_handle *h, DBuf<T> &b, size_t n, bool keep = false) {
     if (keep && b.p) HIPC(h, hipMemcpyAsync(np, b.p, b.cap * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
     if (b.p) {
         HIPC(h, hipStreamSynchronize(h->stream));
+        if (h->bstream) HIPC(h, hipStreamSynchronize(h->bstream));  // (passes launched ahead of the next step may be writing the old block)
         (void)hipFree(b.p);
     }
     b.p = np;
@@ -2118,7 +2119,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             h->cur = h->bstream;
             LAUNCH(h, "voi_gather", k_o_commit, std::max(1u, std::min<uint32_t>(cdiv(nOchunks, 4), 2048)), 256, h->Oxy.p,
                    (const unsigned long long *)h->vmask.p, (const uint32_t *)h->cinfo.p, (const DevState *)ds, h->capO / CHUNK,
-                   h->use_ometa ? h->ometa.p : (OMeta *)nullptr);
+                   h->use_ometa ? h->ometa.p : (OMeta *)nullptr, (const Counters *)dc, (const Counters *)Q(h).d_qctr.p);
         }
         MARK("  mapchain_end");
         h->cur = h->stream;

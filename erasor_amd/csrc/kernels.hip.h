@@ -1067,13 +1067,15 @@ __global__ __launch_bounds__(256) void k_late_gather(const float4 *__restrict__ 
 // record counts what stays.
 __global__ __launch_bounds__(256) void k_o_commit(float2 *__restrict__ Oxy, const unsigned long long *__restrict__ vmask,
                                                    const uint32_t *__restrict__ cinfo, const DevState *__restrict__ st, uint32_t capO_chunks,
-                                                   OMeta *__restrict__ ometa) {
+                                                   OMeta *__restrict__ ometa, const Counters *__restrict__ ctr, const Counters *__restrict__ qctr) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     if (st->ov_bad) return;
     const uint32_t nFchunks = (st->nF + CHUNK - 1) / CHUNK, o_chunk0 = st->o_begin / CHUNK;
     CHAIN_STAMP(12);
+    // (a step whose scan's voxelisation failed leaves no trace in the store -- its gather did nothing, see k_voi_gather: nor does this)
+    if (ctr->err || qctr->err) return;
     const uint32_t nOchunks = capO_chunks - o_chunk0;
     for (uint32_t w = wid; w < nOchunks; w += nwaves) {
         const uint32_t c = nFchunks + w;

@@ -694,7 +694,7 @@ def test_rows_in_the_callers_layout_and_announcements_by_ticket(gpu_mod):
 
     def announce(k):
         buf[:len(scans[k])] = _pcl_rows(scans[k])
-        tickets[k] = g.prefetch_node_rows(buf[:len(scans[k])], 4, sc["T_l2b"], sc["T_b2o"][k])
+        tickets[k] = g.prefetch_node_rows(buf[:len(scans[k])], 4, sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         buf[:] = np.nan  # the caller's buffer is the caller's again: scribble over it
         assert tickets[k] != 0
 
@@ -1037,8 +1037,10 @@ def test_ticket_announcements_survive_a_voxelgrid_mode_flip(gpu_mod):
     tickets = {}
 
     def announce(k):
+        # (with both transforms: the steps overlap -- the passes launched ahead of a step whose chain then reports the overflow, or that has
+        # to run again, must leave the store alone)
         buf[:len(scans[k])] = _pcl_rows(scans[k])
-        tickets[k] = g.prefetch_node_rows(buf[:len(scans[k])], 4, sc["T_l2b"], sc["T_b2o"][k])
+        tickets[k] = g.prefetch_node_rows(buf[:len(scans[k])], 4, sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         buf[:] = np.nan
 
     announce(0)
