@@ -2370,7 +2370,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         if (reserved) (void)hipStreamWaitEvent(h->stream, h->ev_srt4, 0);  // (the reverted list, the reserved offsets, the late table)
         MARK("  ev_srt4 wait");
         if (reserved)
-            LAUNCH(h, "assemble", k_assemble_late, std::min<uint32_t>(rev_grid, B), 256, P, h->Tb2o, (const uint32_t *)h->rev_list.p, (const float4 *)h->spts.p,
+            LAUNCH(h, "assemble", k_assemble_late, std::min<uint32_t>(rev_grid, B) + 1u, 256, P, h->Tb2o, (const uint32_t *)h->rev_list.p, (const float4 *)h->spts.p,
                    (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).qoff.p, (const uint8_t *)h->gflag.p,
                    (const uint32_t *)h->grank.p, (const uint32_t *)h->ng.p, (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p,
                    (const float4 *)h->vox_out.p, (const uint32_t *)h->out_offR.p, (const uint32_t *)h->gres_off.p, (const uint32_t *)h->out_off0.p,

@@ -4012,7 +4012,9 @@ __global__ __launch_bounds__(256) void k_assemble_late(DP P, Xf Tb2o, const uint
         return t;
     };
     uint32_t nd = 0, nst = 0;
-    for (uint32_t rk = blockIdx.x; rk < n_rev; rk += gridDim.x) {
+    // (the launch's LAST workgroup leaves the tables and totals, the others take the bins: side by side)
+    const uint32_t nbin_wg = gridDim.x - 1u;
+    for (uint32_t rk = blockIdx.x; rk < n_rev && blockIdx.x < nbin_wg; rk += nbin_wg) {
         const uint32_t key = rev_list[rk];
         const uint32_t o0 = moff[key], mc = moff[key + 1] - o0;
         uint32_t nv, ng, rj;
@@ -4050,7 +4052,7 @@ __global__ __launch_bounds__(256) void k_assemble_late(DP P, Xf Tb2o, const uint
     }
     (void)gres_off;
     (void)total_binsR;
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == nbin_wg) {
         // dense tables and totals (k_layout4's): prefixes over the reverted bins of their output sizes, ground, rejected points
         if (threadIdx.x < 4) s_carry[threadIdx.x] = 0;
         __syncthreads();
@@ -4103,6 +4105,7 @@ __global__ __launch_bounds__(256) void k_assemble_late(DP P, Xf Tb2o, const uint
         }
         if (threadIdx.x == 0) late_holes[2 * n_rev] = s_carry[3];  // (all of them: what a source index behind the last range is reduced by)
         // dense out_off by key: out_off0[key] + the voxels of the reverted bins before it
+#pragma unroll 4
         for (uint32_t key = threadIdx.x; key < (uint32_t)P.B; key += blockDim.x) {
             const uint32_t rb = rev_before[key];
             uint32_t a = 0;
