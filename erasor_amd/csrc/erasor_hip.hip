@@ -1712,7 +1712,17 @@ static void launch_voi_split(erasor_hip_handle *h, const float4 *F, uint32_t nF,
     const uint32_t capO_chunks = h->capO / CHUNK;
     // (prof 3: the same on every FOURTH launch -- the bracket costs the step it observes ~9 us (gpurun_out/r03k: 0.276 vs 0.267 ms
     // per scan with / without), a sample of the timed region's launches costs a quarter of that)
-    if (ovs) {  // (an overlapped step's pass: on the early stream, beside the per-bin launch of the step in flight)
+    if (ovs && (h->prof == 2 || (h->prof == 3 && (h->n_split_launch++ & 3u) == 0))) {
+        // (the roofline measurement of an overlapped step's pass: start / stop events on the early stream, see below)
+        PendingEvt ke;
+        ke.name_id = prof_id(h, "voi_split");
+        ke.a = get_evt(h);
+        ke.b = get_evt(h);
+        hipExtLaunchKernelGGL(k_voi_split, dim3(grid), dim3(256), 0, h->bstream, ke.a, ke.b, 0, F, nF, nFchunks, (const float2 *)h->Oxy.p, o_begin, o_chunk0,
+                              nOchunks, xc, yc, voi_r2, h->vmask.p, h->hmask.p, h->cinfo.p, dev, capO_chunks, cap_chunks,
+                              h->use_ometa ? h->ometa.p : (OMeta *)nullptr, se, ov);
+        h->pending.push_back(ke);
+    } else if (ovs) {  // (an overlapped step's pass: on the early stream, beside the per-bin launch of the step in flight)
         hipStream_t keep = h->cur;
         h->cur = h->bstream;
         LAUNCH(h, "voi_split", k_voi_split, grid, 256, F, nF, nFchunks, (const float2 *)h->Oxy.p, o_begin, o_chunk0, nOchunks, xc, yc, voi_r2, h->vmask.p,

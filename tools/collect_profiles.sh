@@ -14,11 +14,11 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="timeout 300 python $ROOT/bench.py --steps 20 --warmup 5 --no-extra-workloads --no-pr-rr --no-callback-bench $EXTRA"
 $BENCH > $OUT/bench.json 2> $OUT/bench.stderr
-$BENCH --no-cpu-baseline --profile-all > /dev/null 2> $OUT/bench_kernel_breakdown.txt
+$BENCH --no-cpu-baseline --profile-all --repeats 1 > /dev/null 2> $OUT/bench_kernel_breakdown.txt
 rm -rf /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -- $BENCH --no-cpu-baseline > $OUT/bench_under_rocprofv3.json 2> /dev/null
-timeout 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/rp_fetch -- $BENCH --steps 6 --no-cpu-baseline > /dev/null 2>&1
-timeout 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -- $BENCH --steps 6 --no-cpu-baseline > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -- $BENCH --no-cpu-baseline --repeats 2 > $OUT/bench_under_rocprofv3.json 2> /dev/null
+timeout 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/rp_fetch -- $BENCH --steps 6 --repeats 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -- $BENCH --steps 6 --repeats 1 --no-cpu-baseline > /dev/null 2>&1
 cd $ROOT && python tools/summarize_profiles.py /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write $OUT
 ls -la $OUT
 # the files bench.py reads (roofline.traffic, rocprofv3_kernel_avg_us, dominant_kernel): copies of this tag, with the build they describe
