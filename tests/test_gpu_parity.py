@@ -1145,3 +1145,94 @@ def test_bench_two_ranks_end_to_end_on_one_device(mode_args):
         assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 1e-3 * 3)) / d["value"] < 0.02  # whole-job rate: both ranks' scans over the slower rank's time
     else:
         assert sum(r["steps"] for r in d["per_rank"]) == 3 * 3  # three sequences handed out by the queue, three timed steps each
+
+
+FUZZ_SEEDS = int(os.environ.get("ERASOR_FUZZ_SEEDS", "4"))  # (a soak: ERASOR_FUZZ_SEEDS=40)
+
+
+@pytest.mark.parametrize("version,seed", [(3, i) for i in range(FUZZ_SEEDS)] + [(2, FUZZ_SEEDS + i) for i in range(max(1, FUZZ_SEEDS // 4))])
+def test_random_operation_sequences_keep_parity(gpu_mod, version, seed):
+    """Round 5: steps overlap (conftest forces it), so the step in flight holds state of the NEXT step -- its VoI split, its bucket table,
+    deferred tombstones.  A seeded random walk over everything a caller may do in between: poses out of order, repeated, rotated, far
+    outside the map; scans empty, tiny, truncated, larger than any before (scratch grows while a pass ahead is pending); nodes
+    announced with their pose, with half of it, with the wrong one, or not at all; read-backs and a replaced store between two
+    steps.  Every step and the map after it must be the oracle's."""
+    from erasor_amd import invert_rigid
+    rng = np.random.default_rng(9000 + seed)
+    sc = scenarios.small(version=version)
+    g, o = make_pair(gpu_mod, sc["params"])
+    g.set_map(sc["map"])
+    o.set_map(sc["map"])
+    scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"]]
+    Tb, To, Tl = sc["T_b2o"], sc["T_o2b"], sc["T_l2b"]
+    n = 16
+
+    def rotated(T, yaw, dx, dy):
+        c, s = np.cos(yaw), np.sin(yaw)
+        R = np.eye(4, dtype=np.float32)
+        R[:2, :2] = [[c, -s], [s, c]]
+        M = (np.asarray(T, np.float32).reshape(4, 4) @ R).astype(np.float32)
+        M[0, 3] += np.float32(dx)
+        M[1, 3] += np.float32(dy)
+        return np.ascontiguousarray(M.reshape(16))
+
+    nodes = []
+    for k in range(n):
+        r = rng.random()
+        if k and r < 0.15:
+            b, i = nodes[-1][1], nodes[-1][2]  # stationary sensor
+        else:
+            j = int(rng.integers(len(Tb)))
+            if r < 0.25:
+                b = rotated(Tb[j], 0.0, 4000.0, -3000.0)  # nowhere near the map: the whole VoI-resident region leaves
+            elif r < 0.55:
+                b = rotated(Tb[j], rng.uniform(-3.1, 3.1), rng.uniform(-6, 6), rng.uniform(-6, 6))
+            else:
+                b = np.ascontiguousarray(Tb[j], np.float32)
+            i = np.ascontiguousarray(invert_rigid(b), np.float32) if b is not Tb[j] else To[j]
+        s = scans[int(rng.integers(len(scans)))]
+        r = rng.random()
+        if r < 0.08:
+            s = s[:0]
+        elif r < 0.2:
+            s = s[:int(rng.integers(1, 700))]
+        elif r < 0.45:
+            s = s[int(rng.integers(0, len(s) // 2))::int(rng.integers(1, 4))]
+        elif r < 0.55:
+            s = np.concatenate([s, scans[int(rng.integers(len(scans)))][::2]])  # the largest scan so far
+        nodes.append((np.ascontiguousarray(s, np.float32), b, i))
+
+    def announce(k):
+        s, b, i = nodes[k]
+        r = rng.random()
+        if r < 0.12:
+            return
+        if r < 0.24:
+            g.prefetch(s, Tl)  # the scan only
+        elif r < 0.36:
+            g.prefetch(s, Tl, b)  # no origin2body: split ahead at most
+        elif r < 0.46:
+            w = nodes[int(rng.integers(n))]
+            g.prefetch(s, Tl, w[1], w[2])  # (most likely) the wrong pose
+        else:
+            g.prefetch(s, Tl, b, i)
+
+    ahead = int(rng.integers(1, 3))
+    for j in range(min(ahead, n)):
+        announce(j)
+    for k in range(n):
+        if k + ahead < n:
+            announce(k + ahead)
+        s, b, i = nodes[k]
+        rg = g.step(s, Tl, b, i)
+        ro = o.step(s, Tl, b, i)
+        compare_step(g, o, rg, ro, full=bool(rng.random() < 0.4))
+        r = rng.random()
+        if r < 0.1:  # the store replaced while a pass ahead may be pending
+            m2 = o.get_cloud(7)[::2].copy() if rng.random() < 0.5 else np.concatenate([o.get_cloud(7), sc["map"][::7]])
+            g.set_map(m2)
+            o.set_map(m2)
+        elif r < 0.2:
+            assert g.map_size() == len(o.get_cloud(7))
+            same(g.get_cloud(7), o.get_cloud(7), "whole map between two steps")
+    same(g.get_cloud(7), o.get_cloud(7), "whole map at the end")
