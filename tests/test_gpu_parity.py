@@ -1158,9 +1158,17 @@ def test_random_operation_sequences_keep_parity(gpu_mod, version, seed):
     announced with their pose, with half of it, with the wrong one, or not at all; read-backs and a replaced store between two
     steps.  Every step and the map after it must be the oracle's."""
     from erasor_amd import invert_rigid
+    import copy
     rng = np.random.default_rng(9000 + seed)
     sc = scenarios.small(version=version)
-    g, o = make_pair(gpu_mod, sc["params"])
+    prm = copy.copy(sc["params"])
+    variant = seed % 4  # 0, 1: the sequence's own parameters; 2: large-scale mode, submaps re-centred on the way; 3: another R-POD grid
+    if variant == 2:
+        prm.is_large_scale, prm.submap_size = 1, float(rng.choice([8.0, 25.0, 60.0]))
+    elif variant == 3:
+        prm.num_rings, prm.num_sectors = [(40, 120), (7, 11), (100, 130), (20, 108)][int(rng.integers(4))]
+    whole = (lambda: o.get_map()) if variant == 2 else (lambda: o.get_cloud(7))
+    g, o = make_pair(gpu_mod, prm)
     g.set_map(sc["map"])
     o.set_map(sc["map"])
     scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"]]
@@ -1229,10 +1237,11 @@ def test_random_operation_sequences_keep_parity(gpu_mod, version, seed):
         compare_step(g, o, rg, ro, full=bool(rng.random() < 0.4))
         r = rng.random()
         if r < 0.1:  # the store replaced while a pass ahead may be pending
-            m2 = o.get_cloud(7)[::2].copy() if rng.random() < 0.5 else np.concatenate([o.get_cloud(7), sc["map"][::7]])
+            m2 = whole()[::2].copy() if rng.random() < 0.5 else np.concatenate([whole(), sc["map"][::7]])
             g.set_map(m2)
             o.set_map(m2)
         elif r < 0.2:
-            assert g.map_size() == len(o.get_cloud(7))
+            assert g.map_size() == o.map_size()
             same(g.get_cloud(7), o.get_cloud(7), "whole map between two steps")
+    same(g.get_map(), o.get_map(), "map_arranged_ at the end")
     same(g.get_cloud(7), o.get_cloud(7), "whole map at the end")
