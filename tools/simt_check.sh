@@ -2,7 +2,7 @@
 # Parity of the device code WITHOUT a GPU: builds erasor_hip.hip + kernels against the tests' CPU stand-in of the HIP runtime
 # (tests/cpp/simt_emu) and runs the checks on it.  Test infrastructure; says nothing about timing.
 #   tools/simt_check.sh quick        sort + kernel checks + two look-ahead steps                      (~30 s)
-#   tools/simt_check.sh suite [-k E] tests/test_gpu_parity.py on the stand-in (default: all but the full-size cases, ~40 min)
+#   tools/simt_check.sh suite [-k E] tests/test_gpu_parity.py on the stand-in (default: all but the full-size cases, ~1 h 45 min)
 #   tools/simt_check.sh asan [-k E]  the same under AddressSanitizer (heap blocks = device buffers: out-of-bounds accesses show)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
