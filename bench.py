@@ -82,9 +82,14 @@ def parse_args():
                     help="let --cpu-seconds also bound the oracle's replay of the GPU's steps (default: every step the GPU ran -- warm-up and all "
                          "timed passes -- is replayed and compared, then the final map: ~0.08 s per step on the 10 M-point map)")
     ap.add_argument("--profile-all", action="store_true", help="second pass with per-kernel HIP events (breakdown on stderr)")
-    ap.add_argument("--lookahead", type=int, default=3, choices=[1, 2, 3],
-                    help="nodes announced ahead (erasor_hip_run_nodes / erasor_hip_prefetch_node); round 4: three -- with the main chain at 0.2 ms the\n"
-                         "query chains of two nodes no longer always finish in its shadow (0.204 vs 0.210 ms per scan, gpurun_out/r04al)")
+    ap.add_argument("--lookahead", type=int, default=6, choices=[1, 2, 3, 4, 5, 6, 7],
+                    help="nodes announced ahead (erasor_hip_run_nodes / erasor_hip_prefetch_node).  Round 6: six -- the query chains of announced nodes\n"
+                         "beyond the --chain-lead-th in line share their launches --chain-batch at a time (erasor_hip_chain_batch), and a set of two\n"
+                         "takes about three steps to get through its queue")
+    ap.add_argument("--chain-batch", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="query chains of announced nodes that share one set of launches (1: every chain on its own, round 5's behaviour)")
+    ap.add_argument("--chain-lead", type=int, default=3, choices=[1, 2, 3, 4, 5, 6],
+                    help="a chain is held back for a shared set only while this many chains are in their queues in front of it")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not announce the next scan (erasor_hip_prefetch_scan): every step runs its own query chain first")
     ap.add_argument("--seqs", type=int, default=len(SEQS), help="seq-per-gpu: use only the first N of the five sequences (e.g. 2: what one GPU of config 3's four gets)")
@@ -278,6 +283,7 @@ class Sequence:
         self.n_scan = int(np.mean([len(s) for s in self.scans]))
         self.g = erasor_amd.Erasor(P, device=device_index)
         self.g.set_map_device(d_map.data_ptr(), n_map)
+        self.g.chain_batch(args.chain_batch, args.chain_lead)
         self.lookahead = not args.no_lookahead
         self.LA = args.lookahead
         self.primed = False
@@ -850,6 +856,7 @@ def main():
                    "sharding": ("scan-parallel replicas, one RCCL broadcast of the map, no data-path collective" if args.mode == "replicas"
                                 else "one KITTI-shaped sequence per GPU (00/01/02/05/07 dealt round-robin), no map exchange"),
                    "lookahead_scans": first.LA if first.lookahead else 0,
+                   "chain_batch": {"n_scans": args.chain_batch, "lead": args.chain_lead},
                    "sequences_on_this_rank": len(seqs), "interleave": interleave,
                    "node_loop": "native (erasor_hip_run_nodes: one call for the timed nodes)" if native_loop else "python (prefetch + step per node)"},
         "map_points_x_scans_per_sec": round(value * N_map, 1),
@@ -865,6 +872,8 @@ def main():
         # round 5: steps whose split / chunk scan / gather / bucket table were launched beside the previous step's per-bin launch, and how many
         # of them the step took (the library overlaps where it pays: dense bins, ERASOR_HIP_OVERLAP unset = auto, 1 = always, 0 = never)
         "overlapped_steps": dict(zip(("launched_ahead", "taken"), g.overlap_counts()), mode=os.environ.get("ERASOR_HIP_OVERLAP", "auto")),
+        # round 6: sets of launches shared by the query chains of several announced nodes, and the chains that went into them
+        "shared_chain_launches": dict(zip(("sets", "chains"), g.chain_batch_counts())),
         "pr_rr": pr_rr, "callback_path": callback,
         "roofline": roofline, "cpu_baseline": cpu, "cpu_port": cpu_port, "host": host_identity(),
         "parity_checked_steps": parity["parity_checked_steps"], "parity": parity.get("parity"), "final_map_checked": parity.get("final_map_checked", False),
@@ -894,7 +903,7 @@ def main():
             ("large_scale_05", "config 4 with the chunk records OFF (ERASOR_HIP_NO_OMETA=1): the VoI pass streams the whole map store -- "
                                "the HBM-bound measurement of k_voi_split", [], {"ERASOR_HIP_NO_OMETA": "1"}, False),
             ("seq05_yaml", "config 2, config/seq_05.yaml verbatim", [], {}, False),
-            ("ouster128", "config 5 shape, 1 GPU", ["--lookahead", "3"], {}, False),
+            ("ouster128", "config 5 shape, 1 GPU", [], {}, False),
         )
         for wname, label, xargs, xenv, verified in passes:
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", wname, "--steps", "12" if verified else "20", "--warmup",

@@ -424,6 +424,16 @@ class Erasor:
         self._check(lib().erasor_hip_overlap_counts(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def chain_batch(self, n_scans, lead=3):
+        """the query chains of `n_scans` announced nodes share one set of launches (erasor_hip_chain_batch); 1: every chain on its own"""
+        self._check(lib().erasor_hip_chain_batch(self._h, C.c_int(n_scans), C.c_int(lead)))
+
+    def chain_batch_counts(self):
+        """(sets of shared launches made so far, chains that went into them)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(lib().erasor_hip_chain_batch_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def chain_timing(self, reset=False):
         """(average span of the main stream's chain per step, average time between a step's end and the next chunk scan, steps, average
         period chunk scan -> chunk scan) -- on the device's own clock (erasor_hip_chain_timing)."""

@@ -9,6 +9,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <functional>
@@ -50,65 +51,13 @@ struct DBuf {
 
 }  // namespace
 
-// ---- a launch sequence as a hipGraph -------------------------------------------------------------------------------------------
-// A query chain is ~45 launches of a fixed topology; enqueued one by one they cost the host ~130 us per scan (2.3-3 us each) --
-// two thirds of a step's host time, and THE limit once several sequences share one host thread (erasor_hip_step_async).  The chain
-// is therefore RECORDED (kernel, grid, arguments; nothing launched), kept as an instantiated graph per query side and segment, and
-// replayed with hipGraphLaunch; arguments that differ from the recorded ones (the scan's address and size) are patched into the
-// executable graph node by node.  A different kernel sequence (another sort depth, the pass-through chain) rebuilds the graph.
-struct GNode {
-    const void *func = nullptr;
-    dim3 grid, block;
-    std::vector<uint8_t> blob;   // the arguments, each converted to the kernel's parameter type, at aligned offsets
-    std::vector<uint32_t> off;
-};
-struct GSeg {
-    std::vector<GNode> nodes;
-#ifndef ERASOR_NO_HIPGRAPH
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    std::vector<hipGraphNode_t> gnodes;
-#endif
-    uint64_t n_launch = 0, n_rebuild = 0, n_patch = 0;
-};
-template <class... KP, class... A>
-static void rec_add(std::vector<GNode> *rec, void (*kern)(KP...), dim3 g, dim3 b, A &&...a) {
-    static_assert(sizeof...(KP) == sizeof...(A), "argument count");
-    rec->emplace_back();
-    GNode &n = rec->back();
-    n.func = (const void *)kern;
-    n.grid = g;
-    n.block = b;
-    size_t off = 0;
-    auto put = [&](auto v) {
-        using T = decltype(v);
-        off = (off + alignof(T) - 1) & ~(alignof(T) - 1);
-        n.off.push_back((uint32_t)off);
-        n.blob.resize(off + sizeof(T));
-        memcpy(&n.blob[off], &v, sizeof(T));
-        off += sizeof(T);
-    };
-    (put(static_cast<KP>(std::forward<A>(a))), ...);
-}
-
-static void graph_release(GSeg &seg) {
-#ifndef ERASOR_NO_HIPGRAPH
-    if (seg.exec) (void)hipGraphExecDestroy(seg.exec);
-    if (seg.graph) (void)hipGraphDestroy(seg.graph);
-    seg.exec = nullptr;
-    seg.graph = nullptr;
-    seg.gnodes.clear();
-#endif
-    seg.nodes.clear();
-}
-
 // The query side of a step (see erasor_hip_handle::q)
 // layout of a HOST scan's records: float x, y, z at byte 0, float intensity at byte `ioff`, one record every `stride` bytes
 // (the library's own XYZI rows: 16 / 12; pcl::PointXYZI, what OMU.cpp:237 pcl::fromROSMsg leaves: 32 / 16)
 struct RowFmt {
     uint32_t stride = 16, ioff = 12;
 };
-static constexpr int NSIDE = 4;  // the scan being stepped + up to three announced ahead
+static constexpr int NSIDE = 8;  // the scan being stepped + up to seven announced ahead (round 6: chains of announced scans share launches, see flush_held)
 static constexpr int MAX_AHEAD = NSIDE - 1;
 struct QSide {
     uint32_t capS = 0;
@@ -136,12 +85,7 @@ struct QSide {
     bool h2d_pending = false;         // the chain that reads q.scan has to wait for ev_h2d
     hipEvent_t ev_keys = nullptr;     // voxel keys (and the VoxelGrid overflow flag) are final
     hipEvent_t ev_done = nullptr;     // the whole query chain of the scan is done
-    // round 5: with the steps overlapped two query streams are all the hardware queues leave (main + early + 2: a fifth busy queue slows
-    // every kernel of every queue 3-8 x), and the two chains in flight bound the step.  The chain of a node announced with both transforms
-    // therefore ENDS behind its centroids (ev_p1); its label search, bucketing and bin statistics -- a quarter of its time -- run on the
-    // early stream, behind the early passes of the step in front of the node's own (enqueue_chain_part2), where that stream idles
-    hipEvent_t ev_p1 = nullptr;
-    bool p2_pending = false;          // the chain's second part has not been enqueued yet
+    bool held = false;                // the chain is set up but its launches wait for a set shared with the next announcements (flush_held)
     // bookkeeping of a chain that has been enqueued (erasor_hip_prefetch_scan) but not yet consumed by a step
     const void *src = nullptr;
     size_t src_n = 0;
@@ -156,7 +100,6 @@ struct QSide {
     double pose_x = 0, pose_y = 0;    // T_body2origin translation (OMU.cpp:246-247): all fetch_VoI needs
     bool to_valid = false;            // ... and with T_origin2body (erasor_hip_announce_origin2body): the next step's gather can go ahead too
     float To[16] = {0};
-    GSeg gseg[2];                     // the chain as two graphs: up to the voxel keys (ev_keys), the rest (ev_done)
 };
 
 struct erasor_hip_handle {
@@ -176,10 +119,12 @@ struct erasor_hip_handle {
     bool bstream_own = false;
     hipEvent_t ev_stats = nullptr, ev_srt4 = nullptr, ev_asm = nullptr, ev_early = nullptr;
     unsigned n_chain = 0;
+    // round 6: chains of announced scans are held back until `batch_n` of them can share one set of launches -- unless fewer than
+    // `batch_lead` chains are in their queues in front of them (then latency matters more than queue time)
+    int batch_n = 2, batch_lead = 3;
+    unsigned long long n_batches = 0, n_batched_chains = 0;
     hipStream_t cur = nullptr;      // stream LAUNCH() currently targets
-    std::vector<GNode> *rec = nullptr;  // non-null: LAUNCH() records instead of launching (the query chain as a graph)
-    bool use_graph = false;
-    int pend[MAX_AHEAD] = {0, 0, 0};  // query sides with a prefetched chain in flight, oldest first
+    int pend[MAX_AHEAD] = {0};  // query sides with a prefetched chain in flight (or held back for a shared set of launches), oldest first
     int npend = 0;
     // a scan announced by erasor_hip_prefetch_scan whose chain is not enqueued yet (the step in flight goes first)
     struct {
@@ -457,10 +402,6 @@ void prof_collect(erasor_hip_handle *h, bool force = false) {
 // kernel launch with optional event bracketing on the handle's stream
 #define LAUNCH(h, name, kern, grid, block, ...)                                   \
     do {                                                                          \
-        if ((h)->rec) {                                                           \
-            rec_add((h)->rec, kern, dim3(grid), dim3(block), __VA_ARGS__);        \
-            break;                                                                \
-        }                                                                         \
         PendingEvt pe_;                                                           \
         const bool prof_ = (h)->prof == 1 || ((h)->prof == 2 && strncmp(name, "voi_split", 9) == 0); \
         if (prof_) {                                                              \
@@ -469,7 +410,7 @@ void prof_collect(erasor_hip_handle *h, bool force = false) {
             pe_.b = get_evt(h);                                                   \
             (void)hipEventRecord(pe_.a, CUR(h));                                  \
         }                                                                         \
-        if (g_debug_sync) fprintf(stderr, "[erasor_hip] launch %s grid=%u\n", name, (unsigned)(grid)); \
+        if (g_debug_sync) fprintf(stderr, "[erasor_hip] launch %s grid=%u\n", name, (unsigned)dim3(grid).x); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, CUR(h), __VA_ARGS__);   \
         if (g_debug_sync) {                                                       \
             hipError_t e2_ = hipStreamSynchronize(CUR(h));                        \
@@ -929,8 +870,7 @@ static bool create_sides(erasor_hip_handle *h, int prio) {
     for (int k = 0; k < h->nqs; ++k)
         if (hipStreamCreateWithPriority(&h->qstream[k], hipStreamNonBlocking, prio) != hipSuccess) return false;
     for (int k = 0; k < NSIDE; ++k)
-        if (hipEventCreateWithFlags(&h->q[k].ev_p1, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->q[k].ev_keys, hipEventDisableTiming) != hipSuccess ||
+        if (hipEventCreateWithFlags(&h->q[k].ev_keys, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->q[k].ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->q[k].ev_h2d, hipEventDisableTiming) != hipSuccess)
             return false;
@@ -941,8 +881,8 @@ static bool create_sides(erasor_hip_handle *h, int prio) {
     else if (hipStreamCreateWithPriority(&h->bstream, hipStreamNonBlocking, prio) != hipSuccess) return false;
     h->bstream_own = h->nqs < 3;
     // (events between two streams of ONE device: no system-scope fence -- the cache write-back and invalidation it brings cost the kernels
-    // around it tens of microseconds; ERASOR_HIP_EVT_SYSFENCE=1: the default flags, A/B)
-    const unsigned evf = hipEventDisableTiming | (getenv("ERASOR_HIP_EVT_SYSFENCE") ? 0u : hipEventDisableSystemFence);
+    // around it tens of microseconds)
+    const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
     for (hipEvent_t *e : {&h->ev_stats, &h->ev_srt4, &h->ev_asm, &h->ev_early})
         if (hipEventCreateWithFlags(e, evf) != hipSuccess) return false;
     return hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) == hipSuccess;
@@ -985,18 +925,9 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
     memset(&h->st, 0, sizeof(h->st));
     memset(&h->ctr, 0, sizeof(h->ctr));
     memset(&h->last_res, 0, sizeof(h->last_res));
-    // Every stream at the DEFAULT priority.  Rounds 1-2 gave the main stream the highest and the query streams the lowest: on a single
-    // handle that measures nothing (0.2363 vs 0.2363 ms per scan), but priorities are strict between hardware queues that share a pipe --
-    // with several handles in one process (a handle per sequence, the shim's updaters) a handle's query queues sometimes land beside its
-    // always-busy main queue and starve: its chains then run only while the main stream waits for them, the look-ahead is gone, and the
-    // step takes 0.64 ms instead of 0.22 -- for the whole life of the handle (gpurun_out/r03as-r03av: 10 of 17 runs of the C++ bench's
-    // third handle; 0 of 6 without priorities).  ERASOR_HIP_STREAM_PRIORITIES=1 restores them.
-    int prio_lo = 0, prio_hi = 0;
-    if (getenv("ERASOR_HIP_STREAM_PRIORITIES")) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (getenv("ERASOR_HIP_QUERY_PRIORITY")) {  // (A/B, round 5: the query streams above the main and the early stream)
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        std::swap(prio_lo, prio_hi);
-    }
+    // Every stream at the DEFAULT priority: priorities are strict between hardware queues that share a pipe, and with several handles in
+    // one process a handle's low-priority query queues could land beside its always-busy main queue and starve (EXPERIMENTS, round 3).
+    const int prio_lo = 0, prio_hi = 0;
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         !create_sides(h, prio_lo) ||
         hipHostMalloc((void **)&h->pin, sizeof(HostOut), hipHostMallocDefault) != hipSuccess) {
@@ -1005,12 +936,6 @@ int erasor_hip_create(const erasor_params *p, int device, erasor_hip_handle **ou
     }
     memset(h->pin, 0, sizeof(HostOut));
     h->cur = h->stream;
-#ifndef ERASOR_NO_HIPGRAPH
-    // measured on MI355X / ROCm 7.2 (gpurun_out/r03f): replaying the chain as two graphs costs the host 88-95 us per scan instead of
-    // 120-130 us launch by launch, yet end to end it is no faster: one sequence 0.276-0.282 vs 0.271-0.275 ms per scan, five
-    // interleaved sequences (erasor_hip_step_async) 3000-3100 vs 3540-3590 scans/s.  OFF unless ERASOR_HIP_GRAPH=1.
-    h->use_graph = getenv("ERASOR_HIP_GRAPH") != nullptr;
-#endif
     if (alloc_bins(h)) {
         erasor_hip_destroy(h);
         return ERASOR_E_NO_DEVICE;
@@ -1060,12 +985,9 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->vox_out); release(h->d_st); release(h->d_st_get); release(h->d_ctr);
     for (int k = 0; k < NSIDE; ++k) {
         if (h->q[k].ev_keys) (void)hipEventDestroy(h->q[k].ev_keys);
-        if (h->q[k].ev_p1) (void)hipEventDestroy(h->q[k].ev_p1);
         if (h->q[k].ev_done) (void)hipEventDestroy(h->q[k].ev_done);
         if (h->q[k].ev_h2d) (void)hipEventDestroy(h->q[k].ev_h2d);
         if (h->q[k].stage) (void)hipHostFree(h->q[k].stage);
-        graph_release(h->q[k].gseg[0]);
-        graph_release(h->q[k].gseg[1]);
     }
     for (int k = 0; k < erasor_hip_handle::NQS_MAX; ++k)
         if (h->qstream[k]) (void)hipStreamDestroy(h->qstream[k]);
@@ -1125,6 +1047,8 @@ int erasor_hip_set_map_device(erasor_hip_handle *h, const void *d_xyzi, size_t n
 
 // exact std::sort of (qk_a, qv_a)[0..n) -> (qk_b, qv_b): global levels (one workgroup per big segment, one partition per
 // launch), then every remaining segment is completed inside LDS by one workgroup.
+// (levels beyond lg(n / WIDE_MIN): 4 measured best -- fewer leave k_esort_mid / k_esort_final more than the levels save, EXPERIMENTS r05-5)
+#define ESORT_WIDE_SLACK 4
 static void run_exact_sort(erasor_hip_handle *h, uint32_t n, bool queues_open = false) {
     Counters *dc = Q(h).d_qctr.p;
     if (!queues_open)  // (the scan's voxelisation opens them in its key kernel: k_voxel_keys_es)
@@ -1135,11 +1059,7 @@ static void run_exact_sort(erasor_hip_handle *h, uint32_t n, bool queues_open = 
         // lg(n / WIDE_MIN) + slack levels empty the wide list; whatever is left is routed to the level queue.
         // ERASOR_HIP_SORT_LEVEL_CAP (test hook): cut the level budget short so that the final kernel meets long segments
         static const int level_cap = getenv("ERASOR_HIP_SORT_LEVEL_CAP") ? atoi(getenv("ERASOR_HIP_SORT_LEVEL_CAP")) : 1 << 20;
-#ifndef ESORT_WIDE_SLACK
-#define ESORT_WIDE_SLACK 4
-#endif
-        static const int wide_slack = getenv("ERASOR_HIP_WIDE_SLACK") ? atoi(getenv("ERASOR_HIP_WIDE_SLACK")) : ESORT_WIDE_SLACK;
-        const int wl = std::min(std::min(esort::lg2_floor(n / WIDE_MIN) + wide_slack, 16), level_cap);
+        const int wl = std::min(std::min(esort::lg2_floor(n / WIDE_MIN) + ESORT_WIDE_SLACK, 16), level_cap);
         for (int l = 0; l < wl; ++l) {
             const int cur = l & 1;
             // two launches per level (round 2: three -- the children's routing and median move had a kernel of their own)
@@ -1274,78 +1194,6 @@ static int stage_host_scan(erasor_hip_handle *h, const void *scan_src, uint32_t 
     return ERASOR_OK;
 }
 
-// Replays what LAUNCH() has recorded into `rec` as a graph on `stream`: first use (or another kernel sequence) builds and
-// instantiates it, afterwards only the nodes whose grid or arguments differ are patched.  Any failure of the graph API falls back
-// to launching the recorded kernels one by one (same order, same stream).
-static int graph_flush(erasor_hip_handle *h, GSeg &seg, std::vector<GNode> &rec, hipStream_t stream) {
-#ifndef ERASOR_NO_HIPGRAPH
-    if (rec.empty()) return ERASOR_OK;
-    std::vector<void *> ptrs;
-    auto params = [&](GNode &n) {
-        hipKernelNodeParams p;
-        memset(&p, 0, sizeof(p));
-        p.func = const_cast<void *>(n.func);
-        p.gridDim = n.grid;
-        p.blockDim = n.block;
-        p.sharedMemBytes = 0;
-        ptrs.resize(n.off.size());
-        for (size_t k = 0; k < n.off.size(); ++k) ptrs[k] = &n.blob[n.off[k]];
-        p.kernelParams = ptrs.data();
-        p.extra = nullptr;
-        return p;
-    };
-    bool same = seg.exec != nullptr && seg.nodes.size() == rec.size();
-    for (size_t i = 0; same && i < rec.size(); ++i) same = seg.nodes[i].func == rec[i].func && seg.nodes[i].blob.size() == rec[i].blob.size();
-    bool ok = true;
-    if (!same) {
-        graph_release(seg);
-        ok = hipGraphCreate(&seg.graph, 0) == hipSuccess;
-        hipGraphNode_t prev = nullptr;
-        for (size_t i = 0; ok && i < rec.size(); ++i) {
-            hipKernelNodeParams p = params(rec[i]);
-            hipGraphNode_t gn = nullptr;
-            ok = hipGraphAddKernelNode(&gn, seg.graph, prev ? &prev : nullptr, prev ? 1 : 0, &p) == hipSuccess;
-            seg.gnodes.push_back(gn);
-            prev = gn;
-        }
-        ok = ok && hipGraphInstantiate(&seg.exec, seg.graph, nullptr, nullptr, 0) == hipSuccess;
-        if (ok) seg.nodes = rec;  // (a copy: `rec` stays whole until the launch has succeeded -- the fallback below replays it)
-        ++seg.n_rebuild;
-    } else {
-        for (size_t i = 0; ok && i < rec.size(); ++i) {
-            GNode &o = seg.nodes[i], &n = rec[i];
-            if (o.grid.x == n.grid.x && o.grid.y == n.grid.y && o.grid.z == n.grid.z && o.block.x == n.block.x && o.blob == n.blob) continue;
-            hipKernelNodeParams p = params(n);
-            ok = hipGraphExecKernelNodeSetParams(seg.exec, seg.gnodes[i], &p) == hipSuccess;
-            if (ok) o = n;  // (copied, not moved: see the fallback)
-            ++seg.n_patch;
-        }
-    }
-    if (ok) ok = hipGraphLaunch(seg.exec, stream) == hipSuccess;
-    if (ok) {
-        ++seg.n_launch;
-        rec.clear();
-        return ERASOR_OK;
-    }
-    (void)hipGetLastError();
-    // a graph call failed: this recording -- still complete, nothing was moved out of it -- is launched kernel by kernel, and the
-    // handle stops using graphs (the fallback used to replay entries whose argument blobs had been moved away)
-    for (GNode &n : rec) {
-        hipKernelNodeParams p = params(n);
-        if (hipLaunchKernel(p.func, p.gridDim, p.blockDim, p.kernelParams, 0, stream) != hipSuccess) {
-            h->err = "kernel launch failed (graph fallback)";
-            return ERASOR_E_NO_DEVICE;
-        }
-    }
-    graph_release(seg);
-    h->use_graph = false;  // (do not try again on this handle)
-    rec.clear();
-#else
-    (void)h; (void)seg; (void)rec; (void)stream;
-#endif
-    return ERASOR_OK;
-}
-
 // ---- the handle's worker thread (see erasor_hip_handle::Worker) ----
 static void worker_main(erasor_hip_handle *h) {
     (void)hipSetDevice(h->device);
@@ -1359,13 +1207,11 @@ static void worker_main(erasor_hip_handle *h) {
             job = std::move(w->jobs.front());
             w->jobs.pop_front();
         }
-        const int rc = job();
-        if (rc) w->err.store(rc);
+        (void)job();  // (the job stores its error before it releases its sides, see dispatch_chain)
     }
 }
 static void worker_start(erasor_hip_handle *h) {
-#ifndef ERASOR_NO_WORKER_THREAD  // (a build option, like ERASOR_NO_HIPGRAPH: every launch from the caller's thread)
-    if (getenv("ERASOR_HIP_NO_WORKER")) return;
+#ifndef ERASOR_NO_WORKER_THREAD  // (a build option: every launch from the caller's thread)
     h->worker = new erasor_hip_handle::Worker();
     for (int k = 0; k < NSIDE; ++k) h->worker->busy[k].store(0);
     h->worker->th = std::thread(worker_main, h);
@@ -1384,12 +1230,19 @@ static void worker_stop(erasor_hip_handle *h) {
     delete h->worker;
     h->worker = nullptr;
 }
+static int flush_held(erasor_hip_handle *h);
 // the launches (and event records) of side `side`'s chain have all been made; side < 0: of every side
 static int chain_wait(erasor_hip_handle *h, int side) {
+    bool held = false;
+    for (int k = 0; k < NSIDE; ++k) held = held || ((side < 0 || k == side) && h->q[k].held);
+    if (held) {  // (a chain that was held back for a shared set of launches: whoever needs its events sends the set off)
+        const int rc = flush_held(h);
+        if (rc) return rc;
+    }
     if (!h->worker) return ERASOR_OK;
     for (int k = 0; k < NSIDE; ++k) {
         if (side >= 0 && k != side) continue;
-        while (h->worker->busy[k].load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+        while (h->worker->busy[k].load(std::memory_order_acquire) > 0) std::this_thread::yield();
     }
     const int e = h->worker->err.exchange(0);
     if (e) {
@@ -1422,7 +1275,6 @@ struct SideGuard {
     ~SideGuard() {
         h->qi = qi;
         h->cur = cur;
-        h->rec = nullptr;  // (a recording never outlives the function that started it)
     }
 };
 
@@ -1452,93 +1304,53 @@ static int enqueue_passthrough(erasor_hip_handle *h, const float4 *d_src, uint32
     return ERASOR_OK;
 }
 
-// staged: 0 = the scan comes from the caller now; 1 = announced (h->ann): a host scan lies in the side's staging copy already;
-// 2 = the side's OWN announcement once more (its chain ran in the wrong VoxelGrid mode, step_collect): scan, ticket, hash and pose stay
-static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_src, uint32_t ns, bool src_is_device, const float T_l2b[16],
-                               bool prevox, int staged = 0, bool passthrough = false, RowFmt fmt = RowFmt()) {
-    {
-        const int rc_w = chain_wait(h, side);  // (the side's previous chain: its events are waited for below)
-        if (rc_w) return rc_w;
-    }
-    SideGuard guard(h);
-    h->qi = side;
-    // (the radix fallback for very fine R-POD grids -- and the pass-through chain's radix sort -- share their scratch bank
-    // between the sides: one stream for all of them then)
-    // (while the early stream is in use the chains keep to two query streams: four busy compute queues are all that run side by side)
-    const unsigned nqs_now = (unsigned)(h->ov_mode ? std::min(h->nqs, 2) : h->nqs);
-    hipStream_t qstream = (h->B + 1 <= QB_NB_MAX && !passthrough) ? h->qstream[h->n_chain++ % nqs_now] : h->qstream[0];
-    h->cur = qstream;
-    int rc = alloc_scan(h, std::max(ns, 1u));
-    if (rc) return rc;
-    const DP &P = h->dp;
-    const uint32_t B = h->B, nq = ns;  // nq: upper bound; the actual count lives in d_nvox
+// ---- the launches of ONE scan's chain on `qstream` (the caller's thread or the handle's worker: TlCtx) ----
+struct ChainJob {
+    erasor_hip_handle *h;
+    int side;
+    hipStream_t qstream;
+    uint32_t ns;
+    bool prevox, passthrough, to_worker;
+    float Tl[16];
+};
+static int chain_launches(const ChainJob &j) {
+    erasor_hip_handle *h = j.h;
+    QSide &q = h->q[j.side];
+    const DP P = h->dp;
+    const uint32_t B = h->B, ns = j.ns, nq = j.ns;  // nq: upper bound; the actual count lives in d_nvox
     const int bits = key_bits(B + 1);
-    if (B + 1 <= QB_NB_MAX) {
-        if (ensure(h, Q(h).qb_hist, (size_t)(B + 1) * std::max(1u, cdiv(nq, QB_TILE)) + 8)) return ERASOR_E_NO_DEVICE;
-    } else {
-        const uint32_t nb_q = 256u * std::max(1u, cdiv(nq, RTILE));
-        if (ensure(h, h->hist, nb_q) || ensure(h, h->hist_l, nb_q) || ensure(h, h->hist_t, cdiv(nb_q, 1024) + 2)) return ERASOR_E_NO_DEVICE;
-    }
-    QSide &q = Q(h);
-    // a device-resident scan is read in place (it must stay valid until the step that consumes it has returned);
-    // a host scan is copied now (blocking copy: this side has no work in flight)
-    if (ns && !src_is_device && !staged) {
-        // the side may still be executing a chain that was dropped (a prefetch that no step claimed): its kernels read
-        // q.scan, and a scan that changes between the bounding-box pass and the voxel keys sends them astray
-        if (q.used) HIPC(h, hipEventSynchronize(q.ev_done));
-        if (q.used) HIPC(h, hipEventSynchronize(q.ev_p1));
-        uint64_t fp_staged = 0;
-        rc = stage_host_scan(h, scan_src, ns, qstream, fmt, &fp_staged);  // (on the chain's own stream: ordered before its first kernel)
-        if (rc) return rc;
-        q.h2d_pending = false;
-        q.fp = fp_staged;
-    }
-    if (q.h2d_pending) {  // announced earlier (erasor_hip_prefetch_*): the copy runs on the copy stream
-        (void)hipStreamWaitEvent(qstream, q.ev_h2d, 0);
-        q.h2d_pending = false;
-    }
-    q.scan_in = src_is_device && ns ? (const float4 *)scan_src : (const float4 *)q.scan.p;
-    // the side's previous chain (possibly a dropped one, possibly on the other query stream) must be through with its buffers
-    if (q.used) (void)hipStreamWaitEvent(qstream, q.ev_done, 0);
-    if (q.used) (void)hipStreamWaitEvent(qstream, q.ev_p1, 0);  // (... a dropped one whose second part never ran)
+    const bool prevox = j.prevox, passthrough = j.passthrough;
+    hipStream_t qstream = j.qstream;
     Counters *qc = q.d_qctr.p;
     const uint32_t *nq_dev = q.d_nvox.p;
-    // the voxelising chain as two graphs (see GSeg): recorded by the very LAUNCH() calls below, replayed at the two event records
-    std::vector<GNode> recorded;
-#ifndef ERASOR_NO_HIPGRAPH
-    if (h->use_graph && h->prof != 1 && !g_debug_sync && !passthrough && !prevox && B + 1 <= QB_NB_MAX && ns) h->rec = &recorded;
-#endif
-    // round 5: the common chain's launches are made by the handle's worker thread (everything above -- allocations, the staged copy, the
-    // waits for the side's previous chain -- and the bookkeeping below stay with the caller)
-    const bool to_worker = h->worker && !h->rec && h->prof != 1 && !g_debug_sync && !passthrough && !prevox && B + 1 <= QB_NB_MAX;
-    // round 5: the chain of a node announced with both transforms (its step will overlap the one in front) ends behind its centroids; the
-    // rest follows on the early stream one step before it is needed (see QSide::ev_p1)
-    // (measured slower on both configurations -- the early stream has no room for it once it carries the early passes: opt-in, A/B)
-    static const bool no_split = getenv("ERASOR_HIP_CHAIN_SPLIT") == nullptr || getenv("ERASOR_HIP_NO_OVERLAP") != nullptr ||
-                                 getenv("ERASOR_HIP_NO_RESERVED") != nullptr;
-    const bool split = staged == 1 && h->ann.pose_valid && h->ann.to_valid && !no_split && h->ov_mode && P.version == 3 && !h->rec && h->prof != 1 && !g_debug_sync &&
-                       !passthrough && !prevox && B + 1 <= QB_NB_MAX && nq > 0;
-    struct TlArr {
-        float m[16];
-    } tl_arr;
-    memcpy(tl_arr.m, T_l2b, sizeof(tl_arr.m));
-    auto launches = [h, &q, qc, nq_dev, qstream, ns, nq, B, bits, P, prevox, passthrough, tl_arr, to_worker, split, &recorded]() -> int {
-    const float *T_l2b = tl_arr.m;
+    const float *T_l2b = j.Tl;
     int rc = 0;
+    // (LAUNCH() and Q() look at the thread's context first: the chain's own stream and side, on the worker thread and on the caller's
+    // alike; on the caller's thread the handle's own fields say the same -- the tests' CPU stand-in evaluates a launch's arguments on
+    // its wavefront threads, which have no context of their own)
     TlCtx keep_tl = g_tl;
-    if (to_worker) {
-        g_tl.h = h;
-        g_tl.cur = qstream;
-        g_tl.qi = (int)(&q - h->q);
+    g_tl.h = h;
+    g_tl.cur = qstream;
+    g_tl.qi = j.side;
+    struct HandleCtx {
+        erasor_hip_handle *h;
+        int qi;
+        hipStream_t cur;
+        ~HandleCtx() {
+            if (h) {
+                h->qi = qi;
+                h->cur = cur;
+            }
+        }
+    } handle_ctx{j.to_worker ? nullptr : h, h->qi, h->cur};
+    if (!j.to_worker) {
+        h->qi = j.side;
+        h->cur = qstream;
     }
     struct TlRestore {
         TlCtx k;
         ~TlRestore() { g_tl = k; }
     } tl_restore{keep_tl};
-    {
-        static const int qpad = getenv("ERASOR_HIP_QPAD_US") ? atoi(getenv("ERASOR_HIP_QPAD_US")) : 0;
-        if (qpad > 0) LAUNCH(h, "q_pad", k_pad, 1, 64, (unsigned long long)qpad * 100ull);
-    }
     LAUNCH(h, "q_begin", k_query_begin, 1, 256, qc, q.bb.p, B + 1 <= QB_NB_MAX ? q.qb_tot.p : (uint32_t *)nullptr, B + 1 <= QB_NB_MAX ? B + 1 : 0u,
            q.d_nvox.p, (prevox || passthrough) ? ns : 0u);
     // ---- part 1: bounding box, voxel keys, exact std::sort, runs ----
@@ -1551,14 +1363,9 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
         rc = enqueue_passthrough(h, q.scan_in, ns, T_l2b, q.query.p, q.qkey.p);
         if (rc) return rc;
     } else if (!prevox) {
-        int rc_g = ERASOR_OK;
-        voxelize_query_part1(h, ns, P.leaf_query, [&] {
-            if (h->rec) rc_g = graph_flush(h, q.gseg[0], recorded, qstream);
-            (void)hipEventRecord(q.ev_keys, qstream);
-        });
-        if (rc_g) return rc_g;
-    }
-    else (void)hipEventRecord(q.ev_keys, qstream);
+        voxelize_query_part1(h, ns, P.leaf_query, [&] { (void)hipEventRecord(q.ev_keys, qstream); });
+    } else
+        (void)hipEventRecord(q.ev_keys, qstream);
     // ---- part 2: centroids, label NN, lidar->body, R-POD key ----
     const uint32_t *sq_keys = nullptr, *sq_perm = nullptr;
     if (prevox) {
@@ -1568,10 +1375,6 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     } else if (nq) {
         LAUNCH(h, "q_centroids", k_centroids, cdiv((uint64_t)nq * 8, 256), 256, q.scan_in, (const uint32_t *)q.qk_b.p, (const uint32_t *)q.qv_b.p,
                (const uint32_t *)q.run_begin.p, nq_dev, q.cent.p, q.ukeys.p, q.hkey.p, q.hval.p, q.hbits);
-        if (split) {  // (the rest: enqueue_chain_part2, on another stream)
-            (void)hipEventRecord(q.ev_p1, qstream);
-            return rc;
-        }
         LAUNCH(h, "q_nn", k_query_nn, cdiv((uint64_t)nq * NN_SUB, 256), 256, q.scan_in, (const uint32_t *)q.qv_b.p, (const uint32_t *)q.run_begin.p,
                (const uint32_t *)q.ukeys.p, (const float4 *)q.cent.p, nq_dev, (const VoxGrid *)q.qgrid.p, to_xf(T_l2b), P, qc, q.query.p, q.qkey.p,
                (const uint32_t *)q.hkey.p, (const uint32_t *)q.hval.p, q.hbits);
@@ -1590,35 +1393,218 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     }
     LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)q.sq.p, (const uint32_t *)q.qoff.p, B, q.ccnt.p, q.cmin.p,
            q.cmax.p);
-    if (h->rec) {
-        rc = graph_flush(h, q.gseg[1], recorded, qstream);
-        h->rec = nullptr;
-        if (rc) return rc;
-    }
     (void)hipEventRecord(q.ev_done, qstream);
     return rc;
-    };  // (launches)
-    if (to_worker) {
-        auto *w = h->worker;
-        w->busy[side].fetch_add(1, std::memory_order_acq_rel);
-        {
-            std::lock_guard<std::mutex> lk(w->mu);
-            w->jobs.emplace_back([launches, w, side]() -> int {
-                const int rc_j = launches();
-                w->busy[side].fetch_sub(1, std::memory_order_acq_rel);
-                return rc_j;
-            });
+}
+
+// ---- round 6: the chains of `nb` announced scans as ONE set of launches (see QBatch in kernels.hip.h): blockIdx.y is the scan ----
+static QSideDev side_dev(const QSide &q) {
+    QSideDev d;
+    memset(&d, 0, sizeof(d));
+    d.scan_in = q.scan_in;
+    d.cent = q.cent.p; d.query = q.query.p; d.sq = q.sq.p;
+    d.bb = q.bb.p; d.qk_a = q.qk_a.p; d.qk_b = q.qk_b.p; d.qv_a = q.qv_a.p; d.qv_b = q.qv_b.p; d.qposL = q.qposL.p; d.qposR = q.qposR.p;
+    d.qtops = q.qtops.p; d.run_begin = q.run_begin.p; d.ukeys = q.ukeys.p; d.qkey = q.qkey.p; d.qhead = q.qhead.p; d.wtileL = q.wtileL.p;
+    d.wtileR = q.wtileR.p; d.hkey = q.hkey.p; d.hval = q.hval.p;
+    d.qb_tot = q.qb_tot.p; d.qb_hist = q.qb_hist.p; d.qoff = q.qoff.p; d.ccnt = q.ccnt.p; d.d_nvox = q.d_nvox.p;
+    d.cmin = q.cmin.p; d.cmax = q.cmax.p;
+    d.esq0 = q.esq0.p; d.esq1 = q.esq1.p; d.essmall = q.essmall.p; d.esqs = q.esqs.p;
+    d.wseg0 = q.wseg0.p; d.wseg1 = q.wseg1.p; d.wstate = q.wstate.p;
+    d.qgrid = q.qgrid.p; d.d_qctr = q.d_qctr.p;
+    d.Tl = to_xf(q.Tl);
+    d.n = q.ns;
+    d.hbits = q.hbits;
+    return d;
+}
+struct BatchJob {
+    erasor_hip_handle *h;
+    int sides[QBATCH_MAX];
+    int nb;
+    hipStream_t qstream;
+    QBatch qb;
+    bool to_worker;
+};
+static int batch_launches(const BatchJob &j) {
+    erasor_hip_handle *h = j.h;
+    const DP P = h->dp;
+    const uint32_t B = h->B;
+    const int bits = key_bits(B + 1);
+    const uint32_t nb = (uint32_t)j.nb;
+    hipStream_t qstream = j.qstream;
+    uint32_t nmax = 0;
+    for (int k = 0; k < j.nb; ++k) nmax = std::max(nmax, j.qb.s[k].n);
+    TlCtx keep_tl = g_tl;
+    g_tl.h = h;
+    g_tl.cur = qstream;
+    g_tl.qi = j.sides[0];
+    struct TlRestore {
+        TlCtx k;
+        ~TlRestore() { g_tl = k; }
+    } tl_restore{keep_tl};
+    const QBatch &qb = j.qb;
+#define LAUNCH_B(name, kern, gx, block, ...) LAUNCH(h, name, kern, dim3((gx), nb), block, qb, ##__VA_ARGS__)
+    LAUNCH_B("q_begin", k_query_begin_b, 1, 256, B + 1);
+    LAUNCH_B("q_bbox", k_bbox_b, bbox_grid(nmax), 256);
+    LAUNCH_B("q_keys", k_voxel_keys_es_b, std::max(1u, cdiv(nmax, 256)), 256, P.leaf_query);
+    for (int k = 0; k < j.nb; ++k) (void)hipEventRecord(h->q[j.sides[k]].ev_keys, qstream);  // (the VoxelGrid overflow flags are final)
+    const int wl = std::min(esort::lg2_floor(nmax / WIDE_MIN) + ESORT_WIDE_SLACK, 16);
+    for (int l = 0; l < wl; ++l) {
+        LAUNCH_B("q_esort_wide", k_esort_wide_mark_b, 256, 256, l & 1);
+        LAUNCH_B("q_esort_wide", k_esort_wide_swap_b, 256, 256, l & 1, l == wl - 1 ? 1 : 0);
+    }
+    LAUNCH_B("q_esort", k_esort_mid_b, 256, 1024);
+    LAUNCH_B("q_esort_final", k_esort_final_b, 128, 1024);
+    const uint32_t ntile = std::max(1u, cdiv(nmax, 1024));
+    LAUNCH_B("q_runs", k_run_count_b, ntile, 256);
+    LAUNCH_B("q_runs", k_run_emit_b, ntile, 256);
+    LAUNCH_B("q_centroids", k_centroids_b, cdiv((uint64_t)nmax * 8, 256), 256);
+    LAUNCH_B("q_nn", k_query_nn_b, cdiv((uint64_t)nmax * NN_SUB, 256), 256, P);
+    const uint32_t ntile_ub = std::max(1u, cdiv(nmax, QB_TILE));
+    LAUNCH_B("q_bucket", k_qb_hist_b, ntile_ub, 1024, B + 1);
+    LAUNCH_B("q_bucket", k_qb_scan_b, 1, 1024, B + 1);
+    LAUNCH_B("q_bucket", k_qb_scatter_b, ntile_ub, 1024, B + 1, bits);
+    LAUNCH_B("bin_stats", k_bin_stats_b, cdiv((uint64_t)B * 64, 256), 256, B);
+#undef LAUNCH_B
+    for (int k = 0; k < j.nb; ++k) (void)hipEventRecord(h->q[j.sides[k]].ev_done, qstream);
+    return ERASOR_OK;
+}
+
+// a job for the handle's worker thread (round 5: with the steps overlapped the caller's thread had become the bound), or run right here
+static int dispatch_chain(erasor_hip_handle *h, bool to_worker, const int *sides, int nsides, std::function<int()> job) {
+    if (!to_worker) return job();
+    auto *w = h->worker;
+    int sd[QBATCH_MAX];
+    for (int k = 0; k < nsides; ++k) {
+        sd[k] = sides[k];
+        w->busy[sd[k]].fetch_add(1, std::memory_order_acq_rel);
+    }
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        std::array<int, QBATCH_MAX> sda;
+        for (int k = 0; k < QBATCH_MAX; ++k) sda[k] = k < nsides ? sd[k] : 0;
+        w->jobs.emplace_back([job, w, sda, nsides]() -> int {
+            const int rc_j = job();
+            if (rc_j) w->err.store(rc_j);  // (before the sides are released: whoever waits for them sees the error)
+            for (int k = 0; k < nsides; ++k) w->busy[sda[k]].fetch_sub(1, std::memory_order_acq_rel);
+            return rc_j;
+        });
+    }
+    w->cv.notify_one();
+    return ERASOR_OK;
+}
+// the stream a chain (or a set of chains) goes to.  (The radix fallback for very fine R-POD grids and the pass-through chain's radix
+// sort share their scratch bank between the sides: one stream for all of them.  While the early stream is in use the chains keep to
+// two query streams: four busy compute queues are all that run side by side.)
+static hipStream_t next_chain_stream(erasor_hip_handle *h, bool shared_scratch) {
+    const unsigned nqs_now = (unsigned)(h->ov_mode ? std::min(h->nqs, 2) : h->nqs);
+    return shared_scratch ? h->qstream[0] : h->qstream[h->n_chain++ % nqs_now];
+}
+// what a chain's stream has to wait for before the side's buffers are written: the staged copy of a host scan, the side's previous chain
+static void chain_stream_waits(erasor_hip_handle *h, QSide &q, hipStream_t qstream) {
+    if (q.h2d_pending) {  // announced earlier (erasor_hip_prefetch_*): the copy runs on the copy stream
+        (void)hipStreamWaitEvent(qstream, q.ev_h2d, 0);
+        q.h2d_pending = false;
+    }
+    if (q.used) (void)hipStreamWaitEvent(qstream, q.ev_done, 0);  // (possibly a dropped chain, possibly on the other query stream)
+}
+
+// The chains that were set up and HELD BACK (QSide::held) go into a queue now: two or more as one set of launches, a single one as
+// the plain chain.  Called when the set is full, when a held chain comes within `batch_lead` steps of its own step, and by whoever
+// needs a held side's events (chain_wait).
+static int flush_held(erasor_hip_handle *h) {
+    int sides[NSIDE], n = 0;
+    for (int j = 0; j < h->npend; ++j)
+        if (h->q[h->pend[j]].held) sides[n++] = h->pend[j];
+    for (int k = 0; k < NSIDE; ++k) h->q[k].held = false;  // (a held side that is no longer pending was dropped: nothing to launch)
+    for (int i0 = 0; i0 < n;) {
+        const int nb = std::min(n - i0, std::max(1, std::min(h->batch_n, (int)QBATCH_MAX)));
+        hipStream_t qstream = next_chain_stream(h, false);
+        const bool to_worker = h->worker != nullptr;
+        if (nb == 1) {
+            QSide &q = h->q[sides[i0]];
+            chain_stream_waits(h, q, qstream);
+            ChainJob cj{h, sides[i0], qstream, q.ns, false, false, to_worker, {0}};
+            memcpy(cj.Tl, q.Tl, sizeof(cj.Tl));
+            const int rc = dispatch_chain(h, to_worker, &sides[i0], 1, [cj]() { return chain_launches(cj); });
+            if (rc) return rc;
+        } else {
+            BatchJob bj;
+            bj.h = h;
+            bj.nb = nb;
+            bj.qstream = qstream;
+            bj.to_worker = to_worker;
+            memset(&bj.qb, 0, sizeof(bj.qb));
+            for (int k = 0; k < nb; ++k) {
+                QSide &q = h->q[sides[i0 + k]];
+                chain_stream_waits(h, q, qstream);
+                bj.sides[k] = sides[i0 + k];
+                bj.qb.s[k] = side_dev(q);
+            }
+            const int rc = dispatch_chain(h, to_worker, bj.sides, nb, [bj]() { return batch_launches(bj); });
+            if (rc) return rc;
+            ++h->n_batches;
+            h->n_batched_chains += (unsigned)nb;
         }
-        w->cv.notify_one();
+        i0 += nb;
+    }
+    return ERASOR_OK;
+}
+
+// staged: 0 = the scan comes from the caller now; 1 = announced (h->ann): a host scan lies in the side's staging copy already;
+// 2 = the side's OWN announcement once more (its chain ran in the wrong VoxelGrid mode, step_collect): scan, ticket, hash and pose stay
+// may_hold: the chain may be held back for a set of launches shared with the next announcements (flush_announced decides)
+static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_src, uint32_t ns, bool src_is_device, const float T_l2b[16],
+                               bool prevox, int staged = 0, bool passthrough = false, RowFmt fmt = RowFmt(), bool may_hold = false) {
+    {
+        const int rc_w = chain_wait(h, side);  // (the side's previous chain: its events are waited for below)
+        if (rc_w) return rc_w;
+    }
+    SideGuard guard(h);
+    h->qi = side;
+    int rc = alloc_scan(h, std::max(ns, 1u));
+    if (rc) return rc;
+    const uint32_t B = h->B, nq = ns;
+    if (B + 1 <= QB_NB_MAX) {
+        if (ensure(h, Q(h).qb_hist, (size_t)(B + 1) * std::max(1u, cdiv(nq, QB_TILE)) + 8)) return ERASOR_E_NO_DEVICE;
     } else {
-        rc = launches();
+        const uint32_t nb_q = 256u * std::max(1u, cdiv(nq, RTILE));
+        if (ensure(h, h->hist, nb_q) || ensure(h, h->hist_l, nb_q) || ensure(h, h->hist_t, cdiv(nb_q, 1024) + 2)) return ERASOR_E_NO_DEVICE;
+    }
+    QSide &q = Q(h);
+    // the common chain (voxelising, counting-sort bucketing, nothing profiled launch by launch) may go to the worker thread and may share
+    // its launches with other scans' chains
+    const bool common = !passthrough && !prevox && B + 1 <= QB_NB_MAX && h->prof != 1 && !g_debug_sync;
+    const bool hold = may_hold && common && staged == 1 && h->batch_n >= 2 && ns >= WIDE_MIN && ns <= (1u << 20);
+    hipStream_t qstream = hold ? nullptr : next_chain_stream(h, !(B + 1 <= QB_NB_MAX && !passthrough));
+    // a device-resident scan is read in place (it must stay valid until the step that consumes it has returned);
+    // a host scan is copied now (blocking copy: this side has no work in flight)
+    if (ns && !src_is_device && !staged) {
+        // the side may still be executing a chain that was dropped (a prefetch that no step claimed): its kernels read
+        // q.scan, and a scan that changes between the bounding-box pass and the voxel keys sends them astray
+        if (q.used) HIPC(h, hipEventSynchronize(q.ev_done));
+        uint64_t fp_staged = 0;
+        rc = stage_host_scan(h, scan_src, ns, qstream, fmt, &fp_staged);  // (on the chain's own stream: ordered before its first kernel)
+        if (rc) return rc;
+        q.h2d_pending = false;
+        q.fp = fp_staged;
+    }
+    q.scan_in = src_is_device && ns ? (const float4 *)scan_src : (const float4 *)q.scan.p;
+    q.ns = ns;
+    if (q.Tl != T_l2b) memcpy(q.Tl, T_l2b, sizeof(q.Tl));
+    if (hold) {
+        q.held = true;  // (flush_held: stream, waits and launches)
+    } else {
+        chain_stream_waits(h, q, qstream);
+        const bool to_worker = h->worker && common;
+        ChainJob cj{h, side, qstream, ns, prevox, passthrough, to_worker, {0}};
+        memcpy(cj.Tl, T_l2b, sizeof(cj.Tl));
+        if (to_worker) rc = dispatch_chain(h, true, &side, 1, [cj]() { return chain_launches(cj); });
+        else rc = chain_launches(cj);
         if (rc) return rc;
     }
     q.used = true;
-    q.p2_pending = split;
     q.src = scan_src;
     q.src_n = ns;
-    q.ns = ns;
     q.src_dev = src_is_device;
     if (staged != 2) {
         q.pose_valid = false;  // (flush_announced adds the pose of an announced node)
@@ -1627,36 +1613,6 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
         q.ticket = staged ? h->ann.ticket : 0ull;
     }
     q.fmt = fmt;
-    if (q.Tl != T_l2b) memcpy(q.Tl, T_l2b, sizeof(q.Tl));
-    return ERASOR_OK;
-}
-
-// The second part of a split query chain (see QSide::ev_p1) on `stream`: label search (utils.cpp:96-110), lidar->body + R-POD key
-// (OMU.cpp:240; erasor.cpp:100-115), bucketing, per-bin statistics of the query; records the side's ev_done there.
-static int enqueue_chain_part2(erasor_hip_handle *h, int side, hipStream_t stream) {
-    QSide &q = h->q[side];
-    if (!q.p2_pending) return ERASOR_OK;
-    const int rc_w = chain_wait(h, side);  // (ev_p1 must have been recorded)
-    if (rc_w) return rc_w;
-    SideGuard guard(h);
-    h->qi = side;
-    h->cur = stream;
-    const DP &P = h->dp;
-    const uint32_t B = h->B, nq = q.ns;
-    const int bits = key_bits(B + 1);
-    const uint32_t *nq_dev = q.d_nvox.p;
-    (void)hipStreamWaitEvent(stream, q.ev_p1, 0);
-    LAUNCH(h, "q_nn", k_query_nn, cdiv((uint64_t)nq * NN_SUB, 256), 256, q.scan_in, (const uint32_t *)q.qv_b.p, (const uint32_t *)q.run_begin.p,
-           (const uint32_t *)q.ukeys.p, (const float4 *)q.cent.p, nq_dev, (const VoxGrid *)q.qgrid.p, to_xf(q.Tl), P, q.d_qctr.p, q.query.p, q.qkey.p,
-           (const uint32_t *)q.hkey.p, (const uint32_t *)q.hval.p, q.hbits);
-    const uint32_t ntile_ub = std::max(1u, cdiv(nq, QB_TILE));
-    LAUNCH(h, "q_bucket", k_qb_hist, ntile_ub, 1024, (const uint32_t *)q.qkey.p, nq, nq_dev, B + 1, q.qb_hist.p, q.qb_tot.p);
-    LAUNCH(h, "q_bucket", k_qb_scan, 1, 1024, (const uint32_t *)q.qb_tot.p, B + 1, q.qoff.p);
-    LAUNCH(h, "q_bucket", k_qb_scatter, ntile_ub, 1024, (const uint32_t *)q.qkey.p, (const float4 *)q.query.p, nq, nq_dev, B + 1, bits,
-           (const uint32_t *)q.qb_hist.p, (const uint32_t *)q.qoff.p, q.sq.p);
-    LAUNCH(h, "bin_stats", k_bin_stats, cdiv((uint64_t)B * 64, 256), 256, (const float4 *)q.sq.p, (const uint32_t *)q.qoff.p, B, q.ccnt.p, q.cmin.p, q.cmax.p);
-    (void)hipEventRecord(q.ev_done, stream);
-    q.p2_pending = false;
     return ERASOR_OK;
 }
 
@@ -1664,8 +1620,16 @@ static int enqueue_chain_part2(erasor_hip_handle *h, int side, hipStream_t strea
 static int flush_announced(erasor_hip_handle *h) {
     if (!h->ann.valid) return ERASOR_OK;
     h->ann.valid = false;
+    int in_front = 0, n_held = 0;
+    for (int j = 0; j < h->npend; ++j) (h->q[h->pend[j]].held ? n_held : in_front) += 1;
+    const bool may_hold = h->batch_n >= 2 && in_front >= h->batch_lead;
+    if (n_held && !may_hold) {  // (keeps the queues in announcement order)
+        const int rc_h = flush_held(h);
+        if (rc_h) return rc_h;
+        n_held = 0;
+    }
     const int rc = enqueue_query_chain(h, h->ann.side, h->ann.src, (uint32_t)h->ann.n, h->ann.is_device, h->ann.Tl, false, /*staged=*/1,
-                                       h->q_passthrough, h->ann.fmt);
+                                       h->q_passthrough, h->ann.fmt, may_hold);
     if (rc) return rc;
     h->q[h->ann.side].pose_valid = h->ann.pose_valid;
     h->q[h->ann.side].pose_x = h->ann.pose_x;
@@ -1673,6 +1637,13 @@ static int flush_announced(erasor_hip_handle *h) {
     h->q[h->ann.side].to_valid = h->ann.to_valid;
     memcpy(h->q[h->ann.side].To, h->ann.To, sizeof(h->ann.To));
     h->pend[h->npend++] = h->ann.side;
+    if (h->q[h->ann.side].held ? n_held + 1 >= h->batch_n : n_held > 0) return flush_held(h);
+    return ERASOR_OK;
+}
+// a held chain that has come within `batch_lead` steps of its own step goes off now, alone if it has to
+static int flush_held_if_due(erasor_hip_handle *h) {
+    for (int j = 0; j < h->npend && j < h->batch_lead; ++j)
+        if (h->q[h->pend[j]].held) return flush_held(h);
     return ERASOR_OK;
 }
 
@@ -1681,6 +1652,7 @@ static int flush_announced(erasor_hip_handle *h) {
 static void q_drain(erasor_hip_handle *h) {
     h->npend = 0;
     h->ann.valid = false;
+    for (int k = 0; k < NSIDE; ++k) h->q[k].held = false;  // (held back and never launched: nothing to wait for)
     (void)chain_wait(h, -1);
     if (h->ov.valid) {  // (the passes launched ahead for the node that is dropped here: they run out, nothing takes them)
         h->ov.valid = false;
@@ -1770,10 +1742,9 @@ static void launch_split_ahead(erasor_hip_handle *h, double nx, double ny, uint3
     ++h->n_spec_launched;
     // round 4: ... and the next step's chunk scan behind it: the stream goes on while the host is still collecting this step's results
     // and comes back with the next one (its turnaround, ~10 us, used to be idle time between the split and the scan)
-    static const bool no_early_scan = getenv("ERASOR_HIP_NO_AHEAD_SCAN") != nullptr;
     const bool mb_count = h->B + 1 <= QB_NB_MAX;
     const uint32_t scan_cap = (uint32_t)std::min<size_t>(std::min(h->pvl.cap, h->phl.cap) - 8, 16384);
-    if (!no_early_scan && nchunks_hint + 64u <= scan_cap && h->topv.cap >= 24 && h->toph.cap >= 24 && h->prof != 1) {
+    if (nchunks_hint + 64u <= scan_cap && h->topv.cap >= 24 && h->toph.cap >= 24 && h->prof != 1) {
         hipStream_t keep = h->cur;
         h->cur = h->stream;
         // (round 5: the next step's state, counters and tallies live in the OTHER set, see erasor_hip_handle::alt; it starts from what the
@@ -1786,7 +1757,7 @@ static void launch_split_ahead(erasor_hip_handle *h, double nx, double ny, uint3
         h->spec.scan_cap = scan_cap;
         h->spec.pvl = h->pvl.p;
         h->spec.phl = h->phl.p;
-    } else if (!no_early_scan && h->prof != 1) {
+    } else if (h->prof != 1) {
         // maps beyond k_chunk_scan_one's 16384 chunks (config 4: 38 k): the two-level scan ahead, its grid an upper bound
         const size_t room = std::min(h->pvl.cap, h->phl.cap);
         const uint32_t grid = (uint32_t)cdiv(nchunks_hint + 64u, 1024);
@@ -1829,6 +1800,15 @@ static void swap_sides(erasor_hip_handle *h) {
     std::swap(h->st1b, h->alt.st1b);
 }
 
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+}
+// ERASOR_HIP_OVERLAP unset: does overlapping consecutive steps pay on this handle's workload?  See the definition of OvAuto.
+static bool overlap_auto(erasor_hip_handle *h, uint32_t ns);
 static int step_collect(erasor_hip_handle *h, erasor_step_result *res);
 // First half of a step: everything is ENQUEUED (this scan's query chain unless it is in flight already, the map chain, Scan Ratio
 // Test .. write-back, k_step_end, the next step's VoI split and the next announced scan's query chain); nothing is waited for.
@@ -1927,9 +1907,6 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         h->qi = side;
         rc = chain_wait(h, side);  // (the chain's events are waited for below: they must have been recorded)
         if (rc) return rc;
-        // (a split chain whose second part the step in front did not launch -- it was not that step's next node after all: here and now)
-        rc = enqueue_chain_part2(h, side, h->stream);
-        if (rc) return rc;
     }
     MARK("query chain");
     h->Tl2b = to_xf(T_l2b);
@@ -1998,7 +1975,21 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         if (ensure(h, h->hist2, nb_m) || ensure(h, h->hist2_l, nb_m) || ensure(h, h->hist2_t, cdiv(nb_m, 1024) + 2)) return ERASOR_E_NO_DEVICE;
     }
     const uint32_t *sm_keys = nullptr, *sm_perm = nullptr;
-    bool st1_ahead = false;
+    // v3: the Scan Ratio Test's first pass rides along with the map's bin statistics (k_bin_stats_srt)
+    const bool st1_ahead = P.version == 3 && B <= 1024 * SRT_KPT;
+    // up to 4096 bins the output layout has no launch of its own: k_srt4 prepares what does not depend on R-GPF, every workgroup of
+    // the write-back finishes it (beyond that, and under per-launch profiling: k_layout4 / k_layout)
+    const bool fold = B <= 1024 * SRT_KPT && n_voi > 0;
+    // round 4: v3's second pass is the LAST WORKGROUP of the per-bin launch (k_revert_bins_srt): the revert decision is local to a bin, so
+    // the per-bin workgroups find their bins themselves and nothing on the chain waits for k_srt4
+    const bool srt_in_revert = st1_ahead && h->prof != 1;
+    // round 5: the RESERVED layout (srt4_body): the write-back of everything but the reverted bins does not wait for the per-bin launch.
+    // ERASOR_HIP_OVERLAP: 1 = always, 0 = never, unset = the handle decides (overlap_pays).
+    static const int overlap_env = getenv("ERASOR_HIP_OVERLAP") && getenv("ERASOR_HIP_OVERLAP")[0] ? atoi(getenv("ERASOR_HIP_OVERLAP")) : -1;
+    const bool overlap_pays = overlap_env >= 0 ? overlap_env != 0 : overlap_auto(h, ns);
+    // (decided BEFORE the map chain: a step that does not write the reserved layout must not take passes launched ahead on the assumption
+    // that it would -- their VoI-order source indices count reserved slots, which only the reserved write-back converts)
+    const bool reserved = srt_in_revert && fold && mb_count && !flags && overlap_pays;
     bool use_ov = false;   // this step's split .. bucket table were launched ahead of it and are taken (round 5, OVERLAPPED steps)
     bool stats_ahead = false;  // ... its scatter and bin statistics too
     uint32_t nbk = B + 1;  // buckets of the map's counting sort: the bins + the complement (+ the dead bucket of an overlapped step)
@@ -2014,7 +2005,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         {   // round 5: split, chunk scan, gather and the bucket table may all be there already -- launched beside the previous step's per-bin
             // launch (h->ov) -- if this step is exactly the step that was assumed then: node, pose, transform, store, buffers, room
             const bool ov_launched = h->ov.valid;
-            use_ov = ov_launched && !flags && mb_count && h->ov.seq == h->step_seq && h->ov.epoch == h->store_epoch && h->ov.curF == h->curF &&
+            use_ov = ov_launched && reserved && !flags && mb_count && h->ov.seq == h->step_seq && h->ov.epoch == h->store_epoch && h->ov.curF == h->curF &&
                      h->ov.qside == h->qi && h->ov.x == xc && h->ov.y == yc && memcmp(h->ov.To, T_o2b, sizeof(h->ov.To)) == 0 &&
                      nchunks <= h->ov.cap_chunks && n_voi_room + 64 <= h->ov.cap_voi && h->ov.vmask == (const void *)h->vmask.p &&
                      h->ov.hmask == (const void *)h->hmask.p && h->ov.lmask == (const void *)h->lmask.p && h->ov.cinfo == (const void *)h->cinfo.p &&
@@ -2028,7 +2019,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                         (int)(h->ov.lmask == (const void *)h->lmask.p), (int)(h->ov.cinfo == (const void *)h->cinfo.p), (int)(h->ov.pvl == (const void *)h->pvl.p),
                         (int)(h->ov.phl == (const void *)h->phl.p), (int)(h->ov.voi_ego == (const void *)h->voi_ego.p), (int)(h->ov.mb_hist == (const void *)h->mb_hist.p));
             h->ov.valid = false;
-            stats_ahead = use_ov && h->ov.stats_done && P.version == 3 && B <= 1024 * SRT_KPT && !getenv("ERASOR_HIP_NO_SRT_AHEAD");
+            stats_ahead = use_ov && h->ov.stats_done && st1_ahead;
             if (ov_launched && !use_ov) (void)hipStreamWaitEvent(h->stream, h->ev_early, 0);  // (those passes write what this step's own will)
             if (use_ov) {
                 ++h->n_ov_used;
@@ -2053,10 +2044,6 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                 launch_voi_split(h, (const float4 *)h->F[h->curF].p, h->nF, nFchunks, h->o_begin, o_chunk0, nOchunks, nchunks, xc, yc, voi_r2,
                                  (const DevState *)nullptr, 0u);
             const uint32_t ntop = std::max(1u, cdiv(nchunks, 1024));
-            {
-                static const int mpad = getenv("ERASOR_HIP_MPAD_US") ? atoi(getenv("ERASOR_HIP_MPAD_US")) : 0;
-                if (mpad > 0) LAUNCH(h, "m_pad", k_pad, 1, 64, (unsigned long long)mpad * 100ull);
-            }
             if (scan_done) {
                 // (launched ahead behind the split, see launch_split_ahead)
             } else if (nchunks <= 16384) {
@@ -2112,7 +2099,6 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         }
         // v3: the Scan Ratio Test's first pass rides along, bin by bin (the query's statistics are needed: the join with its chain
         // comes before this launch instead of after it; with nodes announced ahead the chain finished long ago)
-        st1_ahead = P.version == 3 && B <= 1024 * SRT_KPT && !getenv("ERASOR_HIP_NO_SRT_AHEAD");
         if (use_ov && stats_ahead) {
             // (done)
         } else if (st1_ahead) {
@@ -2141,28 +2127,6 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     HIPC(h, hipStreamWaitEvent(h->stream, Q(h).ev_done, 0));  // join: the query's bins are ready
 
     // ---- Scan Ratio Test, R-GPF, per-bin voxelisation (erasor.cpp:332-571) ----
-    // up to 4096 bins the output layout has no launch of its own: k_srt4 prepares what does not depend on R-GPF, every workgroup of
-    // the write-back finishes it (ERASOR_HIP_NO_FOLD=1: the separate k_layout4 launch, for A/B)
-    static const bool no_fold = getenv("ERASOR_HIP_NO_FOLD") != nullptr;
-    const bool fold = B <= 1024 * SRT_KPT && !no_fold && n_voi > 0;
-    // round 4: v3's second pass is the LAST WORKGROUP of the per-bin launch (k_revert_bins_srt): the revert decision is local to a bin, so
-    // the per-bin workgroups find their bins themselves and nothing on the chain waits for k_srt4 (ERASOR_HIP_NO_SRT_FOLD=1: as before)
-    static const bool no_fuse = getenv("ERASOR_HIP_NO_FUSE") != nullptr;
-    static const bool no_srt_fold = getenv("ERASOR_HIP_NO_SRT_FOLD") != nullptr;
-    const bool srt_in_revert = st1_ahead && P.version == 3 && !no_fuse && !no_srt_fold && h->prof != 1;
-    // round 5: the RESERVED layout (srt4_body): the write-back of everything but the reverted bins does not wait for the per-bin launch
-    static const bool no_reserved = getenv("ERASOR_HIP_NO_RESERVED") != nullptr;
-    static const bool leave_all = getenv("ERASOR_HIP_LEAVE_ALL") != nullptr;  // (test switch: every reverted bin reserves places in the outskirts' order)
-    // ERASOR_HIP_OVERLAP: 1 = always, 0 = never, unset = where it pays.  It pays where the per-bin launch is long: the passes beside it need
-    // a stream of their own, and with four busy compute queues being all the hardware runs side by side (a fifth slows every kernel of every
-    // queue 3-8 x) that stream costs one of the three query streams.  Measured (MEASUREMENTS, round 5): 9.8 M-point map, 370 map points per
-    // bin: 0.191 ms per scan without, 0.206 with; 39 M-point dense map, 1500 per bin: 0.37 without, 0.32 with.
-    static const int overlap_env = getenv("ERASOR_HIP_OVERLAP") ? atoi(getenv("ERASOR_HIP_OVERLAP")) : -1;
-    //  config/seq_05.yaml verbatim (530 per bin): 0.204 / 0.193; Ouster-128 (233 k-point scans, 40 per bin: its query chains need the third
-    //  stream): 0.23 / 0.34.  Hence: dense bins AND scans of ordinary size.
-    static const uint32_t overlap_ppb = getenv("ERASOR_HIP_OVERLAP_PPB") ? (uint32_t)atoi(getenv("ERASOR_HIP_OVERLAP_PPB")) : 500u;
-    const bool overlap_pays = overlap_env >= 0 ? overlap_env != 0 : ((uint64_t)h->last_n_voi >= (uint64_t)overlap_ppb * B && ns <= 160000u);
-    const bool reserved = srt_in_revert && fold && mb_count && !no_reserved && !flags && overlap_pays;
     h->ov_mode = reserved;
     bool have_pose = false;  // the NEXT node's pose, if it was announced with it (erasor_hip_prefetch_node)
     double nx = 0, ny = 0;
@@ -2180,10 +2144,9 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     LateEnt *late_out = h->late[h->late_idx ^ 1].p;
     // round 5, OVERLAPPED steps: with the next node announced together with BOTH its transforms (erasor_hip_prefetch_node +
     // erasor_hip_announce_origin2body) its split, chunk scan and gather run beside this step's per-bin launch, on the early stream
-    static const bool no_overlap = getenv("ERASOR_HIP_NO_OVERLAP") != nullptr;
     bool ov_next = false;
     int nxt_side = -1;
-    if (reserved && !no_overlap && have_pose && h->prof != 1 && !submap_would_move(h, nx, ny)) {
+    if (reserved && have_pose && h->prof != 1 && !submap_would_move(h, nx, ny)) {
         if (h->npend == 0 && h->ann.valid && h->ann.to_valid) {
             // (only just announced: its chain goes into its queue NOW -- the gather ahead waits for the chain's error flag)
             const int keep_side = h->qi;
@@ -2206,6 +2169,11 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     if (reserved) {
         // a reverted bin whose points may lie outside the NEXT VoI circle reserves places in the outskirts' order as well: without the
         // next pose, every bin does
+#ifdef ERASOR_HIP_TEST_HOOKS
+        static const bool leave_all = getenv("ERASOR_HIP_LEAVE_ALL") != nullptr;  // (test hook: every reverted bin reserves places in the outskirts' order)
+#else
+        constexpr bool leave_all = false;
+#endif
         const double leave_lim = (have_pose && !leave_all) ? sqrt(P.voi_r2) - hypot(nx - xc, ny - yc) - 0.05 : -1.0;
         // (enqueued BEHIND the per-bin launch, which the main stream is waiting for: see enqueue_early() below)
         enqueue_early = [&, leave_lim]() {
@@ -2368,15 +2336,6 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins_srt, std::min<uint32_t>(rev_grid, B) + (reserved ? 0u : 1u), 1024, P, sa, ra);
         MARK("per-bin launch");
         if (reserved) enqueue_early();
-        if (ov_next) {
-            // the second parts of the chains announced behind this step (QSide::ev_p1), behind the early passes, where that stream idles:
-            // the next node's if it is still due, and the node's behind it -- ONE STEP EARLY, so that it is through long before that
-            // node's bin statistics (launched ahead themselves) ask for it
-            for (int j = 0; j < h->npend && j < 2; ++j) {
-                const int rc_p2 = enqueue_chain_part2(h, h->pend[j], h->bstream);
-                if (rc_p2) return rc_p2;
-            }
-        }
         if (reserved) (void)hipStreamWaitEvent(h->stream, h->ev_srt4, 0);  // (the reverted list, the reserved offsets, the late table)
         MARK("  ev_srt4 wait");
         if (reserved)
@@ -2389,7 +2348,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                    // (an overlapped step read a region with reserved slots as if they were entries: its source indices count them)
                    use_ov ? (const LateEnt *)h->late[h->late_idx].p : (const LateEnt *)nullptr,
                    use_ov ? (const uint32_t *)h->late_holes[h->late_idx].p : (const uint32_t *)nullptr, use_ov ? h->n_late_F : 0u);
-    } else if (P.version == 3 && !no_fuse && h->prof != 1) {
+    } else if (P.version == 3 && h->prof != 1) {
         LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins, std::min<uint32_t>(rev_grid, B), 1024, P, (const uint32_t *)h->rev_list.p, (const DevState *)ds,
                (const uint32_t *)h->vox_off.p, ra);
     } else {
@@ -2438,10 +2397,8 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         // reads the store this step has just written and the extents the step's end commits; a step that finds anything else than
         // what was assumed here (pose, store, buffers) simply runs its own pass.
         // Round 4: that launch also ENDS this step (its last workgroup does k_step_end's work, ERASOR_HIP_NO_END_FOLD=1: a launch of its own)
-        static const bool no_spec = getenv("ERASOR_HIP_NO_AHEAD_SPLIT") != nullptr;
-        static const bool no_end_fold = getenv("ERASOR_HIP_NO_END_FOLD") != nullptr;
         // (large-scale mode, round 4: ahead as well, unless the next node's pose moves the submap)
-        const bool spec = have_pose && !no_spec && !flags && !submap_would_move(h, nx, ny);
+        const bool spec = have_pose && !flags && !submap_would_move(h, nx, ny);
         StepEnd se;
         se.st = ds;
         se.ctr = dc;
@@ -2450,7 +2407,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         se.qctr = (const Counters *)Q(h).d_qctr.p;
         se.q_nvox = (const uint32_t *)Q(h).d_nvox.p;
         se.seq = step_seq;
-        const bool end_in_split = spec && !no_end_fold && h->prof != 1 && !ov_next;
+        const bool end_in_split = spec && h->prof != 1 && !ov_next;
         h->fly.nchunks = nchunks;
         h->fly.spec_launched = ov_next;
         if (ov_next) {
@@ -2472,9 +2429,8 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                    h->alt.moff.p);
             // ... and the stable scatter, the bins' statistics and the Scan Ratio Test's first pass (into the OTHER set of arrays: a getter may
             // still ask for this step's): what is left for the next step's call is its per-bin launch -- the host's turnaround is off the chain
-            static const bool no_ahead_scatter = getenv("ERASOR_HIP_NO_AHEAD_SCATTER") != nullptr;
             h->ov.stats_done = false;
-            if (!no_ahead_scatter && B + 2 <= MBW_NB_MAX) {
+            if (B + 2 <= MBW_NB_MAX) {
                 const int bits2 = key_bits(B + 2);
                 if (B + 2 <= MBW_NB_SMALL)
                     LAUNCH(h, "voi_bucket", k_mb_scatter_w<MBW_NB_SMALL>, ntile_ub, 1024, (const uint32_t *)h->alt.voi_key.p, (const float4 *)h->alt.voi_ego.p,
@@ -2500,7 +2456,8 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     MARK("late gather + table ahead / end");
     {   // the NEXT scan's query chain goes into its queue now, behind this step's own launches; it runs while we wait
         const int keep_side = h->qi;
-        const int rc_next = flush_announced(h);
+        int rc_next = flush_announced(h);
+        if (!rc_next) rc_next = flush_held_if_due(h);  // (a chain held back for a shared set of launches whose own step is near)
         h->qi = keep_side;
         if (rc_next) {
             (void)hipStreamSynchronize(h->stream);
@@ -2530,6 +2487,9 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     return ERASOR_OK;
 }
 
+// (until measured otherwise: where the per-bin launch is long -- dense bins -- and the scans of ordinary size; MEASUREMENTS)
+static bool overlap_auto(erasor_hip_handle *h, uint32_t ns) { return (uint64_t)h->last_n_voi >= 500ull * h->B && ns <= 160000u; }
+
 // Second half: wait for the step's results (k_step_end's last store into the pinned block is the step's number), commit the host
 // mirror of the map store, report.  A VoxelGrid pass-through flip re-runs the step here, synchronously.
 static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
@@ -2549,13 +2509,12 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
     const auto t_host1 = std::chrono::steady_clock::now();
     {   // k_step_end's last store into the pinned block is the step's number: poll it (a blocking stream wait wakes up tens
         // of microseconds late, a visible share of a 0.35 ms step), then fall back to the stream wait
-        static const bool no_spin = getenv("ERASOR_HIP_NO_SPIN") != nullptr;
         volatile unsigned long long *seq = &h->pin->seq;
-        if (!no_spin && !g_debug_sync) {
+        if (!g_debug_sync) {
             const auto t_spin = std::chrono::steady_clock::now();
             unsigned spins = 0;
             while (*seq != step_seq) {
-                __builtin_ia32_pause();
+                cpu_relax();
                 if ((++spins & 0x3FFu) == 0 && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(20)) break;
             }
         }
@@ -2806,13 +2765,13 @@ static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n
     if (h->fly.active) {
         // the step in flight has enqueued everything of its own already: the announced chain starts NOW (nothing to go first), and if
         // this is the node right behind that step and its pose is known, its VoI split goes behind the step as well
-        static const bool no_spec = getenv("ERASOR_HIP_NO_AHEAD_SPLIT") != nullptr;
         const bool next_in_line = h->npend == 0;
         const bool pose = h->ann.pose_valid;
         const double nx = h->ann.pose_x, ny = h->ann.pose_y;
         rc = flush_announced(h);
+        if (!rc) rc = flush_held_if_due(h);
         if (rc) return rc;
-        if (next_in_line && pose && !no_spec && !h->fly.flags && !h->fly.spec_launched && !h->ov.valid && !submap_would_move(h, nx, ny)) {
+        if (next_in_line && pose && !h->fly.flags && !h->fly.spec_launched && !h->ov.valid && !submap_would_move(h, nx, ny)) {
             hipStream_t keep = h->cur;
             h->cur = h->stream;
             launch_split_ahead(h, nx, ny, h->fly.nchunks, nullptr);
@@ -3571,6 +3530,7 @@ int erasor_hip_count_static_dynamic(erasor_hip_handle *h, uint64_t *n_static, ui
 
 int erasor_hip_profiling(erasor_hip_handle *h, int enable) {
     if (!h) return ERASOR_E_INVALID;
+    (void)chain_wait(h, -1);  // (a queued worker job reads h->prof and the event pool: ADVICE r05)
     h->prof = enable;
     return ERASOR_OK;
 }
@@ -3589,6 +3549,7 @@ int erasor_hip_chain_timing(erasor_hip_handle *h, double *main_chain_us, double 
 }
 int erasor_hip_profile_reset(erasor_hip_handle *h) {
     if (!h) return ERASOR_E_INVALID;
+    (void)chain_wait(h, -1);
     (void)hipStreamSynchronize(h->stream);
     for (int k = 0; k < h->nqs; ++k) (void)hipStreamSynchronize(h->qstream[k]);
     prof_collect(h, true);
@@ -3630,6 +3591,20 @@ int erasor_hip_overlap_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t
     if (!h || !launched || !used) return ERASOR_E_INVALID;
     *launched = h->n_ov_launched;
     *used = h->n_ov_used;
+    return ERASOR_OK;
+}
+int erasor_hip_chain_batch(erasor_hip_handle *h, int n_scans, int lead) {
+    if (!h || n_scans < 1 || n_scans > QBATCH_MAX || lead < 1 || lead > MAX_AHEAD - 1) return ERASOR_E_INVALID;
+    NOFLY(h);
+    const int rc = chain_wait(h, -1);  // (chains held back under the old setting go off first)
+    h->batch_n = n_scans;
+    h->batch_lead = lead;
+    return rc;
+}
+int erasor_hip_chain_batch_counts(erasor_hip_handle *h, uint64_t *sets, uint64_t *chains) {
+    if (!h) return ERASOR_E_INVALID;
+    if (sets) *sets = h->n_batches;
+    if (chains) *chains = h->n_batched_chains;
     return ERASOR_OK;
 }
 int erasor_hip_ahead_split_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t *used) {

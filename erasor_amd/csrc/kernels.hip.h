@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(256) void k_gather(const float4 *__restrict__ src, 
 static constexpr uint32_t QB_TILE = 1024;
 static constexpr uint32_t QB_NB_MAX = 12288;  // buckets (B + 1) the LDS table holds
 
-__global__ __launch_bounds__(1024) void k_qb_hist(const uint32_t *__restrict__ keys, uint32_t n_host, const uint32_t *n_dev, uint32_t nb,
+__device__ __forceinline__ void qb_hist_body(const uint32_t *__restrict__ keys, uint32_t n_host, const uint32_t *n_dev, uint32_t nb,
                                                    uint32_t *__restrict__ hist /* [tile][nb] */, uint32_t *__restrict__ tot /* [nb] */) {
     __shared__ uint32_t cnt[QB_NB_MAX];
     const uint32_t n = n_dev ? *n_dev : n_host;
@@ -1305,9 +1305,11 @@ __global__ __launch_bounds__(1024) void k_qb_hist(const uint32_t *__restrict__ k
         if (c) atomicAdd(&tot[b], c);  // bucket totals (integer: order-independent); zeroed by k_query_begin / k_chunk_scan_top
     }
 }
+__global__ __launch_bounds__(1024) void k_qb_hist(const uint32_t *__restrict__ keys, uint32_t n_host, const uint32_t *n_dev, uint32_t nb,
+                                                   uint32_t *__restrict__ hist /* [tile][nb] */, uint32_t *__restrict__ tot /* [nb] */) { qb_hist_body(keys, n_host, n_dev, nb, hist, tot); }
 
 // single workgroup, one thread per bucket: exclusive scan of the bucket totals -> off[b]; off[nb] = n
-__global__ __launch_bounds__(1024) void k_qb_scan(const uint32_t *__restrict__ tot, uint32_t nb, uint32_t *__restrict__ off) {
+__device__ __forceinline__ void qb_scan_body(const uint32_t *__restrict__ tot, uint32_t nb, uint32_t *__restrict__ off) {
     __shared__ uint32_t sm[40];
     constexpr int ROUNDS = QB_NB_MAX / 1024;
     uint32_t s[ROUNDS];
@@ -1328,8 +1330,9 @@ __global__ __launch_bounds__(1024) void k_qb_scan(const uint32_t *__restrict__ t
     }
     if (threadIdx.x == 0) off[nb] = carry;
 }
+__global__ __launch_bounds__(1024) void k_qb_scan(const uint32_t *__restrict__ tot, uint32_t nb, uint32_t *__restrict__ off) { qb_scan_body(tot, nb, off); }
 
-__global__ __launch_bounds__(1024) void k_qb_scatter(const uint32_t *__restrict__ keys, const float4 *__restrict__ src, uint32_t n_host,
+__device__ __forceinline__ void qb_scatter_body(const uint32_t *__restrict__ keys, const float4 *__restrict__ src, uint32_t n_host,
                                                       const uint32_t *n_dev, uint32_t nb, int bits, const uint32_t *__restrict__ hist,
                                                       const uint32_t *__restrict__ off, float4 *__restrict__ dst) {
     __shared__ uint32_t cnt[QB_NB_MAX];
@@ -1375,6 +1378,9 @@ __global__ __launch_bounds__(1024) void k_qb_scatter(const uint32_t *__restrict_
     }
     if (valid) dst[pre + r] = src[i];
 }
+__global__ __launch_bounds__(1024) void k_qb_scatter(const uint32_t *__restrict__ keys, const float4 *__restrict__ src, uint32_t n_host,
+                                                      const uint32_t *n_dev, uint32_t nb, int bits, const uint32_t *__restrict__ hist,
+                                                      const uint32_t *__restrict__ off, float4 *__restrict__ dst) { qb_scatter_body(keys, src, n_host, n_dev, nb, bits, hist, off, dst); }
 
 __device__ __forceinline__ uint32_t fkey_ord(float f) {  // total-order key for float min/max atomics
     const uint32_t b = __float_as_uint(f);
@@ -1652,7 +1658,7 @@ __global__ __launch_bounds__(256) void k_bin_offsets(const uint32_t *__restrict_
 }
 
 // per-bin pseudo-occupancy descriptor (erasor.cpp:87-98): count, min z, max z.  One wavefront per bin.
-__global__ __launch_bounds__(256) void k_bin_stats(const float4 *__restrict__ spts, const uint32_t *__restrict__ off, uint32_t B,
+__device__ __forceinline__ void bin_stats_body(const float4 *__restrict__ spts, const uint32_t *__restrict__ off, uint32_t B,
                                                     uint32_t *__restrict__ cnt, float *__restrict__ minz, float *__restrict__ maxz) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1686,13 +1692,15 @@ __global__ __launch_bounds__(256) void k_bin_stats(const float4 *__restrict__ sp
         maxz[b] = mx;
     }
 }
+__global__ __launch_bounds__(256) void k_bin_stats(const float4 *__restrict__ spts, const uint32_t *__restrict__ off, uint32_t B,
+                                                    uint32_t *__restrict__ cnt, float *__restrict__ minz, float *__restrict__ maxz) { bin_stats_body(spts, off, B, cnt, minz, maxz); }
 
 // ================================================================================================
 // query-scan voxelisation: PCL 1.8 VoxelGrid + label-preserving 1-NN (utils.cpp:80-114; OMU.cpp:238)
 // ================================================================================================
 
 // getMinMax3D (dense): plain min/max; -0.0/+0.0 order is irrelevant downstream (only products/floors of it)
-__global__ __launch_bounds__(256) void k_bbox(const float4 *__restrict__ pts, uint32_t n, uint32_t *bb) {
+__device__ __forceinline__ void bbox_body(const float4 *__restrict__ pts, uint32_t n, uint32_t *bb) {
     __shared__ uint32_t sm[6];
     if (threadIdx.x < 3) sm[threadIdx.x] = 0xFFFFFFFFu;
     if (threadIdx.x >= 3 && threadIdx.x < 6) sm[threadIdx.x] = 0u;
@@ -1720,6 +1728,7 @@ __global__ __launch_bounds__(256) void k_bbox(const float4 *__restrict__ pts, ui
     if (threadIdx.x < 3) atomicMin(&bb[threadIdx.x], sm[threadIdx.x]);
     if (threadIdx.x >= 3 && threadIdx.x < 6) atomicMax(&bb[threadIdx.x], sm[threadIdx.x]);
 }
+__global__ __launch_bounds__(256) void k_bbox(const float4 *__restrict__ pts, uint32_t n, uint32_t *bb) { bbox_body(pts, n, bb); }
 
 struct VoxGrid {  // PCL VoxelGrid geometry of one cloud
     int32_t min_b[3], div_b[3];
@@ -1975,14 +1984,17 @@ __global__ void k_esort_init(uint32_t *K, uint32_t *V, esort::Seg *q0, esort::Se
     esort_init(q0, smallq, qs, w0, ws, n);
 }
 // the scan's voxel keys AND the opening of the sort's queues (thread 0 of workgroup 0: the queues do not depend on the keys)
-__global__ __launch_bounds__(256) void k_voxel_keys_es(const float4 *__restrict__ pts, uint32_t n, const uint32_t *__restrict__ bb,
+__device__ __forceinline__ void voxel_keys_es_body(const float4 *__restrict__ pts, uint32_t n, const uint32_t *__restrict__ bb,
                                                         float leaf, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                         VoxGrid *gout, Counters *ctr, uint32_t *__restrict__ hkey, uint32_t hsize, EsInit es) {
     if (blockIdx.x == 0 && threadIdx.x == 0) esort_init(es.q0, es.smallq, es.qs, es.w0, es.ws, n);
     voxel_keys_body(pts, n, bb, leaf, keys, vals, gout, ctr, hkey, hsize);
 }
+__global__ __launch_bounds__(256) void k_voxel_keys_es(const float4 *__restrict__ pts, uint32_t n, const uint32_t *__restrict__ bb,
+                                                        float leaf, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                        VoxGrid *gout, Counters *ctr, uint32_t *__restrict__ hkey, uint32_t hsize, EsInit es) { voxel_keys_es_body(pts, n, bb, leaf, keys, vals, gout, ctr, hkey, hsize, es); }
 
-__global__ __launch_bounds__(256) void k_esort_wide_mark(const uint32_t *__restrict__ K, const uint32_t *__restrict__ V, uint32_t *__restrict__ posL,
+__device__ __forceinline__ void esort_wide_mark_body(const uint32_t *__restrict__ K, const uint32_t *__restrict__ V, uint32_t *__restrict__ posL,
                                                           uint32_t *__restrict__ posR, WideSeg *__restrict__ wseg, WideState *ws, int cur,
                                                           uint32_t *__restrict__ tileL, uint32_t *__restrict__ tileR) {
     __shared__ uint32_t sm[40];
@@ -2058,6 +2070,9 @@ __global__ __launch_bounds__(256) void k_esort_wide_mark(const uint32_t *__restr
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(256) void k_esort_wide_mark(const uint32_t *__restrict__ K, const uint32_t *__restrict__ V, uint32_t *__restrict__ posL,
+                                                          uint32_t *__restrict__ posR, WideSeg *__restrict__ wseg, WideState *ws, int cur,
+                                                          uint32_t *__restrict__ tileL, uint32_t *__restrict__ tileR) { esort_wide_mark_body(K, V, posL, posR, wseg, ws, cur, tileL, tileR); }
 
 // asc-th entry of a two-level stop list (tile prefix `pre` in LDS, tile-local lists in `list`)
 __device__ __forceinline__ uint32_t wide_lookup(const uint32_t *pre, uint32_t ntiles, const uint32_t *list, uint32_t base, uint32_t asc) {
@@ -2071,7 +2086,7 @@ __device__ __forceinline__ uint32_t wide_lookup(const uint32_t *pre, uint32_t nt
 
 // The level's swaps -- the median move made physical on the way -- and, by the workgroup that owns a segment's first share, the
 // routing of its two children: next wide list (slots and tile ranges by atomics on the level state), level queue, finisher queue.
-__global__ __launch_bounds__(256) void k_esort_wide_swap(uint32_t *K, uint32_t *V, const uint32_t *__restrict__ posL,
+__device__ __forceinline__ void esort_wide_swap_body(uint32_t *K, uint32_t *V, const uint32_t *__restrict__ posL,
                                                           const uint32_t *__restrict__ posR, WideSeg *wseg, WideSeg *wnext, WideState *ws, int cur,
                                                           const uint32_t *__restrict__ tileL, const uint32_t *__restrict__ tileR, esort::Seg *q0,
                                                           esort::Seg *smallq, EsQueues *qs, uint32_t qcap, int last_level, Counters *ctr) {
@@ -2211,6 +2226,10 @@ __global__ __launch_bounds__(256) void k_esort_wide_swap(uint32_t *K, uint32_t *
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(256) void k_esort_wide_swap(uint32_t *K, uint32_t *V, const uint32_t *__restrict__ posL,
+                                                          const uint32_t *__restrict__ posR, WideSeg *wseg, WideSeg *wnext, WideState *ws, int cur,
+                                                          const uint32_t *__restrict__ tileL, const uint32_t *__restrict__ tileR, esort::Seg *q0,
+                                                          esort::Seg *smallq, EsQueues *qs, uint32_t qcap, int last_level, Counters *ctr) { esort_wide_swap_body(K, V, posL, posR, wseg, wnext, ws, cur, tileL, tileR, q0, smallq, qs, qcap, last_level, ctr); }
 
 // one level: each workgroup takes big segments of queue[cur] and performs one partition
 __global__ __launch_bounds__(1024) void k_esort_level(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, esort::Seg *q0,
@@ -2257,7 +2276,7 @@ __global__ __launch_bounds__(1024) void k_esort_level(uint32_t *K, uint32_t *V, 
 // workgroup, depth-first, all of its block-wide partitions in one launch (in LDS when the segment fits: a partition costs
 // a few microseconds there, against ~10 us per partition-and-launch through k_esort_level).  Pieces go to the small queue.
 static constexpr uint32_t ES_MID_LMAX = 8192;
-__global__ __launch_bounds__(1024) void k_esort_mid(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, const esort::Seg *bigq,
+__device__ __forceinline__ void esort_mid_body(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, const esort::Seg *bigq,
                                                      esort::Seg *smallq, EsQueues *qs, int bigcur, uint32_t qcap, Counters *ctr) {
     __shared__ uint32_t sK[ES_MID_LMAX], sV[ES_MID_LMAX], sL[ES_MID_LMAX], sR[ES_MID_LMAX];
     __shared__ uint32_t sm[40];
@@ -2319,10 +2338,12 @@ __global__ __launch_bounds__(1024) void k_esort_mid(uint32_t *K, uint32_t *V, ui
             }
     }
 }
+__global__ __launch_bounds__(1024) void k_esort_mid(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, const esort::Seg *bigq,
+                                                     esort::Seg *smallq, EsQueues *qs, int bigcur, uint32_t qcap, Counters *ctr) { esort_mid_body(K, V, posL, posR, bigq, smallq, qs, bigcur, qcap, ctr); }
 
 // final: every remaining segment (any size) is sorted to completion by one workgroup.
 // Segments <= ES_LMAX run in LDS; larger ones (only if the level budget ran out) run in place in global memory.
-__global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, uint32_t *head,
+__device__ __forceinline__ void esort_final_body(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, uint32_t *head,
                                                       uint32_t *K2, uint32_t *V2, const esort::Seg *smallq, const esort::Seg *bigq,
                                                       EsQueues *qs, int bigcur, Counters *ctr, unsigned long long *dbg) {  // bigcur: queue index (0..2) still holding big segments
     __shared__ uint32_t pool[8 * ESYNC_MAX];  // lds_esort_sync_kv's scratch (pairs | left stops | right stops | counts | cuts)
@@ -2369,6 +2390,9 @@ __global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, 
     }
     if (dbg && threadIdx.x == 0) atomicMax(&dbg[27], wall_clock64());  // last workgroup (working or not) end
 }
+__global__ __launch_bounds__(1024) void k_esort_final(uint32_t *K, uint32_t *V, uint32_t *posL, uint32_t *posR, uint32_t *head,
+                                                      uint32_t *K2, uint32_t *V2, const esort::Seg *smallq, const esort::Seg *bigq,
+                                                      EsQueues *qs, int bigcur, Counters *ctr, unsigned long long *dbg) { esort_final_body(K, V, posL, posR, head, K2, V2, smallq, bigq, qs, bigcur, ctr, dbg); }
 
 // run heads of the sorted voxel keys
 __global__ __launch_bounds__(256) void k_run_heads(const uint32_t *__restrict__ skeys, uint32_t n, uint32_t *__restrict__ flag) {
@@ -2407,7 +2431,7 @@ __device__ __forceinline__ uint32_t run_heads4(const uint32_t *__restrict__ skey
     }
     return c;
 }
-__global__ __launch_bounds__(256) void k_run_count(const uint32_t *__restrict__ skeys, uint32_t n, uint32_t *__restrict__ tops) {
+__device__ __forceinline__ void run_count_body(const uint32_t *__restrict__ skeys, uint32_t n, uint32_t *__restrict__ tops) {
     __shared__ uint32_t sm[40];
     bool hd[4];
     const uint32_t c = run_heads4(skeys, n, blockIdx.x * 1024u + threadIdx.x * 4u, hd);
@@ -2415,7 +2439,8 @@ __global__ __launch_bounds__(256) void k_run_count(const uint32_t *__restrict__ 
     block_excl_scan(c, sm, tot);
     if (threadIdx.x == 0) tops[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(256) void k_run_emit(const uint32_t *__restrict__ skeys, uint32_t n, const uint32_t *__restrict__ tops,
+__global__ __launch_bounds__(256) void k_run_count(const uint32_t *__restrict__ skeys, uint32_t n, uint32_t *__restrict__ tops) { run_count_body(skeys, n, tops); }
+__device__ __forceinline__ void run_emit_body(const uint32_t *__restrict__ skeys, uint32_t n, const uint32_t *__restrict__ tops,
                                                    uint32_t ntile, uint32_t *__restrict__ run_begin, uint32_t *nv_out) {
     __shared__ uint32_t sm[40];
     uint32_t before = 0, all = 0;
@@ -2440,11 +2465,13 @@ __global__ __launch_bounds__(256) void k_run_emit(const uint32_t *__restrict__ s
         *nv_out = nv;
     }
 }
+__global__ __launch_bounds__(256) void k_run_emit(const uint32_t *__restrict__ skeys, uint32_t n, const uint32_t *__restrict__ tops,
+                                                   uint32_t ntile, uint32_t *__restrict__ run_begin, uint32_t *nv_out) { run_emit_body(skeys, n, tops, ntile, run_begin, nv_out); }
 
 __device__ __forceinline__ uint32_t vox_hash(uint32_t key, int hbits) { return (key * 2654435761u) >> (32 - hbits); }
 
 // CentroidPoint<PointXYZI>: float32 running sums in sorted order, each / (float)count
-__global__ __launch_bounds__(256) void k_centroids(const float4 *__restrict__ pts, const uint32_t *__restrict__ skeys,
+__device__ __forceinline__ void centroids_body(const float4 *__restrict__ pts, const uint32_t *__restrict__ skeys,
                                                     const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ run_begin,
                                                     const uint32_t *nv_dev, float4 *__restrict__ cent, uint32_t *__restrict__ ukeys,
                                                     uint32_t *__restrict__ hkey, uint32_t *__restrict__ hval, int hbits) {
@@ -2488,6 +2515,10 @@ __global__ __launch_bounds__(256) void k_centroids(const float4 *__restrict__ pt
     }
     hval[sl] = v;
 }
+__global__ __launch_bounds__(256) void k_centroids(const float4 *__restrict__ pts, const uint32_t *__restrict__ skeys,
+                                                    const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ run_begin,
+                                                    const uint32_t *nv_dev, float4 *__restrict__ cent, uint32_t *__restrict__ ukeys,
+                                                    uint32_t *__restrict__ hkey, uint32_t *__restrict__ hval, int hbits) { centroids_body(pts, skeys, sperm, run_begin, nv_dev, cent, ukeys, hkey, hval, hbits); }
 
 // FLANN L2_Simple: ((0 + dx*dx) + dy*dy) + dz*dz in float32
 __device__ __forceinline__ float l2_simple(float ax, float ay, float az, float bx, float by, float bz) {
@@ -2521,7 +2552,7 @@ __device__ __forceinline__ void nn_merge(float &best, uint32_t &best_i) {
         nn_take(ob, oi, best, best_i);
     }
 }
-__global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts, const uint32_t *__restrict__ sperm,
+__device__ __forceinline__ void query_nn_body(const float4 *__restrict__ pts, const uint32_t *__restrict__ sperm,
                                                    const uint32_t *__restrict__ run_begin, const uint32_t *__restrict__ ukeys,
                                                    const float4 *__restrict__ cent, const uint32_t *nv_dev, const VoxGrid *gp, Xf Tl2b,
                                                    DP P, Counters *ctr, float4 *__restrict__ query, uint32_t *__restrict__ qkey,
@@ -2647,6 +2678,11 @@ __global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts
     query[v] = b;
     qkey[v] = bin_key(P, b.x, b.y, b.z, ctr);
 }
+__global__ __launch_bounds__(256) void k_query_nn(const float4 *__restrict__ pts, const uint32_t *__restrict__ sperm,
+                                                   const uint32_t *__restrict__ run_begin, const uint32_t *__restrict__ ukeys,
+                                                   const float4 *__restrict__ cent, const uint32_t *nv_dev, const VoxGrid *gp, Xf Tl2b,
+                                                   DP P, Counters *ctr, float4 *__restrict__ query, uint32_t *__restrict__ qkey,
+                                                   const uint32_t *__restrict__ hkey, const uint32_t *__restrict__ hval, int hbits) { query_nn_body(pts, sperm, run_begin, ukeys, cent, nv_dev, gp, Tl2b, P, ctr, query, qkey, hkey, hval, hbits); }
 
 // query handed over already voxelised and in the body frame (ERASOR::set_inputs used directly, erasor.cpp:57-73)
 __global__ __launch_bounds__(256) void k_query_direct(const float4 *__restrict__ src, uint32_t n, DP P, Counters *ctr,
@@ -4164,7 +4200,7 @@ __global__ void k_pad(unsigned long long ticks) {
 }
 
 // start of a scan's query chain (its own stream): counters, bounding box, bucket totals, voxel count of this query side
-__global__ void k_query_begin(Counters *qctr, uint32_t *bb, uint32_t *qb_tot, uint32_t qb_n, uint32_t *nvox, uint32_t nvox_init) {
+__device__ __forceinline__ void query_begin_body(Counters *qctr, uint32_t *bb, uint32_t *qb_tot, uint32_t qb_n, uint32_t *nvox, uint32_t nvox_init) {
     for (uint32_t b = threadIdx.x; b < qb_n; b += blockDim.x) qb_tot[b] = 0;  // bucket totals of the query counting sort
     if (threadIdx.x == 0) {
         qctr->n_neg_sector = qctr->n_ambiguous = qctr->n_degenerate = qctr->n_voxel_overflow = qctr->n_sort_fallback = 0;
@@ -4174,6 +4210,7 @@ __global__ void k_query_begin(Counters *qctr, uint32_t *bb, uint32_t *qb_tot, ui
     if (threadIdx.x < 3) bb[threadIdx.x] = 0xFFFFFFFFu;
     if (threadIdx.x >= 3 && threadIdx.x < 6) bb[threadIdx.x] = 0u;
 }
+__global__ void k_query_begin(Counters *qctr, uint32_t *bb, uint32_t *qb_tot, uint32_t qb_n, uint32_t *nvox, uint32_t nvox_init) { query_begin_body(qctr, bb, qb_tot, qb_n, nvox, nvox_init); }
 // ---- mapgen (src/mapgen/mapgen.hpp:198-257): per-scan preparation ----------------------------------------------
 // keep flag of the self-filter (mapgen.hpp:219-228): a point is dropped when pow(x,2) + pow(y,2) (double) is below
 // max_dist_square, a FLOAT holding pow(CAR_BODY_SIZE, 2)
@@ -4304,6 +4341,106 @@ __global__ void k_probe_math(const double *x, const double *y, uint32_t n, doubl
     o_div[i] = x[i] / y[i];
     o_atan2[i] = atan2(y[i], x[i]);
 }
+
+// ================================================================================================
+// round 6: the query chains of SEVERAL announced scans as ONE set of launches (OMU.cpp:237-241 per node; the offline driver knows
+// its nodes ahead, main_in_your_env.cpp:92-123).  Every launch of a chain is bound by latency, not by work (a sort level moves 1 MB
+// in 6-10 us on a chip that is 95 % idle), so a launch that serves the same stage of two to four scans costs what it costs for one:
+// the per-scan queue time of a chain halves to quarters.  Nothing is concatenated: blockIdx.y selects the scan, every scan keeps its
+// own query side (buffers, counters, queues) and the bodies are the single-scan kernels' bodies, unchanged.
+// ================================================================================================
+static constexpr int QBATCH_MAX = 4;
+struct QSideDev {  // one scan's query side as the batched kernels see it (device pointers of erasor_hip.hip's QSide)
+    const float4 *scan_in;
+    float4 *cent, *query, *sq;
+    uint32_t *bb, *qk_a, *qk_b, *qv_a, *qv_b, *qposL, *qposR, *qtops, *run_begin, *ukeys, *qkey, *qhead, *wtileL, *wtileR, *hkey, *hval;
+    uint32_t *qb_tot, *qb_hist, *qoff, *ccnt, *d_nvox;
+    float *cmin, *cmax;
+    esort::Seg *esq0, *esq1, *essmall;
+    EsQueues *esqs;
+    WideSeg *wseg0, *wseg1;
+    WideState *wstate;
+    VoxGrid *qgrid;
+    Counters *d_qctr;
+    Xf Tl;
+    uint32_t n;
+    int32_t hbits;
+};
+struct QBatch {
+    QSideDev s[QBATCH_MAX];
+};
+#define QB_SIDE const QSideDev &q = b.s[blockIdx.y]
+__global__ __launch_bounds__(256) void k_query_begin_b(QBatch b, uint32_t qb_n) {
+    QB_SIDE;
+    query_begin_body(q.d_qctr, q.bb, q.qb_tot, qb_n, q.d_nvox, 0u);
+}
+__global__ __launch_bounds__(256) void k_bbox_b(QBatch b) {
+    QB_SIDE;
+    bbox_body(q.scan_in, q.n, q.bb);
+}
+__global__ __launch_bounds__(256) void k_voxel_keys_es_b(QBatch b, float leaf) {
+    QB_SIDE;
+    EsInit es;
+    es.q0 = q.esq0;
+    es.smallq = q.essmall;
+    es.qs = q.esqs;
+    es.w0 = q.wseg0;
+    es.ws = q.wstate;
+    voxel_keys_es_body(q.scan_in, q.n, q.bb, leaf, q.qk_a, q.qv_a, q.qgrid, q.d_qctr, q.hkey, 1u << q.hbits, es);
+}
+__global__ __launch_bounds__(256) void k_esort_wide_mark_b(QBatch b, int cur) {
+    QB_SIDE;
+    esort_wide_mark_body(q.qk_a, q.qv_a, q.qposL, q.qposR, cur ? q.wseg1 : q.wseg0, q.wstate, cur, q.wtileL, q.wtileR);
+}
+__global__ __launch_bounds__(256) void k_esort_wide_swap_b(QBatch b, int cur, int last_level) {
+    QB_SIDE;
+    esort_wide_swap_body(q.qk_a, q.qv_a, q.qposL, q.qposR, cur ? q.wseg1 : q.wseg0, cur ? q.wseg0 : q.wseg1, q.wstate, cur, q.wtileL, q.wtileR, q.esq0,
+                         q.essmall, q.esqs, 65536u, last_level, q.d_qctr);
+}
+__global__ __launch_bounds__(1024) void k_esort_mid_b(QBatch b) {
+    QB_SIDE;
+    esort_mid_body(q.qk_a, q.qv_a, q.qposL, q.qposR, q.esq0, q.essmall, q.esqs, 0, 65536u, q.d_qctr);
+}
+__global__ __launch_bounds__(1024) void k_esort_final_b(QBatch b) {  // (behind k_esort_mid queue 0 is spent: the empty queue 1 stands for "no big segments")
+    QB_SIDE;
+    esort_final_body(q.qk_a, q.qv_a, q.qposL, q.qposR, q.qhead, q.qk_b, q.qv_b, q.essmall, q.esq1, q.esqs, 1, q.d_qctr, (unsigned long long *)nullptr);
+}
+__global__ __launch_bounds__(256) void k_run_count_b(QBatch b) {
+    QB_SIDE;
+    if (blockIdx.x * 1024u >= q.n && blockIdx.x) return;
+    run_count_body(q.qk_b, q.n, q.qtops);
+}
+__global__ __launch_bounds__(256) void k_run_emit_b(QBatch b) {
+    QB_SIDE;
+    const uint32_t ntile = q.n ? (q.n + 1023u) / 1024u : 1u;  // (k_run_count's grid for THIS scan; the launch is sized for the longest)
+    if (blockIdx.x >= ntile) return;
+    run_emit_body(q.qk_b, q.n, q.qtops, ntile, q.run_begin, q.d_nvox);
+}
+__global__ __launch_bounds__(256) void k_centroids_b(QBatch b) {
+    QB_SIDE;
+    centroids_body(q.scan_in, q.qk_b, q.qv_b, q.run_begin, q.d_nvox, q.cent, q.ukeys, q.hkey, q.hval, q.hbits);
+}
+__global__ __launch_bounds__(256) void k_query_nn_b(QBatch b, DP P) {
+    QB_SIDE;
+    query_nn_body(q.scan_in, q.qv_b, q.run_begin, q.ukeys, q.cent, q.d_nvox, q.qgrid, q.Tl, P, q.d_qctr, q.query, q.qkey, q.hkey, q.hval, q.hbits);
+}
+__global__ __launch_bounds__(1024) void k_qb_hist_b(QBatch b, uint32_t nb) {
+    QB_SIDE;
+    qb_hist_body(q.qkey, q.n, q.d_nvox, nb, q.qb_hist, q.qb_tot);
+}
+__global__ __launch_bounds__(1024) void k_qb_scan_b(QBatch b, uint32_t nb) {
+    QB_SIDE;
+    qb_scan_body(q.qb_tot, nb, q.qoff);
+}
+__global__ __launch_bounds__(1024) void k_qb_scatter_b(QBatch b, uint32_t nb, int bits) {
+    QB_SIDE;
+    qb_scatter_body(q.qkey, q.query, q.n, q.d_nvox, nb, bits, q.qb_hist, q.qoff, q.sq);
+}
+__global__ __launch_bounds__(256) void k_bin_stats_b(QBatch b, uint32_t B) {
+    QB_SIDE;
+    bin_stats_body(q.sq, q.qoff, B, q.ccnt, q.cmin, q.cmax);
+}
+#undef QB_SIDE
 
 }  // namespace ek
 #endif

@@ -185,7 +185,7 @@ int erasor_hip_step_wait(erasor_hip_handle *h, erasor_step_result *res);
 int erasor_hip_step_done(erasor_hip_handle *h);
 
 /* replaces: the node loop of the offline driver (main_in_your_env.cpp:92-123): nodes [first, first + count) of a sequence of n_total,
- * every node announced `lookahead` (0..3) nodes ahead with its pose, stepped one after the other -- the very calls a host loop would
+ * every node announced `lookahead` (0..7) nodes ahead with its pose, stepped one after the other -- the very calls a host loop would
  * make (erasor_hip_prefetch_node, erasor_hip_step[_device]), minus the caller's own time between two steps.  *announced (in / out):
  * nodes [0, *announced) are announced already, so a sequence can be split over several calls.  T_body2origin / T_origin2body: n_total
  * row-major 4x4 matrices each; res: `count` result blocks (may be NULL). */
@@ -313,10 +313,21 @@ int erasor_hip_ahead_split_counts(erasor_hip_handle *h, uint64_t *launched, uint
  * (erasor_hip_prefetch_node*) AND its inverse transform (this call, right after the announcement; the step must then pass the very same
  * 16 floats, tf_body2origin_.inverse() of OfflineMapUpdater.cpp:436) -- that node's fetch_VoI pass, transform and R-POD keys run beside
  * this step's per-bin launch on a second stream; the reserved places are filled in (or left as holes) when the per-bin launch is
- * through.  Results are bit-identical to the plain sequence.  ERASOR_HIP_NO_OVERLAP=1 / ERASOR_HIP_NO_RESERVED=1: off (A/B). */
+ * through.  Results are bit-identical to the plain sequence.  ERASOR_HIP_OVERLAP=0 / =1: never / always (unset: the handle decides). */
 int erasor_hip_announce_origin2body(erasor_hip_handle *h, const float T_origin2body[16]);
 /* steps whose early passes were launched ahead like that / steps that took them */
 int erasor_hip_overlap_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t *used);
+/* Round 6 -- the query chains of SEVERAL announced nodes as one set of launches.  A node's query chain (voxelize_preserving_labels of
+ * its scan, OfflineMapUpdater.cpp:237-241; lidar->body, R-POD keys, per-bin statistics, erasor.cpp:100-115) does not depend on the map,
+ * and every launch of it is bound by latency, not by work: a launch that serves the same stage of n_scans scans costs what it costs for
+ * one.  With n_scans >= 2 the chain of an announced node is held back until n_scans of them can share their launches -- unless fewer
+ * than `lead` chains are in their queues in front of it (or its own step is fewer than `lead` steps away): then it goes off at once, alone.
+ * An offline driver that knows its nodes ahead (main_in_your_env.cpp:92-123; erasor_hip_run_nodes with lookahead >= lead + n_scans) gets
+ * the shared launches; a callback that can announce one node ahead (OfflineMapUpdater.cpp:203) never holds anything back.
+ * n_scans: 1 .. 4 (1: every chain on its own; the default is 2), lead: 1 .. 6 (default 3).  Results do not depend on either. */
+int erasor_hip_chain_batch(erasor_hip_handle *h, int n_scans, int lead);
+/* sets of shared launches made so far / chains that went into them */
+int erasor_hip_chain_batch_counts(erasor_hip_handle *h, uint64_t *sets, uint64_t *chains);
 /* The main stream's dependency chain on the device's own clock (no events, no extra launches: the chunk scan and the step's end stamp
  * the 100 MHz counter): average span of a step from its chunk scan to its end (when the scan is launched ahead, behind the next VoI
  * split, that span contains the stream's wait for the host), average time between a step's end and the next step's chunk scan (the

@@ -332,21 +332,26 @@ inline Pool &pool() {
     return p;
 }
 // run `body` as ONE workgroup of nthreads threads
-inline void run_block(unsigned nthreads, const std::function<void()> &body) {
+inline void run_block(unsigned nthreads, const std::function<void()> &body, unsigned grid_y = 1) {
     if (gridDim.x == 0) gridDim.x = 1;
-    gridDim.y = gridDim.z = 1;
+    gridDim.y = grid_y;
+    gridDim.z = 1;
     pool().run(nthreads, body);
 }
 // a grid of workgroups, one after the other (static __shared__ storage is one workgroup's LDS)
-inline void run_grid(unsigned nblocks, unsigned nthreads, const std::function<void()> &body) {
-    for (unsigned b = 0; b < nblocks; ++b) {
-        blockIdx.x = b;
-        blockIdx.y = blockIdx.z = 0;
-        gridDim.x = nblocks;
-        run_block(nthreads, body);
-    }
+inline void run_grid(unsigned nblocks, unsigned nthreads, const std::function<void()> &body, unsigned nblocks_y = 1) {
+    for (unsigned by = 0; by < nblocks_y; ++by)
+        for (unsigned b = 0; b < nblocks; ++b) {
+            blockIdx.x = b;
+            blockIdx.y = by;
+            blockIdx.z = 0;
+            gridDim.x = nblocks;
+            run_block(nthreads, body, nblocks_y);
+        }
     gridDim.x = 1;
+    gridDim.y = 1;
     blockIdx.x = 0;
+    blockIdx.y = 0;
 }
 }  // namespace simt
 
@@ -599,7 +604,7 @@ inline bool simt_trace_on() {
 #define SIMT_LAUNCH(kern, grid, block, ...)                                                                                    \
     do {                                                                                                                       \
         const auto t0_ = std::chrono::steady_clock::now();                                                                     \
-        simt::run_grid(dim3(grid).x, dim3(block).x, [&] { kern(__VA_ARGS__); });                                               \
+        simt::run_grid(dim3(grid).x, dim3(block).x, [&] { kern(__VA_ARGS__); }, dim3(grid).y);                                               \
         if (simt_trace_on())                                                                                                   \
             fprintf(stderr, "[simt_emu] %s <<<%u, %u>>> %.0f ms\n", #kern, dim3(grid).x, dim3(block).x,                        \
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());               \

@@ -78,6 +78,20 @@ rs = g3.run_nodes(P_, N_, sc["T_l2b"], Tb_, To_, 0, 1, 2, ann) + g3.run_nodes(P_
 same3 = np.array_equal(g3.get_map().view(np.uint32), o2.get_cloud(7).view(np.uint32)) and len(rs) == n3 and ann.value == n3
 print("erasor_hip_run_nodes (two calls, %d nodes, two ahead): final map bit-exact %s" % (n3, same3))
 ok = ok and same3
+# round 6: the same nodes announced SIX ahead: chains beyond the third in line are held back until two (then three) of them share one
+# set of launches (erasor_hip_chain_batch); a held chain whose partner never comes goes off alone when its step is near
+for nb in (2, 3):
+    g4 = erasor_amd.Erasor(scenarios.to_product_params(sc["params"]))
+    g4.set_map(sc["map"])
+    g4.chain_batch(nb, 2)
+    ann4 = C.c_size_t(0)
+    rs4 = g4.run_nodes(P_, N_, sc["T_l2b"], Tb_, To_, 0, n3, 6, ann4)
+    sets, chains = g4.chain_batch_counts()
+    same4 = np.array_equal(g4.get_map().view(np.uint32), o2.get_cloud(7).view(np.uint32)) and all(
+        a.as_dict() == b.as_dict() for a, b in zip(rs4, rs))
+    print("erasor_hip_run_nodes, six ahead, chains in sets of %d: %d sets / %d chains shared their launches; results and final map bit-exact %s"
+          % (nb, sets, chains, same4))
+    ok = ok and same4 and sets >= 1 and chains >= 2
 launched, used = g.ahead_split_counts()
 print("VoI splits launched ahead: %d, used: %d" % (launched, used))
 ok = ok and launched == n_steps - 1  # (whether the next step could use it depends on scratch growth in the first steps)

@@ -859,19 +859,32 @@ import erasor_amd
 if os.environ.get("ERASOR_TEST_SIMT_LIB"):  # (the CPU stand-in build, when the suite itself runs on it)
     erasor_amd.LIB_PATH = os.environ["ERASOR_TEST_SIMT_LIB"]
     erasor_amd._lib = None
+elif os.environ.get("ALT_HOOKS_LIB"):       # (the product's sources with the test hooks compiled in: ERASOR_HIP_LEAVE_ALL is one)
+    import subprocess
+    import hooks
+    subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(os.path.dirname(hooks.HOOKS_LIB)), "..", "erasor_amd", "csrc"), "-s", "hooks"])
+    erasor_amd.LIB_PATH = hooks.HOOKS_LIB
+    erasor_amd._lib = None
 import scenarios
 from oracle import orc
+LA = 5  # nodes announced ahead: beyond the third in line their chains may share launches (erasor_hip_chain_batch)
 for version in (3, 2):
     sc = scenarios.small(version=version)
     g = erasor_amd.Erasor(scenarios.to_product_params(sc["params"]))
     o = orc.Oracle(sc["params"])
     g.set_map(sc["map"])
     o.set_map(sc["map"])
-    scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"][:5]]
-    g.prefetch(scans[0], sc["T_l2b"], sc["T_b2o"][0], sc["T_o2b"][0])
-    for k in range(5):
-        if k + 1 < 5:
-            g.prefetch(scans[k + 1], sc["T_l2b"], sc["T_b2o"][k + 1], sc["T_o2b"][k + 1])
+    if os.environ.get("ALT_CHAIN_BATCH"):
+        g.chain_batch(int(os.environ["ALT_CHAIN_BATCH"]), 2)
+    if os.environ.get("ALT_PROFILE_ALL"):
+        g.profiling(1)
+    n = 8
+    scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"][:n]]
+    for j in range(LA):
+        g.prefetch(scans[j], sc["T_l2b"], sc["T_b2o"][j], sc["T_o2b"][j])
+    for k in range(n):
+        if k + LA < n:
+            g.prefetch(scans[k + LA], sc["T_l2b"], sc["T_b2o"][k + LA], sc["T_o2b"][k + LA])
         rg = g.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         ro = o.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         dg, do = rg.as_dict(), ro.as_dict()
@@ -880,6 +893,11 @@ for version in (3, 2):
         assert np.array_equal(g.get_rejected_indices(), o.get_rejected_indices())
         assert np.array_equal(g.get_status(), o.get_status())
         assert np.array_equal(g.get_cloud(2).view(np.uint32), o.get_cloud(2).view(np.uint32))
+    sets, chains = g.chain_batch_counts()
+    if os.environ.get("ALT_PROFILE_ALL") or os.environ.get("ERASOR_HIP_DEBUG_SYNC") or os.environ.get("ALT_CHAIN_BATCH") == "1":
+        assert sets == 0, (sets, chains)      # (profiled / synchronised launch by launch, or told not to: every chain on its own)
+    else:
+        assert sets >= 1 and chains >= 2 * sets, (sets, chains)
     t = erasor_amd.replicate_map([g], 0)  # a communicator of one; ERASOR_HIP_NO_RCCL=1: the peer-copy path
     assert (t == 2) if os.environ.get("ERASOR_HIP_NO_RCCL") else (t in (1, 2)), t
     assert np.array_equal(g.get_map().view(np.uint32), o.get_map().view(np.uint32)), "map after replicate_map"
@@ -887,36 +905,24 @@ print("ALT-PATH-OK")
 """
 
 
-@pytest.mark.parametrize("env", [{"ERASOR_HIP_GRAPH": "1"}, {"ERASOR_HIP_NO_FUSE": "1", "ERASOR_HIP_NO_FOLD": "1", "ERASOR_HIP_NO_SRT_AHEAD": "1"},
-                                 {"ERASOR_HIP_NO_OMETA": "1", "ERASOR_HIP_STREAM_PRIORITIES": "1"},
-                                 {"ERASOR_HIP_NO_END_FOLD": "1", "ERASOR_HIP_NO_SRT_FOLD": "1", "ERASOR_HIP_NO_AHEAD_SCAN": "1"},
-                                 {"ERASOR_HIP_NO_AHEAD_SPLIT": "1", "ERASOR_HIP_NO_SPIN": "1", "ERASOR_HIP_NO_RCCL": "1", "ERASOR_HIP_HOST_TIMING": "1",
-                                  "ERASOR_HIP_SORT_STAMPS": "1", "ERASOR_HIP_DEBUG_SYNC": "1"},
-                                 {"ERASOR_HIP_QSTREAMS": "3", "ERASOR_HIP_QPAD_US": "20", "ERASOR_HIP_MPAD_US": "20"},
-                                 {"ERASOR_HIP_OVERLAP": "0", "ERASOR_HIP_NO_WORKER": "1", "ERASOR_HIP_WIDE_SLACK": "2"},
-                                 {"ERASOR_HIP_OVERLAP": "1", "ERASOR_HIP_NO_OVERLAP": "1", "ERASOR_HIP_LEAVE_ALL": "1", "ERASOR_HIP_EVT_SYSFENCE": "1",
-                                  "ERASOR_HIP_QUERY_PRIORITY": "1"},
-                                 {"ERASOR_HIP_OVERLAP": "1", "ERASOR_HIP_CHAIN_SPLIT": "1", "ERASOR_HIP_CHAIN_STAMPS": "1", "ERASOR_HIP_LEAVE_ALL": "1",
-                                  "GPU_MAX_HW_QUEUES": "16"},
-                                 {"ERASOR_HIP_OVERLAP": "", "ERASOR_HIP_OVERLAP_PPB": "1", "ERASOR_HIP_NO_RESERVED": ""}],
-                         ids=["query_chain_as_hipgraphs", "separate_rgpf_binvox_layout_srt_launches", "no_chunk_records_stream_priorities",
-                              "step_end_and_srt_as_launches_no_ahead_scan", "nothing_ahead_blocking_wait_peer_copies_diagnostics",
-                              "three_query_streams_padded_chains", "no_overlap_no_worker_thread_fewer_wide_levels",
-                              "reserved_layout_without_passes_ahead_every_bin_may_leave", "overlap_with_split_chains_stamps_third_stream_shared",
-                              "overlap_where_the_bins_are_dense_enough"])
+@pytest.mark.parametrize("env", [{"ERASOR_HIP_NO_OMETA": "1", "ALT_PROFILE_ALL": "1"},
+                                 {"ERASOR_HIP_NO_RCCL": "1", "ERASOR_HIP_HOST_TIMING": "1", "ERASOR_HIP_SORT_STAMPS": "1", "ERASOR_HIP_DEBUG_SYNC": "1"},
+                                 {"ERASOR_HIP_QSTREAMS": "3", "ERASOR_HIP_OVERLAP": "0", "ALT_CHAIN_BATCH": "1"},
+                                 {"ERASOR_HIP_OVERLAP": "1", "ERASOR_HIP_CHAIN_STAMPS": "1", "ERASOR_HIP_LEAVE_ALL": "1", "GPU_MAX_HW_QUEUES": "16",
+                                  "ALT_CHAIN_BATCH": "3", "ALT_HOOKS_LIB": "1"},
+                                 {"ERASOR_HIP_OVERLAP": ""}],
+                         ids=["no_chunk_records_every_launch_profiled", "peer_copies_diagnostics", "three_query_streams_no_overlap_every_chain_on_its_own",
+                              "overlap_stamps_every_bin_may_leave_chains_in_threes", "overlap_left_to_the_handle"])
 def test_alternative_launch_paths_keep_parity(gpu_mod, tmp_path, env):
-    """The paths behind the library's A/B switches are product code too: the query chain replayed as two hipGraphs per side
-    (ERASOR_HIP_GRAPH=1: measured, no gain, opt-in) and the unfused launches (R-GPF and per-bin voxelisation apart, k_layout4,
-    the Scan Ratio Test's first pass inside k_srt4), the VoI pass without the outskirts' chunk records and rounds 1-2's stream priorities,
-    round 4's folds undone (the step's end and the Scan Ratio Test's second pass as launches, no chunk scan ahead), nothing launched
-    ahead + a blocking wait + peer copies in replicate_map + the three diagnostics, three query streams with both chains padded
-    (every getenv switch of the library is in one of these cases, in test_map_store_slack* or in test_gpu_hooks.py)
-    -- five look-ahead steps of a v3 and a v2 sequence each, in a process of its
-    own (the switches are read once), every step against the oracle."""
+    """The paths behind the library's remaining switches are product code too (round 6: eleven switches, the ablation switches of
+    rounds 3-5 are gone with the paths that measured as no gain): the VoI pass without the outskirts' chunk records and -- under
+    erasor_hip_profiling(1) -- the unfused launches (R-GPF and per-bin voxelisation apart, k_layout4, k_srt4 and the step's end as
+    launches of their own); peer copies in replicate_map + the diagnostics; three query streams, no overlap, no shared chain launches;
+    the overlap forced with every reverted bin reserving outskirts places (a test hook: the hooks build) and chains shared in threes;
+    the overlap left to the handle's own measurement -- look-ahead steps of a v3 and a v2 sequence each, in a process of its own (the
+    switches are read once), every step against the oracle."""
     import subprocess
     import sys
-    if os.environ.get("ERASOR_TEST_SIMT_LIB") and "ERASOR_HIP_GRAPH" in env:
-        pytest.skip("the CPU stand-in has no graph API")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "alt_worker.py"
     script.write_text(ALT_PATH_WORKER % (root, root))
@@ -1225,7 +1231,10 @@ def test_random_operation_sequences_keep_parity(gpu_mod, version, seed):
         else:
             g.prefetch(s, Tl, b, i)
 
-    ahead = int(rng.integers(1, 3))
+    # (round 6: up to six nodes ahead -- beyond the `lead`-th in line a chain is held back until `n_scans` of them share one set of launches,
+    # erasor_hip_chain_batch: a held chain may be dropped, claimed early by its own step, or flushed by a read-back in between)
+    ahead = int(rng.integers(1, 7))
+    g.chain_batch(int(rng.integers(1, 5)), int(rng.integers(1, 4)))
     for j in range(min(ahead, n)):
         announce(j)
     for k in range(n):
