@@ -620,11 +620,11 @@ def test_prefetched_scans_give_the_same_results(gpu_mod, version, ahead):
         rg = g.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         ro = o.step(scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         compare_step(g, o, rg, ro, full=True)
-    with pytest.raises(gpu_mod.ErasorError):  # nothing consumed in between: the fifth announcement has no side left
-        for j in range(5):
-            g.prefetch(scans[j], sc["T_l2b"])
-        raise AssertionError("five announcements were accepted")
-    g.voxelize_preserving_labels(sc["scans"][0][:100], 0.3)  # (standalone call: drops the four announcements)
+    with pytest.raises(gpu_mod.ErasorError):  # nothing consumed in between: the ninth announcement has no side left (eight query sides)
+        for j in range(9):
+            g.prefetch(scans[j % n], sc["T_l2b"])
+        raise AssertionError("nine announcements were accepted")
+    g.voxelize_preserving_labels(sc["scans"][0][:100], 0.3)  # (standalone call: drops the eight announcements)
     # a prefetch that is not honoured: the announced scan is dropped, the step's own scan is processed
     g.prefetch(scans[0], sc["T_l2b"])
     k = n
@@ -1061,22 +1061,23 @@ def test_ticket_announcements_survive_a_voxelgrid_mode_flip(gpu_mod):
         flips += 1 if k in (0, 3, 4) else 0
         compare_step(g, o, rg, ro, full=True)
     assert flips == 3
-    # four announced, the first of them in flight, then a fifth: the only side left is the step's own -> refused, nothing clobbered
-    # (it used to be handed out and its scan, staging copy and bins overwritten under the running step)
+    # eight announced (as many as there are query sides), the first of them in flight, then a ninth: the only side left is the step's own
+    # -> refused, nothing clobbered (it used to be handed out and its scan, staging copy and bins overwritten under
+    # the running step)
     g2, o2 = make_pair(gpu_mod, sc["params"])
     g2.set_map(sc["map"])
     o2.set_map(sc["map"])
-    sc_scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"][:6]]
-    for k in range(4):
+    sc_scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"][:10]]
+    for k in range(8):
         g2.prefetch(sc_scans[k], sc["T_l2b"], sc["T_b2o"][k])
     g2.step_async(sc_scans[0], T_l2b=sc["T_l2b"], T_b2o=sc["T_b2o"][0], T_o2b=sc["T_o2b"][0])
     with pytest.raises(gpu_mod.ErasorError) as e:
-        g2.prefetch(sc_scans[4], sc["T_l2b"], sc["T_b2o"][4])
+        g2.prefetch(sc_scans[8], sc["T_l2b"], sc["T_b2o"][8])
     assert e.value.rc == -4
     rg = g2.step_wait()
     ro = o2.step(sc_scans[0], sc["T_l2b"], sc["T_b2o"][0], sc["T_o2b"][0])
     compare_step(g2, o2, rg, ro, full=True)
-    for k in range(1, 5):
+    for k in range(1, 9):
         rg = g2.step(sc_scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         ro = o2.step(sc_scans[k], sc["T_l2b"], sc["T_b2o"][k], sc["T_o2b"][k])
         compare_step(g2, o2, rg, ro, full=(k == 4))
