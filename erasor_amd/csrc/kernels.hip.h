@@ -209,6 +209,30 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *sm, ui
     return pre + inc - v;
 }
 
+// N exclusive block scans behind ONE pair of barriers (round 6: srt4_body ran eight scans one after the other -- sixteen workgroup barriers of
+// 1024 threads on the head of the early stream's chain).  sm: 16 * N words.
+template <int N>
+__device__ __forceinline__ void block_excl_scan_n(const uint32_t (&v)[N], uint32_t *sm, uint32_t (&pre)[N], uint32_t (&total)[N]) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    uint32_t inc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) inc[j] = esort::wave_incl_scan(v[j]);
+    __syncthreads();  // (sm may still be read by an earlier scan's second level)
+    if (lane == 63) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) sm[j * 16 + wave] = inc[j];
+    }
+    __syncthreads();
+    const uint32_t w1 = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const uint32_t wt = lane < nw ? sm[j * 16 + lane] : 0u;
+        const uint32_t wi = esort::wave_incl_scan(wt);
+        total[j] = __builtin_amdgcn_readlane(wi, 63);
+        pre[j] = __builtin_amdgcn_readlane(wi - wt, w1) + inc[j] - v[j];
+    }
+}
+
 // wave-wide reductions on DPP row shifts (the value every lane gets back is lane 63's inclusive result): a __shfl_down / __shfl_xor
 // ladder is six dependent ds_bpermute round trips (~100 cycles each) at the end of a wavefront that lives a few microseconds
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x) { return __builtin_amdgcn_readlane(esort::wave_incl_scan(x), 63); }
@@ -2965,32 +2989,18 @@ __device__ __forceinline__ void srt4_body(const DP &P, uint32_t *sm, S1P s_st1, 
             }
         }
     }
-    uint32_t t0, t1;
-    uint32_t p0 = block_excl_scan(nrv, sm, t0);
-    uint32_t p1 = block_excl_scan(ncap, sm, t1);
+    // everything the prefixes are taken over, then ONE pass of six scans (round 6)
+    uint32_t sz[SRT_KPT], cr[SRT_KPT], szR[SRT_KPT], gR[SRT_KPT];
+    bool ml[SRT_KPT];
+    uint32_t sums[6] = {nrv, ncap, 0u, 0u, 0u, 0u};  // reverted bins, their voxel scratch, dense sizes, curr_rejected, reserved sizes, reserved ground
+    const double zb = fmax(fabs(P.min_h), fabs(P.max_h));
 #pragma unroll
-    for (int j = 0; j < SRT_KPT; ++j)
+    for (int j = 0; j < SRT_KPT; ++j) {
+        sz[j] = cr[j] = szR[j] = gR[j] = 0;
+        ml[j] = false;
         if (k0 + j < B) {
-            const bool rv = act[j] == 1;
-            rev_idx[k0 + j] = rv ? p0 : 0xFFFFFFFFu;
-            if (rv) {
-                rev_list[p0] = (uint32_t)(k0 + j);
-                vox_off[p0] = moff_pos ? moff_pos[k0 + j] + qoff_pos[k0 + j] : p1;
-                ++p0;
-                p1 += bs[j].mc + bs[j].cc;
-            }
-        }
-    if (threadIdx.x == 0) {
-        st->n_rev = t0;
-        st->vox_scratch_total = t1;
-    }
-    if (out_off0) {
-        uint32_t sz[SRT_KPT], cr[SRT_KPT], ssz = 0, scr = 0;
-#pragma unroll
-        for (int j = 0; j < SRT_KPT; ++j) {
-            sz[j] = cr[j] = 0;
-            if (k0 + j < B) {
-                const uint32_t mc = bs[j].mc, cc = bs[j].cc;
+            const uint32_t mc = bs[j].mc, cc = bs[j].cc;
+            if (out_off0) {
                 if (act[j] == 1) sz[j] = 0;             // curr + ground, voxelised (v3) or not (v2): known after R-GPF
                 else if (act[j] == 2) sz[j] = cc + mc;  // merge_bins: curr then map (erasor.cpp:296-307)
                 else if (act[j] == 3) sz[j] = cc;
@@ -2998,39 +3008,10 @@ __device__ __forceinline__ void srt4_body(const DP &P, uint32_t *sm, S1P s_st1, 
                     sz[j] = mc;
                     if (act[j] == 4) cr[j] = cc;
                 }
-                ssz += sz[j];
-                scr += cr[j];
+                sums[2] += sz[j];
+                sums[3] += cr[j];
             }
-        }
-        uint32_t t2, t3;
-        uint32_t p2 = block_excl_scan(ssz, sm, t2);
-        uint32_t p3 = block_excl_scan(scr, sm, t3);
-        uint32_t pr = block_excl_scan(nrv, sm, t0);  // (the reverted bins before this thread's first bin, again: p0 has moved on)
-#pragma unroll
-        for (int j = 0; j < SRT_KPT; ++j)
-            if (k0 + j < B) {
-                out_off0[k0 + j] = p2;
-                crej_off[k0 + j] = p3;
-                rev_before[k0 + j] = pr;
-                p2 += sz[j];
-                p3 += cr[j];
-                pr += act[j] == 1 ? 1u : 0u;
-            }
-        if (threadIdx.x == 0) {
-            st->total_bins0 = t2;
-            st->n_curr_rejected = t3;
-        }
-    }
-    if (out_offR) {
-        const double zb = fmax(fabs(P.min_h), fabs(P.max_h));
-        uint32_t szR[SRT_KPT], gR[SRT_KPT], ssz = 0, sg = 0;
-        bool ml[SRT_KPT];
-#pragma unroll
-        for (int j = 0; j < SRT_KPT; ++j) {
-            szR[j] = gR[j] = 0;
-            ml[j] = false;
-            if (k0 + j < B) {
-                const uint32_t mc = bs[j].mc, cc = bs[j].cc;
+            if (out_offR) {
                 if (act[j] == 1) {
                     // can a point of this bin lie outside the next VoI circle?  Its egocentric radius is below the ring's outer edge (a
                     // voxel centroid is a mean of such points), |z| below zb; the sensor moves by what leave_lim has been reduced by
@@ -3042,14 +3023,52 @@ __device__ __forceinline__ void srt4_body(const DP &P, uint32_t *sm, S1P s_st1, 
                 } else {
                     szR[j] = mc;  // (v3: a bin that is not reverted keeps its map points)
                 }
-                ssz += szR[j];
-                sg += gR[j];
+                sums[4] += szR[j];
+                sums[5] += gR[j];
             }
         }
-        uint32_t t4, t5, t6;
-        uint32_t p4 = block_excl_scan(ssz, sm, t4);
-        uint32_t p5 = block_excl_scan(sg, sm, t5);
-        uint32_t pr = block_excl_scan(nrv, sm, t6);
+    }
+    uint32_t pre[6], tot[6];
+    block_excl_scan_n<6>(sums, sm, pre, tot);
+    {
+        uint32_t p0 = pre[0], p1 = pre[1];
+#pragma unroll
+        for (int j = 0; j < SRT_KPT; ++j)
+            if (k0 + j < B) {
+                const bool rv = act[j] == 1;
+                rev_idx[k0 + j] = rv ? p0 : 0xFFFFFFFFu;
+                if (rv) {
+                    rev_list[p0] = (uint32_t)(k0 + j);
+                    vox_off[p0] = moff_pos ? moff_pos[k0 + j] + qoff_pos[k0 + j] : p1;
+                    ++p0;
+                    p1 += bs[j].mc + bs[j].cc;
+                }
+            }
+    }
+    if (threadIdx.x == 0) {
+        st->n_rev = tot[0];
+        st->vox_scratch_total = tot[1];
+    }
+    if (out_off0) {
+        uint32_t p2 = pre[2], p3 = pre[3], pr = pre[0];
+#pragma unroll
+        for (int j = 0; j < SRT_KPT; ++j)
+            if (k0 + j < B) {
+                out_off0[k0 + j] = p2;
+                crej_off[k0 + j] = p3;
+                rev_before[k0 + j] = pr;
+                p2 += sz[j];
+                p3 += cr[j];
+                pr += act[j] == 1 ? 1u : 0u;
+            }
+        if (threadIdx.x == 0) {
+            st->total_bins0 = tot[2];
+            st->n_curr_rejected = tot[3];
+        }
+    }
+    if (out_offR) {
+        const uint32_t t4 = tot[4], t5 = tot[5], t6 = tot[0];
+        uint32_t p4 = pre[4], p5 = pre[5], pr = pre[0];
 #pragma unroll
         for (int j = 0; j < SRT_KPT; ++j)
             if (k0 + j < B) {
@@ -3094,7 +3113,7 @@ __global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict_
                                                 const uint32_t *__restrict__ moff_pos = nullptr, const uint32_t *__restrict__ qoff_pos = nullptr,
                                                 uint32_t *__restrict__ out_offR = nullptr, uint32_t *__restrict__ gres_off = nullptr,
                                                 LateEnt *__restrict__ late = nullptr, double leave_lim = -1.0) {
-    __shared__ uint32_t sm[40];
+    __shared__ uint32_t sm[96];  // (six scans' wavefront totals, see block_excl_scan_n)
     __shared__ uint8_t s_st1[1024 * SRT_KPT];
     CHAIN_STAMP(3);
     srt4_body(P, sm, s_st1, mcnt, mmin, mmax, ccnt, cmin, cmax, st1, status, action, rev_idx, rev_list, vox_off, st, out_off0, rev_before, crej_off,

@@ -801,8 +801,8 @@ __shared__ SrtArgs g_srt_args;
 __device__ __attribute__((noinline)) void srt4_call() {
     const SrtArgs a = g_srt_args;
     const DP P = g_dp;
-    uint32_t *sm = g_rev_pool;                                       // 40 words
-    uint8_t *s_st1 = reinterpret_cast<uint8_t *>(g_rev_pool + 64);  // 1024 * SRT_KPT bytes
+    uint32_t *sm = g_rev_pool;                                        // 96 words (block_excl_scan_n<6>)
+    uint8_t *s_st1 = reinterpret_cast<uint8_t *>(g_rev_pool + 128);  // 1024 * SRT_KPT bytes
     srt4_body(P, sm, s_st1, a.mcnt, a.mmin, a.mmax, a.ccnt, a.cmin, a.cmax, a.st1, a.status, a.action, a.rev_idx, a.rev_list, a.vox_off, a.st, a.out_off0,
               a.rev_before, a.crej_off, a.st1_in, a.moff, a.qoff);
 }
