@@ -83,5 +83,44 @@ int main(int argc, char **argv) {
         }
         printf("\n");
     }
+    // ---- what an event costs a chain of dependent launches (round 6): between two launches of ONE stream, (a) nothing, (b) an event record,
+    // (c) a wait for an event another stream recorded long ago (complete when hipStreamWaitEvent is called: the runtime drops it), (d) both,
+    // (e) a LIVE join: the other stream records behind a kernel that ends at about the same time; with 4 x longer kernels: (f) nothing,
+    // (g) a wait that is enqueued before its event is complete but satisfied when the queue gets to it, (h) the same + a record ----
+    {
+        hipEvent_t ev[2], evl;
+        hipEventCreateWithFlags(&ev[0], hipEventDisableTiming | hipEventDisableSystemFence);
+        hipEventCreateWithFlags(&ev[1], hipEventDisableTiming | hipEventDisableSystemFence);
+        hipEventCreateWithFlags(&evl, hipEventDisableTiming | hipEventDisableSystemFence);
+        hipLaunchKernelGGL(k_chase, dim3(1), dim3(256), 0, st[1], tab, N - 1, 1, 0u, stamps, hw, sink);
+        hipEventRecord(ev[1], st[1]);
+        hipDeviceSynchronize();
+        const char *names[8] = {"nothing", "event record", "wait on a signalled event", "record + signalled wait", "live join with a second stream",
+                                "(long kernels) nothing", "(long kernels) wait enqueued early, satisfied when reached", "(long kernels) the same + a record"};
+        for (int mode = 0; mode < 8; ++mode) {
+            hipDeviceSynchronize();
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < launches; ++i) {
+                if (mode >= 6) {  // the other stream: a short kernel and its event, long before this stream gets to the wait
+                    hipLaunchKernelGGL(k_chase, dim3(1), dim3(256), 0, st[1], tab, N - 1, 4, (unsigned)(i * 7), stamps + 2 * (launches + i), hw + launches + i, sink);
+                    hipEventRecord(evl, st[1]);
+                }
+                hipLaunchKernelGGL(k_chase, dim3(1), dim3(256), 0, st[0], tab, N - 1, mode >= 5 ? 4 * hops : hops, (unsigned)(i * 131), stamps + 2 * i, hw + i, sink);
+                if (mode >= 6) hipStreamWaitEvent(st[0], evl, 0);
+                if (mode == 7) hipEventRecord(ev[0], st[0]);
+                if (mode == 1 || mode == 3) hipEventRecord(ev[0], st[0]);
+                if (mode == 2 || mode == 3) hipStreamWaitEvent(st[0], ev[1], 0);
+                if (mode == 4) {
+                    hipLaunchKernelGGL(k_chase, dim3(1), dim3(256), 0, st[1], tab, N - 1, hops, (unsigned)(i * 7), stamps + 2 * (launches + i), hw + launches + i, sink);
+                    hipEventRecord(evl, st[1]);
+                    hipStreamWaitEvent(st[0], evl, 0);
+                }
+            }
+            hipDeviceSynchronize();
+            const double span = (double)(stamps[2 * (launches - 1) + 1] - stamps[0]) * 0.01 / launches;
+            printf("between two launches of a chain: %-62s %.2f us per launch (device clock), %.2f (wall)\n", names[mode], span,
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / launches);
+        }
+    }
     return 0;
 }
