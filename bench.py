@@ -148,7 +148,7 @@ def committed_profile(prof_tag):
     """what the separate rocprofv3 passes of THIS build measured (profiles/*_latest*): k_voi_split's PMC traffic and average
     duration, and the kernel that tops the GPU-time table.  None for everything when the device sources have changed since."""
     import csv
-    out = {"traffic": None, "voi_split_avg_us": None, "dominant": None, "stale": None, "step_traffic": None, "step_traffic_steps_only": None}
+    out = {"traffic": None, "voi_split_avg_us": None, "dominant": None, "critical": None, "stale": None, "step_traffic": None, "step_traffic_steps_only": None}
     try:
         with open(os.path.join(ROOT, "profiles", "latest_meta%s.json" % prof_tag)) as f:
             meta = json.load(f)
@@ -185,6 +185,20 @@ def committed_profile(prof_tag):
             dom["achieved_GBps"] = round(tb / (float(top["AverageNs"]) * 1e-9) / 1e9, 1)
             dom["frac_of_hbm_peak"] = round(dom["achieved_GBps"] / PEAK_HBM_GBPS, 4)
         out["dominant"] = dom
+        # the kernel that owns the step's dependency chain: the per-bin launch (R-GPF + per-bin voxelisation, one workgroup per reverted bin)
+        for r in rows:
+            if "k_revert_bins_srt" in r["Name"]:
+                cname = "k_revert_bins_srt"
+                crit = {"name": cname, "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "max_us": round(float(r["MaxNs"]) / 1e3, 2),
+                        "launches_per_scan": round(int(r["Calls"]) / steps, 2), "share_of_gpu_time": round(float(r["TotalDurationNs"]) / tot, 4),
+                        "bound": "latency (one 1024-thread workgroup per reverted bin: exact std::sort emulation, sequential float32 sums, one-lane SVD)",
+                        "source": "from_profiles (rocprofv3 --kernel-trace --stats)"}
+                tb = per_kernel.get(cname)
+                if tb:
+                    crit["traffic_bytes_per_launch"] = int(tb)
+                    crit["achieved_GBps"] = round(tb / (float(r["AverageNs"]) * 1e-9) / 1e9, 1)
+                    crit["frac_of_hbm_peak"] = round(crit["achieved_GBps"] / PEAK_HBM_GBPS, 4)
+                out["critical"] = crit
     except Exception:
         pass
     return out
@@ -384,13 +398,16 @@ def cpu_baseline(args, P, m, seq, l2b7, gpu_results=None, gpu_final=None):
         if tcpu > args.cpu_seconds / 2:
             break
     r.close()
-    refd = {"value": round(ns / tcpu, 3), "unit": "scans/s", "cores": 1, "kind": "reference",
+    refd = {"value": round(ns / tcpu, 3), "unit": "scans/s", "cores": 1, "kind": "reference sources over stand-in headers (NOT a reference build)",
+            "kind_note": "the reference's build needs ROS, PCL, Eigen and tf, none of which this image has: by the task's rules it is unbuildable here and "
+                         "this figure does not count as the reference's -- it times the reference's own source text (its full-map copies included) "
+                         "compiled against the oracle's restated third-party arithmetic; cpu_baseline is the oracle port",
             "sample": "%d callback_node steps of the same workload (same %d-pt map, same scans) through oracle/_ref = the reference's "
                       "unmodified erasor.cpp / erasor_utils.cpp / OfflineMapUpdater.cpp (-O2, 1 thread, like the single-threaded node); "
                       "PCL/Eigen/ROS underneath are the stand-ins of oracle/stubs (publishing is a no-op)" % (ns, len(m)),
             "ms_per_scan": round(tcpu / ns * 1e3, 1),
             "reference_spans_ms": {"Extracting VoI": round(sv / ns * 1e3, 1), "ERASOR": round(se / ns * 1e3, 1)}}
-    return refd, port, parity
+    return port, refd, parity
 
 
 def _ref_sequence_worker(job):
@@ -429,8 +446,8 @@ def cpu_sequence_parallel(args, seqs, maps, l2b7):
     wall = time.perf_counter() - t0
     steps = sum(r[0] for r in res)
     slowest = max(r[1] for r in res)
-    return {"value": round(steps / slowest, 3), "unit": "scans/s", "cores": cores, "kind": "reference",
-            "sample": "%d sequences x %d callback_node steps, one single-threaded reference updater (oracle/_ref) per sequence on %d host "
+    return {"value": round(steps / slowest, 3), "unit": "scans/s", "cores": cores, "kind": "reference sources over stand-in headers (NOT a reference build)",
+            "sample": "%d sequences x %d callback_node steps, one single-threaded updater of the reference's sources (oracle/_ref) per sequence on %d host "
                       "cores side by side; aggregate steps / slowest worker's stepping time (wall incl. start-up %.1f s)"
                       % (len(jobs), n_steps, cores, wall)}
 
@@ -737,7 +754,7 @@ def main():
                 "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": traffic,
                 "step_traffic": cp["step_traffic"],  # every kernel of the PMC pass / its steps, corrected like `traffic` (profiles/pmc_latest*.json)
                 "step_traffic_steps_only": cp["step_traffic_steps_only"],  # ... without the kernels that run once per pass (set_map)
-                "traffic_source": src_note, "dominant_kernel": cp["dominant"],
+                "traffic_source": src_note, "dominant_kernel": cp["dominant"], "critical_kernel": cp["critical"],
                 "bytes_per_launch": int(alg_bytes),
                 "bytes_note": "what a launch has to READ: float4 of the VoI-resident part + {x,y} pairs (8 B) of the outskirts chunks whose bounding "
                               "box meets the VoI circle + a 32-byte record per outskirts chunk + masks; chunks outside the circle are skipped by "
@@ -793,10 +810,10 @@ def main():
         first.lookahead = True
 
     # ---- CPU baseline: the reference's own sources (oracle/_ref) and the oracle port, one thread, bounded sample ----
-    cpu = cpu_port = None
+    cpu = cpu_refsrc = None
     parity = {"parity_checked_steps": 0, "parity": "not checked in this run (no CPU leg)"}
     if world_size == 1 and not args.no_cpu_baseline and args.mode == "replicas":
-        cpu, cpu_port, parity = cpu_baseline(args, P, m, first, l2b7, step_results, gpu_final)
+        cpu, cpu_refsrc, parity = cpu_baseline(args, P, m, first, l2b7, step_results, gpu_final)
     elif world_size == 1 and not args.no_cpu_baseline:
         cpu = cpu_sequence_parallel(args, seqs, maps, l2b7)
 
@@ -845,6 +862,9 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "repeats": len(pass_s),
         "ms_per_step_min": round(min(pass_s) / max(K * len(seqs), 1) * 1e3, 4), "ms_per_step_max": round(max(pass_s) / max(K * len(seqs), 1) * 1e3, 4),
         "ms_per_step_all": [round(e_ / max(K * len(seqs), 1) * 1e3, 4) for e_ in pass_s],
+        # (rounds 1-4 reported ONE pass -- this is that pass, the first K steps behind the warm-up; cross-round comparisons of the
+        # headline should say which of the two statistics they use)
+        "ms_per_step_first_pass": round(pass_s[0] / max(K * len(seqs), 1) * 1e3, 4),
         "repeats_note": "the K-step timed pass (barrier + device synchronisation on both sides, MAX over ranks) run `repeats` times in this one "
                         "invocation, the sequence continuing from pass to pass; ms_per_step / value are the median pass",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -870,12 +890,13 @@ def main():
                              "K steps between two device synchronisations) also pays for draining the query chains of the nodes announced beyond "
                              "the last timed step, once per pass",
         # round 5: steps whose split / chunk scan / gather / bucket table were launched beside the previous step's per-bin launch, and how many
-        # of them the step took (the library overlaps where it pays: dense bins, ERASOR_HIP_OVERLAP unset = auto, 1 = always, 0 = never)
-        "overlapped_steps": dict(zip(("launched_ahead", "taken"), g.overlap_counts()), mode=os.environ.get("ERASOR_HIP_OVERLAP", "auto")),
+        # of them the step took (ERASOR_HIP_OVERLAP unset = the handle measures both modes and keeps the faster, 1 = always, 0 = never)
+        "overlapped_steps": dict(zip(("launched_ahead", "taken"), g.overlap_counts()), mode=os.environ.get("ERASOR_HIP_OVERLAP", "auto"),
+                                 auto=dict(zip(("mode_now", "plain_period_us", "overlapped_period_us"), g.overlap_auto()))),
         # round 6: sets of launches shared by the query chains of several announced nodes, and the chains that went into them
         "shared_chain_launches": dict(zip(("sets", "chains"), g.chain_batch_counts())),
         "pr_rr": pr_rr, "callback_path": callback,
-        "roofline": roofline, "cpu_baseline": cpu, "cpu_port": cpu_port, "host": host_identity(),
+        "roofline": roofline, "cpu_baseline": cpu, "cpu_reference_sources": cpu_refsrc, "host": host_identity(),
         "parity_checked_steps": parity["parity_checked_steps"], "parity": parity.get("parity"), "final_map_checked": parity.get("final_map_checked", False),
         "rccl_ranks": rccl_ranks, "backend": backend if dist is not None else None,
         "per_rank": [{"rank": i, "steps": int(v[0]), "map_rejected": int(v[1]), "reverted_bins": int(v[2]), "final_map_points": int(v[3]),
@@ -907,7 +928,7 @@ def main():
         )
         for wname, label, xargs, xenv, verified in passes:
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", wname, "--steps", "12" if verified else "20", "--warmup",
-                   "3" if verified else "5", "--no-extra-workloads", "--no-pr-rr", "--no-callback-bench", "--repeats", "1" if verified else "3"] + xargs
+                   "3" if verified else "5", "--no-extra-workloads", "--no-pr-rr", "--no-callback-bench", "--repeats", "1" if verified else "7"] + xargs
             if not verified:
                 cmd.append("--no-cpu-baseline")
             t_sub = time.time()
@@ -924,7 +945,7 @@ def main():
                               "is_large_scale": d["config"].get("is_large_scale"), "lookahead_scans": d["config"].get("lookahead_scans"),
                               "environment": xenv,
                               "parity_checked_steps": d.get("parity_checked_steps"), "final_map_checked": d.get("final_map_checked"),
-                              "cpu_baseline": d.get("cpu_baseline"), "cpu_port": d.get("cpu_port"),
+                              "cpu_baseline": d.get("cpu_baseline"), "cpu_reference_sources": d.get("cpu_reference_sources"),
                               "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "avg_launch_us",
                                                                   "launches", "step_alg_bytes", "step_achieved", "step_frac", "needed_bytes",
                                                                   "time_target_us")},

@@ -424,6 +424,12 @@ class Erasor:
         self._check(lib().erasor_hip_overlap_counts(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def overlap_auto(self):
+        """(mode the next step will use: 1 overlapped / 0 plain, period measured plain, period measured overlapped [us; 0: not yet])"""
+        m, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
+        self._check(lib().erasor_hip_overlap_auto(self._h, C.byref(m), C.byref(a), C.byref(b)))
+        return m.value, a.value, b.value
+
     def chain_batch(self, n_scans, lead=3):
         """the query chains of `n_scans` announced nodes share one set of launches (erasor_hip_chain_batch); 1: every chain on its own"""
         self._check(lib().erasor_hip_chain_batch(self._h, C.c_int(n_scans), C.c_int(lead)))

@@ -198,7 +198,21 @@ struct erasor_hip_handle {
     DBuf<unsigned long long> lab_slots;  // [16][8] label tallies of the assemble kernels (one cache line per slot)
     double tm_span = 0, tm_gap = 0, tm_period = 0;  // erasor_hip_chain_timing: sums in microseconds
     unsigned long long tm_last_open = 0;
-    uint64_t tm_n = 0, tm_ngap = 0;
+    uint64_t tm_n = 0, tm_ngap = 0, tm_nper = 0;
+    // ERASOR_HIP_OVERLAP unset: the handle decides by measurement whether consecutive steps overlap (round 5 had a threshold fitted to the
+    // five bench workloads here).  The period of a step -- end to end on the device's own clock, consecutive steps only -- is sampled in
+    // the mode in use; once OVA_W samples are in, the other mode gets OVA_W steps of its own (the first OVA_SKIP after a change of mode
+    // are not counted), and the mode with the shorter period (mean of the lower three quarters of its samples; plain has to win by 2 %)
+    // runs on.  Both are measured again every OVA_AGAIN steps: a sequence changes (denser map, other bins).  Results never depend on it.
+    struct OvAuto {
+        int mode = 1;            // 1: overlapped, 0: plain
+        int skip = 8;            // samples still to be ignored (start-up, a change of mode)
+        int n[2] = {0, 0};
+        double s[2][16];
+        double est[2] = {0, 0};  // 0: not measured
+        unsigned long long since_decision = 0;
+        bool decided = false;
+    } ova;
     unsigned long long tm_last_end = 0, tm_last_seq = 0;
     unsigned long long step_seq = 0;  // steps issued so far (k_step_end echoes it into the pinned block)
     // a step that has been enqueued (erasor_hip_step_async) and not collected yet (erasor_hip_step_wait)
@@ -1809,6 +1823,7 @@ static inline void cpu_relax() {
 }
 // ERASOR_HIP_OVERLAP unset: does overlapping consecutive steps pay on this handle's workload?  See the definition of OvAuto.
 static bool overlap_auto(erasor_hip_handle *h, uint32_t ns);
+static void overlap_auto_sample(erasor_hip_handle *h, double period_us);
 static int step_collect(erasor_hip_handle *h, erasor_step_result *res);
 // First half of a step: everything is ENQUEUED (this scan's query chain unless it is in flight already, the map chain, Scan Ratio
 // Test .. write-back, k_step_end, the next step's VoI split and the next announced scan's query chain); nothing is waited for.
@@ -2487,8 +2502,43 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     return ERASOR_OK;
 }
 
-// (until measured otherwise: where the per-bin launch is long -- dense bins -- and the scans of ordinary size; MEASUREMENTS)
-static bool overlap_auto(erasor_hip_handle *h, uint32_t ns) { return (uint64_t)h->last_n_voi >= 500ull * h->B && ns <= 160000u; }
+// (see erasor_hip_handle::OvAuto)
+static constexpr int OVA_W = 8, OVA_SKIP = 3;
+static constexpr unsigned long long OVA_AGAIN = 600;
+static bool overlap_auto(erasor_hip_handle *h, uint32_t) { return h->ova.mode != 0; }
+static void overlap_auto_sample(erasor_hip_handle *h, double period_us) {
+    auto &a = h->ova;
+    ++a.since_decision;
+    if (a.skip > 0) {
+        --a.skip;
+        return;
+    }
+    if (a.decided) {
+        if (a.since_decision >= OVA_AGAIN) {  // measure both again, the mode in use first
+            a.decided = false;
+            a.n[0] = a.n[1] = 0;
+            a.est[0] = a.est[1] = 0;
+        }
+        return;
+    }
+    const int m = a.mode;
+    if (a.n[m] < OVA_W) a.s[m][a.n[m]++] = period_us;
+    if (a.n[m] < OVA_W) return;
+    std::sort(a.s[m], a.s[m] + OVA_W);
+    double sum = 0;
+    const int keep = OVA_W * 3 / 4;
+    for (int i = 0; i < keep; ++i) sum += a.s[m][i];
+    a.est[m] = sum / keep;
+    if (a.est[m ^ 1] == 0) {  // the other mode's turn
+        a.mode = m ^ 1;
+        a.skip = OVA_SKIP;
+        return;
+    }
+    a.mode = (a.est[0] * 1.02 < a.est[1]) ? 0 : 1;
+    if (a.mode != m) a.skip = OVA_SKIP;
+    a.decided = true;
+    a.since_decision = 0;
+}
 
 // Second half: wait for the step's results (k_step_end's last store into the pinned block is the step's number), commit the host
 // mirror of the map store, report.  A VoxelGrid pass-through flip re-runs the step here, synchronously.
@@ -2528,10 +2578,17 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
         const unsigned long long t_open = h->st.t_open, t_end = h->pin->t_end;
         if (t_end > t_open) {
             h->tm_span += (double)(t_end - t_open) * 0.01;
-            if (h->tm_last_end && t_open > h->tm_last_end && h->tm_last_seq + 1 == step_seq) {
-                h->tm_gap += (double)(t_open - h->tm_last_end) * 0.01;
-                h->tm_period += (double)(t_open - h->tm_last_open) * 0.01;  // chunk scan to chunk scan: the main stream's period
-                ++h->tm_ngap;
+            if (h->tm_last_end && h->tm_last_seq + 1 == step_seq) {
+                if (t_open > h->tm_last_end) {  // (not for an overlapped step: its chunk scan ran beside the step before it)
+                    h->tm_gap += (double)(t_open - h->tm_last_end) * 0.01;
+                    ++h->tm_ngap;
+                }
+                if (t_end > h->tm_last_end) {
+                    const double per = (double)(t_end - h->tm_last_end) * 0.01;  // end of a step to the end of the next: the period
+                    h->tm_period += per;
+                    ++h->tm_nper;
+                    overlap_auto_sample(h, per);
+                }
             }
             ++h->tm_n;
         }
@@ -3538,11 +3595,11 @@ int erasor_hip_chain_timing(erasor_hip_handle *h, double *main_chain_us, double 
     if (!h) return ERASOR_E_INVALID;
     if (main_chain_us) *main_chain_us = h->tm_n ? h->tm_span / (double)h->tm_n : 0.0;
     if (between_steps_us) *between_steps_us = h->tm_ngap ? h->tm_gap / (double)h->tm_ngap : 0.0;
-    if (period_us) *period_us = h->tm_ngap ? h->tm_period / (double)h->tm_ngap : 0.0;
+    if (period_us) *period_us = h->tm_nper ? h->tm_period / (double)h->tm_nper : 0.0;
     if (steps) *steps = h->tm_n;
     if (reset) {
         h->tm_span = h->tm_gap = h->tm_period = 0;
-        h->tm_n = h->tm_ngap = 0;
+        h->tm_n = h->tm_ngap = h->tm_nper = 0;
         h->tm_last_end = 0;
     }
     return ERASOR_OK;
@@ -3591,6 +3648,13 @@ int erasor_hip_overlap_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t
     if (!h || !launched || !used) return ERASOR_E_INVALID;
     *launched = h->n_ov_launched;
     *used = h->n_ov_used;
+    return ERASOR_OK;
+}
+int erasor_hip_overlap_auto(erasor_hip_handle *h, int *mode, double *plain_period_us, double *overlapped_period_us) {
+    if (!h) return ERASOR_E_INVALID;
+    if (mode) *mode = h->ova.mode;
+    if (plain_period_us) *plain_period_us = h->ova.est[0];
+    if (overlapped_period_us) *overlapped_period_us = h->ova.est[1];
     return ERASOR_OK;
 }
 int erasor_hip_chain_batch(erasor_hip_handle *h, int n_scans, int lead) {

@@ -317,6 +317,10 @@ int erasor_hip_ahead_split_counts(erasor_hip_handle *h, uint64_t *launched, uint
 int erasor_hip_announce_origin2body(erasor_hip_handle *h, const float T_origin2body[16]);
 /* steps whose early passes were launched ahead like that / steps that took them */
 int erasor_hip_overlap_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t *used);
+/* ERASOR_HIP_OVERLAP unset: the handle decides by measurement (period of a step on the device's clock, a few steps in either mode, again
+ * every 600 steps) whether consecutive steps overlap.  *mode: 1 overlapped, 0 plain -- what the next step will use; the two periods the
+ * last decision compared, in microseconds (0: not measured yet). */
+int erasor_hip_overlap_auto(erasor_hip_handle *h, int *mode, double *plain_period_us, double *overlapped_period_us);
 /* Round 6 -- the query chains of SEVERAL announced nodes as one set of launches.  A node's query chain (voxelize_preserving_labels of
  * its scan, OfflineMapUpdater.cpp:237-241; lidar->body, R-POD keys, per-bin statistics, erasor.cpp:100-115) does not depend on the map,
  * and every launch of it is bound by latency, not by work: a launch that serves the same stage of n_scans scans costs what it costs for

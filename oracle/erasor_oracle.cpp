@@ -4,17 +4,23 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file.
 // The product (erasor_amd/csrc, liberasor_hip.so) never links, imports or calls it.
 //
-// Parity status: every line of REFERENCE-OWNED logic restated here (erasor.cpp, erasor_utils.cpp,
-// OfflineMapUpdater.cpp hot path, mapgen.hpp via oracle/orc.py) is pinned bit-for-bit against the reference's own
-// sources: oracle/ref.mk compiles them UNMODIFIED against stand-in ros/pcl/Eigen/tf headers (oracle/stubs/) into
-// oracle/_ref/liberasor_ref.so, and tests/test_oracle_vs_ref.py demands identical clouds, R-POD tables, SRT status,
-// plane normals and label counters on every scenario of the GPU suite; tests/golden/ref_*.npz freeze _ref's outputs.
-// What is still "restated, unpinned" is exactly oracle/third_party_restated.h — the third-party arithmetic the
-// reference calls but does not vendor (PCL 1.8.1 transformPointCloud / computeMeanAndCovarianceMatrix / VoxelGrid,
-// Eigen 3.3.4 JacobiSVD 3x3 / dense products / Matrix4f::inverse, tf Quaternion -> Matrix3x3; versions = Ubuntu
-// 18.04 / ROS Melodic, README.md:41-43, CMakeLists.txt:36 only asks for PCL >= 1.7, no lockfile) — shared by this
-// file and by the stubs, plus libstdc++ std::sort (the real one is called on both sides) and the exact 1-NN
-// (implemented twice: voxel-grid search here, exact kd-tree in the stub; ties -> lowest index on both).
+// Parity status: **PARITY UNPINNED** in the task's sense.  The reference ships no tests, golden vectors or fixtures for this path, and its
+// own build needs ROS, PCL, Eigen, tf and Boost -- none of them in this image --, so by the task's rules the reference is UNBUILDABLE here:
+// a build against stand-ins for the headers it lacks does not count as the reference, and nothing below claims it does.
+// What exists instead, and what it is worth (round-1 review asked for it; kept as a CROSS-CHECK, labelled as such everywhere):
+//   * oracle/ref.mk compiles the reference's own source text (erasor.cpp, erasor_utils.cpp, OfflineMapUpdater.cpp, mapgen.hpp) UNMODIFIED,
+//     where it lies, against stand-in ros / pcl / Eigen / tf headers (oracle/stubs/, our own minimal types) into oracle/_ref/, and
+//     tests/test_oracle_vs_ref.py demands bit-identical clouds, R-POD tables, SRT status, plane normals and label counters between that and
+//     this file on every scenario of the GPU suite; tests/golden/ref_*.npz freeze its outputs.  This checks the restatement of every line
+//     of REFERENCE-OWNED control flow and arithmetic (the Scan Ratio Test, R-GPF's bookkeeping, fetch_VoI, the assembly order ...);
+//   * it checks NOTHING about the third-party arithmetic: oracle/third_party_restated.h (PCL 1.8.1 transformPointCloud /
+//     computeMeanAndCovarianceMatrix / VoxelGrid, Eigen 3.3.4 JacobiSVD 3x3 / dense products / Matrix4f::inverse, tf Quaternion ->
+//     Matrix3x3; versions = Ubuntu 18.04 / ROS Melodic, README.md:41-43; CMakeLists.txt:36 only asks for PCL >= 1.7, no lockfile) is
+//     shared by this file and by the stand-ins, so agreement there is a tautology.  That part is restated from the libraries' published
+//     algorithms and has its own known-answer tests (tests/test_oracle_known_answers.py); libstdc++'s std::sort is the real one on
+//     both sides; the exact 1-NN is implemented twice (voxel-grid search here, exact kd-tree in the stand-in; ties -> lowest index);
+//   * the only part pinned to the REAL reference is the PR / RR evaluator: scripts/analysis_runner.py is imported from /root/reference
+//     by tests/golden/make_eval_golden.py and erasor_amd/evalmap.py must reproduce its numbers (tests/test_evalmap.py).
 //
 // Reference citations use these short names (paths under /root/reference):
 //   erasor.h   = include/erasor/erasor.h

@@ -1,8 +1,10 @@
 # oracle/ref.mk — builds oracle/_ref/liberasor_ref.so: the reference's OWN hot-path sources, compiled
 # UNMODIFIED from where they lie under /root/reference, against the stand-in headers in oracle/stubs/
 # (ros / pcl / Eigen / tf are not installed; their arithmetic delegates to oracle/third_party_restated.h).
-# TEST INFRASTRUCTURE ONLY: tests/test_oracle_vs_ref.py pins oracle/erasor_oracle.cpp to this library,
-# bench.py's cpu_baseline may time it (kind "reference").  Outputs go to oracle/_ref/ only (git-ignored,
+# NOT A REFERENCE BUILD in the task's sense (the reference needs ROS / PCL / Eigen / tf, which this image lacks: unbuildable here) -- a
+# CROSS-CHECK of the oracle's restatement of the reference-owned logic, see the header of erasor_oracle.cpp.
+# TEST INFRASTRUCTURE ONLY: tests/test_oracle_vs_ref.py compares oracle/erasor_oracle.cpp with this library,
+# bench.py times it beside the oracle (cpu_reference_sources; cpu_baseline is the oracle port).  Outputs go to oracle/_ref/ only (git-ignored,
 # travels to the GPU box as a prebuilt file; /root/reference does not exist there).
 # Flags follow the reference's build: no -march (CMakeLists.txt:4), so no FMA contraction.
 # -fno-gnu-unique: oracle/ref.py loads one private copy of the library per object; GNU_UNIQUE symbols (statics of

@@ -934,6 +934,66 @@ def test_alternative_launch_paths_keep_parity(gpu_mod, tmp_path, env):
     assert out.returncode == 0 and "ALT-PATH-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+AUTO_FLIP_WORKER = """
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r + "/tests")
+import os
+os.environ.pop("ERASOR_HIP_OVERLAP", None)  # (the suite forces the overlap: here the handle decides)
+import erasor_amd
+if os.environ.get("ERASOR_TEST_SIMT_LIB"):
+    erasor_amd.LIB_PATH = os.environ["ERASOR_TEST_SIMT_LIB"]
+    erasor_amd._lib = None
+import scenarios
+import test_gpu_parity as T
+from oracle import orc
+sc = scenarios.small()
+g = erasor_amd.Erasor(scenarios.to_product_params(sc["params"]))
+o = orc.Oracle(sc["params"])
+g.set_map(sc["map"])
+o.set_map(sc["map"])
+nf = len(sc["scans"])
+order = [k %% nf if (k // nf) %% 2 == 0 else nf - 1 - k %% nf for k in range(int(os.environ.get("AUTO_FLIP_STEPS", "44")))]  # down the street and back
+scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"]]
+LA = 2
+for j in range(LA):
+    g.prefetch(scans[order[j]], sc["T_l2b"], sc["T_b2o"][order[j]], sc["T_o2b"][order[j]])
+modes = []
+for k, f in enumerate(order):
+    if k + LA < len(order):
+        f2 = order[k + LA]
+        g.prefetch(scans[f2], sc["T_l2b"], sc["T_b2o"][f2], sc["T_o2b"][f2])
+    rg = g.step(scans[f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+    ro = o.step(scans[f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+    T.compare_step(g, o, rg, ro, full=(k %% 5 == 0))  # (the dynamic-point mask's indices at every step: what ADVICE r05 saw go wrong)
+    modes.append(g.overlap_auto()[0])
+m, p_plain, p_ov = g.overlap_auto()
+launched, taken = g.overlap_counts()
+print("AUTO-FLIP-OK", "modes", "".join(str(x) for x in modes), "periods", round(p_plain, 1), round(p_ov, 1), "overlapped steps", launched, taken)
+assert 0 in modes and 1 in modes and p_plain > 0 and p_ov > 0, (modes, p_plain, p_ov)
+assert 0 < taken < len(order)
+"""
+
+
+def test_the_handle_decides_between_overlapped_and_plain_steps_midway(gpu_mod, tmp_path):
+    """ERASOR_HIP_OVERLAP unset (round 6): the handle measures a few steps overlapped, a few plain, keeps the faster -- so the layout of the
+    VoI-resident region (reserved / dense) and the stream that runs the next step's passes change IN THE MIDDLE of a sequence, with passes
+    launched ahead pending.  ADVICE r05 (high): a step that took passes launched ahead and then wrote the dense layout reported wrong
+    indices in its dynamic-point mask; since round 6 a step that does not write the reserved layout runs its own passes.  Every step of a
+    sequence that crosses both changes against the oracle, in a process of its own (the switch is read once)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "auto_flip_worker.py"
+    script.write_text(AUTO_FLIP_WORKER % (root, root))
+    env = dict(os.environ)
+    if os.environ.get("ERASOR_TEST_SIMT_LIB"):
+        pytest.skip("44 steps: an hour on the CPU stand-in (tools/simt_check.sh runs it with AUTO_FLIP_STEPS)")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0 and "AUTO-FLIP-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 # ---------------------------------------------------------------------------------------------
 # round 5: the holes the bench's own line printed (other_workloads passes with parity_checked_steps == 0), ADVICE r04
 # ---------------------------------------------------------------------------------------------
