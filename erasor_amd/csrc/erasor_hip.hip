@@ -201,17 +201,18 @@ struct erasor_hip_handle {
     uint64_t tm_n = 0, tm_ngap = 0, tm_nper = 0;
     // ERASOR_HIP_OVERLAP unset: the handle decides by measurement whether consecutive steps overlap (round 5 had a threshold fitted to the
     // five bench workloads here).  The period of a step -- end to end on the device's own clock, consecutive steps only -- is sampled in
-    // the mode in use; once OVA_W samples are in, the other mode gets OVA_W steps of its own (the first OVA_SKIP after a change of mode
-    // are not counted), and the mode with the shorter period (mean of the lower three quarters of its samples; plain has to win by 2 %)
-    // runs on.  Both are measured again every OVA_AGAIN steps: a sequence changes (denser map, other bins).  Results never depend on it.
+    // blocks: plain, overlapped, overlapped, plain (OVA_W samples each; a sequence drifts -- its first steps revert more bins --, and
+    // this order cancels a linear drift; the first OVA_SKIP samples after a change of mode are not counted), and the mode with the
+    // shorter mean period runs on (plain has to lose by 2 %).  Measured again every OVA_AGAIN steps.  Results never depend on it.
     struct OvAuto {
-        int mode = 1;            // 1: overlapped, 0: plain
-        int skip = 8;            // samples still to be ignored (start-up, a change of mode)
-        int n[2] = {0, 0};
-        double s[2][16];
-        double est[2] = {0, 0};  // 0: not measured
+        int mode = 0;            // 1: overlapped, 0: plain -- what the next step uses
+        int block = 0;           // 0..3: the block being sampled (modes 0 1 1 0); 4: decided
+        int skip = 4;            // samples still to be ignored (start-up, a change of mode)
+        int n = 0;               // samples of the current block
+        double sum[2] = {0, 0};
+        int cnt[2] = {0, 0};
+        double est[2] = {0, 0};  // the last decision's mean periods (0: not measured)
         unsigned long long since_decision = 0;
-        bool decided = false;
     } ova;
     unsigned long long tm_last_end = 0, tm_last_seq = 0;
     unsigned long long step_seq = 0;  // steps issued so far (k_step_end echoes it into the pinned block)
@@ -1244,6 +1245,11 @@ static void worker_stop(erasor_hip_handle *h) {
     delete h->worker;
     h->worker = nullptr;
 }
+// ERASOR_HIP_OVERLAP: 1 = consecutive steps overlap wherever they can, 0 = never, unset = the handle decides by measurement (OvAuto)
+static bool overlap_wanted(const erasor_hip_handle *h) {
+    static const int overlap_env = getenv("ERASOR_HIP_OVERLAP") && getenv("ERASOR_HIP_OVERLAP")[0] ? atoi(getenv("ERASOR_HIP_OVERLAP")) : -1;
+    return overlap_env >= 0 ? overlap_env != 0 : h->ova.mode != 0;
+}
 static int flush_held(erasor_hip_handle *h);
 // the launches (and event records) of side `side`'s chain have all been made; side < 0: of every side
 static int chain_wait(erasor_hip_handle *h, int side) {
@@ -1636,7 +1642,10 @@ static int flush_announced(erasor_hip_handle *h) {
     h->ann.valid = false;
     int in_front = 0, n_held = 0;
     for (int j = 0; j < h->npend; ++j) (h->q[h->pend[j]].held ? n_held : in_front) += 1;
-    const bool may_hold = h->batch_n >= 2 && in_front >= h->batch_lead;
+    // (only while the steps overlap: the early passes then take the third query stream and two chains in flight bound the step -- shared
+    // launches halve a chain's queue time; plain steps have three query streams, where holding a chain back only delays it: 9.8 M-point
+    // map 0.190 ms per scan alone, 0.196 in sets of two, MEASUREMENTS R6)
+    const bool may_hold = h->batch_n >= 2 && in_front >= h->batch_lead && overlap_wanted(h);
     if (n_held && !may_hold) {  // (keeps the queues in announcement order)
         const int rc_h = flush_held(h);
         if (rc_h) return rc_h;
@@ -1822,7 +1831,6 @@ static inline void cpu_relax() {
 #endif
 }
 // ERASOR_HIP_OVERLAP unset: does overlapping consecutive steps pay on this handle's workload?  See the definition of OvAuto.
-static bool overlap_auto(erasor_hip_handle *h, uint32_t ns);
 static void overlap_auto_sample(erasor_hip_handle *h, double period_us);
 static int step_collect(erasor_hip_handle *h, erasor_step_result *res);
 // First half of a step: everything is ENQUEUED (this scan's query chain unless it is in flight already, the map chain, Scan Ratio
@@ -2000,8 +2008,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     const bool srt_in_revert = st1_ahead && h->prof != 1;
     // round 5: the RESERVED layout (srt4_body): the write-back of everything but the reverted bins does not wait for the per-bin launch.
     // ERASOR_HIP_OVERLAP: 1 = always, 0 = never, unset = the handle decides (overlap_pays).
-    static const int overlap_env = getenv("ERASOR_HIP_OVERLAP") && getenv("ERASOR_HIP_OVERLAP")[0] ? atoi(getenv("ERASOR_HIP_OVERLAP")) : -1;
-    const bool overlap_pays = overlap_env >= 0 ? overlap_env != 0 : overlap_auto(h, ns);
+    const bool overlap_pays = overlap_wanted(h);
     // (decided BEFORE the map chain: a step that does not write the reserved layout must not take passes launched ahead on the assumption
     // that it would -- their VoI-order source indices count reserved slots, which only the reserved write-back converts)
     const bool reserved = srt_in_revert && fold && mb_count && !flags && overlap_pays;
@@ -2503,40 +2510,45 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
 }
 
 // (see erasor_hip_handle::OvAuto)
-static constexpr int OVA_W = 8, OVA_SKIP = 3;
+static constexpr int OVA_W = 4, OVA_SKIP = 3;
 static constexpr unsigned long long OVA_AGAIN = 600;
-static bool overlap_auto(erasor_hip_handle *h, uint32_t) { return h->ova.mode != 0; }
 static void overlap_auto_sample(erasor_hip_handle *h, double period_us) {
     auto &a = h->ova;
-    ++a.since_decision;
+    static const int block_mode[4] = {0, 1, 1, 0};
+    if (a.block >= 4) {  // decided: measure again after a while
+        if (++a.since_decision >= OVA_AGAIN) {
+            a.block = 0;
+            a.n = 0;
+            a.sum[0] = a.sum[1] = 0;
+            a.cnt[0] = a.cnt[1] = 0;
+            if (a.mode != block_mode[0]) {
+                a.mode = block_mode[0];
+                a.skip = OVA_SKIP;
+            }
+        }
+        return;
+    }
     if (a.skip > 0) {
         --a.skip;
         return;
     }
-    if (a.decided) {
-        if (a.since_decision >= OVA_AGAIN) {  // measure both again, the mode in use first
-            a.decided = false;
-            a.n[0] = a.n[1] = 0;
-            a.est[0] = a.est[1] = 0;
+    a.sum[a.mode] += period_us;
+    ++a.cnt[a.mode];
+    if (++a.n < OVA_W) return;
+    a.n = 0;
+    ++a.block;
+    if (a.block < 4) {
+        if (block_mode[a.block] != a.mode) {
+            a.mode = block_mode[a.block];
+            a.skip = OVA_SKIP;
         }
         return;
     }
-    const int m = a.mode;
-    if (a.n[m] < OVA_W) a.s[m][a.n[m]++] = period_us;
-    if (a.n[m] < OVA_W) return;
-    std::sort(a.s[m], a.s[m] + OVA_W);
-    double sum = 0;
-    const int keep = OVA_W * 3 / 4;
-    for (int i = 0; i < keep; ++i) sum += a.s[m][i];
-    a.est[m] = sum / keep;
-    if (a.est[m ^ 1] == 0) {  // the other mode's turn
-        a.mode = m ^ 1;
-        a.skip = OVA_SKIP;
-        return;
-    }
-    a.mode = (a.est[0] * 1.02 < a.est[1]) ? 0 : 1;
-    if (a.mode != m) a.skip = OVA_SKIP;
-    a.decided = true;
+    a.est[0] = a.sum[0] / a.cnt[0];
+    a.est[1] = a.sum[1] / a.cnt[1];
+    const int m = (a.est[1] * 1.02 < a.est[0]) ? 1 : 0;
+    if (m != a.mode) a.skip = OVA_SKIP;
+    a.mode = m;
     a.since_decision = 0;
 }
 

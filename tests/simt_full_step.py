@@ -1,8 +1,11 @@
 """Helper of tests/test_full_step_on_cpu.py (run as a subprocess): drives the library built by that test -- the product's
 erasor_hip.hip + kernels compiled unmodified against tests/cpp/simt_emu -- through the ctypes wrapper and compares every
 step with the oracle.  TEST INFRASTRUCTURE: the product never loads this library (erasor_amd.lib() loads liberasor_hip.so only)."""
+import os
 import sys
 import time
+
+os.environ.setdefault("ERASOR_HIP_OVERLAP", "1")  # (like tests/conftest.py: the path with the most moving parts)
 
 import numpy as np
 

@@ -896,8 +896,8 @@ for version in (3, 2):
     sets, chains = g.chain_batch_counts()
     if os.environ.get("ALT_PROFILE_ALL") or os.environ.get("ERASOR_HIP_DEBUG_SYNC") or os.environ.get("ALT_CHAIN_BATCH") == "1":
         assert sets == 0, (sets, chains)      # (profiled / synchronised launch by launch, or told not to: every chain on its own)
-    else:
-        assert sets >= 1 and chains >= 2 * sets, (sets, chains)
+    elif os.environ.get("ERASOR_HIP_OVERLAP") == "1" and version == 3:
+        assert sets >= 1 and chains >= 2 * sets, (sets, chains)  # (chains are held back for shared launches while the steps overlap)
     t = erasor_amd.replicate_map([g], 0)  # a communicator of one; ERASOR_HIP_NO_RCCL=1: the peer-copy path
     assert (t == 2) if os.environ.get("ERASOR_HIP_NO_RCCL") else (t in (1, 2)), t
     assert np.array_equal(g.get_map().view(np.uint32), o.get_map().view(np.uint32)), "map after replicate_map"
