@@ -2218,7 +2218,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                    (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p, (const float4 *)h->vox_out.p, (const uint32_t *)h->out_offR.p,
                    (const uint32_t *)h->rev_before.p, (const uint32_t *)h->ng.p);
         MARK("  assemble early");
-        (void)hipEventRecord(h->ev_asm, h->bstream);
+        if (!ov_next) (void)hipEventRecord(h->ev_asm, h->bstream);  // (an overlapped step joins at ev_early: one packet less on the early chain)
         MARK("  ev_asm record");
         if (ov_next) {
             const QSide &nq_ = h->q[nxt_side];
