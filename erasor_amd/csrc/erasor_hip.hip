@@ -231,6 +231,7 @@ struct erasor_hip_handle {
         uint32_t nchunks = 0;     // chunk count of the step's own VoI pass (grid hint of a split launched ahead later)
         bool spec_launched = false;
         bool reserved = false;    // the write-back uses the reserved layout (round 5)
+        bool deep = false;        // the caller had announced at least batch_lead nodes beyond this step (OvAuto samples only such steps)
     } fly;
     HostOut *pin = nullptr;         // pinned host block k_step_end reports into
     int bank = 0;                   // scratch bank of scan/radix helpers (0: query chains, 1: map chain)
@@ -1245,10 +1246,17 @@ static void worker_stop(erasor_hip_handle *h) {
     delete h->worker;
     h->worker = nullptr;
 }
-// ERASOR_HIP_OVERLAP: 1 = consecutive steps overlap wherever they can, 0 = never, unset = the handle decides by measurement (OvAuto)
-static bool overlap_wanted(const erasor_hip_handle *h) {
-    static const int overlap_env = getenv("ERASOR_HIP_OVERLAP") && getenv("ERASOR_HIP_OVERLAP")[0] ? atoi(getenv("ERASOR_HIP_OVERLAP")) : -1;
-    return overlap_env >= 0 ? overlap_env != 0 : h->ova.mode != 0;
+// ERASOR_HIP_OVERLAP: 1 = consecutive steps overlap wherever they can, 0 = never, unset = the handle decides: by measurement (OvAuto), and
+// only for a caller that announces DEEP -- at least `batch_lead` nodes beyond the step's own.  Overlapped steps leave the query chains two
+// streams, which is enough only when the chains share their launches, and chains are held back for that only with `batch_lead` of them
+// in their queues in front (flush_announced): a callback that announces one or two nodes ahead gets plain steps and three query
+// streams (0.19 against 0.20-0.21 ms per scan with two ahead; the drop-in path's callback_next_announced_ms 0.42 against 0.50).
+static int overlap_env() {
+    static const int v = getenv("ERASOR_HIP_OVERLAP") && getenv("ERASOR_HIP_OVERLAP")[0] ? atoi(getenv("ERASOR_HIP_OVERLAP")) : -1;
+    return v;
+}
+static bool overlap_wanted(const erasor_hip_handle *h, int announced_beyond) {
+    return overlap_env() >= 0 ? overlap_env() != 0 : (h->ova.mode != 0 && announced_beyond >= h->batch_lead);
 }
 static int flush_held(erasor_hip_handle *h);
 // the launches (and event records) of side `side`'s chain have all been made; side < 0: of every side
@@ -1616,8 +1624,7 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     } else {
         chain_stream_waits(h, q, qstream);
         // (round 6: a chain the step needs AT ONCE -- its own scan, not announced ahead -- is launched right here: handing it to the worker
-        // and waiting for the worker's event records put a thread wake-up, 20-30 us, in front of every un-announced step: what
-        // ms_per_step_without_lookahead lost between rounds 4 and 5, 0.402 -> 0.436 ms)
+        // only to wait for the worker's event records puts a thread wake-up in front of the step)
         const bool to_worker = h->worker && common && staged != 0;
         ChainJob cj{h, side, qstream, ns, prevox, passthrough, to_worker, {0}};
         memcpy(cj.Tl, T_l2b, sizeof(cj.Tl));
@@ -1648,7 +1655,7 @@ static int flush_announced(erasor_hip_handle *h) {
     // (only while the steps overlap: the early passes then take the third query stream and two chains in flight bound the step -- shared
     // launches halve a chain's queue time; plain steps have three query streams, where holding a chain back only delays it: 9.8 M-point
     // map 0.190 ms per scan alone, 0.196 in sets of two, MEASUREMENTS R6)
-    const bool may_hold = h->batch_n >= 2 && in_front >= h->batch_lead && overlap_wanted(h);
+    const bool may_hold = h->batch_n >= 2 && in_front >= h->batch_lead && overlap_wanted(h, in_front);
     if (n_held && !may_hold) {  // (keeps the queues in announcement order)
         const int rc_h = flush_held(h);
         if (rc_h) return rc_h;
@@ -2011,7 +2018,9 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     const bool srt_in_revert = st1_ahead && h->prof != 1;
     // round 5: the RESERVED layout (srt4_body): the write-back of everything but the reverted bins does not wait for the per-bin launch.
     // ERASOR_HIP_OVERLAP: 1 = always, 0 = never, unset = the handle decides (overlap_pays).
-    const bool overlap_pays = overlap_wanted(h);
+    const int announced_beyond = h->npend + (h->ann.valid ? 1 : 0);  // nodes announced behind this step's own
+    const bool overlap_pays = overlap_wanted(h, announced_beyond);
+    h->fly.deep = announced_beyond >= h->batch_lead;
     // (decided BEFORE the map chain: a step that does not write the reserved layout must not take passes launched ahead on the assumption
     // that it would -- their VoI-order source indices count reserved slots, which only the reserved write-back converts)
     const bool reserved = srt_in_revert && fold && mb_count && !flags && overlap_pays;
@@ -2602,7 +2611,7 @@ static int step_collect(erasor_hip_handle *h, erasor_step_result *res) {
                     const double per = (double)(t_end - h->tm_last_end) * 0.01;  // end of a step to the end of the next: the period
                     h->tm_period += per;
                     ++h->tm_nper;
-                    overlap_auto_sample(h, per);
+                    if (h->fly.deep) overlap_auto_sample(h, per);
                 }
             }
             ++h->tm_n;

@@ -956,7 +956,7 @@ o.set_map(sc["map"])
 nf = len(sc["scans"])
 order = [k %% nf if (k // nf) %% 2 == 0 else nf - 1 - k %% nf for k in range(int(os.environ.get("AUTO_FLIP_STEPS", "44")))]  # down the street and back
 scans = [np.ascontiguousarray(s, np.float32) for s in sc["scans"]]
-LA = 2
+LA = 4  # (the handle considers overlapping only for a caller that announces at least three nodes beyond the step's own)
 for j in range(LA):
     g.prefetch(scans[order[j]], sc["T_l2b"], sc["T_b2o"][order[j]], sc["T_o2b"][order[j]])
 modes = []
