@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh <tag> [bench.py args]     -> gpurun_out/profiles_<tag>/...
 # Passes (each its own process; counters never share a run with tracing, as the pool requires):
 #   1. plain bench.py (+ per-kernel HIP-event breakdown)
-#   2. timeout 240 rocprofv3 --kernel-trace --stats
+#   2. timeout 240 rocprofv3 --kernel-trace --stats   (the SAME command as pass 1: seven 20-step passes, so that the averages describe the same mix of steps)
 #   3. timeout 240 rocprofv3 --pmc FETCH_SIZE        4. timeout 240 rocprofv3 --pmc WRITE_SIZE
 TAG=${1:-run}
 shift
@@ -16,7 +16,7 @@ BENCH="timeout 300 python $ROOT/bench.py --steps 20 --warmup 5 --no-extra-worklo
 $BENCH > $OUT/bench.json 2> $OUT/bench.stderr
 $BENCH --no-cpu-baseline --profile-all --repeats 1 > /dev/null 2> $OUT/bench_kernel_breakdown.txt
 rm -rf /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -- $BENCH --no-cpu-baseline --repeats 2 > $OUT/bench_under_rocprofv3.json 2> /dev/null
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -- $BENCH --no-cpu-baseline > $OUT/bench_under_rocprofv3.json 2> /dev/null
 timeout 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/rp_fetch -- $BENCH --steps 6 --repeats 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -- $BENCH --steps 6 --repeats 1 --no-cpu-baseline > /dev/null 2>&1
 cd $ROOT && python tools/summarize_profiles.py /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write $OUT
