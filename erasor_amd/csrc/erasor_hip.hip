@@ -117,7 +117,7 @@ struct erasor_hip_handle {
     // k_voi_split / k_chunk_scan_* / k_voi_gather in overlap mode), and the events the two streams meet at
     hipStream_t bstream = nullptr;
     bool bstream_own = false;
-    hipEvent_t ev_stats = nullptr, ev_srt4 = nullptr, ev_asm = nullptr, ev_early = nullptr;
+    hipEvent_t ev_stats = nullptr, ev_srt4 = nullptr, ev_asm = nullptr, ev_early = nullptr, ev_scan = nullptr;
     unsigned n_chain = 0;
     // round 6: chains of announced scans are held back until `batch_n` of them can share one set of launches -- unless fewer than
     // `batch_lead` chains are in their queues in front of them (then latency matters more than queue time)
@@ -899,7 +899,7 @@ static bool create_sides(erasor_hip_handle *h, int prio) {
     // (events between two streams of ONE device: no system-scope fence -- the cache write-back and invalidation it brings cost the kernels
     // around it tens of microseconds)
     const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
-    for (hipEvent_t *e : {&h->ev_stats, &h->ev_srt4, &h->ev_asm, &h->ev_early})
+    for (hipEvent_t *e : {&h->ev_stats, &h->ev_srt4, &h->ev_asm, &h->ev_early, &h->ev_scan})
         if (hipEventCreateWithFlags(e, evf) != hipSuccess) return false;
     return hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) == hipSuccess;
 }
@@ -990,7 +990,7 @@ void erasor_hip_destroy(erasor_hip_handle *h) {
     release(h->alt.voi_ego); release(h->alt.voi_key); release(h->alt.voi_src); release(h->alt.moff); release(h->alt.d_st); release(h->alt.d_ctr);
     release(h->alt.spts); release(h->alt.ssrc); release(h->alt.rk_a); release(h->alt.mcnt); release(h->alt.mmin); release(h->alt.mmax); release(h->alt.st1b);
     release(h->alt.lab_slots);
-    for (hipEvent_t e : {h->ev_stats, h->ev_srt4, h->ev_asm, h->ev_early})
+    for (hipEvent_t e : {h->ev_stats, h->ev_srt4, h->ev_asm, h->ev_early, h->ev_scan})
         if (e) (void)hipEventDestroy(e);
     if (h->bstream && h->bstream_own) (void)hipStreamDestroy(h->bstream);
     release(h->nvox); release(h->ng); release(h->out_off); release(h->ground_off); release(h->rej_off); release(h->crej_off);
@@ -2266,6 +2266,8 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                        h->use_ometa ? h->ometa.p : (OMeta *)nullptr, h->capO / CHUNK, cap2, (const DevState *)ds, cap_voi);
             }
             MARK("  split + scan ahead");
+            // (round 6: the late gather needs the masks and the chunk prefix, not the gather: it joins HERE and runs beside the gather ahead)
+            (void)hipEventRecord(h->ev_scan, h->bstream);
             (void)hipStreamWaitEvent(h->bstream, nq_.ev_keys, 0);  // k_voi_gather must see that query side's error flag
             MARK("  ev_keys wait");
             {
@@ -2449,8 +2451,13 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             // THIS step --, then that step's bucket histogram and column scan: the stream works through the host's turnaround
             const QSide &nq_ = h->q[nxt_side];
             MARK("assemble late");
-            (void)hipStreamWaitEvent(h->stream, h->ev_early, 0);
-            MARK("  ev_early wait");
+            // round 6: the late gather joins the early stream behind the next step's split and chunk scan (ev_scan) -- it fills the late
+            // table's places in VoI order, which the gather ahead leaves alone, and reads nothing that gather writes -- and runs BESIDE that
+            // gather; what needs both, the bucket histogram, joins at ev_early.  On the 9.8 M-point map the early stream's passes are the
+            // longer branch in three steps of four: the late gather (8 us + a boundary) no longer follows them (measured, one box, medians of
+            // seven passes twice: 0.1903 / 0.1876 -> 0.1885 / 0.1848 ms per scan; 39 M-point map 0.326 / 0.330 -> 0.3155 / 0.3197)
+            (void)hipStreamWaitEvent(h->stream, h->ev_scan, 0);
+            MARK("  ev_scan wait");
             LAUNCH(h, "voi_gather", k_late_gather, std::min<uint32_t>(2 * B, 128u) + 1u, 256, (const float4 *)Fnew, (const LateEnt *)late_out, (const DevState *)ds,
                    h->Oxy.p, h->Ozi.p, (const unsigned long long *)h->vmask.p, (const unsigned long long *)h->hmask.p, (const uint32_t *)h->pvl.p,
                    (const uint32_t *)h->phl.p, (const uint32_t *)h->topv.p, (const uint32_t *)h->toph.p, nx, ny, P.voi_r2, to_xf(nq_.To), P, h->alt.d_st.p,
@@ -2458,6 +2465,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             const uint32_t ntile_tab = std::max(1u, cdiv(n_voi, MB_TILE));
             const uint32_t ntile_ub = h->last_n_voi ? std::min(ntile_tab, std::max(64u, cdiv((uint64_t)h->last_n_voi * 3 / 2, MB_TILE))) : ntile_tab;
             const uint32_t *nvoi_next = &h->alt.d_st.p->voi_total;
+            (void)hipStreamWaitEvent(h->stream, h->ev_early, 0);  // (the gather ahead)
             LAUNCH(h, "voi_bucket", k_mb_hist, ntile_ub, 1024, (const uint32_t *)h->alt.voi_key.p, n_voi, nvoi_next, B + 2, h->mb_hist.p, h->mb_tot.p);
             LAUNCH(h, "voi_bucket", k_mb_colscan, cdiv(B + 2, MB_PAD), 256, h->mb_hist.p, n_voi, nvoi_next, B + 2, (const uint32_t *)h->mb_tot.p,
                    h->alt.moff.p);
