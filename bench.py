@@ -845,13 +845,14 @@ def main():
         t_cb = time.time()
         try:
             with tempfile.TemporaryDirectory(prefix="erasor_cppbench_") as d:
-                subprocess.run([sys.executable, os.path.join(ROOT, "tools", "export_cpp_bench.py"), d, str(K + W + 2)], check=True, capture_output=True, timeout=300)
+                subprocess.run([sys.executable, os.path.join(ROOT, "tools", "export_cpp_bench.py"), d, str(K + W + 8)], check=True, capture_output=True, timeout=300)
                 r = subprocess.run([demo, "--bench", d, str(K), str(W)], capture_output=True, text=True, timeout=300)
                 j = json.loads(r.stdout.strip().split("\n")[-1])
             callback = {"callback_ms": j["ms_per_callback"], "callback_next_announced_ms": j["ms_per_callback_next_node_announced"],
                         "of_which_announce_next_ms": j["of_which_announce_next"],
                         "callback_next_announced_deferred_ms": j.get("ms_per_callback_next_node_announced_deferred"),
-                        "c_abi_device_resident_two_ahead_ms": j["ms_per_step_device_resident_two_ahead"], "passes_agree": j.get("four_passes_agree"),
+                        "callback_nodes_announced_deep_ms": j.get("ms_per_callback_nodes_announced_deep"), "deep_lookahead": j.get("deep_lookahead"),
+                        "c_abi_device_resident_two_ahead_ms": j["ms_per_step_device_resident_two_ahead"], "passes_agree": j.get("passes_agree"),
                         "note": j["callback_note"] + "; one node ahead is all a callback can know, so the query chain of the next node (~0.25 ms alone) "
                                 "bounds this path, not the main chain", "wall_s": round(time.time() - t_cb, 1)}
         except Exception as e:  # (never takes the headline down)

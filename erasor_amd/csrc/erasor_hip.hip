@@ -3682,6 +3682,13 @@ int erasor_hip_overlap_counts(erasor_hip_handle *h, uint64_t *launched, uint64_t
     *used = h->n_ov_used;
     return ERASOR_OK;
 }
+int erasor_hip_drop_announced(erasor_hip_handle *h) {
+    if (!h) return ERASOR_E_INVALID;
+    NOFLY(h);
+    HIPC(h, hipSetDevice(h->device));
+    q_drain(h);
+    return ERASOR_OK;
+}
 int erasor_hip_overlap_auto(erasor_hip_handle *h, int *mode, double *plain_period_us, double *overlapped_period_us) {
     if (!h) return ERASOR_E_INVALID;
     if (mode) *mode = h->ova.mode;

@@ -5,6 +5,7 @@
 #include <array>
 #include <chrono>
 #include <cstdio>
+#include <deque>
 #include <fstream>
 #include <memory>
 #include <sstream>
@@ -112,17 +113,54 @@ static int run_config(const std::string &yaml, int max_frames, int device, bool 
         snprintf(name, sizeof(name), "/pcds/%06d.pcd", i);
         return erasor_utils::load_pcd(drv.data_dir + name, c) != -1;
     };
-    pcl::PointCloud<pcl::PointXYZI> scan, next;
-    bool have = drv.init_idx < (int)poses.size() && load(drv.init_idx, scan);
-    uint64_t ticket = 0, next_ticket = 0;  // (the ticket of an announced node goes to its callback: nothing is recognised by content)
-    for (int i = drv.init_idx; have && i < (int)poses.size() && done < max_frames; ++i, ++done) {
-        // offline: the next node's cloud is read (and announced) before this node is processed
-        const bool have_next = i + 1 < (int)poses.size() && done + 1 < max_frames && load(i + 1, next);
-        next_ticket = have_next ? updater.announce_next(next, erasor_utils::eigen2geoPose(poses[i + 1])) : 0;
-        updater.callback_node(i, erasor_utils::eigen2geoPose(poses[i]), scan, ticket);
-        scan.points.swap(next.points);
-        ticket = next_ticket;
-        have = have_next;
+    // offline: the driver knows its nodes ahead (main_in_your_env.cpp:92-123 reads them from disk one by one).  Round 6: up to `lookahead`
+    // nodes (ERASOR_DEMO_LOOKAHEAD, default 6) are read and ANNOUNCED before the node in front of them is processed -- their query chains
+    // then share their launches and consecutive steps overlap (erasor_shim.h: set_lookahead); every node is stepped by the ticket of its
+    // announcement.  Results do not depend on it.
+    const int lookahead = std::max(1, std::min(getenv("ERASOR_DEMO_LOOKAHEAD") ? atoi(getenv("ERASOR_DEMO_LOOKAHEAD")) : 6, 7));
+    updater.set_lookahead(lookahead);
+    struct Ahead {
+        pcl::PointCloud<pcl::PointXYZI> cloud;
+        uint64_t ticket = 0;
+        bool announced = false;  // (false: refused for now -- gate or capacity --, tried again before the next callback unless it is the upcoming node)
+    };
+    std::deque<Ahead> q;  // q[0] = the upcoming node i, q[j] = node i + j
+    const int last = std::min((int)poses.size(), drv.init_idx + max_frames);  // one past the last node to process
+    auto fill = [&](int i) {
+        while ((int)q.size() < lookahead + 1 && i + (int)q.size() < last) {
+            q.emplace_back();
+            if (!load(i + (int)q.size() - 1, q.back().cloud)) {
+                q.pop_back();
+                return false;
+            }
+        }
+        return true;
+    };
+    bool have = drv.init_idx < last && fill(drv.init_idx) && !q.empty();
+    for (int i = drv.init_idx; have && i < last; ++i, ++done) {
+        (void)fill(i);
+        if (i == drv.init_idx && lookahead > 1) q[0].ticket = updater.announce_upcoming(q[0].cloud, erasor_utils::eigen2geoPose(poses[i]));
+        // announce, in node order, every node behind the upcoming one that is not announced yet (a node the updater refuses -- gated out, or
+        // as many outstanding as it takes -- stops the round: announcements are made in order)
+        for (size_t j = 1; j < q.size(); ++j) {
+            if (q[j].announced) continue;
+            if (i > drv.init_idx && j + 1 == q.size() && updater.outstanding() < updater.lookahead()) {
+                // the pipeline is full: the one new node of this round is staged INSIDE the upcoming callback, while its step runs on the
+                // GPU (announce_next_deferred; its own callback finds the ticket by the sequence number)
+                updater.announce_next_deferred(i + (int)j, q[j].cloud, erasor_utils::eigen2geoPose(poses[i + (int)j]));
+                q[j].announced = true;
+                break;
+            }
+            q[j].ticket = updater.announce_next(q[j].cloud, erasor_utils::eigen2geoPose(poses[i + (int)j]));
+            q[j].announced = true;  // (ticket 0: gated out by removal_interval, or full: either way this node is stepped without a ticket)
+            if (!q[j].ticket && updater.outstanding() >= updater.lookahead()) {
+                q[j].announced = false;  // full: again before the next callback
+                break;
+            }
+        }
+        updater.callback_node(i, erasor_utils::eigen2geoPose(poses[i]), q[0].cloud, q[0].ticket);
+        q.pop_front();
+        have = !q.empty() || (i + 1 < last && fill(i + 1) && !q.empty());
     }
     if (nodes_done) *nodes_done = done;
     if (done == 0 && !have) return 3;
@@ -325,9 +363,10 @@ static int bench_mode(int argc, char **argv) {
     cfg.verbose = false;
     pcl::PointCloud<pcl::PointXYZI> map0;
     if (!read_bin(dir + "/map.bin", map0)) return 3;
-    std::vector<pcl::PointCloud<pcl::PointXYZI>> scans(K + W + 2);
-    std::vector<geometry_msgs::Pose> odom(K + W + 2);
-    for (int i = 0; i < K + W + 2; ++i) {
+    const int NS = std::min(n_nodes, K + W + 8);  // (the deep pass announces up to six nodes ahead: as many more as were exported)
+    std::vector<pcl::PointCloud<pcl::PointXYZI>> scans(NS);
+    std::vector<geometry_msgs::Pose> odom(NS);
+    for (int i = 0; i < NS; ++i) {
         char name[64];
         snprintf(name, sizeof(name), "/scan_%06d.bin", i);
         if (!read_bin(dir + name, scans[i])) return 3;
@@ -335,15 +374,35 @@ static int bench_mode(int argc, char **argv) {
         odom[i].position.x = v[0]; odom[i].position.y = v[1]; odom[i].position.z = v[2];
         odom[i].orientation.x = v[3]; odom[i].orientation.y = v[4]; odom[i].orientation.z = v[5]; odom[i].orientation.w = v[6];
     }
-    double ms_cb[3] = {0, 0, 0}, ms_announce = 0;
-    unsigned long long rejected[3] = {0, 0, 0}, map_out[3] = {0, 0, 0};
-    for (int pass = 0; pass < 3; ++pass) {
+    double ms_cb[4] = {0, 0, 0, 0}, ms_announce = 0;
+    unsigned long long rejected[4] = {0, 0, 0, 0}, map_out[4] = {0, 0, 0, 0};
+    const int deep_la = std::max(1, std::min(6, NS - (K + W)));
+    for (int pass = 0; pass < 4; ++pass) {
         erasor::OfflineMapUpdater updater(cfg);
         updater.set_global_map(map0);
         double t0 = 0;
         uint64_t ticket = 0, next_ticket = 0;
+        std::vector<uint64_t> tk(NS, 0);
+        int announced_upto = 0;  // (pass 3: nodes [1, announced_upto] are announced)
+        if (pass == 3) {
+            updater.set_lookahead(deep_la);
+            tk[0] = updater.announce_upcoming(scans[0], odom[0]);  // (a first callback without a ticket would drop the nodes announced behind it)
+        }
         for (int i = 0; i < W + K; ++i) {
             if (i == W) t0 = now_ms();
+            if (pass == 3) {  // round 6: as many nodes ahead as the updater takes, in node order, each stepped by its ticket
+                while (announced_upto < std::min(i + deep_la, NS - 1) && updater.outstanding() < updater.lookahead()) {
+                    ++announced_upto;
+                    if (i > 0 && announced_upto == i + deep_la) {  // the pipeline is full: the round's one new node is staged beside this callback's step
+                        updater.announce_next_deferred(announced_upto, scans[announced_upto], odom[announced_upto]);
+                        break;
+                    }
+                    tk[announced_upto] = updater.announce_next(scans[announced_upto], odom[announced_upto]);
+                }
+                updater.callback_node(i, odom[i], scans[i], tk[i]);
+                if (i >= W) rejected[pass] += updater.map_rejected.size();
+                continue;
+            }
             if (pass == 1) {
                 const double ta = now_ms();
                 next_ticket = updater.announce_next(scans[i + 1], odom[i + 1]);
@@ -406,14 +465,14 @@ static int bench_mode(int argc, char **argv) {
         for (void *p : d_scan) erasor_hip_device_free(h, p);
         erasor_hip_destroy(h);
     }
-    const bool same = rejected[0] == rejected[1] && rejected[0] == rejected[2] && rejected[0] == rejected_dev && map_out[0] == map_out[1] &&
-                      map_out[0] == map_out[2] && map_out[0] == map_out_dev;
+    const bool same = rejected[0] == rejected[1] && rejected[0] == rejected[2] && rejected[0] == rejected[3] && rejected[0] == rejected_dev &&
+                      map_out[0] == map_out[1] && map_out[0] == map_out[2] && map_out[0] == map_out[3] && map_out[0] == map_out_dev;
     printf("{\"bench\": \"erasor_offline_demo --bench (C++, no Python in the loop)\", \"nodes_timed\": %d, \"warmup\": %d, \"map_points\": %zu, "
            "\"scan_points\": %zu, \"ms_per_callback\": %.4f, \"ms_per_callback_next_node_announced\": %.4f, "
-           "\"of_which_announce_next\": %.4f, \"ms_per_callback_next_node_announced_deferred\": %.4f, \"ms_per_step_device_resident_two_ahead\": %.4f, \"callback_note\": \"OfflineMapUpdater::callback_node: host PointXYZI cloud in "
+           "\"of_which_announce_next\": %.4f, \"ms_per_callback_next_node_announced_deferred\": %.4f, \"ms_per_callback_nodes_announced_deep\": %.4f, \"deep_lookahead\": %d, \"ms_per_step_device_resident_two_ahead\": %.4f, \"callback_note\": \"OfflineMapUpdater::callback_node: host PointXYZI cloud in "
            "(32-byte records staged as they lie; an announced node is stepped by its ticket), map_rejected / query_rejected clouds copied back to the host\", "
-           "\"map_rejected_points\": %llu, \"final_map_points\": %llu, \"four_passes_agree\": %s}\n",
-           K, W, map0.size(), scans[W].size(), ms_cb[0], ms_cb[1], ms_announce / K, ms_cb[2], ms_dev, rejected[0], map_out[0], same ? "true" : "false");
+           "\"map_rejected_points\": %llu, \"final_map_points\": %llu, \"passes_agree\": %s}\n",
+           K, W, map0.size(), scans[W].size(), ms_cb[0], ms_cb[1], ms_announce / K, ms_cb[2], ms_cb[3], deep_la, ms_dev, rejected[0], map_out[0], same ? "true" : "false");
     return same ? 0 : 5;
 }
 

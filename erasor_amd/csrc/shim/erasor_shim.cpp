@@ -370,12 +370,18 @@ void OfflineMapUpdater::announce_next_deferred(int seq, const Cloud &lidar, cons
     def_odom_ = odom;
     def_seq_ = seq;
 }
-// the deferred announcement, made now (by the callback in front of the announced node: stack_count_ counts that callback already)
+// the deferred announcement, made now -- inside a callback_node (stack_count_ counts that callback already), while its step runs on the GPU.
+// It is about the node behind the last one announced (with one node ahead: the next callback)
 void OfflineMapUpdater::stage_deferred() {
     if (!def_cloud_) return;
     const Cloud &lidar = *def_cloud_;
     def_cloud_ = nullptr;
-    if ((stack_count_ + 1) % cfg_.params.removal_interval != 0 || has_next_) return;  // gated out (OMU.cpp:206-209) / one ahead already
+    const int cb_no = std::max(ahead_upto_, stack_count_) + 1;
+    if (cb_no % cfg_.params.removal_interval != 0) {  // gated out (OMU.cpp:206-209)
+        ahead_upto_ = cb_no;
+        return;
+    }
+    if (n_ahead_ >= max_ahead_) return;  // as many ahead as the updater takes
     float Tl[16], Tb[16];
     mat16(tf_lidar2body_, Tl);
     mat16(erasor_utils::geoPose2eigen(def_odom_), Tb);
@@ -386,9 +392,9 @@ void OfflineMapUpdater::stage_deferred() {
         mat16(erasor_utils::inverse(erasor_utils::geoPose2eigen(def_odom_)), To);
         check(h_, erasor_hip_announce_origin2body(h_, To), "erasor_hip_announce_origin2body");
     }
-    has_next_ = true;
-    auto_ticket_ = t;
-    auto_seq_ = def_seq_;
+    ++n_ahead_;
+    ahead_upto_ = cb_no;
+    auto_tickets_.emplace_back(def_seq_, t);
 }
 void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, const Cloud &lidar, uint64_t ticket) {
     // the deferred announcement points at a caller local: whatever way this callback ends, it does not outlive it
@@ -397,8 +403,12 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
         ~ClearDeferred() { p = nullptr; }
     } clear_deferred{def_cloud_};
     stack_count_++;
-    if (!ticket && auto_ticket_ && auto_seq_ == seq) ticket = auto_ticket_;  // announced through announce_next_deferred
-    auto_ticket_ = 0;
+    for (auto it = auto_tickets_.begin(); it != auto_tickets_.end(); ++it)  // announced through announce_next_deferred
+        if (it->first == seq) {
+            if (!ticket) ticket = it->second;
+            auto_tickets_.erase(it);
+            break;
+        }
     if (stack_count_ % cfg_.params.removal_interval != 0) {  // OMU.cpp:206-209,327-329 "PASS!"
         if (cfg_.verbose) printf(" PASS! \n");
         stage_deferred();
@@ -416,7 +426,7 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
         if (ticket) {
             // (in two halves: a deferred announcement of the node behind this one is staged while this step runs on the GPU)
             check(h_, erasor_hip_step_ticket_async(h_, ticket, Tb, To), "erasor_hip_step_ticket_async");
-            has_next_ = false;
+            if (n_ahead_ > 0) --n_ahead_;
             try {
                 stage_deferred();
             } catch (...) {
@@ -426,8 +436,16 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
             }
             check(h_, erasor_hip_step_wait(h_, &last), "erasor_hip_step_wait");
         } else {
+            // (deep announcements are consumed by ticket: a cloud that comes without one is a fresh scan, and the library drops every
+            // announcement when it meets one -- erasor_hip_step_rows recognises at most the OLDEST by content; with one node ahead that is
+            // the old behaviour)
             check(h_, erasor_hip_step_rows(h_, lidar.points.data(), lidar.size(), kRowStride, kRowIntensity, Tl, Tb, To, &last), "erasor_hip_step_rows");
-            has_next_ = false;  // (whatever was announced has been consumed or dropped by this step)
+            if (n_ahead_ > 1) {  // the step consumed the oldest or dropped all: make it "all" (a standalone call drops what is left)
+                check(h_, erasor_hip_drop_announced(h_), "erasor_hip_drop_announced");
+            }
+            n_ahead_ = 0;  // (whatever was announced has been consumed or dropped by this step)
+            ahead_upto_ = stack_count_;
+            auto_tickets_.clear();
             stage_deferred();
         }
         if (last.n_ambiguous)  // (never seen on transformed clouds; said aloud because bin equality is only PROVABLE when it is zero)
@@ -446,10 +464,17 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
 }
 uint64_t OfflineMapUpdater::announce_next(const Cloud &lidar) { return announce(lidar, nullptr); }
 uint64_t OfflineMapUpdater::announce_next(const Cloud &lidar, const geometry_msgs::Pose &odom) { return announce(lidar, &odom); }
-uint64_t OfflineMapUpdater::announce(const Cloud &lidar, const geometry_msgs::Pose *odom) {
+uint64_t OfflineMapUpdater::announce_upcoming(const Cloud &lidar, const geometry_msgs::Pose &odom) { return announce(lidar, &odom, true); }
+uint64_t OfflineMapUpdater::announce(const Cloud &lidar, const geometry_msgs::Pose *odom, bool upcoming) {
     // called BEFORE callback_node(current) with the cloud of the node after it: current is callback number stack_count_ + 1
-    if ((stack_count_ + 2) % cfg_.params.removal_interval != 0) return 0;  // that node will be gated out (OMU.cpp:206-209)
-    if (has_next_) return 0;                                                 // one cloud ahead is what callback_node can honour
+    // (round 6: up to max_ahead_ nodes, in node order: this call is about the node behind the last one announced or gated)
+    if (upcoming && (n_ahead_ > 0 || ahead_upto_ > stack_count_)) return 0;  // (only in front of everything else)
+    const int cb_no = upcoming ? stack_count_ + 1 : std::max(ahead_upto_, stack_count_ + 1) + 1;
+    if (cb_no % cfg_.params.removal_interval != 0) {  // that node will be gated out (OMU.cpp:206-209): nothing to announce
+        ahead_upto_ = cb_no;
+        return 0;
+    }
+    if (n_ahead_ >= max_ahead_) return 0;  // as many nodes ahead as callback_node can honour (one unless set_lookahead said more)
     float Tl[16], Tb[16];
     mat16(tf_lidar2body_, Tl);
     if (odom) mat16(erasor_utils::geoPose2eigen(*odom), Tb);  // OMU.cpp:219: the whole node is known, the next fetch_VoI pass goes ahead too
@@ -461,9 +486,11 @@ uint64_t OfflineMapUpdater::announce(const Cloud &lidar, const geometry_msgs::Po
         mat16(erasor_utils::inverse(erasor_utils::geoPose2eigen(*odom)), To);
         check(h_, erasor_hip_announce_origin2body(h_, To), "erasor_hip_announce_origin2body");
     }
-    has_next_ = true;
+    ++n_ahead_;
+    ahead_upto_ = cb_no;
     return ticket;
 }
+void OfflineMapUpdater::set_lookahead(int n) { max_ahead_ = std::max(1, std::min(n, 7)); }
 void OfflineMapUpdater::get_map(Cloud &dst) {
     size_t n = 0;
     check(h_, erasor_hip_map_size(h_, &n), "erasor_hip_map_size");

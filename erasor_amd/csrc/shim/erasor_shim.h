@@ -12,6 +12,7 @@
 #include "erasor_shim_queue.h"
 #include <memory>
 #include <stdexcept>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -156,6 +157,18 @@ public:
     // ... and its odometry, when the whole next node is known (erasor_hip_prefetch_node: the VoI pass of the next callback is
     // launched ahead as well)
     uint64_t announce_next(const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose &odom);
+    // Round 6 -- DEEP look-ahead for drivers that know their nodes ahead (main_in_your_env.cpp:92-123 reads them from disk): after
+    // set_lookahead(n), n = 1 .. 7, announce_next may be called for up to n nodes beyond the upcoming callback, IN NODE ORDER (each call is
+    // about the node behind the last one announced); it returns 0 -- and announces nothing -- for a node the removal_interval gate skips
+    // and when n nodes are outstanding (call again before a later callback).  With three or more nodes ahead the library lets consecutive
+    // steps overlap and the announced nodes' query chains share their launches (erasor_hip_chain_batch): the offline rate of the C ABI
+    // through the reference's own class.  Deep announcements are consumed BY TICKET: a callback without one drops them all.
+    void set_lookahead(int n);
+    // ... and the node the UPCOMING callback itself brings, while nothing is announced yet (the first node of a sequence: a callback
+    // without a ticket in front of announced nodes would drop them); 0 if something is announced already or the gate skips the node
+    uint64_t announce_upcoming(const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose &odom);
+    int lookahead() const { return max_ahead_; }
+    int outstanding() const { return n_ahead_; }  // nodes announced and not yet stepped
     // the callback of an announced node, by ticket (0: like the three-argument form)
     void callback_node(int seq, const geometry_msgs::Pose &odom, const pcl::PointCloud<pcl::PointXYZI> &lidar, uint64_t ticket);
     // The same announcement WITHOUT the copy on the caller's time: the cloud is staged by the UPCOMING callback_node while that node's
@@ -163,7 +176,11 @@ public:
     // and unchanged until that callback has returned; the callback of node `seq` then finds its ticket by itself.
     void announce_next_deferred(int seq, const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose &odom);
     // is node `seq` staged (its callback will not look at the cloud it is handed)?
-    bool staged(int seq) const { return auto_ticket_ != 0 && auto_seq_ == seq; }
+    bool staged(int seq) const {
+        for (const auto &a : auto_tickets_)
+            if (a.first == seq) return true;
+        return false;
+    }
     void save_static_map(float voxel_size);                    // OMU.cpp:174-196
     void get_map(pcl::PointCloud<pcl::PointXYZI> &dst);        // *map_arranged_
     erasor_hip_handle *handle() { return h_; }                 // for adapters that read more of the last step (ros1_adapter.cpp)
@@ -177,13 +194,17 @@ private:
     erasor_hip_handle *h_ = nullptr;
     Eigen::Matrix4f tf_lidar2body_, tf_body2origin_;
     int stack_count_ = 0;
-    bool has_next_ = false;  // a node is announced and not yet consumed (one cloud ahead is what callback_node can honour)
+    // nodes announced and not yet consumed; round 6: up to max_ahead_ of them (set_lookahead), in node order.  ahead_upto_: callback
+    // number (stack_count_ counts callbacks, gated ones too) of the last node an announcement was made -- or skipped by the gate -- for
+    int n_ahead_ = 0, max_ahead_ = 1, ahead_upto_ = 0;
     const pcl::PointCloud<pcl::PointXYZI> *def_cloud_ = nullptr;  // announce_next_deferred: staged by the upcoming callback
     geometry_msgs::Pose def_odom_;
-    int def_seq_ = 0, auto_seq_ = 0;
-    uint64_t auto_ticket_ = 0;  // ticket of the node announced that way (its callback takes it when the sequence number matches)
+    int def_seq_ = 0;
+    // tickets of the nodes announced that way, by sequence number (their callbacks take them by themselves); round 6: several, since with
+    // set_lookahead(n) the deferred announcement is about the node behind the last announced one, not about the next callback
+    std::deque<std::pair<int, uint64_t>> auto_tickets_;
     void stage_deferred();
-    uint64_t announce(const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose *odom);
+    uint64_t announce(const pcl::PointCloud<pcl::PointXYZI> &lidar, const geometry_msgs::Pose *odom, bool upcoming = false);
 };
 // main_in_your_env.cpp:66-70: the driver's own rosparams
 struct DriverConfig {

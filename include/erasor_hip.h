@@ -330,6 +330,11 @@ int erasor_hip_overlap_auto(erasor_hip_handle *h, int *mode, double *plain_perio
  * the shared launches; a callback that can announce one node ahead (OfflineMapUpdater.cpp:203) never holds anything back.
  * n_scans: 1 .. 4 (1: every chain on its own; the default is 2), lead: 1 .. 6 (default 3).  Results do not depend on either. */
 int erasor_hip_chain_batch(erasor_hip_handle *h, int n_scans, int lead);
+/* Forget every node that is announced and not yet stepped (their chains run out, passes launched ahead of them are discarded): what a
+ * step does by itself when it meets a scan that is not the oldest announced one (erasor_hip_prefetch_scan), as a call of its own -- for a
+ * caller that lost track of its announcements (the shim's OfflineMapUpdater: a callback without a ticket while several nodes are
+ * announced by ticket, OfflineMapUpdater.cpp:203 has no notion of either). */
+int erasor_hip_drop_announced(erasor_hip_handle *h);
 /* sets of shared launches made so far / chains that went into them */
 int erasor_hip_chain_batch_counts(erasor_hip_handle *h, uint64_t *sets, uint64_t *chains);
 /* The main stream's dependency chain on the device's own clock (no events, no extra launches: the chunk scan and the step's end stamp
