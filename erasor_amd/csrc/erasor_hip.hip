@@ -591,7 +591,7 @@ int grow_map_scratch(erasor_hip_handle *h, uint64_t need) {
     return rc ? ERASOR_E_NO_DEVICE : 0;
 }
 
-int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
+static int alloc_scan_side(erasor_hip_handle *h, uint32_t ns) {
     if (ns <= Q(h).capS && Q(h).capS) return 0;
     const uint32_t S = ns + ns / 4 + 1024;
     Q(h).capS = S;
@@ -607,6 +607,26 @@ int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
     rc |= ensure(h, Q(h).wseg0, WSEG_MAX) | ensure(h, Q(h).wseg1, WSEG_MAX) | ensure(h, Q(h).wstate, 1) | ensure(h, Q(h).wtileL, WTILES_MAX) | ensure(h, Q(h).wtileR, WTILES_MAX);
     rc |= ensure(h, Q(h).esq0, 65536) | ensure(h, Q(h).esq1, 65536) | ensure(h, Q(h).esq2, 65536) | ensure(h, Q(h).essmall, 65536);
     return rc ? ERASOR_E_NO_DEVICE : 0;
+}
+
+// The query side in use gets room for a scan of ns points -- and, round 6, every IDLE side with it: eight sides take turns, and a side's
+// first scan used to pay for ~40 device allocations (and a pinned staging buffer) in the middle of a sequence, 5-7 ms once per side: a
+// visible share of a 20-node pass (erasor_offline_demo --bench: 0.35 or 0.70 ms per callback depending on where the first uses fell).
+int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
+    int rc = alloc_scan_side(h, ns);
+    if (rc || g_tl.h == h) return rc;  // (the worker thread never allocates)
+    const int me = h->qi;
+    for (int k = 0; k < NSIDE && !rc; ++k) {
+        QSide &q = h->q[k];
+        if (k == me || (q.capS && ns <= q.capS) || q.held || (h->ann.valid && h->ann.side == k)) continue;
+        bool busy = h->worker && h->worker->busy[k].load(std::memory_order_acquire) > 0;
+        for (int j = 0; j < h->npend; ++j) busy = busy || h->pend[j] == k;
+        if (busy || (q.used && hipEventQuery(q.ev_done) != hipSuccess)) continue;  // (a dropped chain may still be running on it)
+        h->qi = k;
+        rc = alloc_scan_side(h, ns);
+    }
+    h->qi = me;
+    return rc;
 }
 
 // per-step scratch whose size depends on (VoI size + query size)
@@ -1190,6 +1210,12 @@ static int stage_host_scan(erasor_hip_handle *h, const void *scan_src, uint32_t 
         q.stage = nullptr;
         q.stage_cap = (size_t)ns + ns / 4 + 1024;
         HIPC(h, hipHostMalloc((void **)&q.stage, q.stage_cap * sizeof(float4), hipHostMallocDefault));
+        for (int k = 0; k < NSIDE; ++k) {  // (round 6: the sides that have never staged anything get their pinned buffers now, see alloc_scan)
+            QSide &o = h->q[k];
+            if (o.stage || &o == &q) continue;
+            if (hipHostMalloc((void **)&o.stage, q.stage_cap * sizeof(float4), hipHostMallocDefault) == hipSuccess) o.stage_cap = q.stage_cap;
+            else o.stage = nullptr;
+        }
     }
     RowHash rh;
     const unsigned char *p = static_cast<const unsigned char *>(scan_src);
@@ -3152,6 +3178,22 @@ static int d2h(erasor_hip_handle *h, void *dst, const void *src, size_t bytes) {
     HIPC(h, hipStreamSynchronize(h->stream));
     return ERASOR_OK;
 }
+// A read-back of something a COLLECTED step left behind and nothing enqueued since overwrites (map_rejected / curr_rejected: written by the
+// step's write-back, next by the following step's): on the copy stream, without waiting for the main stream -- which, when the step's
+// end is seen, already holds the launches made ahead for the NEXT step (bucket histogram .. bin statistics, ~50 us).  The step's end is
+// written by the last kernel of the step, behind the kernels that wrote these clouds: what the host has seen end is in device memory.
+static int d2h_collected(erasor_hip_handle *h, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return ERASOR_OK;
+    HIPC(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->cstream));
+    HIPC(h, hipStreamSynchronize(h->cstream));
+    return ERASOR_OK;
+}
+static int out_cloud_collected(erasor_hip_handle *h, const float4 *d, size_t cnt, float *dst, size_t cap, size_t *n) {
+    if (n) *n = cnt;
+    if (!dst) return ERASOR_OK;
+    if (cnt > cap) return ERASOR_E_CAPACITY;
+    return d2h_collected(h, dst, d, cnt * sizeof(float4));
+}
 static int out_cloud(erasor_hip_handle *h, const float4 *d, size_t cnt, float *dst, size_t cap, size_t *n) {
     if (n) *n = cnt;
     if (!dst) return ERASOR_OK;
@@ -3232,8 +3274,11 @@ int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap
     if (which == ERASOR_CLOUD_MAP) return erasor_hip_get_map(h, dst, cap, n);
     if (!h->have_step) return ERASOR_E_STATE;
     HIPC(h, hipSetDevice(h->device));
-    HIPC(h, hipStreamSynchronize(h->stream));
     const DevState &s = h->st;
+    // (round 6: the two clouds a callback publishes every node, OMU.cpp:316-320, do not wait for what is launched ahead of the next step)
+    if (which == ERASOR_CLOUD_MAP_REJECTED) return out_cloud_collected(h, h->rejected.p, s.n_rejected, dst, cap, n);
+    if (which == ERASOR_CLOUD_CURR_REJECTED) return out_cloud_collected(h, h->curr_rejected.p, s.n_curr_rejected, dst, cap, n);
+    HIPC(h, hipStreamSynchronize(h->stream));
     switch (which) {
         case ERASOR_CLOUD_QUERY_VOI: return out_cloud(h, Q(h).query.p, h->last_nq, dst, cap, n);
         case ERASOR_CLOUD_MAP_VOI: {
@@ -3261,8 +3306,6 @@ int erasor_hip_get_cloud(erasor_hip_handle *h, int which, float *dst, size_t cap
             release(tmp);
             return rc_c;
         }
-        case ERASOR_CLOUD_MAP_REJECTED: return out_cloud(h, h->rejected.p, s.n_rejected, dst, cap, n);
-        case ERASOR_CLOUD_CURR_REJECTED: return out_cloud(h, h->curr_rejected.p, s.n_curr_rejected, dst, cap, n);
         case ERASOR_CLOUD_STATIC_ESTIMATE:
         case ERASOR_CLOUD_COMPLEMENT:
         case ERASOR_CLOUD_GROUND_VIZ: {

@@ -44,9 +44,10 @@ void check(erasor_hip_handle *h, int rc, const char *what) {
     if (rc == ERASOR_E_UNSUPPORTED || rc == ERASOR_E_INVALID) throw std::invalid_argument(msg);  // as OMU.cpp:125,149,274,312
     throw std::runtime_error(msg);
 }
-void fetch_cloud(erasor_hip_handle *h, int which, Cloud &dst) {
-    size_t n = 0;
-    check(h, erasor_hip_get_cloud(h, which, nullptr, 0, &n), "erasor_hip_get_cloud");
+// n_known: the cloud's size, when the step's result block has said it already (one call less)
+void fetch_cloud(erasor_hip_handle *h, int which, Cloud &dst, long n_known = -1) {
+    size_t n = n_known >= 0 ? (size_t)n_known : 0;
+    if (n_known < 0) check(h, erasor_hip_get_cloud(h, which, nullptr, 0, &n), "erasor_hip_get_cloud");
     std::vector<float> v(n * 4 + 4);
     check(h, erasor_hip_get_cloud(h, which, v.data(), n, &n), "erasor_hip_get_cloud");
     from_xyzi(v, n, dst);
@@ -451,8 +452,8 @@ void OfflineMapUpdater::callback_node(int seq, const geometry_msgs::Pose &odom, 
         if (last.n_ambiguous)  // (never seen on transformed clouds; said aloud because bin equality is only PROVABLE when it is zero)
             fprintf(stderr, "[erasor shim] node %d: %u point(s) within 1e-11 of a sector boundary: their bin is not provably the reference's (device atan2 vs glibc)\n",
                     seq, last.n_ambiguous);
-        fetch_cloud(h_, ERASOR_CLOUD_MAP_REJECTED, map_rejected);
-        fetch_cloud(h_, ERASOR_CLOUD_CURR_REJECTED, query_rejected);
+        fetch_cloud(h_, ERASOR_CLOUD_MAP_REJECTED, map_rejected, (long)last.n_map_rejected);
+        fetch_cloud(h_, ERASOR_CLOUD_CURR_REJECTED, query_rejected, (long)last.n_curr_rejected);
         ++num_processed;
         if (cfg_.verbose) {  // print_status (OMU.cpp:451-465)
             printf("ERASOR Input: %llu = %llu + %llu - %llu\n", (unsigned long long)last.n_voi, (unsigned long long)last.n_static_estimate,

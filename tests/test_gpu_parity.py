@@ -989,7 +989,7 @@ def test_the_handle_decides_between_overlapped_and_plain_steps_midway(gpu_mod, t
     script.write_text(AUTO_FLIP_WORKER % (root, root))
     env = dict(os.environ)
     if os.environ.get("ERASOR_TEST_SIMT_LIB"):
-        pytest.skip("44 steps: an hour on the CPU stand-in (tools/simt_check.sh runs it with AUTO_FLIP_STEPS)")
+        pytest.skip("44 steps: an hour on the CPU stand-in")
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=280, env=env)
     assert out.returncode == 0 and "AUTO-FLIP-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
