@@ -97,11 +97,17 @@ def parse_args():
                     help="seq-per-gpu: which rank runs which sequence -- 'queue': the next sequence goes to whichever rank is idle (BASELINE config 3: "
                          "the fifth sequence onto the first free GPU; every rank prepares all sequences, a shared counter hands them out); "
                          "'static': dealt round-robin in advance")
-    ap.add_argument("--interleave", choices=["async", "threads", "off"], default="off",
+    ap.add_argument("--interleave", choices=["async", "threads", "pairs", "off"], default="off",
                     help="seq-per-gpu with several sequences on one rank: off = one sequence after the other (default: measured fastest on one "
                          "MI355X -- the chains of two sequences slow each other down more than the overlap gains: 2 sequences 3864 scans/s one "
                          "after the other vs 3145 interleaved, 5 sequences 3766 vs 2877, gpurun_out/r03n); async = one host thread keeps every "
-                         "sequence's step in flight (erasor_hip_step_async / _wait); threads = one host thread per sequence, blocking steps")
+                         "sequence's step in flight (erasor_hip_step_async / _wait); threads = one host thread per sequence, blocking steps; pairs (round 6) = "
+                         "threads, two sequences at a time, every handle with ONE query stream (ERASOR_HIP_QSTREAMS=1): four busy queues on the "
+                         "process's four compute pipes -- the layout in which sharing a GPU pays (1.5 x for two sequences)")
+    ap.add_argument("--interleave-group", type=int, default=0,
+                    help="--interleave threads: how many sequences run side by side (0: all of the rank's).  Round 6: a process has FOUR compute pipes;\n"
+                         "with ERASOR_HIP_QSTREAMS=1 a handle keeps two queues busy (main + one query stream), so TWO sequences side by side have a\n"
+                         "pipe per queue: 2 is the group that pays (7950-8010 scans/s against 5310 one after the other)")
     ap.add_argument("--python-loop", action="store_true",
                     help="drive the timed steps from a Python loop (prefetch + step per node) instead of ONE erasor_hip_run_nodes call "
                          "(the offline driver's node loop in native code: the same calls, without ~20 us of interpreter time between two steps)")
@@ -454,6 +460,12 @@ def cpu_sequence_parallel(args, seqs, maps, l2b7):
 
 def main():
     args = parse_args()
+    if args.interleave == "pairs":
+        # round 6: two sequences side by side, each handle with ONE query stream (main + query = two busy compute queues; the process has
+        # four compute pipes): the layout in which independent sequences DO share a GPU -- 7900-8060 scans/s for two against 5400 one
+        # after the other.  (Read by the library when a handle is created: set before the first one.)
+        os.environ.setdefault("ERASOR_HIP_QSTREAMS", "1")
+        args.interleave, args.interleave_group = "threads", 2
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)  # does not return
     import torch
@@ -615,11 +627,13 @@ def main():
             t[3], t[4], t[5] = r_.n_map_out, r_.n_static, r_.n_dynamic
             per_seq[i] = (t, r_)
 
-        ths = [threading.Thread(target=drive, args=(i, s)) for i, (_, s) in enumerate(seqs)]
-        for t_ in ths:
-            t_.start()
-        for t_ in ths:
-            t_.join()
+        grp = args.interleave_group if args.interleave_group > 0 else len(seqs)
+        for g0 in range(0, len(seqs), grp):  # (handles were created in this order: the members of a group hold neighbouring compute pipes)
+            ths = [threading.Thread(target=drive, args=(i, s)) for i, (_, s) in list(enumerate(seqs))[g0:g0 + grp]]
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join()
         for t, r_ in per_seq:
             totals += t
             last = r_

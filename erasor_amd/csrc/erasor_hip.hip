@@ -913,15 +913,36 @@ static bool create_sides(erasor_hip_handle *h, int prio) {
     // (round 5: every stream that has run something keeps a hardware queue, and with more than four of them in this process' reach -- main,
     // query streams, early stream; the framework's own on top -- every kernel of every queue slows down 3-8 x, busy or not.  So the early
     // stream IS the third query stream where there is one: a step uses it either for a chain or for its early passes, see ov_mode)
+    // Round 6: a stream of its own for the early passes (fewer than three query streams) and the copy stream are created WHEN FIRST NEEDED
+    // (early_stream / copy_stream).  The runtime deals a process's streams onto the four compute pipes in the order they are created
+    // (tools/queue_probe.hip), and two busy queues of one pipe are time-sliced: a handle that creates four streams and keeps two of them busy
+    // -- ERASOR_HIP_QSTREAMS=1: main + one query stream -- left the second handle of the process the SAME two pipes; with two streams per
+    // handle, two sequences interleaved on one GPU have a pipe for each of their four queues: 7950-8010 scans/s against 5310 one after the
+    // other (1.5 x; MEASUREMENTS R6), where rounds 3-5 measured 0.8-1.07 x.
     if (h->nqs >= 3) h->bstream = h->qstream[2];
-    else if (hipStreamCreateWithPriority(&h->bstream, hipStreamNonBlocking, prio) != hipSuccess) return false;
-    h->bstream_own = h->nqs < 3;
+    h->bstream_own = false;
     // (events between two streams of ONE device: no system-scope fence -- the cache write-back and invalidation it brings cost the kernels
     // around it tens of microseconds)
     const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
     for (hipEvent_t *e : {&h->ev_stats, &h->ev_srt4, &h->ev_asm, &h->ev_early, &h->ev_scan})
         if (hipEventCreateWithFlags(e, evf) != hipSuccess) return false;
-    return hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) == hipSuccess;
+    h->cstream = nullptr;
+    return true;
+}
+// the early stream of overlapped steps (one of the query streams when there are three; else created on first use)
+static bool early_stream(erasor_hip_handle *h) {
+    if (h->bstream) return true;
+    if (hipStreamCreateWithFlags(&h->bstream, hipStreamNonBlocking) != hipSuccess) {
+        h->bstream = nullptr;
+        return false;
+    }
+    h->bstream_own = true;
+    return true;
+}
+// the copy stream (host scans announced ahead, read-backs of a collected step): created on first use
+static hipStream_t copy_stream(erasor_hip_handle *h) {
+    if (!h->cstream && hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess) h->cstream = nullptr;
+    return h->cstream ? h->cstream : h->stream;
 }
 
 // A handle runs its chains on four streams, and HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4):
@@ -1282,7 +1303,9 @@ static int overlap_env() {
     return v;
 }
 static bool overlap_wanted(const erasor_hip_handle *h, int announced_beyond) {
-    return overlap_env() >= 0 ? overlap_env() != 0 : (h->ova.mode != 0 && announced_beyond >= h->batch_lead);
+    // (a handle that was given ONE query stream is meant to keep to two busy queues -- several handles on one GPU: it does not try the
+    // overlap, whose early passes are a third queue)
+    return overlap_env() >= 0 ? overlap_env() != 0 : (h->ova.mode != 0 && announced_beyond >= h->batch_lead && h->nqs >= 2);
 }
 static int flush_held(erasor_hip_handle *h);
 // the launches (and event records) of side `side`'s chain have all been made; side < 0: of every side
@@ -1681,7 +1704,9 @@ static int flush_announced(erasor_hip_handle *h) {
     // (only while the steps overlap: the early passes then take the third query stream and two chains in flight bound the step -- shared
     // launches halve a chain's queue time; plain steps have three query streams, where holding a chain back only delays it: 9.8 M-point
     // map 0.190 ms per scan alone, 0.196 in sets of two, MEASUREMENTS R6)
-    const bool may_hold = h->batch_n >= 2 && in_front >= h->batch_lead && overlap_wanted(h, in_front);
+    // (... or the handle has ONE query stream -- ERASOR_HIP_QSTREAMS=1: several handles that share a GPU must keep to four busy compute queues
+    // between them, two each: main + one query stream, and one query stream is enough only for chains that share launches)
+    const bool may_hold = h->batch_n >= 2 && in_front >= h->batch_lead && (overlap_wanted(h, in_front) || h->nqs == 1);
     if (n_held && !may_hold) {  // (keeps the queues in announcement order)
         const int rc_h = flush_held(h);
         if (rc_h) return rc_h;
@@ -2049,7 +2074,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
     h->fly.deep = announced_beyond >= h->batch_lead;
     // (decided BEFORE the map chain: a step that does not write the reserved layout must not take passes launched ahead on the assumption
     // that it would -- their VoI-order source indices count reserved slots, which only the reserved write-back converts)
-    const bool reserved = srt_in_revert && fold && mb_count && !flags && overlap_pays;
+    const bool reserved = srt_in_revert && fold && mb_count && !flags && overlap_pays && early_stream(h);
     bool use_ov = false;   // this step's split .. bucket table were launched ahead of it and are taken (round 5, OVERLAPPED steps)
     bool stats_ahead = false;  // ... its scatter and bin statistics too
     uint32_t nbk = B + 1;  // buckets of the map's counting sort: the bins + the complement (+ the dead bucket of an overlapped step)
@@ -2857,9 +2882,9 @@ static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n
         rc = chain_wait(h, side);
         if (rc) return rc;
         if (Q(h).used) HIPC(h, hipEventSynchronize(Q(h).ev_done));  // (a dropped chain may still be reading this side's scan)
-        rc = stage_host_scan(h, scan_xyzi, (uint32_t)n, h->cstream, fmt, &h->ann.fp);
+        rc = stage_host_scan(h, scan_xyzi, (uint32_t)n, copy_stream(h), fmt, &h->ann.fp);
         if (rc) return rc;
-        HIPC(h, hipEventRecord(Q(h).ev_h2d, h->cstream));
+        HIPC(h, hipEventRecord(Q(h).ev_h2d, copy_stream(h)));
         Q(h).h2d_pending = true;
     } else
         h->ann.fp = 0ull;
@@ -3184,8 +3209,9 @@ static int d2h(erasor_hip_handle *h, void *dst, const void *src, size_t bytes) {
 // written by the last kernel of the step, behind the kernels that wrote these clouds: what the host has seen end is in device memory.
 static int d2h_collected(erasor_hip_handle *h, void *dst, const void *src, size_t bytes) {
     if (!bytes) return ERASOR_OK;
-    HIPC(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->cstream));
-    HIPC(h, hipStreamSynchronize(h->cstream));
+    hipStream_t cs = copy_stream(h);
+    HIPC(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cs));
+    HIPC(h, hipStreamSynchronize(cs));
     return ERASOR_OK;
 }
 static int out_cloud_collected(erasor_hip_handle *h, const float4 *d, size_t cnt, float *dst, size_t cap, size_t *n) {

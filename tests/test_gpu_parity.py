@@ -896,7 +896,7 @@ for version in (3, 2):
     sets, chains = g.chain_batch_counts()
     if os.environ.get("ALT_PROFILE_ALL") or os.environ.get("ERASOR_HIP_DEBUG_SYNC") or os.environ.get("ALT_CHAIN_BATCH") == "1":
         assert sets == 0, (sets, chains)      # (profiled / synchronised launch by launch, or told not to: every chain on its own)
-    elif os.environ.get("ERASOR_HIP_OVERLAP") == "1" and version == 3:
+    elif (os.environ.get("ERASOR_HIP_OVERLAP") == "1" and version == 3) or os.environ.get("ALT_EXPECT_SETS"):
         assert sets >= 1 and chains >= 2 * sets, (sets, chains)  # (chains are held back for shared launches while the steps overlap)
     t = erasor_amd.replicate_map([g], 0)  # a communicator of one; ERASOR_HIP_NO_RCCL=1: the peer-copy path
     assert (t == 2) if os.environ.get("ERASOR_HIP_NO_RCCL") else (t in (1, 2)), t
@@ -908,10 +908,12 @@ print("ALT-PATH-OK")
 @pytest.mark.parametrize("env", [{"ERASOR_HIP_NO_OMETA": "1", "ALT_PROFILE_ALL": "1"},
                                  {"ERASOR_HIP_NO_RCCL": "1", "ERASOR_HIP_HOST_TIMING": "1", "ERASOR_HIP_SORT_STAMPS": "1", "ERASOR_HIP_DEBUG_SYNC": "1"},
                                  {"ERASOR_HIP_QSTREAMS": "3", "ERASOR_HIP_OVERLAP": "0", "ALT_CHAIN_BATCH": "1"},
+                                 {"ERASOR_HIP_QSTREAMS": "1", "ERASOR_HIP_OVERLAP": "0", "ALT_EXPECT_SETS": "1"},
                                  {"ERASOR_HIP_OVERLAP": "1", "ERASOR_HIP_CHAIN_STAMPS": "1", "ERASOR_HIP_LEAVE_ALL": "1", "GPU_MAX_HW_QUEUES": "16",
                                   "ALT_CHAIN_BATCH": "3", "ALT_HOOKS_LIB": "1"},
                                  {"ERASOR_HIP_OVERLAP": ""}],
                          ids=["no_chunk_records_every_launch_profiled", "peer_copies_diagnostics", "three_query_streams_no_overlap_every_chain_on_its_own",
+                              "one_query_stream_chains_share_launches_side_streams_on_demand",
                               "overlap_stamps_every_bin_may_leave_chains_in_threes", "overlap_left_to_the_handle"])
 def test_alternative_launch_paths_keep_parity(gpu_mod, tmp_path, env):
     """The paths behind the library's remaining switches are product code too (round 6: eleven switches, the ablation switches of
