@@ -113,6 +113,26 @@ def test_step_parity_on_synthetic_sequences(gpu_mod, seq, version, steps):
         compare_step(g, o, rg, ro)
 
 
+def test_equal_heights_in_every_bin_keep_parity(gpu_mod):
+    """Map heights on a 1/32 m lattice: in every reverted bin many points share a z, so the ORDER std::sort(src_copy, point_cmp)
+    (erasor.cpp:239-240) leaves equal keys in decides the seeds' order and with it the float32 sums of the first plane fit -- the case the
+    introsort emulation exists for (round 6 tried a plain bitonic z-order with the emulation only for bins with such ties: the bench
+    map's pole rings tie in most reverted bins, see EXPERIMENTS r06-6).  Every step against the oracle, bit for bit."""
+    sc = scenarios.small()
+    m = sc["map"].copy()
+    m[:, 2] = np.round(m[:, 2] * 32) / 32
+    g, o = make_pair(gpu_mod, sc["params"])
+    g.set_map(m)
+    o.set_map(m)
+    n_rev = 0
+    for f in range(4):
+        ro = o.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        rg = g.step(sc["scans"][f], sc["T_l2b"], sc["T_b2o"][f], sc["T_o2b"][f])
+        compare_step(g, o, rg, ro)
+        n_rev += rg.n_reverted_bins
+    assert n_rev > 8, n_rev
+
+
 @pytest.mark.parametrize("rings,sectors", [(40, 120), (100, 130)])
 def test_fine_rpod_grids_take_the_other_bucketing_paths(gpu_mod, rings, sectors):
     """4800 bins: map scatter by wavefront turns (beyond the 4096-bucket LDS table of the wavefront-major scatter);
