@@ -78,6 +78,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="stop the CPU leg after this much CPU work")
+    ap.add_argument("--verify-prefix-seconds", type=float, default=0.0,
+                    help="with --no-cpu-baseline: replay the FIRST steps the GPU ran (warm-up first) on the oracle for this much CPU time and compare every "
+                         "erasor_step_result -- the bounded check of the extra passes of the default run (the headline and one config-4 pass replay every step)")
     ap.add_argument("--no-verify-all", dest="verify_all", action="store_false",
                     help="let --cpu-seconds also bound the oracle's replay of the GPU's steps (default: every step the GPU ran -- warm-up and all "
                          "timed passes -- is replayed and compared, then the final map: ~0.08 s per step on the 10 M-point map)")
@@ -414,6 +417,32 @@ def cpu_baseline(args, P, m, seq, l2b7, gpu_results=None, gpu_final=None):
             "ms_per_scan": round(tcpu / ns * 1e3, 1),
             "reference_spans_ms": {"Extracting VoI": round(sv / ns * 1e3, 1), "ERASOR": round(se / ns * 1e3, 1)}}
     return port, refd, parity
+
+
+def verify_prefix(args, P, m, seq, gpu_results):
+    """the oracle over the first steps the GPU ran, bounded by --verify-prefix-seconds of CPU work: every erasor_step_result compared"""
+    import ctypes as C
+    from oracle import orc  # checker only -- never on the product path
+    po = orc.Params()
+    C.memmove(C.byref(po), C.byref(P), C.sizeof(po))
+    o = orc.Oracle(po)
+    o.set_map(m)
+    ns, tcpu = 0, 0.0
+    for k in range(min(len(gpu_results), seq.n_frames)):
+        tc = time.perf_counter()
+        ro = o.step(seq.scans[k], seq.Tl, seq.Tb[k], seq.To[k])
+        tcpu += time.perf_counter() - tc
+        do, dg = ro.as_dict(), gpu_results[k].as_dict()
+        bad = [f for f in do if f not in ("n_ambiguous", "n_sort_fallback") and do[f] != dg[f]]
+        if bad or dg["n_ambiguous"]:
+            raise SystemExit("bench.py: PARITY FAILURE at step %d (GPU vs oracle): %s" % (k, {f: (dg[f], do[f]) for f in bad} or "n_ambiguous != 0"))
+        ns += 1
+        if tcpu > args.verify_prefix_seconds:
+            break
+    o.close()
+    return {"parity_checked_steps": ns, "final_map_checked": False,
+            "parity": "erasor_step_result of the first %d of %d GPU steps (warm-up first, bench call pattern) == the oracle's (%.1f s of CPU: a bounded check)"
+                      % (ns, len(gpu_results), tcpu)}
 
 
 def _ref_sequence_worker(job):
@@ -830,6 +859,8 @@ def main():
         cpu, cpu_refsrc, parity = cpu_baseline(args, P, m, first, l2b7, step_results, gpu_final)
     elif world_size == 1 and not args.no_cpu_baseline:
         cpu = cpu_sequence_parallel(args, seqs, maps, l2b7)
+    elif world_size == 1 and args.mode == "replicas" and args.verify_prefix_seconds > 0 and step_results:
+        parity = verify_prefix(args, P, m, first, step_results)
 
     # ---- PR / RR of the map the timed pass has left (BASELINE.json: "PR/RR vs ref"): the reference's protocol (scripts/analysis_runner.py
     # :74-105 restated in erasor_amd/evalmap.py, pinned to the original's outputs by tests/test_evalmap.py) against the initial map as
@@ -945,7 +976,7 @@ def main():
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", wname, "--steps", "12" if verified else "20", "--warmup",
                    "3" if verified else "5", "--no-extra-workloads", "--no-pr-rr", "--no-callback-bench", "--repeats", "1" if verified else "7"] + xargs
             if not verified:
-                cmd.append("--no-cpu-baseline")
+                cmd += ["--no-cpu-baseline", "--verify-prefix-seconds", "4"]  # (the first steps of the pass against the oracle, 4 s of CPU)
             t_sub = time.time()
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=dict(os.environ, **xenv))
@@ -959,7 +990,7 @@ def main():
                               "map_points": d["config"]["map_points"], "scan_points": d["config"]["scan_points"],
                               "is_large_scale": d["config"].get("is_large_scale"), "lookahead_scans": d["config"].get("lookahead_scans"),
                               "environment": xenv,
-                              "parity_checked_steps": d.get("parity_checked_steps"), "final_map_checked": d.get("final_map_checked"),
+                              "parity_checked_steps": d.get("parity_checked_steps"), "final_map_checked": d.get("final_map_checked"), "parity": d.get("parity"),
                               "cpu_baseline": d.get("cpu_baseline"), "cpu_reference_sources": d.get("cpu_reference_sources"),
                               "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "avg_launch_us",
                                                                   "launches", "step_alg_bytes", "step_achieved", "step_frac", "needed_bytes",
