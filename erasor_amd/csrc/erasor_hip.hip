@@ -2271,7 +2271,9 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                h->out_off0.p, h->rev_before.p, h->crej_off.p, (const uint8_t *)h->st1b.p, (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).qoff.p,
                h->out_offR.p, h->gres_off.p, late_out, leave_lim);
         MARK("  k_srt4");
-        (void)hipEventRecord(h->ev_srt4, h->bstream);
+        // (round 6: an overlapped step's late write-back joins at ev_scan, further down this stream and long there when the per-bin launch
+        // ends: one packet less between k_srt4 and the early write-back)
+        if (!ov_next) (void)hipEventRecord(h->ev_srt4, h->bstream);
         MARK("  ev_srt4 record");
         if (n_voi)
             LAUNCH(h, "assemble", (k_assemble_map<true, false, true>), std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p,
@@ -2423,7 +2425,8 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins_srt, std::min<uint32_t>(rev_grid, B) + (reserved ? 0u : 1u), 1024, P, sa, ra);
         MARK("per-bin launch");
         if (reserved) enqueue_early();
-        if (reserved) (void)hipStreamWaitEvent(h->stream, h->ev_srt4, 0);  // (the reverted list, the reserved offsets, the late table)
+        // (the reverted list, the reserved offsets, the late table; ev_scan: also the next step's masks and chunk prefix, for the late gather)
+        if (reserved) (void)hipStreamWaitEvent(h->stream, ov_next ? h->ev_scan : h->ev_srt4, 0);
         MARK("  ev_srt4 wait");
         if (reserved)
             LAUNCH(h, "assemble", k_assemble_late, std::min<uint32_t>(rev_grid, B) + 1u, 256, P, h->Tb2o, (const uint32_t *)h->rev_list.p, (const float4 *)h->spts.p,
@@ -2507,7 +2510,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             // gather; what needs both, the bucket histogram, joins at ev_early.  On the 9.8 M-point map the early stream's passes are the
             // longer branch in three steps of four: the late gather (8 us + a boundary) no longer follows them (measured, one box, medians of
             // seven passes twice: 0.1903 / 0.1876 -> 0.1885 / 0.1848 ms per scan; 39 M-point map 0.326 / 0.330 -> 0.3155 / 0.3197)
-            (void)hipStreamWaitEvent(h->stream, h->ev_scan, 0);
+            // (joined at ev_scan in front of the late write-back already)
             MARK("  ev_scan wait");
             LAUNCH(h, "voi_gather", k_late_gather, std::min<uint32_t>(2 * B, 128u) + 1u, 256, (const float4 *)Fnew, (const LateEnt *)late_out, (const DevState *)ds,
                    h->Oxy.p, h->Ozi.p, (const unsigned long long *)h->vmask.p, (const unsigned long long *)h->hmask.p, (const uint32_t *)h->pvl.p,

@@ -371,6 +371,7 @@ struct OvSplit {  // round 5: the split of an OVERLAPPED step (see k_voi_split);
     const DevState *prev = nullptr;        // the state of the step in flight: extents of the region it writes, entries of its late table
     unsigned long long *lmask = nullptr;   // per tile of the VoI-resident region: the slots that belong to the late table
 };
+static constexpr uint32_t SPLIT_LATE_LDS = 512;     // late-table entries k_voi_split keeps in LDS (beyond: read where they lie)
 static constexpr uint32_t CINFO_READ = 0x80000000u;  // cinfo: voi count | valid count << 16 | "the chunk was read"
 static constexpr uint32_t CINFO_HMASK = 0x7FFFu;
 __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F, uint32_t nF, uint32_t nFchunks,
@@ -425,6 +426,16 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
         if (nFchunks + nOchunks > cap_chunks) return;  // (the step sees that too and runs the pass itself)
     }
     const uint32_t nchunks = nFchunks + nOchunks;
+    // round 6: a workgroup that meets the VoI-resident region takes the late table (two entries per reverted bin of the step in flight) into
+    // LDS once -- a wavefront used to walk it in global memory: five dependent round trips of binary search at its head, then an entry
+    // per tile
+    __shared__ LateEnt s_late[SPLIT_LATE_LDS];
+    const bool late_lds = n_late != 0u && n_late <= SPLIT_LATE_LDS && (blockIdx.x * (blockDim.x >> 6) < nFchunks || nwaves < nFchunks);  // (the same in every thread of the workgroup)
+    if (late_lds) {
+        for (uint32_t i = threadIdx.x; i < n_late; i += blockDim.x) s_late[i] = ov.late[i];
+        __syncthreads();
+    }
+    const auto late_at = [&](uint32_t i) -> LateEnt { return late_lds ? s_late[i] : ov.late[i]; };
     for (uint32_t c = wid; c < nchunks; c += nwaves) {
         unsigned long long myv = 0, myh = 0, myl = 0;
         uint32_t cv = 0, ch = 0, read_flag = 0;
@@ -498,7 +509,7 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
                 uint32_t lo = 0, hi = n_late;
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi) >> 1;
-                    const LateEnt e = ov.late[mid];
+                    const LateEnt e = late_at(mid);
                     if (e.start + e.ntotal <= c * CHUNK) lo = mid + 1;
                     else hi = mid;
                 }
@@ -525,7 +536,7 @@ __global__ __launch_bounds__(256) void k_voi_split(const float4 *__restrict__ F,
                         const uint32_t pos = base + tt * TILE, tile0 = c * CHUNK + tt * TILE;
                         bool ldat = false, lph = false;
                         for (uint32_t e = e0; e < n_late; ++e) {
-                            const LateEnt le = ov.late[e];
+                            const LateEnt le = late_at(e);
                             if (le.start >= tile0 + TILE) break;
                             if (le.start + le.ntotal <= tile0) continue;
                             ldat = ldat || (pos >= le.start && pos < le.start + le.ndata);
@@ -2948,6 +2959,12 @@ __device__ __forceinline__ void srt4_body(const DP &P, uint32_t *sm, S1P s_st1, 
     const int B = P.B;
     const int k0 = threadIdx.x * SRT_KPT;
     BinStat bs[SRT_KPT];
+    // (round 6: what the tail of this function used to fetch behind the scans -- a reverted bin's place in the voxel scratch, the size of
+    // the complement -- is fetched HERE, beside the statistics: two dependent round trips less for a launch that is one workgroup of them)
+    uint32_t vpos[SRT_KPT];
+#pragma unroll
+    for (int j = 0; j < SRT_KPT; ++j) vpos[j] = (moff_pos && k0 + j < B) ? moff_pos[k0 + j] + qoff_pos[k0 + j] : 0u;
+    const uint32_t ncompl_pre = (out_offR && moff_all) ? moff_all[B + 1] - moff_all[B] : 0u;
     if (st1_in && P.version == 3) {
 #pragma unroll
         for (int j = 0; j < SRT_KPT; ++j)
@@ -3039,7 +3056,7 @@ __device__ __forceinline__ void srt4_body(const DP &P, uint32_t *sm, S1P s_st1, 
                 rev_idx[k0 + j] = rv ? p0 : 0xFFFFFFFFu;
                 if (rv) {
                     rev_list[p0] = (uint32_t)(k0 + j);
-                    vox_off[p0] = moff_pos ? moff_pos[k0 + j] + qoff_pos[k0 + j] : p1;
+                    vox_off[p0] = moff_pos ? vpos[j] : p1;
                     ++p0;
                     p1 += bs[j].mc + bs[j].cc;
                 }
@@ -3092,7 +3109,7 @@ __device__ __forceinline__ void srt4_body(const DP &P, uint32_t *sm, S1P s_st1, 
                 p5 += gR[j];
             }
         if (threadIdx.x == 0) {
-            const uint32_t ncompl = moff_all[B + 1] - moff_all[B];
+            const uint32_t ncompl = ncompl_pre;
             st->total_binsR = t4;
             st->ground_res = t5;
             st->n_late = 2u * t6;
