@@ -210,6 +210,7 @@ struct erasor_hip_handle {
         int skip = 4;            // samples still to be ignored (start-up, a change of mode)
         int n = 0;               // samples of the current block
         double sum[2] = {0, 0};
+        double mx[2] = {0, 0};   // the largest sample of each mode: left out of its mean (one hiccup in eight samples must not decide 600 steps)
         int cnt[2] = {0, 0};
         double est[2] = {0, 0};  // the last decision's mean periods (0: not measured)
         unsigned long long since_decision = 0;
@@ -1827,7 +1828,7 @@ static void launch_split_ahead(erasor_hip_handle *h, double nx, double ny, uint3
     // round 4: ... and the next step's chunk scan behind it: the stream goes on while the host is still collecting this step's results
     // and comes back with the next one (its turnaround, ~10 us, used to be idle time between the split and the scan)
     const bool mb_count = h->B + 1 <= QB_NB_MAX;
-    const uint32_t scan_cap = (uint32_t)std::min<size_t>(std::min(h->pvl.cap, h->phl.cap) - 8, 16384);
+    const uint32_t scan_cap = (uint32_t)std::min<size_t>(std::min(std::min(h->pvl.cap, h->phl.cap), h->cinfo.cap) - 8, 16384);  // (k_chunk_scan_one reads cinfo up to here)
     if (nchunks_hint + 64u <= scan_cap && h->topv.cap >= 24 && h->toph.cap >= 24 && h->prof != 1) {
         hipStream_t keep = h->cur;
         h->cur = h->stream;
@@ -2594,6 +2595,7 @@ static void overlap_auto_sample(erasor_hip_handle *h, double period_us) {
             a.block = 0;
             a.n = 0;
             a.sum[0] = a.sum[1] = 0;
+            a.mx[0] = a.mx[1] = 0;
             a.cnt[0] = a.cnt[1] = 0;
             if (a.mode != block_mode[0]) {
                 a.mode = block_mode[0];
@@ -2607,6 +2609,7 @@ static void overlap_auto_sample(erasor_hip_handle *h, double period_us) {
         return;
     }
     a.sum[a.mode] += period_us;
+    a.mx[a.mode] = std::max(a.mx[a.mode], period_us);
     ++a.cnt[a.mode];
     if (++a.n < OVA_W) return;
     a.n = 0;
@@ -2618,8 +2621,9 @@ static void overlap_auto_sample(erasor_hip_handle *h, double period_us) {
         }
         return;
     }
-    a.est[0] = a.sum[0] / a.cnt[0];
-    a.est[1] = a.sum[1] / a.cnt[1];
+    // (means without each mode's largest sample: a page fault or a late host thread in one of eight steps is not the mode's doing)
+    a.est[0] = a.cnt[0] > 1 ? (a.sum[0] - a.mx[0]) / (a.cnt[0] - 1) : a.sum[0] / a.cnt[0];
+    a.est[1] = a.cnt[1] > 1 ? (a.sum[1] - a.mx[1]) / (a.cnt[1] - 1) : a.sum[1] / a.cnt[1];
     const int m = (a.est[1] * 1.02 < a.est[0]) ? 1 : 0;
     if (m != a.mode) a.skip = OVA_SKIP;
     a.mode = m;

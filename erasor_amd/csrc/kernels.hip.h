@@ -733,6 +733,26 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restr
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     CHAIN_STAMP(6);
     bool ov_bad = false;
+    // round 6: launched ahead, the number of chunks comes from the device state -- the counts used to be fetched BEHIND it.  They are now
+    // fetched beside it, as far as the array goes (cap_dev: what cinfo and the prefix arrays hold); what lies beyond the chunks in use
+    // is dropped below.  One dependent round trip less for a launch that is a single workgroup of them.
+    const uint32_t lim = capO_chunks_dev ? min(cap_dev, 16384u) : nchunks;
+    const uint32_t base = tid * 16;
+    uint32_t ci[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t b4 = base + g * 4;
+        if (b4 + 3 < lim) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(cinfo + b4);
+            ci[g * 4 + 0] = q.x;
+            ci[g * 4 + 1] = q.y;
+            ci[g * 4 + 2] = q.z;
+            ci[g * 4 + 3] = q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ci[g * 4 + j] = b4 + j < lim ? cinfo[b4 + j] : 0u;
+        }
+    }
     if (capO_chunks_dev) {
         const DevState *src = prev ? prev : st;
         const uint32_t nF = prev ? src->nF_new : src->nF, ob = prev ? src->o_new_begin : src->o_begin;
@@ -743,22 +763,9 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restr
         init = *src;
         init.nF = nF;
         init.o_begin = ob;
-    }
-    const uint32_t base = tid * 16;
-    uint32_t ci[16];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint32_t b4 = base + g * 4;
-        if (b4 + 3 < nchunks) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(cinfo + b4);
-            ci[g * 4 + 0] = q.x;
-            ci[g * 4 + 1] = q.y;
-            ci[g * 4 + 2] = q.z;
-            ci[g * 4 + 3] = q.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ci[g * 4 + j] = b4 + j < nchunks ? cinfo[b4 + j] : 0u;
-        }
+        for (int j = 0; j < 16; ++j)
+            if (base + j >= nchunks) ci[j] = 0u;  // (counts of chunks this step does not have: whatever an earlier step left there)
     }
     // (the step's housekeeping rides in the shadow of the loads)
     if (lab_slots && tid < 128) lab_slots[tid] = 0;
@@ -884,17 +891,18 @@ __global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F
     const uint64_t lt = lanemask_lt();
     const bool ovm = lmask != nullptr;
     CHAIN_STAMP(7);
-    if (ovm) {
-        if (st->ov_bad) return;
-        nF = st->nF;
-        nFchunks = (nF + CHUNK - 1) / CHUNK;
-        o_chunk0 = st->o_begin / CHUNK;
-        nOchunks = capO_chunks - o_chunk0;
-    }
     // (round 4: the error flags, the step's state and the first item's records are fetched TOGETHER -- behind one another they were three
-    // dependent round trips at the head of a wavefront that lives five or six)
+    // dependent round trips at the head of a wavefront that lives five or six; round 6: the overlapped step's flag and extents with them)
     const uint32_t err_a = ctr->err, err_b = qctr->err;
     const uint32_t validF = st->validF, voiF = st->voiF, o_new_begin = st->o_new_begin;
+    if (ovm) {
+        const uint32_t f_ov = st->ov_bad, nF_dev = st->nF, ob_dev = st->o_begin;
+        if (f_ov) return;
+        nF = nF_dev;
+        nFchunks = (nF + CHUNK - 1) / CHUNK;
+        o_chunk0 = ob_dev / CHUNK;
+        nOchunks = capO_chunks - o_chunk0;
+    }
     uint32_t dyn_leave = 0, stat_leave = 0, dyn_enter = 0, stat_enter = 0;
     // Work items: a chunk of the VoI-resident region is nearly all VoI (every tile fetches, transforms and runs the R-POD key), and
     // there are only ~800 of them for a 0.8 M-point VoI -- fewer wavefronts than SIMDs, each with 16 dependent rounds.  They are cut
@@ -1022,12 +1030,14 @@ __global__ __launch_bounds__(256) void k_late_gather(const float4 *__restrict__ 
         if (threadIdx.x == 0 && se.st) step_end_body(se.st, se.ctr, se.out, se.lab_slots, se.qctr, se.q_nvox, se.seq);
         return;
     }
-    if (st->ov_bad || ctr->err || qctr->err) return;  // (the step that finds this out runs its own passes / fails like any other)
+    // (round 6: the three flags and the two extents in one round trip -- as a chain of short-circuit tests they were up to four)
+    const uint32_t f_ov = st->ov_bad, f_e = ctr->err, f_q = qctr->err;
+    const uint32_t n_late = prev->n_late;
+    const uint32_t o_new_begin = st->o_new_begin;
+    if (f_ov | f_e | f_q) return;  // (the step that finds this out runs its own passes / fails like any other)
     CHAIN_STAMP(9);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint64_t lt = lanemask_lt();
-    const uint32_t n_late = prev->n_late;
-    const uint32_t o_new_begin = st->o_new_begin;
     uint32_t dead = 0, ph_unused = 0, n_left = 0, dyn_leave = 0, stat_leave = 0, bad = 0;
     for (uint32_t e = blockIdx.x; e < n_late; e += gridDim.x - 1) {
         const LateEnt le = late[e];
@@ -4087,13 +4097,15 @@ __global__ __launch_bounds__(256) void k_assemble_late(DP P, Xf Tb2o, const uint
     // (the launch's LAST workgroup leaves the tables and totals, the others take the bins: side by side)
     const uint32_t nbin_wg = gridDim.x - 1u;
     for (uint32_t rk = blockIdx.x; rk < n_rev && blockIdx.x < nbin_wg; rk += nbin_wg) {
+        // (round 6: everything that depends on rk alone -- the bin's key, its two table entries, its place in the voxel scratch, its counts --
+        // is fetched in ONE round trip, ahead of the prefix of rejected points: they used to follow it one behind the other)
         const uint32_t key = rev_list[rk];
-        const uint32_t o0 = moff[key], mc = moff[key + 1] - o0;
-        uint32_t nv, ng, rj;
-        sizes(rk, nv, ng, rj);
-        const uint32_t rej0 = rej_before(rk);
         const LateEnt eb = late[rk], eg = late[n_rev + rk];
         const uint32_t vo = vox_off[rk];
+        const uint32_t ng = ng_arr[rk], nvx = nvox[rk];
+        const uint32_t o0 = moff[key], mc = moff[key + 1] - o0;
+        const uint32_t nv = (qoff[key + 1] - qoff[key]) > 0 ? nvx : 0u;  // an unoccupied bin_curr: r_pod2pc skips the bin (erasor.cpp:313)
+        const uint32_t rej0 = rej_before(rk);
         for (uint32_t v = threadIdx.x; v < eb.ntotal; v += blockDim.x) {
             float4 w = hole;
             if (v < nv) {

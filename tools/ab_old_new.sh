@@ -6,7 +6,7 @@ cd $ROOT
 A="--no-cpu-baseline --no-extra-workloads --no-callback-bench --no-pr-rr"
 run() { timeout 300 python $1/bench.py $A $2 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print('$3', d['ms_per_step'], d['ms_per_step_all'], 'taken', d['overlapped_steps']['taken'], 'auto', [round(x,1) for x in (d['overlapped_steps']['auto']['plain_period_us'], d['overlapped_steps']['auto']['overlapped_period_us'])])"; }
-for wl in "" "--workload large_scale_05"; do
+for wl in ${AB_WORKLOADS:-"" "--workload large_scale_05"}; do
   for cfg in "--steps 20 --warmup 5 --repeats 7" "--steps 100 --warmup 5 --repeats 5"; do
     echo "== $wl $cfg"
     for rep in 1 2; do
