@@ -870,7 +870,7 @@ __global__ __launch_bounds__(1024) void k_chunk_scan_one(const uint32_t *__restr
 // R-POD key (erasor.cpp:124-139), write into VoI order; tombstone outskirts sources; move the
 // points that left the VoI from the F region to the front of the outskirts region.
 // ================================================================================================
-__global__ __launch_bounds__(256) void k_voi_gather(const float4 *__restrict__ F, uint32_t nF, uint32_t nFchunks,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_voi_gather(const float4 *__restrict__ F, uint32_t nF, uint32_t nFchunks,
                                                      float2 *__restrict__ Oxy, float2 *__restrict__ Ozi, uint32_t o_chunk0,
                                                      uint32_t nOchunks, const unsigned long long *__restrict__ vmask,
                                                      const unsigned long long *__restrict__ hmask,
