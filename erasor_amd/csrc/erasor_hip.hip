@@ -2267,22 +2267,45 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         (void)hipStreamWaitEvent(h->bstream, h->ev_stats, 0);
         MARK("  ev_stats record + wait");
         h->cur = h->bstream;  // ---- the early stream: beside the per-bin launch
-        LAUNCH(h, "srt", k_srt4, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
-               (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds,
-               h->out_off0.p, h->rev_before.p, h->crej_off.p, (const uint8_t *)h->st1b.p, (const uint32_t *)h->moff.p, (const uint32_t *)Q(h).qoff.p,
-               h->out_offR.p, h->gres_off.p, late_out, leave_lim);
-        MARK("  k_srt4");
-        // (round 6: an overlapped step's late write-back joins at ev_scan, further down this stream and long there when the per-bin launch
-        // ends: one packet less between k_srt4 and the early write-back)
+        // (round 6: ONE launch -- every workgroup of the early write-back derives the reserved offsets it needs from the status bytes itself,
+        // the launch's last workgroup is k_srt4 for everything behind it: see k_assemble_early)
+        {
+            EarlyArgs ea;
+            ea.mcnt = h->mcnt.p;
+            ea.mmin = h->mmin.p;
+            ea.mmax = h->mmax.p;
+            ea.ccnt = Q(h).ccnt.p;
+            ea.cmin = Q(h).cmin.p;
+            ea.cmax = Q(h).cmax.p;
+            ea.st1 = h->st1.p;
+            ea.status = h->status.p;
+            ea.action = h->action.p;
+            ea.rev_idx = h->rev_idx.p;
+            ea.rev_list = h->rev_list.p;
+            ea.vox_off = h->vox_off.p;
+            ea.st = ds;
+            ea.out_off0 = h->out_off0.p;
+            ea.rev_before = h->rev_before.p;
+            ea.crej_off = h->crej_off.p;
+            ea.st1_in = h->st1b.p;
+            ea.moff = h->moff.p;
+            ea.qoff = Q(h).qoff.p;
+            ea.out_offR = h->out_offR.p;
+            ea.gres_off = h->gres_off.p;
+            ea.late = late_out;
+            ea.leave_lim = leave_lim;
+            ea.skeys = sm_keys;
+            ea.spts = h->spts.p;
+            ea.Fnew = Fnew;
+            ea.cnt = h->lab_slots.p;
+            // (one round of workgroups: a 1024-thread workgroup of this kernel has a compute unit to itself, and the per-bin launch and the query
+            // chains hold some of the 256)
+            LAUNCH(h, "srt+assemble", k_assemble_early, std::min<uint32_t>(cdiv(n_voi, 1024), 200) + 1u, 1024, P, h->Tb2o, ea);
+        }
+        MARK("  k_srt4 + assemble early");
+        // (an overlapped step's late write-back joins at ev_scan, further down this stream and long there when the per-bin launch ends)
         if (!ov_next) (void)hipEventRecord(h->ev_srt4, h->bstream);
         MARK("  ev_srt4 record");
-        if (n_voi)
-            LAUNCH(h, "assemble", (k_assemble_map<true, false, true>), std::min<uint32_t>(cdiv(n_voi, 256), 2048), 256, P, h->Tb2o, (const uint8_t *)h->action.p,
-                   (const uint32_t *)h->rev_idx.p, sm_keys, (const float4 *)h->spts.p, (const uint32_t *)h->ssrc.p, (const uint32_t *)h->moff.p,
-                   (const uint32_t *)Q(h).ccnt.p, (const uint8_t *)h->gflag.p, (const uint32_t *)h->grank.p, h->out_off.p, h->ground_off.p, h->rej_off.p, ds, Fnew,
-                   h->rejected.p, h->rejected_src.p, h->lab_slots.p, 0u, (const uint32_t *)h->rev_list.p, (const uint32_t *)Q(h).qoff.p,
-                   (const uint32_t *)h->nvox.p, (const uint32_t *)h->vox_off.p, (const float4 *)h->vox_out.p, (const uint32_t *)h->out_offR.p,
-                   (const uint32_t *)h->rev_before.p, (const uint32_t *)h->ng.p);
         MARK("  assemble early");
         if (!ov_next) (void)hipEventRecord(h->ev_asm, h->bstream);  // (an overlapped step joins at ev_early: one packet less on the early chain)
         MARK("  ev_asm record");

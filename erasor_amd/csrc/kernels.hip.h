@@ -3153,10 +3153,13 @@ __global__ __launch_bounds__(1024) void k_srt4(DP P, const uint32_t *__restrict_
 // bins, two block scans) while ONE extra workgroup of the same launch does k_srt4's work for the kernels behind it (status / action /
 // layout prefixes): the Scan Ratio Test's second pass leaves the main stream's dependency chain (14 us + a kernel boundary).
 // sel[0] = bin key, sel[2] = number of reverted bins (the bin's share of the voxel scratch begins at moff[key] + qoff[key]).
-__shared__ uint32_t g_sel[4];
+// Round 6: sel[4 .. 7] = the bin's range of the bucketed map (begin, points) and of the bucketed scan -- the few threads that own a reverted
+// bin fetch their bins' offsets BESIDE the block scan, so the workgroup does not pay a round trip of its own for them behind it.
+__shared__ uint32_t g_sel[8];
 __shared__ uint32_t g_selsm[40];
 // (out of line, like the sort: a register allocation of its own instead of a share of the per-bin kernel's 128 VGPRs)
-__device__ __attribute__((noinline)) void rev_select_call(int B, const uint8_t *__restrict__ st1b, uint32_t rk) {
+__device__ __attribute__((noinline)) void rev_select_call(int B, const uint8_t *__restrict__ st1b, uint32_t rk, const uint32_t *__restrict__ moff,
+                                                          const uint32_t *__restrict__ qoff) {
     uint32_t *sm = g_selsm, *sel = g_sel;
     const int k0 = threadIdx.x * SRT_KPT;
     uint32_t rvm = 0;
@@ -3172,6 +3175,17 @@ __device__ __attribute__((noinline)) void rev_select_call(int B, const uint8_t *
         }
     }
     const uint32_t nrv = (uint32_t)__popc(rvm);
+    uint32_t mo[SRT_KPT + 1], qo[SRT_KPT + 1];
+#pragma unroll
+    for (int j = 0; j <= SRT_KPT; ++j) mo[j] = qo[j] = 0u;
+    if (rvm) {  // (in flight during the scan)
+#pragma unroll
+        for (int j = 0; j <= SRT_KPT; ++j) {
+            const int k = min(k0 + j, B);
+            mo[j] = moff[k];
+            qo[j] = qoff[k];
+        }
+    }
     uint32_t t0;
     uint32_t p0 = block_excl_scan(nrv, sm, t0);
     if (threadIdx.x == 0) sel[2] = t0;
@@ -3179,7 +3193,13 @@ __device__ __attribute__((noinline)) void rev_select_call(int B, const uint8_t *
 #pragma unroll
         for (int j = 0; j < SRT_KPT; ++j)
             if ((rvm >> j) & 1u) {
-                if (p0 == rk) sel[0] = (uint32_t)(k0 + j);
+                if (p0 == rk) {
+                    sel[0] = (uint32_t)(k0 + j);
+                    sel[4] = mo[j];
+                    sel[5] = mo[j + 1] - mo[j];
+                    sel[6] = qo[j];
+                    sel[7] = qo[j + 1] - qo[j];
+                }
                 ++p0;
             }
     }
@@ -4000,6 +4020,126 @@ __global__ __launch_bounds__(256) void k_assemble_map(DP P, Xf Tb2o, const uint8
     block_commit_labels(nd, nst, cnt);
 }
 
+// Round 6 (second half): the EARLY write-back of a step in the reserved layout WITHOUT a k_srt4 launch in front of it.  On config 2 the early
+// stream's chain (k_srt4 15.5 us -> early write-back 9.5 -> next split -> chunk scan -> gather) is the longer branch of an overlapped step in
+// three steps of four, and k_srt4 -- one workgroup, two rounds of global accesses, ten output arrays -- is a sixth of it.  All the write-back
+// needs of it is, per bin, "reverted or not" and the bin's reserved offset (srt4_body's out_offR) and the two extents, and in v3 both follow
+// from the first-pass status bytes and the two counts (erasor.cpp:510-511: the decision is local to a bin): EVERY workgroup builds that table
+// itself in LDS -- one round trip for 3 x 2160 values, one pass of two block scans: the arithmetic of srt4_body's reserved branch, value for
+// value -- and the launch's LAST workgroup is k_srt4 (srt4_body, unchanged) for everything behind it: the next split's late table, the late
+// write-back, the getters.  One launch, one kernel boundary and ~13 us less on the early chain; same results.
+struct EarlyArgs {
+    // srt4_body's (the launch's last workgroup)
+    const uint32_t *mcnt;
+    const float *mmin, *mmax;
+    const uint32_t *ccnt;
+    const float *cmin, *cmax;
+    uint8_t *st1, *status, *action;
+    uint32_t *rev_idx, *rev_list, *vox_off;
+    DevState *st;
+    uint32_t *out_off0, *rev_before, *crej_off;
+    const uint8_t *st1_in;
+    const uint32_t *moff, *qoff;
+    uint32_t *out_offR, *gres_off;
+    LateEnt *late;
+    double leave_lim;
+    // the write-back's
+    const uint32_t *skeys;
+    const float4 *spts;
+    float4 *Fnew;
+    unsigned long long *cnt;
+};
+__global__ __launch_bounds__(1024) void k_assemble_early(DP P, Xf Tb2o, EarlyArgs a) {
+    __shared__ uint32_t sm[96];
+    __shared__ uint32_t s_base[1024 * SRT_KPT];  // a bin's reserved offset minus its offset in VoI order: point i of the bin goes to s_base[key] + i
+    __shared__ uint8_t s_st1[1024 * SRT_KPT];    // the k_srt4 workgroup: first-pass statuses; the others: 1 = reverted (k_assemble_late writes the bin)
+    if (blockIdx.x == 0) {  // (the FIRST workgroup: dispatched with the first round, whatever the grid)
+        if (g_stamps_on && threadIdx.x == 0) g_stamps[3] = wall_clock64();
+        srt4_body(P, sm, s_st1, a.mcnt, a.mmin, a.mmax, a.ccnt, a.cmin, a.cmax, a.st1, a.status, a.action, a.rev_idx, a.rev_list, a.vox_off, a.st, a.out_off0,
+                  a.rev_before, a.crej_off, a.st1_in, a.moff, a.qoff, a.out_offR, a.gres_off, a.late, a.leave_lim, a.moff);
+        return;
+    }
+    if (g_stamps_on && blockIdx.x == 1 && threadIdx.x == 0) g_stamps[4] = wall_clock64();
+    const int B = P.B;
+    const int k0 = threadIdx.x * SRT_KPT;
+    const uint32_t n_act = a.st->voi_total;  // (the step's own state, not k_srt4's)
+    uint32_t szR[SRT_KPT], mo[SRT_KPT];
+    bool rv[SRT_KPT];
+    uint32_t sums[2] = {0u, 0u};  // reserved sizes, reserved ground: srt4_body's sums[4], sums[5]
+    const double zb = fmax(fabs(P.min_h), fabs(P.max_h));
+#pragma unroll
+    for (int j = 0; j < SRT_KPT; ++j) {
+        szR[j] = 0;
+        mo[j] = 0;
+        rv[j] = false;
+        if (k0 + j < B) {
+            const uint8_t v = a.st1_in[k0 + j];
+            const uint32_t mc = a.mcnt[k0 + j], cc = a.ccnt[k0 + j];
+            mo[j] = a.moff[k0 + j];
+            rv[j] = (v & 0x7Fu) == ST_MAP && (v & 0x80u);  // srt_second, v3: MAP_IS_HIGHER and the map bin taller than 0.5 m
+            if (rv[j]) {
+                const int ring = (k0 + j) % P.R;
+                const double rho = (ring + 1 >= P.R) ? P.max_r : (double)(ring + 1) * P.ring_size;
+                const bool ml = !(sqrt(rho * rho + zb * zb) * (1.0 + 1e-5) < a.leave_lim);
+                szR[j] = cc > 0 ? (mc + cc) * (ml ? 2u : 1u) : 0u;
+                sums[1] += mc * (ml ? 2u : 1u);
+            } else {
+                szR[j] = mc;
+            }
+            sums[0] += szR[j];
+        }
+    }
+    const uint32_t mo_compl = a.moff[B];
+    uint32_t pre[2], tot[2];
+    block_excl_scan_n<2>(sums, sm, pre, tot);
+    {
+        uint32_t p4 = pre[0];
+#pragma unroll
+        for (int j = 0; j < SRT_KPT; ++j)
+            if (k0 + j < B) {
+                s_base[k0 + j] = p4 - mo[j];
+                s_st1[k0 + j] = rv[j] ? 1 : 0;
+                p4 += szR[j];
+            }
+    }
+    __syncthreads();
+    const uint32_t base_compl = tot[0] + tot[1] - mo_compl;  // the complement follows the bins and the ground part (n_static_est)
+    uint32_t nd = 0, nst = 0;
+    const uint32_t gmap = gridDim.x - 1u;
+    // (a workgroup of 1024 threads at 70 VGPRs has a compute unit to itself: the grid is one round of workgroups -- see the launch -- and
+    // every thread keeps four points in flight)
+    const uint32_t stride = gmap * blockDim.x;
+    auto place = [&](uint32_t i, uint32_t key, const float4 &p) {
+        uint32_t nwr = 0;
+        if (key == (uint32_t)B) {
+            a.Fnew[base_compl + i] = xform(Tb2o, p);
+            nwr = 1;
+        } else if (!s_st1[key]) {
+            a.Fnew[s_base[key] + i] = xform(Tb2o, p);
+            nwr = 1;
+        }
+        if (is_dynamic_label(p.w)) nd += nwr; else nst += nwr;
+    };
+    uint32_t i = (blockIdx.x - 1u) * blockDim.x + threadIdx.x;
+    for (; i + 3u * stride < n_act; i += 4u * stride) {
+        uint32_t key[4];
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = a.skeys[i + (uint32_t)u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = a.spts[i + (uint32_t)u * stride];  // (a slot of the dead bucket holds zeros: read, not used)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (key[u] <= (uint32_t)B) place(i + (uint32_t)u * stride, key[u], p[u]);  // (> B: a VoI-order slot kept for a late point that never came)
+    }
+    for (; i < n_act; i += stride) {
+        const uint32_t key = a.skeys[i];
+        if (key > (uint32_t)B) continue;
+        place(i, key, a.spts[i]);
+    }
+    block_commit_labels(nd, nst, a.cnt);
+}
+
 // scan-side contributions: v3 voxelised reverted bins; v2 curr points of reverted / merged / curr-only bins
 template <bool XFORM>
 __global__ __launch_bounds__(256) void k_assemble_bins(DP P, Xf Tb2o, const uint8_t *__restrict__ action,
@@ -4081,18 +4221,7 @@ __global__ __launch_bounds__(256) void k_assemble_late(DP P, Xf Tb2o, const uint
         rj = mc - g;
         sz = cc > 0 ? nvox[rk] : 0u;  // an unoccupied bin_curr: r_pod2pc skips the bin (erasor.cpp:313)
     };
-    // rejected points before reverted bin rk (dense map_rejected): summed by the workgroup that needs it
-    auto rej_before = [&](uint32_t rk) -> uint32_t {
-        uint32_t a = 0;
-        for (uint32_t r = threadIdx.x; r < rk; r += blockDim.x) {
-            uint32_t sz, g, rj;
-            sizes(r, sz, g, rj);
-            a += rj;
-        }
-        uint32_t t;
-        (void)block_excl_scan(a, s_sm, t);
-        return t;
-    };
+    // (rejected points before reverted bin rk -- the dense map_rejected -- are summed by the workgroup that needs them: below)
     uint32_t nd = 0, nst = 0;
     // (the launch's LAST workgroup leaves the tables and totals, the others take the bins: side by side)
     const uint32_t nbin_wg = gridDim.x - 1u;
@@ -4103,9 +4232,27 @@ __global__ __launch_bounds__(256) void k_assemble_late(DP P, Xf Tb2o, const uint
         const LateEnt eb = late[rk], eg = late[n_rev + rk];
         const uint32_t vo = vox_off[rk];
         const uint32_t ng = ng_arr[rk], nvx = nvox[rk];
+        // (round 6, second half: the earlier bins' keys and ground counts -- the prefix of rejected points -- travel in the SAME two round
+        // trips as the bin's own key and range: thread r takes bin r; behind them they were two more)
+        const uint32_t r_first = threadIdx.x;
+        uint32_t key_r = 0, ng_r = 0;
+        if (r_first < rk) {
+            key_r = rev_list[r_first];
+            ng_r = ng_arr[r_first];
+        }
         const uint32_t o0 = moff[key], mc = moff[key + 1] - o0;
         const uint32_t nv = (qoff[key + 1] - qoff[key]) > 0 ? nvx : 0u;  // an unoccupied bin_curr: r_pod2pc skips the bin (erasor.cpp:313)
-        const uint32_t rej0 = rej_before(rk);
+        uint32_t rej0;
+        {
+            uint32_t a = 0;
+            if (r_first < rk) a = (moff[key_r + 1] - moff[key_r]) - ng_r;
+            for (uint32_t r = threadIdx.x + blockDim.x; r < rk; r += blockDim.x) {
+                uint32_t sz, g, rj;
+                sizes(r, sz, g, rj);
+                a += rj;
+            }
+            (void)block_excl_scan(a, s_sm, rej0);
+        }
         for (uint32_t v = threadIdx.x; v < eb.ntotal; v += blockDim.x) {
             float4 w = hole;
             if (v < nv) {
@@ -4140,53 +4287,52 @@ __global__ __launch_bounds__(256) void k_assemble_late(DP P, Xf Tb2o, const uint
         // dense tables and totals (k_layout4's): prefixes over the reverted bins of their output sizes, ground, rejected points
         if (threadIdx.x < 4) s_carry[threadIdx.x] = 0;
         __syncthreads();
+        // (round 6, second half: the five prefixes in ONE pass of scans -- they were five pairs of barriers behind four dependent round
+        // trips; the ground entries' holes follow the bins' in the table, so their prefix is lifted by the bins' total once that is known)
+        if (threadIdx.x == 0) s_carry[3] = 0;
+        __shared__ uint32_t s_carry4;
+        __shared__ uint32_t s_smn[80];
+        if (threadIdx.x == 0) s_carry4 = 0;
+        __syncthreads();
         for (uint32_t base = 0; base < n_rev; base += blockDim.x) {
             const uint32_t rk = base + threadIdx.x;
-            uint32_t sz = 0, g = 0, rj = 0, hl = 0;
+            uint32_t v[5] = {0u, 0u, 0u, 0u, 0u};  // output size, ground, rejected, holes of the bin's range, holes of its ground range
             if (rk < n_rev) {
-                sizes(rk, sz, g, rj);
-                hl = late[rk].ntotal - sz;
+                const uint32_t nt_b = late[rk].ntotal, nt_g = late[n_rev + rk].ntotal;
+                sizes(rk, v[0], v[1], v[2]);
+                v[3] = nt_b - v[0];
+                v[4] = nt_g - v[1];
             }
-            uint32_t t0, t1, t2, t3;
-            const uint32_t p0 = block_excl_scan(sz, s_sm, t0);
-            const uint32_t p1 = block_excl_scan(g, s_sm, t1);
-            const uint32_t p2 = block_excl_scan(rj, s_sm, t2);
-            const uint32_t p3 = block_excl_scan(hl, s_sm, t3);
-            const uint32_t c0 = s_carry[0], c1 = s_carry[1], c2 = s_carry[2], c3 = s_carry[3];
+            uint32_t pre[5], tot[5];
+            block_excl_scan_n<5>(v, s_smn, pre, tot);
+            const uint32_t c0 = s_carry[0], c1 = s_carry[1], c2 = s_carry[2], c3 = s_carry[3], c4 = s_carry4;
             if (rk < n_rev) {
                 // (late_holes[i]: holes in the ranges before entry i; the bins' entries first, the ground entries follow below)
-                late_holes[rk] = c3 + p3;
-                ground_off[rk] = c1 + p1;
-                rej_off[rk] = c2 + p2;
-                if (rk < ASM_RVMAX) s_cvl[rk] = c0 + p0;  // voxels of the reverted bins before rk (out_off by key, below)
+                late_holes[rk] = c3 + pre[3];
+                late_holes[n_rev + rk] = c4 + pre[4];  // (+ the bins' holes in all: below)
+                ground_off[rk] = c1 + pre[1];
+                rej_off[rk] = c2 + pre[2];
+                if (rk < ASM_RVMAX) s_cvl[rk] = c0 + pre[0];  // voxels of the reverted bins before rk (out_off by key, below)
             }
             __syncthreads();
             if (threadIdx.x == 0) {
-                s_carry[0] = c0 + t0;
-                s_carry[1] = c1 + t1;
-                s_carry[2] = c2 + t2;
-                s_carry[3] = c3 + t3;
+                s_carry[0] = c0 + tot[0];
+                s_carry[1] = c1 + tot[1];
+                s_carry[2] = c2 + tot[2];
+                s_carry[3] = c3 + tot[3];
+                s_carry4 = c4 + tot[4];
             }
             __syncthreads();
         }
         const uint32_t sum_sz = s_carry[0], sum_g = s_carry[1], sum_rj = s_carry[2], holes_bins = s_carry[3];
         if (threadIdx.x == 0 && n_rev < ASM_RVMAX + 1) s_cvl[n_rev] = sum_sz;
-        __syncthreads();
-        // ground entries' holes
-        if (threadIdx.x == 0) s_carry[3] = holes_bins;
-        __syncthreads();
-        for (uint32_t base = 0; base < n_rev; base += blockDim.x) {
+        for (uint32_t base = 0; base < n_rev; base += blockDim.x) {  // (every thread lifts what it wrote itself)
             const uint32_t rk = base + threadIdx.x;
-            uint32_t hl = 0;
-            if (rk < n_rev) hl = late[n_rev + rk].ntotal - ng_arr[rk];
-            uint32_t t3;
-            const uint32_t p3 = block_excl_scan(hl, s_sm, t3);
-            const uint32_t c3 = s_carry[3];
-            if (rk < n_rev) late_holes[n_rev + rk] = c3 + p3;
-            __syncthreads();
-            if (threadIdx.x == 0) s_carry[3] = c3 + t3;
-            __syncthreads();
+            if (rk < n_rev) late_holes[n_rev + rk] += holes_bins;
         }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry[3] = holes_bins + s_carry4;
+        __syncthreads();
         if (threadIdx.x == 0) late_holes[2 * n_rev] = s_carry[3];  // (all of them: what a source index behind the last range is reduced by)
         // dense out_off by key: out_off0[key] + the voxels of the reverted bins before it
 #pragma unroll 4

@@ -53,6 +53,11 @@ struct RevArgs {  // the per-bin launch's pointers (kernel arguments, copied to 
 struct RevBin {
     uint32_t rk, key, vo;  // entry of the reverted list, bin key, the bin's offset in the voxel scratch
     uint32_t state, m, nc;  // voxelisation: what is left to do (BV_*), cloud size, curr points among them
+    // round 6: what every phase used to fetch from global memory at its head (a dependent round trip each, ~0.7 us of one workgroup's chain):
+    // the bin's range of the bucketed map / scan, fetched ONCE by rev_set_bin; the ground count and whether R-GPF has left the bin's
+    // coordinates (pool words [PB_CAP, 4 * PB_CAP)) and ground list (words [0, ng)) in LDS for the voxelisation behind it
+    uint32_t o0, M, qo, cc;
+    uint32_t ng, in_lds;
     unsigned long long t_a, t_b;
 };
 enum : uint32_t { BV_DONE = 0, BV_SORT = 1, BV_RARE = 2 };
@@ -66,7 +71,8 @@ __shared__ uint32_t g_tab[64];
 __shared__ uint32_t g_sbb[6];
 __shared__ uint32_t g_carry;
 __shared__ float g_n[3];
-__shared__ double g_th, g_lpr;
+__shared__ double g_th, g_lpr, g_pd;
+__shared__ uint32_t g_chg;
 __shared__ unsigned long long g_t[12], g_es[24];
 __shared__ RevArgs g_ra;
 __shared__ RevBin g_rb;
@@ -109,7 +115,7 @@ __device__ __attribute__((noinline)) void rg_rare_call() {
     const RevArgs a = g_ra;
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
     const uint32_t rk = g_rb.rk, key = g_rb.key;
-    const uint32_t o0 = a.moff[key], M = a.moff[key + 1] - o0;
+    const uint32_t o0 = g_rb.o0, M = g_rb.M;
     const float4 *pts = a.spts + o0;
     uint32_t *K = a.gsK + o0, *V = a.gsV + o0;
     for (uint32_t i = tid; i < M; i += bs) {
@@ -129,8 +135,7 @@ __device__ __attribute__((noinline)) void rg_rare_call() {
 // (1) std::sort(src_copy, point_cmp), erasor.cpp:239-240: (z key, bin-local index) pairs into the pool; the caller runs the sort
 __device__ __attribute__((noinline)) void rg_keys_call() {
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
-    const uint32_t key = g_rb.key;
-    const uint32_t o0 = g_ra.moff[key], M = g_ra.moff[key + 1] - o0;
+    const uint32_t o0 = g_rb.o0, M = g_rb.M;
     const float4 *pts = g_ra.spts + o0;
     if (g_ra.dbg && tid == 0) {
         g_rb.t_a = wall_clock64();
@@ -145,8 +150,8 @@ __device__ __attribute__((noinline)) void rg_keys_call() {
 __device__ __attribute__((noinline)) void rg_fit_call() {
     const DP P = g_dp;
     const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = bs >> 6;
-    const uint32_t rk = g_rb.rk, key = g_rb.key;
-    const uint32_t o0 = g_ra.moff[key], M = g_ra.moff[key + 1] - o0;
+    const uint32_t rk = g_rb.rk;
+    const uint32_t o0 = g_rb.o0, M = g_rb.M;
     const float4 *pts = g_ra.spts + o0;
     uint8_t *gflag = g_ra.gflag;
     uint32_t *grank = g_ra.grank, *glist_out = g_ra.glist, *ng_out = g_ra.ng_arr;
@@ -159,6 +164,9 @@ __device__ __attribute__((noinline)) void rg_fit_call() {
     float *sProd = reinterpret_cast<float *>(pool + 4 * PB_CAP);
 #define RG_STAMP(i) do { if (dbg && tid == 0) g_t[i] = wall_clock64(); } while (0)
     RG_STAMP(1);
+    // (round 6: the first row of the bin's points is on its way while the seeds are counted -- the staging below used to start its round trip
+    // to global memory behind them)
+    const float4 q_first = tid < M ? pts[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
     // sorted keys in sL, sorted bin-local indices in sR
     uint32_t drop = 0, ng = 0;
     {
@@ -170,12 +178,17 @@ __device__ __attribute__((noinline)) void rg_fit_call() {
         drop = tot;
         const uint32_t Ms = M - drop;
         // --- extract_initial_seeds_ (erasor.cpp:204-231) ---
-        if (tid == 0) {
+        if (wave == 0) {  // (round 6: the lowest heights are FETCHED by 64 lanes at a time -- one LDS round trip instead of one per value of the
+            // single lane that used to walk them -- and added in the reference's order, in double, from the lanes' registers)
             uint32_t cl = 0;
             if (P.num_lowest >= 0 && Ms > (uint32_t)P.num_lowest && P.gf_lpr > 0) cl = min((uint32_t)P.gf_lpr, Ms - (uint32_t)P.num_lowest);
             double sum = 0;
-            for (uint32_t t = 0; t < cl; ++t) sum += (double)key_to_float(sL[drop + (uint32_t)P.num_lowest + t]);
-            g_lpr = cl != 0 ? sum / (int)cl : 0;
+            for (uint32_t base = 0; base < cl; base += 64u) {
+                const uint32_t cn = min(64u, cl - base);
+                const uint32_t vb = lane < cn ? __float_as_uint(key_to_float(sL[drop + (uint32_t)P.num_lowest + base + lane])) : 0u;
+                for (uint32_t t = 0; t < cn; ++t) sum += (double)__uint_as_float(__builtin_amdgcn_readlane(vb, t));
+            }
+            if (lane == 0) g_lpr = cl != 0 ? sum / (int)cl : 0;
         }
         __syncthreads();
         const double seed_thr = g_lpr + P.gf_seeds_h;
@@ -190,7 +203,12 @@ __device__ __attribute__((noinline)) void rg_fit_call() {
     for (uint32_t k = tid; k < ng; k += bs) glist[k] = sR[drop + k];
     __syncthreads();  // sV / sL / sR are dead from here on
     float *X = reinterpret_cast<float *>(sV), *Y = reinterpret_cast<float *>(sL), *Z = reinterpret_cast<float *>(sR);
-    for (uint32_t i = tid; i < M; i += bs) {
+    if (tid < M) {
+        X[tid] = q_first.x;
+        Y[tid] = q_first.y;
+        Z[tid] = q_first.z;
+    }
+    for (uint32_t i = tid + bs; i < M; i += bs) {
         const float4 q = pts[i];
         X[i] = q.x;
         Y[i] = q.y;
@@ -199,7 +217,25 @@ __device__ __attribute__((noinline)) void rg_fit_call() {
     __syncthreads();
     RG_STAMP(2);
     const uint32_t E = (M + bs - 1) / bs;  // points per thread in the classification (<= 4)
+    // Round 6 (second half): a fit whose ground list is the list of the fit before it IS that fit.  From the second iteration on the list is
+    // the previous classification's result in source order; when two successive classifications mark the same points (three bins of four on
+    // the synthetic sequences: R-GPF has converged after one iteration), the next iteration's nine sums run over the same values in the same
+    // order and its decomposition sees the same matrix -- the plane is copied, the sums (2-12 us) and the one-lane SVD (4-5 us) are not run.
+    // (The seeds of iteration 0 come in sorted order, not in source order: iteration 1 always fits.)
+    uint64_t pbal[4] = {0ull, 0ull, 0ull, 0ull};
+    bool same_list = false;
     for (int it = 0; it < P.gf_iter; ++it) {
+      if (it >= 2 && same_list) {
+        if (tid == 0) {
+            if (ng == 0) atomicAdd(&ctr->n_degenerate, 1u);
+            plane_n[((size_t)rk * P.gf_iter + it) * 3 + 0] = g_n[0];
+            plane_n[((size_t)rk * P.gf_iter + it) * 3 + 1] = g_n[1];
+            plane_n[((size_t)rk * P.gf_iter + it) * 3 + 2] = g_n[2];
+            plane_d[(size_t)rk * P.gf_iter + it] = g_pd;
+            g_chg = 0u;
+        }
+        __syncthreads();
+      } else {
         // --- estimate_plane_: pcl::computeMeanAndCovarianceMatrix, nine float32 accumulators in list order ---
         // The nine products of every list element are formed by ALL threads (parallel, order-free) into LDS rows padded to RG_RS floats
         // (nine lanes, nine banks, 128-bit reads); then lane a of wave 0 adds row a strictly in list order -- the only part that has to be
@@ -326,6 +362,8 @@ __device__ __attribute__((noinline)) void rg_fit_call() {
                 g_n[1] = n1;
                 g_n[2] = n2_;
                 g_th = P.gf_dist - d;
+                g_pd = d;
+                g_chg = 0u;
                 plane_n[((size_t)rk * P.gf_iter + it) * 3 + 0] = n0;
                 plane_n[((size_t)rk * P.gf_iter + it) * 3 + 1] = n1;
                 plane_n[((size_t)rk * P.gf_iter + it) * 3 + 2] = n2_;
@@ -334,6 +372,7 @@ __device__ __attribute__((noinline)) void rg_fit_call() {
         }
         __syncthreads();
         if (it == 0) RG_STAMP(4);
+      }
         // --- points * normal_ < th_dist_d_ in source order (erasor.cpp:265-281) ---
         const float n0 = g_n[0], n1 = g_n[1], n2_ = g_n[2];
         const double th = g_th;
@@ -351,7 +390,17 @@ __device__ __attribute__((noinline)) void rg_fit_call() {
             bal[e] = __ballot(g);
             if (lane == 0) g_tab[e * 16 + wave] = (e < E && wave < nw) ? (uint32_t)__popcll(bal[e]) : 0u;
         }
+        {   // (does this classification mark the points the previous one marked?  g_chg was cleared behind the fit, two barriers ago)
+            bool chg = false;
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                chg = chg || bal[e] != pbal[e];
+                pbal[e] = bal[e];
+            }
+            if (chg && lane == 0) g_chg = 1u;
+        }
         __syncthreads();
+        same_list = it >= 1 && g_chg == 0u;
         if (wave == 0) {  // exclusive scan of the 64 (e-major, wave-minor) counts
             const uint32_t v = g_tab[lane];
             const uint32_t inc = esort::wave_incl_scan(v);  // (DPP row shifts)
@@ -378,7 +427,11 @@ __device__ __attribute__((noinline)) void rg_fit_call() {
         if (it == 0) RG_STAMP(5);
     }
     for (uint32_t k = tid; k < ng; k += bs) glist_out[o0 + k] = glist[k];
-    if (tid == 0) ng_out[rk] = ng;
+    if (tid == 0) {
+        ng_out[rk] = ng;
+        g_rb.ng = ng;  // (the voxelisation behind this call takes the count, the list and the coordinates from LDS)
+        g_rb.in_lds = 1u;
+    }
     if (dbg && tid == 0) {  // diagnostics (ERASOR_HIP_SORT_STAMPS): the slowest bin's split between the z-sort and the rest, 10 ns ticks
         const unsigned long long t_c = wall_clock64(), t_a = g_rb.t_a, t_b = g_rb.t_b;
         if (atomicMax(&dbg[16], t_c - t_a) < t_c - t_a) {
@@ -401,8 +454,7 @@ __device__ __attribute__((noinline)) void rg_fit_call() {
 
 // R-GPF of the bin in g_rb (workgroup-uniform control flow; ends with the bin's ground list / count in global memory)
 __device__ __forceinline__ void rgpf_stage() {
-    const uint32_t key = g_rb.key;
-    const uint32_t M = g_ra.moff[key + 1] - g_ra.moff[key];
+    const uint32_t M = g_rb.M;
     if (g_ra.dbg && threadIdx.x == 0) {  // diagnostics: reverted bins, those beyond the pool, points
         atomicAdd(&g_ra.dbg[23], 1ull + (M > PB_CAP ? (1ull << 32) : 0ull));
         atomicAdd(&g_ra.dbg[63], (unsigned long long)M);
@@ -428,9 +480,9 @@ __device__ __forceinline__ float4 bv_input(uint32_t j, uint32_t nc, const float4
 __device__ __attribute__((noinline)) void bv_rare_call() {  // clouds beyond the pool: global scratch, brute-force search (binvox_core)
     const DP P = g_dp;
     const RevArgs a = g_ra;
-    const uint32_t rk = g_rb.rk, key = g_rb.key, vo = g_rb.vo, vb = a.vox_base;
-    const uint32_t mo = a.moff[key], qo = a.qoff[key];
-    const uint32_t nc = a.qoff[key + 1] - qo, m = nc + a.ng_arr[rk];
+    const uint32_t rk = g_rb.rk, vo = g_rb.vo, vb = a.vox_base;
+    const uint32_t mo = g_rb.o0, qo = g_rb.qo;
+    const uint32_t nc = g_rb.cc, m = nc + a.ng_arr[rk];
     binvox_core(P, m, nc, a.sq + qo, a.spts + mo, a.glist + mo, a.gsK + vb + vo, a.gsV + vb + vo, a.gsK2 + vb + vo, a.gsV2 + vb + vo, a.gsC + vo,
                 a.gsL + vb + vo, a.gsR + vb + vo, a.gsH + a.h_base + (vo >> 5) + 2 * rk, g_qa, g_qb, g_qcnt, g_sm, g_sbb, &g_carry, a.vox_out + vo,
                 a.nvox_out + rk, a.ctr);
@@ -440,9 +492,10 @@ __device__ __attribute__((noinline)) void bv_rare_call() {  // clouds beyond the
 __device__ __attribute__((noinline)) void bv_keys_call() {
     const DP P = g_dp;
     const uint32_t tid = threadIdx.x, bs = blockDim.x, lane = tid & 63u;
-    const uint32_t rk = g_rb.rk, key = g_rb.key, vo = g_rb.vo;
-    const uint32_t mo = g_ra.moff[key], qo = g_ra.qoff[key];
-    const uint32_t nc = g_ra.qoff[key + 1] - qo, ngr = g_ra.ng_arr[rk];
+    const uint32_t rk = g_rb.rk, vo = g_rb.vo;
+    const uint32_t mo = g_rb.o0, qo = g_rb.qo;
+    const uint32_t in_lds = g_rb.in_lds;
+    const uint32_t nc = g_rb.cc, ngr = in_lds ? g_rb.ng : g_ra.ng_arr[rk];
     const uint32_t m = nc + ngr;
     uint32_t *nvox_out = g_ra.nvox_out;
     if (tid == 0) {
@@ -463,7 +516,23 @@ __device__ __attribute__((noinline)) void bv_keys_call() {
     const uint32_t *glb = g_ra.glist + mo;
     float4 *vout = g_ra.vox_out + vo;
     float4 *sC = reinterpret_cast<float4 *>(g_rev_pool + 4 * PB_CAP);
-    for (uint32_t j = tid; j < m; j += bs) sC[j] = bv_input(j, nc, sqb, sptb, glb);
+    if (in_lds) {
+        // round 6: the reverted ground comes from where R-GPF left it -- list and coordinates in LDS, only the label from global memory (one
+        // round trip, not the list's and then the points')
+        const uint32_t *gl = g_rev_pool;
+        const float *X = reinterpret_cast<const float *>(g_rev_pool + PB_CAP), *Y = reinterpret_cast<const float *>(g_rev_pool + 2 * PB_CAP),
+                    *Z = reinterpret_cast<const float *>(g_rev_pool + 3 * PB_CAP);
+        for (uint32_t j = tid; j < m; j += bs) {
+            if (j < nc) {
+                sC[j] = sqb[j];
+            } else {
+                const uint32_t gi = gl[j - nc];
+                sC[j] = make_float4(X[gi], Y[gi], Z[gi], sptb[gi].w);
+            }
+        }
+    } else {
+        for (uint32_t j = tid; j < m; j += bs) sC[j] = bv_input(j, nc, sqb, sptb, glb);
+    }
     if (tid < 3) g_sbb[tid] = 0xFFFFFFFFu;
     if (tid >= 3 && tid < 6) g_sbb[tid] = 0u;
     __syncthreads();
@@ -535,9 +604,9 @@ __device__ __attribute__((noinline)) void bv_label_call() {
     float4 *sC = reinterpret_cast<float4 *>(pool + 4 * PB_CAP);
     float4 *vout = g_ra.vox_out + g_rb.vo;
     if (m > ESYNC_MAX) {  // the sort of more than 2048 keys took the upper half of the pool: the cloud again
-        const uint32_t key = g_rb.key, nc = g_rb.nc;
-        const float4 *sqb = g_ra.sq + g_ra.qoff[key], *sptb = g_ra.spts + g_ra.moff[key];
-        const uint32_t *glb = g_ra.glist + g_ra.moff[key];
+        const uint32_t nc = g_rb.nc;
+        const float4 *sqb = g_ra.sq + g_rb.qo, *sptb = g_ra.spts + g_rb.o0;
+        const uint32_t *glb = g_ra.glist + g_rb.o0;
         for (uint32_t j = tid; j < m; j += bs) sC[j] = bv_input(j, nc, sqb, sptb, glb);
     }
     // ---- run heads: unique keys (ascending) -> sK, run begins -> sV ----
@@ -734,12 +803,32 @@ __device__ __forceinline__ void rev_open(const DP &P, const RevArgs &ra) {  // o
     }
     __syncthreads();
 }
+static constexpr uint32_t VO_BY_POSITION = 0xFFFFFFFFu;  // rev_set_bin: the bin's share of the voxel scratch begins at moff[key] + qoff[key]
 __device__ __forceinline__ void rev_set_bin(uint32_t rk, uint32_t key, uint32_t vo) {
     __syncthreads();  // the previous bin's LDS (and g_rb) is dead
     if (threadIdx.x == 0) {
+        uint32_t o0, M, q0, cc;
+        if (vo == VO_BY_POSITION) {  // (the fused launch: rev_select_call has fetched the ranges beside its scan)
+            o0 = g_sel[4];
+            M = g_sel[5];
+            q0 = g_sel[6];
+            cc = g_sel[7];
+        } else {
+            const uint32_t o1 = g_ra.moff[key + 1], q1 = g_ra.qoff[key + 1];  // (four loads in flight together)
+            o0 = g_ra.moff[key];
+            q0 = g_ra.qoff[key];
+            M = o1 - o0;
+            cc = q1 - q0;
+        }
         g_rb.rk = rk;
         g_rb.key = key;
-        g_rb.vo = vo;
+        g_rb.vo = vo == VO_BY_POSITION ? o0 + q0 : vo;
+        g_rb.o0 = o0;
+        g_rb.M = M;
+        g_rb.qo = q0;
+        g_rb.cc = cc;
+        g_rb.ng = 0u;
+        g_rb.in_lds = 0u;
     }
     __syncthreads();
 }
@@ -825,10 +914,10 @@ __global__ __launch_bounds__(1024) void k_revert_bins_srt(DP P, SrtArgs sa, RevA
     for (uint32_t rk = blockIdx.x;; rk += stride) {
         __syncthreads();  // (g_sel of the previous round has been read)
         const unsigned long long w1 = ra.dbg ? wall_clock64() : 0ull;
-        rev_select_call(P.B, sa.st1_in, rk);
+        rev_select_call(P.B, sa.st1_in, rk, ra.moff, ra.qoff);
         const uint32_t key = g_sel[0], n_rev = g_sel[2];
         if (rk >= n_rev) break;
-        rev_set_bin(rk, key, ra.moff[key] + ra.qoff[key]);
+        rev_set_bin(rk, key, VO_BY_POSITION);
         const unsigned long long w2 = ra.dbg ? wall_clock64() : 0ull;
         rgpf_stage();
         __threadfence_block();
@@ -842,7 +931,7 @@ __global__ __launch_bounds__(1024) void k_revert_bins_srt(DP P, SrtArgs sa, RevA
                 ra.dbg[66] = w2 - w1;
                 ra.dbg[67] = w3 - w2;
                 ra.dbg[68] = w4 - w3;
-                ra.dbg[69] = ra.moff[key + 1] - ra.moff[key];
+                ra.dbg[69] = g_rb.M;
                 ra.dbg[70] = g_rb.m;
             }
         }
