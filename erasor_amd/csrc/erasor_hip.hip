@@ -27,6 +27,12 @@
 #include <vector>
 
 #include "../../include/erasor_hip.h"
+#ifndef ERASOR_REV_GRID
+#define ERASOR_REV_GRID 128u  // workgroups of the per-bin launch (one reverted bin each; more bins than workgroups: a grid-stride loop)
+#endif
+#ifndef ERASOR_EARLY_GMAP
+#define ERASOR_EARLY_GMAP 200u  // workgroups of k_assemble_early that write the map back (build options: A/B with tools/ab_dirs.sh, EXPERIMENTS r06-8)
+#endif
 #include "kernels.hip.h"
 
 using namespace ek;
@@ -92,7 +98,8 @@ struct QSide {
     float Tl[16] = {0};
     uint32_t ns = 0;
     bool src_dev = false;             // src is a device pointer (read in place; not fingerprinted)
-    uint64_t fp = 0;                  // host scans are copied when they are announced: hash of EVERY record of that copy
+    uint64_t fp = 0;                  // host scans are copied when they are announced: hash of EVERY record of that copy ...
+    bool fp_valid = false;            // ... taken when somebody asks for it (round 6: a scan that is stepped by its ticket is never hashed)
     uint64_t ticket = 0;              // the announcement's ticket (erasor_hip_prefetch_node_rows -> erasor_hip_step_ticket)
     RowFmt fmt;                       // record layout of src (host scans)
     bool used = false;                // ev_done has been recorded at least once
@@ -134,6 +141,7 @@ struct erasor_hip_handle {
         float Tl[16] = {0};
         int side = 0;
         uint64_t fp = 0;
+        bool fp_valid = false;
         uint64_t ticket = 0;
         RowFmt fmt;
         bool pose_valid = false;
@@ -1221,6 +1229,15 @@ static uint64_t scan_fingerprint(const void *host_rows, size_t n, RowFmt fmt) {
     return rh.done(n);
 }
 
+// the hash of the copy a side has staged (float4 rows in its pinned buffer), taken when a step has to recognise its scan by content
+static uint64_t staged_fingerprint(QSide &q, size_t n) {
+    if (!q.fp_valid) {
+        q.fp = scan_fingerprint(q.stage, n, RowFmt());
+        q.fp_valid = true;
+    }
+    return q.fp;
+}
+
 // A HOST scan on its way into query side Q(h): REPACKED into the side's pinned staging buffer NOW -- one pass that also hashes every
 // record (the caller's buffer is free again when this returns) --, from there asynchronously into q.scan on `stream`.  The side's
 // previous chain must be through with q.scan and the staging buffer (the caller has waited for q.ev_done).
@@ -1239,21 +1256,39 @@ static int stage_host_scan(erasor_hip_handle *h, const void *scan_src, uint32_t 
             else o.stage = nullptr;
         }
     }
-    RowHash rh;
     const unsigned char *p = static_cast<const unsigned char *>(scan_src);
     uint32_t *dst = reinterpret_cast<uint32_t *>(q.stage);
-    if (scan_src == (const void *)q.stage) {  // (a step run again from its own staged copy: already in place)
-        for (uint32_t i = 0; i < ns; ++i) rh.add(dst[4 * i], dst[4 * i + 1], dst[4 * i + 2], dst[4 * i + 3]);
-    } else {
-        for (uint32_t i = 0; i < ns; ++i, p += fmt.stride) {
-            uint32_t w[4];
-            memcpy(w, p, 12);
-            memcpy(w + 3, p + fmt.ioff, 4);
-            memcpy(dst + 4 * (size_t)i, w, 16);
-            rh.add(w[0], w[1], w[2], w[3]);
+    if (!fp_out) {
+        // Round 6 (second half): the repack alone.  The hash is a chain of dependent multiplies, ~0.1 ms per scan on the caller's thread, and
+        // it is only ever compared when a step comes WITHOUT a ticket and has to recognise its announcement by content: it is taken then,
+        // from this staged copy (staged_fingerprint), not here -- the drop-in callback path steps by ticket and never pays for it.
+        if (scan_src != (const void *)q.stage) {
+            if (fmt.stride == 16 && fmt.ioff == 12) {
+                memcpy(dst, p, (size_t)ns * 16);
+            } else {
+                for (uint32_t i = 0; i < ns; ++i, p += fmt.stride) {
+                    uint32_t w[4];
+                    memcpy(w, p, 12);
+                    memcpy(w + 3, p + fmt.ioff, 4);
+                    memcpy(dst + 4 * (size_t)i, w, 16);
+                }
+            }
         }
+    } else {
+        RowHash rh;
+        if (scan_src == (const void *)q.stage) {  // (a step run again from its own staged copy: already in place)
+            for (uint32_t i = 0; i < ns; ++i) rh.add(dst[4 * i], dst[4 * i + 1], dst[4 * i + 2], dst[4 * i + 3]);
+        } else {
+            for (uint32_t i = 0; i < ns; ++i, p += fmt.stride) {
+                uint32_t w[4];
+                memcpy(w, p, 12);
+                memcpy(w + 3, p + fmt.ioff, 4);
+                memcpy(dst + 4 * (size_t)i, w, 16);
+                rh.add(w[0], w[1], w[2], w[3]);
+            }
+        }
+        *fp_out = rh.done(ns);
     }
-    if (fp_out) *fp_out = rh.done(ns);
     HIPC(h, hipMemcpyAsync(q.scan.p, q.stage, (size_t)ns * sizeof(float4), hipMemcpyHostToDevice, stream));
     return ERASOR_OK;
 }
@@ -1660,11 +1695,11 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
         // the side may still be executing a chain that was dropped (a prefetch that no step claimed): its kernels read
         // q.scan, and a scan that changes between the bounding-box pass and the voxel keys sends them astray
         if (q.used) HIPC(h, hipEventSynchronize(q.ev_done));
-        uint64_t fp_staged = 0;
-        rc = stage_host_scan(h, scan_src, ns, qstream, fmt, &fp_staged);  // (on the chain's own stream: ordered before its first kernel)
+        rc = stage_host_scan(h, scan_src, ns, qstream, fmt, nullptr);  // (on the chain's own stream: ordered before its first kernel)
         if (rc) return rc;
         q.h2d_pending = false;
-        q.fp = fp_staged;
+        q.fp = 0ull;
+        q.fp_valid = false;  // (staged_fingerprint, if anybody ever asks)
     }
     q.scan_in = src_is_device && ns ? (const float4 *)scan_src : (const float4 *)q.scan.p;
     q.ns = ns;
@@ -1689,7 +1724,10 @@ static int enqueue_query_chain(erasor_hip_handle *h, int side, const void *scan_
     if (staged != 2) {
         q.pose_valid = false;  // (flush_announced adds the pose of an announced node)
         q.to_valid = false;
-        if (!src_is_device && staged) q.fp = h->ann.fp;  // (not staged: the hash the staging pass has just taken)
+        if (!src_is_device && staged) {  // (the announcement's hash, if it has been taken)
+            q.fp = h->ann.fp;
+            q.fp_valid = h->ann.fp_valid;
+        }
         q.ticket = staged ? h->ann.ticket : 0ull;
     }
     q.fmt = fmt;
@@ -1957,6 +1995,10 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                                h->q[h->pend[0]].src_dev == src_is_device && memcmp(h->q[h->pend[0]].Tl, T_l2b, sizeof(h->q[0].Tl)) == 0 &&
                                h->q[h->pend[0]].fmt.stride == fmt.stride && h->q[h->pend[0]].fmt.ioff == fmt.ioff;
         const uint64_t fp_now = (!src_is_device && (ann_cand || pend_cand)) ? scan_fingerprint(scan_src, n_scan, fmt) : 0ull;
+        if (ann_cand && !src_is_device && !h->ann.fp_valid) {  // (the announced copy is hashed now that somebody asks)
+            h->ann.fp = staged_fingerprint(h->q[h->ann.side], h->ann.n);
+            h->ann.fp_valid = true;
+        }
         if (ann_cand && (src_is_device || h->ann.fp == fp_now)) {
             rc = flush_announced(h);  // announced, not yet started (first scan of a sequence): start it now, it is ours
             if (rc) return rc;
@@ -1965,8 +2007,9 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             // the step runs again in the other VoxelGrid mode (step_collect): the nodes announced behind it are NOT this scan and are not
             // dropped -- a ticket has no caller buffer to come back with --; their chains (which ran in the old mode) go again below
         } else if (h->npend > 0) {
-            const QSide &c = h->q[h->pend[0]];
-            if (ticket || (!prevox && c.src == scan_src && c.src_n == n_scan && c.src_dev == src_is_device && (src_is_device || c.fp == fp_now) &&
+            QSide &c = h->q[h->pend[0]];
+            if (ticket || (!prevox && c.src == scan_src && c.src_n == n_scan && c.src_dev == src_is_device &&
+                           (src_is_device || (pend_cand && staged_fingerprint(c, c.src_n) == fp_now)) &&
                            memcmp(c.Tl, T_l2b, sizeof(c.Tl)) == 0 && c.fmt.stride == fmt.stride && c.fmt.ioff == fmt.ioff)) {
                 side = h->pend[0];
                 for (int j = 1; j < h->npend; ++j) h->pend[j - 1] = h->pend[j];
@@ -2300,7 +2343,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
             ea.cnt = h->lab_slots.p;
             // (one round of workgroups: a 1024-thread workgroup of this kernel has a compute unit to itself, and the per-bin launch and the query
             // chains hold some of the 256)
-            LAUNCH(h, "srt+assemble", k_assemble_early, std::min<uint32_t>(cdiv(n_voi, 1024), 200) + 1u, 1024, P, h->Tb2o, ea);
+            LAUNCH(h, "srt+assemble", k_assemble_early, std::min<uint32_t>(cdiv(n_voi, 1024), ERASOR_EARLY_GMAP) + 1u, 1024, P, h->Tb2o, ea);
         }
         MARK("  k_srt4 + assemble early");
         // (an overlapped step's late write-back joins at ev_scan, further down this stream and long there when the per-bin launch ends)
@@ -2395,7 +2438,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         LAUNCH(h, "srt", k_srt, 1, 1024, P, (const uint32_t *)h->mcnt.p, (const float *)h->mmin.p, (const float *)h->mmax.p, (const uint32_t *)Q(h).ccnt.p,
            (const float *)Q(h).cmin.p, (const float *)Q(h).cmax.p, h->st1.p, h->status.p, h->action.p, h->rev_idx.p, h->rev_list.p, h->vox_off.p, ds);
     // R-GPF and the per-bin voxelisation walk the reverted-bin LIST on a small fixed grid (n_rev is on the device)
-    const uint32_t rev_grid = 128u;
+    const uint32_t rev_grid = ERASOR_REV_GRID;
     // v3: R-GPF and the per-bin voxelisation of a reverted bin in ONE launch (k_revert_bins); ERASOR_HIP_NO_FUSE=1: two launches (A/B)
     RevArgs ra;
     ra.moff = h->moff.p;
@@ -2912,12 +2955,17 @@ static int prefetch_common(erasor_hip_handle *h, const void *scan_xyzi, size_t n
         rc = chain_wait(h, side);
         if (rc) return rc;
         if (Q(h).used) HIPC(h, hipEventSynchronize(Q(h).ev_done));  // (a dropped chain may still be reading this side's scan)
-        rc = stage_host_scan(h, scan_xyzi, (uint32_t)n, copy_stream(h), fmt, &h->ann.fp);
+        rc = stage_host_scan(h, scan_xyzi, (uint32_t)n, copy_stream(h), fmt, nullptr);
         if (rc) return rc;
+        h->ann.fp = 0ull;
+        h->ann.fp_valid = false;
+        Q(h).fp_valid = false;  // (the side's buffer holds a new copy)
         HIPC(h, hipEventRecord(Q(h).ev_h2d, copy_stream(h)));
         Q(h).h2d_pending = true;
-    } else
+    } else {
         h->ann.fp = 0ull;
+        h->ann.fp_valid = false;
+    }
     h->ann.valid = true;
     h->ann.is_device = src_is_device != 0;
     h->ann.src = scan_xyzi;
