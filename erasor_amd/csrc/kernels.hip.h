@@ -4183,7 +4183,8 @@ __global__ __launch_bounds__(256) void k_assemble_bins(DP P, Xf Tb2o, const uint
 // (what k_layout4 / k_assemble_map<., true> leave), the late table's `actual` column and the holes before every entry.
 // src_late / src_holes / n_src_late: the late table of the step that WROTE the region this step read (its source indices count reserved
 // slots: idx - holes before idx = the logical index), nullptr / 0: that region was dense.
-__device__ __forceinline__ uint32_t late_logical(uint32_t src, const LateEnt *__restrict__ tab, const uint32_t *__restrict__ holes, uint32_t n) {
+template <class TP, class HP>
+__device__ __forceinline__ uint32_t late_logical(uint32_t src, TP tab, HP holes, uint32_t n) {
     if (!n) return src;
     uint32_t lo = 0, hi = n;  // first entry whose range ends beyond src
     while (lo < hi) {
@@ -4210,6 +4211,21 @@ __global__ __launch_bounds__(256) void k_assemble_late(DP P, Xf Tb2o, const uint
     __shared__ uint32_t s_sm[40];
     __shared__ uint32_t s_carry[4];
     __shared__ uint32_t s_cvl[ASM_RVMAX + 1];
+    // (round 6, second half: the late table of the region that was read -- a few dozen entries -- is staged in LDS while the bin's own loads are
+    // on their way: every rejected point's source index is converted by a binary search in it, five or six DEPENDENT reads, which from
+    // global memory were ~4 us of this launch's chain)
+    constexpr uint32_t SRC_LATE_LDS = 512;
+    __shared__ uint32_t s_src_end[SRC_LATE_LDS], s_src_holes[SRC_LATE_LDS + 1];
+    const bool src_in_lds = n_src_late != 0 && n_src_late <= SRC_LATE_LDS;
+    if (src_in_lds) {
+        for (uint32_t i = threadIdx.x; i <= n_src_late; i += blockDim.x) {
+            if (i < n_src_late) {
+                const LateEnt e = src_late[i];
+                s_src_end[i] = e.start + e.ntotal;
+            }
+            s_src_holes[i] = src_holes[i];
+        }
+    }
     const uint32_t n_rev = st->n_rev;
     CHAIN_STAMP(8);
     const uint32_t total_binsR = st->total_binsR;
@@ -4271,7 +4287,20 @@ __global__ __launch_bounds__(256) void k_assemble_late(DP P, Xf Tb2o, const uint
                 if (is_dynamic_label(p.w)) ++nd; else ++nst;
             } else {
                 rejected[rej0 + gr] = xform(Tb2o, p);  // map_rejected_ is handed out in the map frame (OMU.cpp:287)
-                rejected_src[rej0 + gr] = late_logical(ssrc[i], src_late, src_holes, n_src_late);
+                const uint32_t sidx = ssrc[i];
+                uint32_t lg;
+                if (src_in_lds) {  // (late_logical's search, the table in LDS)
+                    uint32_t lo = 0, hi = n_src_late;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_src_end[mid] <= sidx) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    lg = sidx - s_src_holes[lo];
+                } else {
+                    lg = late_logical(sidx, src_late, src_holes, n_src_late);
+                }
+                rejected_src[rej0 + gr] = lg;
             }
         }
         for (uint32_t v = ng + threadIdx.x; v < eg.ntotal; v += blockDim.x) Fnew[eg.start + v] = hole;
