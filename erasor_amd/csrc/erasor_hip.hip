@@ -150,6 +150,7 @@ struct erasor_hip_handle {
         float To[16] = {0};
     } ann;
     int last_ann_side = -1;  // the side of the most recent announcement (erasor_hip_announce_origin2body attaches to it)
+    int step_side = -1;      // the side of the step in flight / of the last step collected: its arrays are read by that step's launches and by the getters
     uint64_t next_ticket = 1;
     // the NEXT step's VoI split, launched ahead (behind this step's k_step_end) when the next scan was announced with its pose
     struct {
@@ -627,7 +628,9 @@ int alloc_scan(erasor_hip_handle *h, uint32_t ns) {
     const int me = h->qi;
     for (int k = 0; k < NSIDE && !rc; ++k) {
         QSide &q = h->q[k];
-        if (k == me || (q.capS && ns <= q.capS) || q.held || (h->ann.valid && h->ann.side == k)) continue;
+        // (NOT the side of the step in flight or last collected: the Scan Ratio Test, the per-bin launch, the write-back and the getters read its
+        // bucketed scan -- a side whose chain has run out is not an idle side; found by the 240-walk soak, not by the suite's four walks)
+        if (k == me || k == h->step_side || (q.capS && ns <= q.capS) || q.held || (h->ann.valid && h->ann.side == k)) continue;
         bool busy = h->worker && h->worker->busy[k].load(std::memory_order_acquire) > 0;
         for (int j = 0; j < h->npend; ++j) busy = busy || h->pend[j] == k;
         if (busy || (q.used && hipEventQuery(q.ev_done) != hipSuccess)) continue;  // (a dropped chain may still be running on it)
@@ -2033,6 +2036,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
                 if (rc) return rc;
             }
         h->qi = side;
+        h->step_side = side;
         rc = chain_wait(h, side);  // (the chain's events are waited for below: they must have been recorded)
         if (rc) return rc;
     }
