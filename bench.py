@@ -89,7 +89,7 @@ def parse_args():
                     help="nodes announced ahead (erasor_hip_run_nodes / erasor_hip_prefetch_node).  Round 6: six -- the query chains of announced nodes\n"
                          "beyond the --chain-lead-th in line share their launches --chain-batch at a time (erasor_hip_chain_batch), and a set of two\n"
                          "of three takes about three steps to get through its queue")
-    ap.add_argument("--chain-batch", type=int, default=3, choices=[1, 2, 3, 4],
+    ap.add_argument("--chain-batch", type=int, default=2, choices=[1, 2, 3, 4],
                     help="query chains of announced nodes that share one set of launches (1: every chain on its own, round 5's behaviour)")
     ap.add_argument("--chain-lead", type=int, default=3, choices=[1, 2, 3, 4, 5, 6],
                     help="a chain is held back for a shared set only while this many chains are in their queues in front of it")
