@@ -2491,7 +2491,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         sa.st1_in = h->st1b.p;
         sa.moff = h->moff.p;
         sa.qoff = Q(h).qoff.p;
-        if (reserved) sa.status = nullptr;  // (k_srt4 runs as a launch of its own, on the early stream: no extra workgroup)
+        if (reserved) sa.status = nullptr;  // (k_srt4 is the first workgroup of k_assemble_early, on the early stream: no extra workgroup here)
         if (reserved) (void)hipEventRecord(h->ev_stats, h->stream);  // (the bin statistics are there: the early stream may start)
         LAUNCH(h, "rgpf+bin_voxelize", k_revert_bins_srt, std::min<uint32_t>(rev_grid, B) + (reserved ? 0u : 1u), 1024, P, sa, ra);
         MARK("per-bin launch");
@@ -2557,7 +2557,7 @@ static int step_enqueue(erasor_hip_handle *h, const void *scan_src, size_t n_sca
         // stream runs it while the host collects this step's results and the caller comes back with the next scan -- the pass
         // reads the store this step has just written and the extents the step's end commits; a step that finds anything else than
         // what was assumed here (pose, store, buffers) simply runs its own pass.
-        // Round 4: that launch also ENDS this step (its last workgroup does k_step_end's work, ERASOR_HIP_NO_END_FOLD=1: a launch of its own)
+        // Round 4: that launch also ENDS this step (its last workgroup does k_step_end's work)
         // (large-scale mode, round 4: ahead as well, unless the next node's pose moves the submap)
         const bool spec = have_pose && !flags && !submap_would_move(h, nx, ny);
         StepEnd se;

@@ -895,7 +895,8 @@ __device__ __attribute__((noinline)) void srt4_call() {
     srt4_body(P, sm, s_st1, a.mcnt, a.mmin, a.mmax, a.ccnt, a.cmin, a.cmax, a.st1, a.status, a.action, a.rev_idx, a.rev_list, a.vox_off, a.st, a.out_off0,
               a.rev_before, a.crej_off, a.st1_in, a.moff, a.qoff);
 }
-// (round 5: sa.status == nullptr -- no extra workgroup: k_srt4 runs as a launch of its own on the stream that writes the map back EARLY)
+// (round 5: sa.status == nullptr -- no extra workgroup: k_srt4's work is done on the stream that writes the map back EARLY -- round 6: as the
+// first workgroup of k_assemble_early)
 __global__ __launch_bounds__(1024) void k_revert_bins_srt(DP P, SrtArgs sa, RevArgs ra) {
     const bool has_srt = sa.status != nullptr;
     const uint32_t stride = gridDim.x - (has_srt ? 1u : 0u);
